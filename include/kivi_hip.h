@@ -1,0 +1,152 @@
+/*
+ * kivi_hip.h -- C ABI of libkivi_hip.so: the MI355X (gfx950) implementation of
+ * KIVI's quant/ hot path.  Plain pointers and sizes only: every pointer is a
+ * DEVICE pointer owned by the caller, every kernel is enqueued on the
+ * hipStream_t passed as `stream` (NULL = the default stream) and nothing here
+ * synchronises or allocates.  Return value: 0 on success, a positive hipError_t
+ * if a launch failed, a negative KIVI_E* code if the arguments are rejected
+ * (kivi_last_error() then holds a message; thread-local).
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the jy-yuan/KIVI tree).  INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Layout vocabulary (reference: models/llama_kivi.py:454-455, "hook state"):
+ *   fpi = 32 / bits codes per int32 word, element i of a word at bit bits*i
+ *   K_code_T (B, nh_kv, D, Tq/fpi) int32   K_scale_T, K_mn_T (B, nh_kv, D, Tq/g) fp16
+ *   V_code   (B, nh_kv, Tv, D/fpi) int32   V_scale,  V_mn    (B, nh_kv, Tv, D/g) fp16
+ * Strides are in ELEMENTS of the tensor they describe (int32 words / halves).
+ */
+#ifndef KIVI_HIP_H
+#define KIVI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KIVI_ABI_VERSION 1
+
+#define KIVI_EINVAL (-1)       /* unsupported bits / group size / shape */
+#define KIVI_EALIGN (-2)       /* pointer or stride alignment the kernels rely on is violated */
+#define KIVI_EUNSUPPORTED (-3) /* valid in the reference, not implemented here */
+
+typedef void* kivi_stream_t; /* hipStream_t */
+
+int kivi_abi_version(void);
+const char* kivi_last_error(void);
+
+/* ---------------------------------------------------------------- pack --- */
+
+/*
+ * Fused group-wise asymmetric quantise + pack along the LAST dim.
+ * Replaces triton_quantize_and_pack_along_last_dim (quant/new_pack.py:217-252:
+ * two Triton kernels + five elementwise torch kernels + an int32 temporary) and
+ * its pure-torch twin quant_and_pack_vcache (quant/new_pack.py:30-48).
+ *   x      (rows, T) fp16, contiguous          T % group_size == 0, T % fpi == 0
+ *   code   (rows, T/fpi) int32                 scale, mn (rows, T/group_size) fp16
+ * bits in {2,4,8}.  Results are bit-identical to the reference op sequence
+ * (per-op fp16 rounding, round-half-even); a constant group (scale 0 -> 0/0)
+ * yields code 0 as the reference's CUDA float->int conversion does.
+ */
+int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, void* mn, int64_t rows, int64_t T,
+                            int group_size, int bits, kivi_stream_t stream);
+
+/*
+ * Per-channel K quantise + pack straight from the un-transposed K tensor:
+ * reads k[b, h, t, :] = k + b*k_sb + h*k_sh + t*k_st (D contiguous halves) and
+ * writes the hook-state layout (groups of `group_size` TOKENS per channel d):
+ *   code [b, h, d, code_off + t/fpi],  scale/mn [b, h, d, sm_off + t/group_size]
+ * Replaces `key_states.transpose(2, 3).contiguous()` + the pack call at
+ * models/llama_kivi.py:345 and :436 (and quant_and_pack_kcache,
+ * quant/new_pack.py:8-27, whose codes are the transpose of these).
+ * The *_off arguments let a pre-allocated cache be appended in place.
+ */
+int kivi_quant_pack_k_tmajor(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* code, int64_t code_sb,
+                             int64_t code_sh, int64_t code_sr, int64_t code_off, void* scale, void* mn,
+                             int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, int64_t sm_off, int B, int nh, int64_t T,
+                             int D, int group_size, int bits, kivi_stream_t stream);
+
+/*
+ * Unpack + dequantise along the last dim: out = fp16(fp16(fp16(q) * scale) + mn).
+ * Replaces unpack_and_dequant_vcache (quant/new_pack.py:69-83); with the K^T
+ * layout it also serves unpack_and_dequant_kcache (:51-66).
+ */
+int kivi_unpack_dequant_lastdim(const void* code, const void* scale, const void* mn, void* out, int64_t rows,
+                                int64_t T, int group_size, int bits, kivi_stream_t stream);
+
+/* Raw code pack along the last dim: pack_tensor (quant/new_pack.py:86-107) / _pack_along_last_dim (:132-154).
+ * data (rows, T) int32 -> code (rows, T/fpi) int32, OR of data << bits*i (no masking, like the reference). */
+int kivi_pack_codes_lastdim(const void* data_i32, void* code, int64_t rows, int64_t T, int bits,
+                            kivi_stream_t stream);
+
+/* Raw code unpack (quant/new_pack.py:110-129, unpack_tensor with pack_dim = last): int16 out. */
+int kivi_unpack_codes_lastdim(const void* code, void* out_i16, int64_t rows, int64_t T, int bits,
+                              kivi_stream_t stream);
+
+/* ---------------------------------------------------------- fused GEMV --- */
+
+/*
+ * qK^T over the packed per-channel K cache, hook-state layout, no transposes:
+ *   out[b, h, t] = fp16( sum_d q[b,h,d] * (scale[b,hk,d,t/g] * code[b,hk,d,t] + mn[b,hk,d,t/g]) )
+ * with hk = h / (nh / nh_kv), fp32 arithmetic, one final rounding.
+ * Replaces cuda_bmm_fA_qB_outer (quant/matmul.py:178-219, including its three
+ * `.transpose(1,2).contiguous()` copies) -> kivi_gemv.gemv_forward_cuda_outer_dim
+ * (quant/csrc/gemv_cuda.cu:511-557) -> bgemv2/4_kernel_outer_dim (:265-427) at the
+ * call site models/llama_kivi.py:324.  bits in {2,4}; q_len must be 1.
+ *   q    (B, nh, D)  at q + b*q_sb + h*q_sh          out (B, nh, T) at out + b*out_sb + h*out_sh
+ *   code (B, nh_kv, D, >=T/fpi) strides code_sb/sh/sr  scale, mn (B, nh_kv, D, >=T/g) strides sm_sb/sh/sr
+ */
+int kivi_gemv_k(const void* q, int64_t q_sb, int64_t q_sh, const void* code, int64_t code_sb, int64_t code_sh,
+                int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
+                void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T,
+                int group_size, int bits, kivi_stream_t stream);
+
+/*
+ * sV over the packed per-token V cache:
+ *   out[b, h, d] = fp16( sum_t a[b,h,t] * (scale[b,hk,t,d/g] * code[b,hk,t,d] + mn[b,hk,t,d/g]) )
+ * Replaces the same reference chain at the call site models/llama_kivi.py:382
+ * (fA there is the non-contiguous slice attn_weights[..., :-value_full_length];
+ * a_sb/a_sh carry its strides so no copy is needed).
+ *   a    (B, nh, Tv) at a + b*a_sb + h*a_sh          out (B, nh, D)
+ *   code (B, nh_kv, Tv, D/fpi) strides code_sb/sh/sr  scale, mn (B, nh_kv, Tv, D/g) strides sm_sb/sh/sr
+ */
+int kivi_gemv_v(const void* a, int64_t a_sb, int64_t a_sh, const void* code, int64_t code_sb, int64_t code_sh,
+                int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
+                void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D,
+                int group_size, int bits, kivi_stream_t stream);
+
+/*
+ * ABI twin of the reference's native entry point on ITS kernel-input layout
+ * (torch::Tensor gemv_forward_cuda_outer_dim, quant/csrc/gemv_cuda.h:13-21,
+ * gemv_cuda.cu:511-557): in (BS, 1, IC) fp16, kernel (BS_kv, OC/fpi, IC) int32,
+ * scale/zeros (BS_kv, OC/g, IC) fp16, out (BS, 1, OC) fp16, BS_kv = BS*nh_kv/nh.
+ * Kept for callers that already hold transposed tensors (quant/gemv.py:117,154).
+ */
+int kivi_gemv_outer_dim(const void* in, const void* kernel, const void* scale, const void* zeros, void* out,
+                        int64_t BS, int64_t IC, int64_t OC, int bit, int group_size, int nh, int nh_kv,
+                        kivi_stream_t stream);
+
+/* ------------------------------------------------- tuning / bench hooks --- */
+
+/* Kernel variants of kivi_gemv_k (same arguments + variant id; -1 = the default heuristic).
+ * Used by bench.py and the parity tests to check every variant; not part of the drop-in surface. */
+int kivi_gemv_k_num_variants(void);
+const char* kivi_gemv_k_variant_name(int variant);
+int kivi_gemv_k_variant(int variant, const void* q, int64_t q_sb, int64_t q_sh, const void* code, int64_t code_sb,
+                        int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
+                        int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                        int nh_kv, int D, int64_t T, int group_size, int bits, kivi_stream_t stream);
+
+int kivi_gemv_v_num_variants(void);
+const char* kivi_gemv_v_variant_name(int variant);
+int kivi_gemv_v_variant(int variant, const void* a, int64_t a_sb, int64_t a_sh, const void* code, int64_t code_sb,
+                        int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
+                        int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                        int nh_kv, int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIVI_HIP_H */

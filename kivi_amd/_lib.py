@@ -1,0 +1,89 @@
+"""ctypes binding of libkivi_hip.so (C ABI: include/kivi_hip.h).
+
+Fails loudly: if the shared library has not been built (python -m kivi_amd.build
+or __graft_entry__.build()) importing any op raises; nothing here falls back to
+PyTorch or to the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkivi_hip.so")
+
+_i64, _i32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+
+_GEMV_ARGS = [_vp, _i64, _i64,            # q / a + strides
+              _vp, _i64, _i64, _i64,      # code + strides
+              _vp, _vp, _i64, _i64, _i64,  # scale, mn + strides
+              _vp, _i64, _i64]            # out + strides
+
+# name -> (restype, argtypes); must list every symbol include/kivi_hip.h declares
+SIGNATURES = {
+    "kivi_abi_version": (_i32, []),
+    "kivi_last_error": (ctypes.c_char_p, []),
+    "kivi_quant_pack_lastdim": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "kivi_quant_pack_k_tmajor": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
+                                        _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_unpack_dequant_lastdim": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "kivi_pack_codes_lastdim": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
+    "kivi_unpack_codes_lastdim": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
+    "kivi_gemv_k": (_i32, _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "kivi_gemv_v": (_i32, _GEMV_ARGS + [_i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_gemv_outer_dim": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "kivi_gemv_k_num_variants": (_i32, []),
+    "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),
+    "kivi_gemv_k_variant": (_i32, [_i32] + _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "kivi_gemv_v_num_variants": (_i32, []),
+    "kivi_gemv_v_variant_name": (ctypes.c_char_p, [_i32]),
+    "kivi_gemv_v_variant": (_i32, [_i32] + _GEMV_ARGS + [_i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class KiviHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise (never fall back) if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KiviHipError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m kivi_amd.build). "
+            "kivi_amd has no CPU / PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kivi_abi_version() != 1:
+        raise KiviHipError(f"ABI version mismatch: library reports {lib.kivi_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().kivi_last_error().decode(errors="replace")
+        raise KiviHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr(t: torch.Tensor) -> ctypes.c_void_p:
+    """hipStream_t of torch's current stream on the tensor's device."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise KiviHipError(f"{name} must live on the GPU (got device={t.device}); kivi_amd has no CPU path")
+
+
+def ptr(t: torch.Tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr())

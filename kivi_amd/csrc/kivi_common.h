@@ -1,0 +1,162 @@
+// Shared device helpers for the KIVI gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kivi_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+
+#define KIVI_WAVE 64
+
+// ---- argument / launch error plumbing (host side) -------------------------
+void kivi_set_error(const char* fmt, ...);
+
+#define KIVI_REQUIRE(cond, code, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            kivi_set_error(__VA_ARGS__);   \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+static inline int kivi_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        kivi_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ---- device helpers -------------------------------------------------------
+template <typename T, bool NT>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+// Buffer (SRSRC) loads: wave-uniform 128-bit descriptor + scalar row offset +
+// 32-bit per-lane offset; out-of-range lanes read 0 (hardware bounds check).
+// The descriptor inputs must be provably wave-uniform (blockIdx / readfirstlane).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    // readfirstlane makes the uniformity provable: otherwise hipcc wraps every
+    // buffer op in a waterfall loop (cdna_hip_programming.md T20).
+    const uint64_t p = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    bytes = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+template <typename T, bool NT>
+__device__ __forceinline__ T buf_load(rsrc_t r, uint32_t voff, uint32_t soff) {
+    constexpr int AUX = NT ? 2 : 0;  // aux bit 1 = nt (streamed once)
+    if constexpr (sizeof(T) == 2) return (T)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX);
+    else if constexpr (sizeof(T) == 4) return (T)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
+    else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+    else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+
+__device__ __forceinline__ float h2f_bits(uint16_t h) { return (float)__builtin_bit_cast(f16, h); }
+__device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (f16)f); }
+
+// acc + f32(half in the low / high 16 bits of m) * b, one instruction.  The
+// half operand is an fp16 SUBNORMAL holding a masked code (value
+// code * 4^k * 2^-24); v_fma_mix_f32 converts it exactly and accumulates in fp32.
+__device__ __forceinline__ float fma_mix_lo(uint32_t m, float b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(m), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(uint32_t m, float b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(m), "v"(b), "v"(c));
+    return d;
+}
+
+// Unpack strategies for the fused GEMV inner loop (see DESIGN.md "VALU budget").
+enum : int {
+    KIVI_UNPACK_BFE = 0,    // v_bfe_u32 + v_cvt_f32_u32 + v_fma_f32            (3 op / code)
+    KIVI_UNPACK_UBYTE = 1,  // byte-plane mask + v_cvt_f32_ubyteN + v_fma_f32    (2.25 op / code)
+    KIVI_UNPACK_MIX = 2,    // half-plane mask + v_fma_mix_f32 on fp16 subnormals (1.56 op / code)
+};
+
+// Accumulate one packed word `w` (FPI = 32/BITS codes) into acc[FPI]:
+//   acc[p] += code_p * POSTINV[p] * qs          (POSTINV = power of two, undone by post_scale)
+// qs must be pre-multiplied by 2^24 in MIX mode (qs_factor()).
+template <int BITS, int MODE>
+__device__ __forceinline__ void accum_word(uint32_t w, float qs, float* acc) {
+    constexpr int FPI = 32 / BITS;
+    if constexpr (MODE == KIVI_UNPACK_BFE) {
+#pragma unroll
+        for (int p = 0; p < FPI; p++) {
+            float c = (float)((w >> (BITS * p)) & ((1u << BITS) - 1u));
+            acc[p] = __builtin_fmaf(c, qs, acc[p]);
+        }
+    } else if constexpr (MODE == KIVI_UNPACK_UBYTE) {
+        constexpr int PER_BYTE = 8 / BITS;                 // codes per byte: 4 (2-bit) or 2 (4-bit)
+        constexpr uint32_t M0 = (BITS == 2) ? 0x03030303u : 0x0F0F0F0Fu;
+#pragma unroll
+        for (int k = 0; k < PER_BYTE; k++) {
+            uint32_t mb = w & (M0 << (BITS * k));
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                float c = (float)((mb >> (8 * b)) & 0xFFu);  // v_cvt_f32_ubyte{b}: code * 2^(BITS*k)
+                acc[b * PER_BYTE + k] = __builtin_fmaf(c, qs, acc[b * PER_BYTE + k]);
+            }
+        }
+    } else {
+        // fp16 mantissa = bits 0..9 of each half: 5 two-bit fields (or 2 four-bit fields) are
+        // readable in place; the remaining fields of each half are brought down by ONE shift.
+        constexpr int HALF = FPI / 2;                      // codes per 16-bit half: 8 or 4
+        constexpr int INPLACE = (BITS == 2) ? 5 : 2;       // fields that sit inside the mantissa
+        constexpr int SHIFT = (BITS == 2) ? 6 : 8;         // brings field INPLACE.. down to >= bit 4 / 0
+        constexpr int K0 = (BITS == 2) ? 2 : 0;            // first field index after the shift
+        constexpr uint32_t M0 = (BITS == 2) ? 0x00030003u : 0x000F000Fu;
+#pragma unroll
+        for (int k = 0; k < INPLACE; k++) {
+            uint32_t m = w & (M0 << (BITS * k));
+            acc[k] = fma_mix_lo(m, qs, acc[k]);
+            acc[k + HALF] = fma_mix_hi(m, qs, acc[k + HALF]);
+        }
+        uint32_t ws = w >> SHIFT;
+#pragma unroll
+        for (int k = INPLACE; k < HALF; k++) {
+            uint32_t m = ws & (M0 << (BITS * (k - INPLACE + K0)));
+            acc[k] = fma_mix_lo(m, qs, acc[k]);
+            acc[k + HALF] = fma_mix_hi(m, qs, acc[k + HALF]);
+        }
+    }
+}
+
+// Factor that turns the accumulated value of code position p back into
+// sum(code * qs_true):  acc[p] * post_scale(p).
+template <int BITS, int MODE>
+__device__ __forceinline__ constexpr float post_scale(int p) {
+    constexpr int FPI = 32 / BITS;
+    if constexpr (MODE == KIVI_UNPACK_BFE) {
+        return 1.0f;
+    } else if constexpr (MODE == KIVI_UNPACK_UBYTE) {
+        constexpr int PER_BYTE = 8 / BITS;
+        int k = p % PER_BYTE;
+        return 1.0f / (float)(1u << (BITS * k));
+    } else {
+        constexpr int HALF = FPI / 2;
+        constexpr int INPLACE = (BITS == 2) ? 5 : 2;
+        constexpr int K0 = (BITS == 2) ? 2 : 0;
+        int k = p % HALF;
+        int field = (k < INPLACE) ? k : (k - INPLACE + K0);
+        return 1.0f / (float)(1u << (BITS * field));
+    }
+}
+
+// qs pre-factor: MIX reads masked codes as fp16 subnormals (x 2^-24).
+template <int MODE>
+__device__ __forceinline__ constexpr float qs_factor() {
+    return MODE == KIVI_UNPACK_MIX ? 16777216.0f : 1.0f;
+}

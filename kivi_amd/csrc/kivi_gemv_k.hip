@@ -1,0 +1,463 @@
+// qK^T over the packed per-channel K cache (hook-state layout), gfx950.
+//
+// Replaces cuda_bmm_fA_qB_outer + bgemv{2,4}_kernel_outer_dim of the reference
+// (quant/matmul.py:178-219, quant/csrc/gemv_cuda.cu:265-427) for the call at
+// models/llama_kivi.py:324, reading K_code_T (B,nh_kv,D,T/fpi) directly.
+//
+// Mapping (wave64).  The dot axis d is the LOOP axis; the packed axis t is
+// spread over lanes, so a lane owns WPL consecutive words (= WPL*fpi tokens)
+// of every channel row and there is NO cross-lane reduction:
+//   one wave-instruction reads 64*WPL*4 contiguous bytes of one code row,
+//   plus 64*NGL halves of the matching scale and mn rows.
+// Per code the VALU work is one mask (shared by two codes) + one v_fma_mix_f32;
+// scale is folded into q once per (row, group) and the zero-point term
+// sum_d q[d]*mn[d,G] is hoisted out of the per-token work (one fma per group).
+// DSPLIT waves of a block split the channel range and combine through LDS.
+#include <type_traits>
+
+#include "kivi_common.h"
+
+namespace {
+
+struct GemvKArgs {
+    const uint16_t* q;
+    int64_t q_sb, q_sh;
+    const uint32_t* code;
+    int64_t code_sb, code_sh, code_sr;
+    const uint16_t* scale;
+    const uint16_t* mn;
+    int64_t sm_sb, sm_sh, sm_sr;
+    uint16_t* out;
+    int64_t out_sb, out_sh;
+    int nh, ratio, D;
+    int64_t T, Tw;
+    int units_per_b;   // nh / R
+    int tile_blocks;   // blocks per (b, head unit)
+    uint32_t code_extent, sm_extent;  // bytes spanned by one (b, kv head) slab
+};
+
+template <int N> struct WordVec;
+template <> struct WordVec<1> { typedef uint32_t type; };
+template <> struct WordVec<2> { typedef u32x2 type; };
+template <> struct WordVec<4> { typedef u32x4 type; };
+
+template <int N, typename V>
+__device__ __forceinline__ uint32_t vec_get(const V& v, int j) {
+    if constexpr (N == 1) return v;
+    else return v[j];
+}
+
+constexpr int KQ_MAXD = 256;
+
+template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
+__global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
+    constexpr int FPI = 32 / BITS;
+    constexpr int TPL = WPL * FPI;                   // tokens per lane
+    constexpr int NGL = (TPL >= G) ? (TPL / G) : 1;  // quant groups per lane
+    static_assert(NGL == 1 || NGL == 2, "lane spans at most two groups");
+    static_assert(G % FPI == 0, "a word never straddles two groups");
+    constexpr int NACC = TPL;
+    constexpr int TILES_PER_BLOCK = 4 / DSPLIT;
+    constexpr int Q = NACC / DSPLIT;                 // tokens per lane each wave finalises
+    static_assert(Q % 4 == 0, "finalisation stores 8 or 16 bytes per lane");
+    typedef typename WordVec<WPL>::type WV;
+    typedef typename std::conditional<NGL == 1, uint16_t, uint32_t>::type SV;
+
+    __shared__ float q_lds[R][KQ_MAXD];
+    // cross-wave exchange: every wave keeps 1/DSPLIT of its accumulators and hands the rest over
+    __shared__ float red[DSPLIT > 1 ? 4 * (DSPLIT - 1) * R * Q * 64 : 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
+    const int unit = blockIdx.x / a.tile_blocks;     // (b, head unit)
+    const int tb = blockIdx.x - unit * a.tile_blocks;
+    const int b = unit / a.units_per_b;
+    const int hu = unit - b * a.units_per_b;
+    const int h0 = hu * R;                            // first query head of the unit
+    const int hk = h0 / a.ratio;                      // kv head (gemv_cuda.cu:361-365)
+    const int tile = tb * TILES_PER_BLOCK + wave / DSPLIT;
+    const int tib = wave / DSPLIT;                    // tile index inside the block
+    const int dpart = wave % DSPLIT;
+
+    // stage q (R heads x D) as fp32 in LDS: uniform-address reads in the row loop
+    for (int i = threadIdx.x; i < R * a.D; i += 256) {
+        int r = i / a.D, d = i - r * a.D;
+        q_lds[r][d] = h2f_bits(a.q[b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + d]);
+    }
+    __syncthreads();
+
+    const int64_t word0 = ((int64_t)tile * 64 + lane) * WPL;
+    const bool valid = word0 < a.Tw;
+    const int64_t g0 = (word0 * FPI) / G;
+
+    const int DP = (a.D + DSPLIT - 1) / DSPLIT;
+    const int d0 = dpart * DP;
+    const int d1 = (d0 + DP < a.D) ? d0 + DP : a.D;
+
+    // wave-uniform buffer descriptors over this (b, kv head) slab; per-row scalar offsets,
+    // 32-bit per-lane byte offsets.  Lanes past the row end are masked by `valid`.
+    const rsrc_t rc = make_rsrc(a.code + b * a.code_sb + hk * a.code_sh, a.code_extent);
+    const rsrc_t rs = make_rsrc(a.scale + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
+    const rsrc_t rm = make_rsrc(a.mn + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
+    const uint32_t coff = (uint32_t)(word0 * 4);
+    const uint32_t soff = (uint32_t)(g0 * 2);
+    const uint32_t cstep = (uint32_t)(a.code_sr * 4), sstep = (uint32_t)(a.sm_sr * 2);
+
+    float acc[R][NACC];
+    float zacc[R][NGL];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[r][i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NGL; g++) zacc[r][g] = 0.f;
+    }
+
+    auto row = [&](int d, const WV& w, SV sraw, SV mraw) {
+        float scf[NGL], mz[NGL];
+        if constexpr (NGL == 1) {
+            scf[0] = h2f_bits(sraw) * qs_factor<MODE>();
+            mz[0] = h2f_bits(mraw);
+        } else {
+            scf[0] = h2f_bits((uint16_t)(sraw & 0xFFFFu)) * qs_factor<MODE>();
+            scf[1] = h2f_bits((uint16_t)(sraw >> 16)) * qs_factor<MODE>();
+            mz[0] = h2f_bits((uint16_t)(mraw & 0xFFFFu));
+            mz[1] = h2f_bits((uint16_t)(mraw >> 16));
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float qd = q_lds[r][d];
+            float qs[NGL];
+#pragma unroll
+            for (int g = 0; g < NGL; g++) {
+                qs[g] = qd * scf[g];
+                zacc[r][g] = __builtin_fmaf(qd, mz[g], zacc[r][g]);
+            }
+#pragma unroll
+            for (int j = 0; j < WPL; j++) {
+                const int g = (NGL == 1) ? 0 : (j * FPI) / G;
+                accum_word<BITS, MODE>(vec_get<WPL>(w, j), qs[g], &acc[r][j * FPI]);
+            }
+        }
+    };
+    // batch `bi` = rows d0 + bi*U .. +U-1
+    auto load_batch = [&](int bi, WV* wb, SV* sb, SV* mb) {
+        const uint32_t dr = (uint32_t)(d0 + bi * U);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            wb[u] = buf_load<WV, NT>(rc, coff, (dr + u) * cstep);
+            sb[u] = buf_load<SV, NT>(rs, soff, (dr + u) * sstep);
+            mb[u] = buf_load<SV, NT>(rm, soff, (dr + u) * sstep);
+        }
+    };
+    auto compute_batch = [&](int bi, const WV* wb, const SV* sb, const SV* mb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) row(d0 + bi * U + u, wb[u], sb[u], mb[u]);
+    };
+
+    if (valid) {
+        // ping-pong register buffers: batch n+1 is in flight while batch n is consumed
+        WV wA[U], wB[U];
+        SV sA[U], sB[U], mA[U], mB[U];
+        const int nfull = (d1 - d0) / U;
+        if (nfull > 0) load_batch(0, wA, sA, mA);
+        int it = 0;
+        for (; it + 2 <= nfull; it += 2) {
+            load_batch(it + 1, wB, sB, mB);
+            compute_batch(it, wA, sA, mA);
+            if (it + 2 < nfull) load_batch(it + 2, wA, sA, mA);
+            compute_batch(it + 1, wB, sB, mB);
+        }
+        if (it < nfull) compute_batch(it, wA, sA, mA);
+        for (int d = d0 + nfull * U; d < d1; d++) {  // channel tail (D/DSPLIT not a multiple of U)
+            WV w = buf_load<WV, NT>(rc, coff, (uint32_t)d * cstep);
+            SV sv = buf_load<SV, NT>(rs, soff, (uint32_t)d * sstep);
+            SV mv = buf_load<SV, NT>(rm, soff, (uint32_t)d * sstep);
+            row(d, w, sv, mv);
+        }
+    }
+
+    // acc -> sum_d q*scale*code + sum_d q*mn   (partial over this wave's channels)
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int i = 0; i < NACC; i++) {
+            const int g = (NGL == 1) ? 0 : (i / G);
+            acc[r][i] = __builtin_fmaf(acc[r][i], post_scale<BITS, MODE>(i % FPI), zacc[r][g]);
+        }
+
+    if constexpr (DSPLIT == 1) {
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint16_t* op = a.out + b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + word0 * FPI;
+#pragma unroll
+                for (int c = 0; c < NACC / 8; c++) {
+                    u16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = f2h_bits(acc[r][c * 8 + e]);
+                    *(u16x8*)(op + c * 8) = v;
+                }
+            }
+        }
+    } else {
+        // red[tib][dst dpart][slot][r][i][lane]; slot = source dpart with dst skipped
+        float keep[R][Q];
+#pragma unroll
+        for (int dq = 0; dq < DSPLIT; dq++) {
+            if (dq == dpart) {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int i = 0; i < Q; i++) keep[r][i] = acc[r][dq * Q + i];
+            } else if (valid) {
+                const int slot = dpart < dq ? dpart : dpart - 1;
+                float* dst = red + (size_t)(((tib * DSPLIT + dq) * (DSPLIT - 1) + slot) * R * Q) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int i = 0; i < Q; i++) dst[(r * Q + i) * 64] = acc[r][dq * Q + i];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            const float* src = red + (size_t)((tib * DSPLIT + dpart) * (DSPLIT - 1) * R * Q) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+#pragma unroll
+                for (int i = 0; i < Q; i++)
+#pragma unroll
+                    for (int sl = 0; sl < DSPLIT - 1; sl++) keep[r][i] += src[((sl * R + r) * Q + i) * 64];
+                uint16_t* op = a.out + b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + word0 * FPI + dpart * Q;
+                if constexpr (Q % 8 == 0) {
+#pragma unroll
+                    for (int c = 0; c < Q / 8; c++) {
+                        u16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = f2h_bits(keep[r][c * 8 + e]);
+                        *(u16x8*)(op + c * 8) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < Q / 4; c++) {
+                        typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+                        u16x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = f2h_bits(keep[r][c * 4 + e]);
+                        *(u16x4*)(op + c * 4) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Shape-agnostic fallback: one thread per output word, any group size that is a
+// multiple of fpi, any D.  Same arithmetic, BFE unpack.
+template <int BITS>
+__global__ __launch_bounds__(256) void gemv_k_generic(const GemvKArgs a, int G) {
+    constexpr int FPI = 32 / BITS;
+    const int wblocks = (int)((a.Tw + 255) / 256);
+    const int bh = blockIdx.x / wblocks;
+    const int64_t w = (int64_t)(blockIdx.x - bh * wblocks) * 256 + threadIdx.x;
+    const int b = bh / a.nh, h = bh - b * a.nh;
+    const int hk = h / a.ratio;
+    if (w >= a.Tw) return;
+    const int64_t g = (w * FPI) / G;
+    const uint32_t* cp = a.code + b * a.code_sb + hk * a.code_sh + w;
+    const uint16_t* sp = a.scale + b * a.sm_sb + hk * a.sm_sh + g;
+    const uint16_t* mp = a.mn + b * a.sm_sb + hk * a.sm_sh + g;
+    const uint16_t* qp = a.q + b * a.q_sb + (int64_t)h * a.q_sh;
+    float acc[FPI];
+#pragma unroll
+    for (int p = 0; p < FPI; p++) acc[p] = 0.f;
+    float z = 0.f;
+    for (int d = 0; d < a.D; d++) {
+        const float qd = h2f_bits(qp[d]);
+        const float qs = qd * h2f_bits(sp[(int64_t)d * a.sm_sr]);
+        z = __builtin_fmaf(qd, h2f_bits(mp[(int64_t)d * a.sm_sr]), z);
+        accum_word<BITS, KIVI_UNPACK_BFE>(cp[(int64_t)d * a.code_sr], qs, acc);
+    }
+    uint16_t* op = a.out + b * a.out_sb + (int64_t)h * a.out_sh + w * FPI;
+#pragma unroll
+    for (int p = 0; p < FPI; p++) op[p] = f2h_bits(acc[p] + z);
+}
+
+// ------------------------------------------------------------------ host side
+
+typedef void (*KLaunch)(const GemvKArgs&, dim3, hipStream_t);
+
+template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
+void launch_k(const GemvKArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemv_k_kernel<BITS, G, WPL, DSPLIT, R, U, MODE, NT>), grid, dim3(256), 0, s, a);
+}
+
+struct KVariant {
+    const char* name;
+    int bits, G, wpl, dsplit, R, U, mode, nt;
+    KLaunch fn;
+};
+
+#define KV(BITS, G, WPL, DS, R, U, MODE, NT)                                                        \
+    {"k_b" #BITS "_g" #G "_w" #WPL "_ds" #DS "_r" #R "_u" #U "_m" #MODE "_nt" #NT, BITS, G, WPL, DS, R, U, \
+     MODE, NT, launch_k<BITS, G, WPL, DS, R, U, MODE, (NT != 0)>}
+
+const KVariant k_variants[] = {
+    // ---- 2-bit, g=32, MHA: the north-star shape.  First entry = default.
+    KV(2, 32, 4, 2, 1, 4, 2, 0),
+    KV(2, 32, 4, 2, 1, 4, 2, 1),
+    KV(2, 32, 4, 2, 1, 8, 2, 0),
+    KV(2, 32, 4, 2, 1, 8, 2, 1),
+    KV(2, 32, 4, 1, 1, 4, 2, 0),
+    KV(2, 32, 4, 1, 1, 4, 2, 1),
+    KV(2, 32, 4, 1, 1, 8, 2, 0),
+    KV(2, 32, 4, 1, 1, 8, 2, 1),
+    KV(2, 32, 4, 4, 1, 4, 2, 0),
+    KV(2, 32, 4, 4, 1, 8, 2, 1),
+    KV(2, 32, 2, 4, 1, 4, 2, 0),
+    KV(2, 32, 2, 4, 1, 4, 2, 1),
+    KV(2, 32, 2, 4, 1, 8, 2, 0),
+    KV(2, 32, 2, 4, 1, 8, 2, 1),
+    KV(2, 32, 2, 2, 1, 8, 2, 0),
+    KV(2, 32, 2, 2, 1, 8, 2, 1),
+    KV(2, 32, 2, 1, 1, 8, 2, 0),
+    KV(2, 32, 2, 1, 1, 8, 2, 1),
+    KV(2, 32, 2, 1, 1, 16, 2, 1),
+    // unpack-strategy A/B on two geometries
+    KV(2, 32, 4, 2, 1, 4, 0, 0),
+    KV(2, 32, 4, 2, 1, 4, 1, 0),
+    KV(2, 32, 2, 4, 1, 4, 0, 0),
+    KV(2, 32, 2, 4, 1, 4, 1, 0),
+    // ---- 2-bit, other group sizes
+    KV(2, 64, 4, 2, 1, 4, 2, 0),
+    KV(2, 64, 2, 4, 1, 4, 2, 0),
+    KV(2, 128, 4, 2, 1, 4, 2, 0),
+    KV(2, 128, 2, 4, 1, 4, 2, 0),
+    // ---- 4-bit
+    KV(4, 32, 4, 2, 1, 4, 2, 0),
+    KV(4, 32, 4, 4, 1, 4, 2, 0),
+    KV(4, 32, 2, 4, 1, 4, 2, 0),
+    KV(4, 64, 4, 2, 1, 4, 2, 0),
+    KV(4, 64, 2, 4, 1, 4, 2, 0),
+    KV(4, 128, 4, 2, 1, 4, 2, 0),
+    KV(4, 128, 2, 4, 1, 4, 2, 0),
+    KV(4, 32, 4, 2, 1, 4, 0, 0),
+    // ---- GQA: R query heads share every unpacked code (no channel split: R*TPL accumulators)
+    KV(2, 32, 2, 1, 4, 4, 2, 0),
+    KV(2, 32, 1, 1, 4, 8, 2, 0),
+    KV(2, 32, 1, 2, 4, 8, 2, 0),
+    KV(2, 32, 2, 1, 2, 4, 2, 0),
+    KV(2, 32, 1, 1, 8, 8, 2, 0),
+    KV(4, 32, 2, 1, 4, 4, 2, 0),
+    KV(2, 64, 2, 1, 4, 4, 2, 0),
+    KV(2, 128, 2, 1, 4, 4, 2, 0),
+};
+constexpr int k_nvariants = sizeof(k_variants) / sizeof(k_variants[0]);
+
+bool k_variant_fits(const KVariant& v, const GemvKArgs& a, int bits, int G) {
+    if (v.bits != bits || v.G != G) return false;
+    if (a.ratio % v.R != 0 && !(v.R == 1)) return false;
+    if (a.D > KQ_MAXD) return false;
+    if (a.code_extent == 0 || a.sm_extent == 0) return false;  // slab too large for a buffer descriptor
+    const int fpi = 32 / bits;
+    const int tpl = v.wpl * fpi;
+    const int ngl = tpl >= G ? tpl / G : 1;
+    // vector-load alignment: every row start must be a multiple of the vector width
+    if (a.Tw % v.wpl) return false;
+    if ((a.code_sr % v.wpl) || (a.code_sh % v.wpl) || (a.code_sb % v.wpl)) return false;
+    if (((uintptr_t)a.code) % (4 * v.wpl)) return false;
+    if ((a.sm_sr % ngl) || (a.sm_sh % ngl) || (a.sm_sb % ngl)) return false;
+    if (((uintptr_t)a.scale) % (2 * ngl) || ((uintptr_t)a.mn) % (2 * ngl)) return false;
+    // 16-byte output stores
+    if ((a.out_sh % 8) || (a.out_sb % 8) || ((uintptr_t)a.out % 16) || (a.T % 8)) return false;
+    return true;
+}
+
+int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream_t s) {
+    (void)nh_kv;
+    const int fpi = 32 / bits;
+    if (variant >= 0) {
+        KIVI_REQUIRE(variant < k_nvariants, KIVI_EINVAL, "kivi_gemv_k_variant: no variant %d", variant);
+        const KVariant& v = k_variants[variant];
+        KIVI_REQUIRE(k_variant_fits(v, a, bits, G), KIVI_EINVAL,
+                     "kivi_gemv_k_variant: %s does not fit this problem (bits=%d g=%d ratio=%d Tw=%lld)", v.name, bits,
+                     G, a.ratio, (long long)a.Tw);
+        const int tiles = (int)((a.Tw + 64 * v.wpl - 1) / (64 * v.wpl));
+        const int tpb = 4 / v.dsplit;
+        a.units_per_b = a.nh / v.R;
+        a.tile_blocks = (tiles + tpb - 1) / tpb;
+        v.fn(a, dim3((unsigned)((int64_t)B * a.units_per_b * a.tile_blocks)), s);
+        return kivi_launch_status(v.name);
+    }
+    // heuristic: first fitting variant with the largest usable R; table order = preference
+    int best = -1;
+    for (int i = 0; i < k_nvariants; i++) {
+        const KVariant& v = k_variants[i];
+        if (v.mode != KIVI_UNPACK_MIX) continue;
+        if (!k_variant_fits(v, a, bits, G)) continue;
+        if (a.ratio % v.R) continue;
+        if (best < 0 || v.R > k_variants[best].R) best = i;
+    }
+    if (best >= 0) return k_run(best, a, B, nh_kv, G, bits, s);
+    // generic fallback
+    dim3 grid((unsigned)(((a.Tw + 255) / 256) * (int64_t)B * a.nh));
+    if (bits == 2) hipLaunchKernelGGL(gemv_k_generic<2>, grid, dim3(256), 0, s, a, G);
+    else hipLaunchKernelGGL(gemv_k_generic<4>, grid, dim3(256), 0, s, a, G);
+    (void)fpi;
+    return kivi_launch_status("gemv_k_generic");
+}
+
+int k_check_and_fill(GemvKArgs& a, const void* q, int64_t q_sb, int64_t q_sh, const void* code, int64_t code_sb,
+                     int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
+                     int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                     int nh_kv, int D, int64_t T, int group_size, int bits) {
+    KIVI_REQUIRE(bits == 2 || bits == 4, KIVI_EINVAL, "kivi_gemv_k: bits must be 2 or 4 (matmul.py:215), got %d", bits);
+    KIVI_REQUIRE(nh_kv > 0 && nh > 0 && nh % nh_kv == 0, KIVI_EINVAL,
+                 "kivi_gemv_k: nh %% nh_kv != 0 (matmul.py:216): nh=%d nh_kv=%d", nh, nh_kv);
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(group_size > 0 && group_size % fpi == 0, KIVI_EINVAL,
+                 "kivi_gemv_k: group_size %d must be a positive multiple of %d", group_size, fpi);
+    KIVI_REQUIRE(T >= 0 && T % fpi == 0 && T % group_size == 0, KIVI_EINVAL,
+                 "kivi_gemv_k: T=%lld must be a multiple of group_size=%d", (long long)T, group_size);
+    KIVI_REQUIRE(B > 0 && D > 0, KIVI_EINVAL, "kivi_gemv_k: empty batch or head_dim");
+    a.q = (const uint16_t*)q; a.q_sb = q_sb; a.q_sh = q_sh;
+    a.code = (const uint32_t*)code; a.code_sb = code_sb; a.code_sh = code_sh; a.code_sr = code_sr;
+    a.scale = (const uint16_t*)scale; a.mn = (const uint16_t*)mn;
+    a.sm_sb = sm_sb; a.sm_sh = sm_sh; a.sm_sr = sm_sr;
+    a.out = (uint16_t*)out; a.out_sb = out_sb; a.out_sh = out_sh;
+    a.nh = nh; a.ratio = nh / nh_kv; a.D = D; a.T = T; a.Tw = T / fpi;
+    a.units_per_b = nh; a.tile_blocks = 1;
+    const int64_t ce = ((int64_t)(D - 1) * code_sr + a.Tw) * 4;
+    const int64_t se = ((int64_t)(D - 1) * sm_sr + T / group_size) * 2;
+    a.code_extent = (ce > 0 && ce < (int64_t)0xFFFFFFFFll) ? (uint32_t)ce : 0;
+    a.sm_extent = (se > 0 && se < (int64_t)0xFFFFFFFFll) ? (uint32_t)se : 0;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kivi_gemv_k_num_variants(void) { return k_nvariants; }
+extern "C" const char* kivi_gemv_k_variant_name(int v) {
+    return (v >= 0 && v < k_nvariants) ? k_variants[v].name : "";
+}
+
+extern "C" int kivi_gemv_k_variant(int variant, const void* q, int64_t q_sb, int64_t q_sh, const void* code,
+                                   int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
+                                   const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out,
+                                   int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T,
+                                   int group_size, int bits, kivi_stream_t stream) {
+    GemvKArgs a;
+    int rc = k_check_and_fill(a, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                              out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits);
+    if (rc) return rc;
+    if (T == 0) return 0;
+    return k_run(variant, a, B, nh_kv, group_size, bits, (hipStream_t)stream);
+}
+
+extern "C" int kivi_gemv_k(const void* q, int64_t q_sb, int64_t q_sh, const void* code, int64_t code_sb,
+                           int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
+                           int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                           int nh_kv, int D, int64_t T, int group_size, int bits, kivi_stream_t stream) {
+    return kivi_gemv_k_variant(-1, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr,
+                               out, out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits, stream);
+}

@@ -1,0 +1,382 @@
+// sV over the packed per-token V cache (hook-state layout), gfx950.
+//
+// Replaces cuda_bmm_fA_qB_outer + bgemv{2,4}_kernel_outer_dim of the reference
+// (quant/matmul.py:178-219, quant/csrc/gemv_cuda.cu:265-427) for the call at
+// models/llama_kivi.py:382, reading V_code (B,nh_kv,Tv,D/fpi) directly.
+//
+// Mapping (wave64).  Here the dot axis t runs ACROSS lanes: one wave-instruction
+// reads 64 x 16 contiguous bytes = TPI = 64/LPR whole token rows of codes (LPR
+// lanes per row, 4 words per lane), plus the matching scale / mn / a entries.
+// A lane accumulates its EPL = 4*fpi channels over every TPI-th token in fp32
+// (one mask per two codes + one v_fma_mix_f32 per code, a*scale folded once per
+// (token, group), zero-point term hoisted), then the 64/LPR lanes that own the
+// same channels are combined with a halving butterfly (EPL-EPL/TPI shuffles
+// instead of EPL*log2(TPI)) and the 4 waves of the block through LDS.
+#include <type_traits>
+
+#include "kivi_common.h"
+
+namespace {
+
+struct GemvVArgs {
+    const uint16_t* a;
+    int64_t a_sb, a_sh;
+    const uint32_t* code;
+    int64_t code_sb, code_sh, code_sr;
+    const uint16_t* scale;
+    const uint16_t* mn;
+    int64_t sm_sb, sm_sh, sm_sr;
+    uint16_t* out;
+    int64_t out_sb, out_sh;
+    int nh, ratio, D;
+    int64_t Tv;
+    int units_per_b;
+    uint32_t code_extent, sm_extent, a_extent;
+};
+
+template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
+__global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
+    constexpr int FPI = 32 / BITS;
+    constexpr int LPR = DW / WPL;               // lanes per token row
+    static_assert(LPR >= 1 && LPR <= 16 && (LPR & (LPR - 1)) == 0, "D/fpi must be 4, 8, 16 or 32 words");
+    typedef typename std::conditional<WPL == 4, u32x4, u32x2>::type WV;
+    constexpr int TPI = 64 / LPR;               // tokens per wave-iteration
+    constexpr int EPL = WPL * FPI;              // channels per lane
+    constexpr int D = DW * FPI;
+    constexpr int NGL = (EPL >= G) ? (EPL / G) : 1;
+    static_assert(NGL == 1 || NGL == 2, "lane spans at most two groups");
+    constexpr int NFIN = D / 64;                // channels per lane after the butterfly
+    static_assert(NFIN >= 1, "head_dim >= 64");
+    typedef typename std::conditional<NGL == 1, uint16_t, uint32_t>::type SV;
+
+    __shared__ float red[4][R][D];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x;
+    const int b = unit / a.units_per_b;
+    const int hu = unit - b * a.units_per_b;
+    const int h0 = hu * R;
+    const int hk = h0 / a.ratio;
+    const int lr = lane % LPR;                  // which 4-word slice of the row
+    const int lt = lane / LPR;                  // token inside the iteration
+
+    const rsrc_t rc = make_rsrc(a.code + b * a.code_sb + hk * a.code_sh, a.code_extent);
+    const rsrc_t rs = make_rsrc(a.scale + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
+    const rsrc_t rm = make_rsrc(a.mn + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
+    rsrc_t ra[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) ra[r] = make_rsrc(a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh, a.a_extent);
+
+    const int gi0 = (lr * EPL) / G;             // first group index of this lane inside a row
+    const uint32_t coff = (uint32_t)(((int64_t)lt * a.code_sr + lr * WPL) * 4);
+    const uint32_t soff = (uint32_t)(((int64_t)lt * a.sm_sr + gi0) * 2);
+    const uint32_t aoff = (uint32_t)(lt * 2);
+    const uint32_t cstep = (uint32_t)(a.code_sr * 4 * TPI);  // bytes per chunk of TPI tokens
+    const uint32_t sstep = (uint32_t)(a.sm_sr * 2 * TPI);
+    const uint32_t astep = (uint32_t)(2 * TPI);
+
+    float acc[R][EPL];
+    float zacc[R][NGL];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int i = 0; i < EPL; i++) acc[r][i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NGL; g++) zacc[r][g] = 0.f;
+    }
+
+    auto tok = [&](const WV& w, SV sraw, SV mraw, const uint16_t* av) {
+        float scf[NGL], mz[NGL];
+        if constexpr (NGL == 1) {
+            scf[0] = h2f_bits(sraw) * qs_factor<MODE>();
+            mz[0] = h2f_bits(mraw);
+        } else {
+            scf[0] = h2f_bits((uint16_t)(sraw & 0xFFFFu)) * qs_factor<MODE>();
+            scf[1] = h2f_bits((uint16_t)(sraw >> 16)) * qs_factor<MODE>();
+            mz[0] = h2f_bits((uint16_t)(mraw & 0xFFFFu));
+            mz[1] = h2f_bits((uint16_t)(mraw >> 16));
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float ar = h2f_bits(av[r]);
+            float as[NGL];
+#pragma unroll
+            for (int g = 0; g < NGL; g++) {
+                as[g] = ar * scf[g];
+                zacc[r][g] = __builtin_fmaf(ar, mz[g], zacc[r][g]);
+            }
+#pragma unroll
+            for (int j = 0; j < WPL; j++) {
+                const int g = (NGL == 1) ? 0 : (j * FPI) / G;
+                accum_word<BITS, MODE>(w[j], as[g], &acc[r][j * FPI]);
+            }
+        }
+    };
+
+    // chunk c = TPI tokens; wave w owns chunks w, w+4, ...; batch = U chunks of this wave
+    const int nchunk = (int)((a.Tv + TPI - 1) / TPI);
+    const int my_chunks = (nchunk > wave) ? (nchunk - wave + 3) / 4 : 0;
+    const int nbatch = (my_chunks + U - 1) / U;  // out-of-range chunks read zeros (bounds check)
+
+    // The chunk offset goes into the (bounds-checked) per-lane voffset: soffset is excluded
+    // from the hardware range check, and the tail relies on out-of-range rows reading 0.
+    auto load_batch = [&](int bi, WV* wb, SV* sb, SV* mb, uint16_t (*ab)[R]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = (uint32_t)((bi * U + u) * 4 + wave);
+            wb[u] = buf_load<WV, NT>(rc, coff + c * cstep, 0);
+            sb[u] = buf_load<SV, NT>(rs, soff + c * sstep, 0);
+            mb[u] = buf_load<SV, NT>(rm, soff + c * sstep, 0);
+#pragma unroll
+            for (int r = 0; r < R; r++) ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
+        }
+    };
+    auto compute_batch = [&](const WV* wb, const SV* sb, const SV* mb, const uint16_t (*ab)[R]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) tok(wb[u], sb[u], mb[u], ab[u]);
+    };
+
+    {
+        WV wA[U], wB[U];
+        SV sA[U], sB[U], mA[U], mB[U];
+        uint16_t aA[U][R], aB[U][R];
+        if (nbatch > 0) load_batch(0, wA, sA, mA, aA);
+        int it = 0;
+        for (; it + 2 <= nbatch; it += 2) {
+            load_batch(it + 1, wB, sB, mB, aB);
+            compute_batch(wA, sA, mA, aA);
+            if (it + 2 < nbatch) load_batch(it + 2, wA, sA, mA, aA);
+            compute_batch(wB, sB, mB, aB);
+        }
+        if (it < nbatch) compute_batch(wA, sA, mA, aA);
+    }
+
+    // undo the positional power-of-two factors, then combine the TPI lanes that share `lr`
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int i = 0; i < EPL; i++) acc[r][i] *= post_scale<BITS, MODE>(i % FPI);
+#pragma unroll
+        for (int g = 0; g < NGL; g++) {
+#pragma unroll
+            for (int m = LPR; m < 64; m <<= 1) zacc[r][g] += __shfl_xor(zacc[r][g], m);
+        }
+    }
+    int eoff = 0;  // first surviving channel (inside this lane's EPL slice)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int n = EPL;
+        int off = 0;
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) {
+            const int half = n / 2;
+            const bool upper = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < half; i++) {
+                const float send = upper ? acc[r][i] : acc[r][i + half];
+                const float keep = upper ? acc[r][i + half] : acc[r][i];
+                acc[r][i] = keep + __shfl_xor(send, m);
+            }
+            off += upper ? half : 0;
+            n = half;
+        }
+        eoff = off;
+    }
+    // lane now holds NFIN channels: d = lr*EPL + eoff + i
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int i = 0; i < NFIN; i++) {
+            const int e = eoff + i;
+            const int g = (NGL == 1) ? 0 : (e / G);
+            // select without dynamic register indexing
+            float z = zacc[r][0];
+            if constexpr (NGL == 2) z = (g == 1) ? zacc[r][1] : zacc[r][0];
+            red[wave][r][lr * EPL + e] = acc[r][i] + z;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        const float s = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = f2h_bits(s);
+    }
+}
+
+// Shape-agnostic fallback: one thread per output word (fpi channels), loops over tokens.
+template <int BITS>
+__global__ __launch_bounds__(64) void gemv_v_generic(const GemvVArgs a, int G, int Dw) {
+    constexpr int FPI = 32 / BITS;
+    const int w = blockIdx.y * 64 + threadIdx.x;
+    const int bh = blockIdx.x;
+    const int b = bh / a.nh, h = bh - b * a.nh;
+    const int hk = h / a.ratio;
+    if (w >= Dw) return;
+    const int g = (w * FPI) / G;
+    const uint32_t* cp = a.code + b * a.code_sb + hk * a.code_sh + w;
+    const uint16_t* sp = a.scale + b * a.sm_sb + hk * a.sm_sh + g;
+    const uint16_t* mp = a.mn + b * a.sm_sb + hk * a.sm_sh + g;
+    const uint16_t* ap = a.a + b * a.a_sb + (int64_t)h * a.a_sh;
+    float acc[FPI];
+#pragma unroll
+    for (int p = 0; p < FPI; p++) acc[p] = 0.f;
+    float z = 0.f;
+    for (int64_t t = 0; t < a.Tv; t++) {
+        const float at = h2f_bits(ap[t]);
+        const float as = at * h2f_bits(sp[t * a.sm_sr]);
+        z = __builtin_fmaf(at, h2f_bits(mp[t * a.sm_sr]), z);
+        accum_word<BITS, KIVI_UNPACK_BFE>(cp[t * a.code_sr], as, acc);
+    }
+    uint16_t* op = a.out + b * a.out_sb + (int64_t)h * a.out_sh + (int64_t)w * FPI;
+#pragma unroll
+    for (int p = 0; p < FPI; p++) op[p] = f2h_bits(acc[p] + z);
+}
+
+// ------------------------------------------------------------------ host side
+
+typedef void (*VLaunch)(const GemvVArgs&, dim3, hipStream_t);
+
+template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
+void launch_v(const GemvVArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT>), grid, dim3(256), 0, s, a);
+}
+
+struct VVariant {
+    const char* name;
+    int bits, G, dw, wpl, R, U, mode, nt;
+    VLaunch fn;
+};
+
+#define VV(BITS, G, DW, WPL, R, U, MODE, NT)                                                               \
+    {"v_b" #BITS "_g" #G "_dw" #DW "_w" #WPL "_r" #R "_u" #U "_m" #MODE "_nt" #NT, BITS, G, DW, WPL, R, U, MODE, \
+     NT, launch_v<BITS, G, DW, WPL, R, U, MODE, (NT != 0)>}
+
+const VVariant v_variants[] = {
+    // ---- 2-bit, D=128 (DW=8), g=32, MHA: first entry = default
+    VV(2, 32, 8, 4, 1, 2, 2, 0),
+    VV(2, 32, 8, 4, 1, 2, 2, 1),
+    VV(2, 32, 8, 4, 1, 4, 2, 0),
+    VV(2, 32, 8, 4, 1, 4, 2, 1),
+    VV(2, 32, 8, 4, 1, 1, 2, 0),
+    VV(2, 32, 8, 4, 1, 1, 2, 1),
+    VV(2, 32, 8, 2, 1, 4, 2, 0),
+    VV(2, 32, 8, 2, 1, 4, 2, 1),
+    VV(2, 32, 8, 2, 1, 8, 2, 1),
+    VV(2, 32, 8, 4, 1, 2, 0, 0),
+    VV(2, 32, 8, 4, 1, 2, 1, 0),
+    // other group sizes / head dims
+    VV(2, 64, 8, 4, 1, 2, 2, 0),
+    VV(2, 128, 8, 4, 1, 2, 2, 0),
+    VV(2, 32, 4, 4, 1, 2, 2, 0),
+    VV(2, 64, 4, 4, 1, 2, 2, 0),
+    VV(2, 32, 16, 4, 1, 2, 2, 0),
+    VV(2, 64, 16, 4, 1, 2, 2, 0),
+    VV(2, 128, 16, 4, 1, 2, 2, 0),
+    // ---- 4-bit (D=128 -> DW=16; D=64 -> DW=8)
+    VV(4, 32, 16, 4, 1, 4, 2, 0),
+    VV(4, 64, 16, 4, 1, 4, 2, 0),
+    VV(4, 128, 16, 4, 1, 4, 2, 0),
+    VV(4, 32, 8, 4, 1, 4, 2, 0),
+    VV(4, 64, 8, 4, 1, 4, 2, 0),
+    VV(4, 32, 16, 4, 1, 4, 0, 0),
+    // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
+    VV(2, 32, 8, 2, 4, 2, 2, 0),
+    VV(2, 32, 8, 2, 2, 4, 2, 0),
+    VV(2, 64, 8, 2, 4, 2, 2, 0),
+    VV(2, 128, 8, 2, 4, 2, 2, 0),
+    VV(4, 32, 16, 4, 4, 2, 2, 0),
+    VV(2, 32, 8, 2, 8, 1, 2, 0),
+};
+constexpr int v_nvariants = sizeof(v_variants) / sizeof(v_variants[0]);
+
+bool v_variant_fits(const VVariant& v, const GemvVArgs& a, int bits, int G) {
+    if (v.bits != bits || v.G != G) return false;
+    const int fpi = 32 / bits;
+    if (a.D != v.dw * fpi) return false;
+    if (a.ratio % v.R) return false;
+    if (a.code_extent == 0 || a.sm_extent == 0 || a.a_extent == 0) return false;
+    const int epl = v.wpl * fpi;
+    const int ngl = epl >= G ? epl / G : 1;
+    if ((a.code_sr % v.wpl) || (a.code_sh % v.wpl) || (a.code_sb % v.wpl) || ((uintptr_t)a.code % (4 * v.wpl)))
+        return false;
+    if ((a.sm_sr % ngl) || (a.sm_sh % ngl) || (a.sm_sb % ngl)) return false;
+    if (((uintptr_t)a.scale % (2 * ngl)) || ((uintptr_t)a.mn % (2 * ngl))) return false;
+    // per-lane byte offsets (incl. the <= 40 chunks a wave may overshoot the tail by) must not wrap
+    if ((a.Tv + 64 * 41) * a.code_sr * 4 >= (int64_t)0xFFFFFFFFll) return false;
+    return true;
+}
+
+int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
+    if (variant >= 0) {
+        KIVI_REQUIRE(variant < v_nvariants, KIVI_EINVAL, "kivi_gemv_v_variant: no variant %d", variant);
+        const VVariant& v = v_variants[variant];
+        KIVI_REQUIRE(v_variant_fits(v, a, bits, G), KIVI_EINVAL,
+                     "kivi_gemv_v_variant: %s does not fit this problem (bits=%d g=%d D=%d ratio=%d)", v.name, bits, G,
+                     a.D, a.ratio);
+        a.units_per_b = a.nh / v.R;
+        v.fn(a, dim3((unsigned)((int64_t)B * a.units_per_b)), s);
+        return kivi_launch_status(v.name);
+    }
+    int best = -1;
+    for (int i = 0; i < v_nvariants; i++) {
+        const VVariant& v = v_variants[i];
+        if (v.mode != KIVI_UNPACK_MIX) continue;
+        if (!v_variant_fits(v, a, bits, G)) continue;
+        if (best < 0 || v.R > v_variants[best].R) best = i;
+    }
+    if (best >= 0) return v_run(best, a, B, G, bits, s);
+    const int fpi = 32 / bits;
+    const int Dw = a.D / fpi;
+    dim3 grid((unsigned)(B * a.nh), (unsigned)((Dw + 63) / 64));
+    if (bits == 2) hipLaunchKernelGGL(gemv_v_generic<2>, grid, dim3(64), 0, s, a, G, Dw);
+    else hipLaunchKernelGGL(gemv_v_generic<4>, grid, dim3(64), 0, s, a, G, Dw);
+    return kivi_launch_status("gemv_v_generic");
+}
+
+}  // namespace
+
+extern "C" int kivi_gemv_v_num_variants(void) { return v_nvariants; }
+extern "C" const char* kivi_gemv_v_variant_name(int v) {
+    return (v >= 0 && v < v_nvariants) ? v_variants[v].name : "";
+}
+
+extern "C" int kivi_gemv_v_variant(int variant, const void* av, int64_t a_sb, int64_t a_sh, const void* code,
+                                   int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
+                                   const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out,
+                                   int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D,
+                                   int group_size, int bits, kivi_stream_t stream) {
+    KIVI_REQUIRE(bits == 2 || bits == 4, KIVI_EINVAL, "kivi_gemv_v: bits must be 2 or 4 (matmul.py:215), got %d", bits);
+    KIVI_REQUIRE(nh_kv > 0 && nh > 0 && nh % nh_kv == 0, KIVI_EINVAL,
+                 "kivi_gemv_v: nh %% nh_kv != 0 (matmul.py:216): nh=%d nh_kv=%d", nh, nh_kv);
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(group_size > 0 && group_size % fpi == 0, KIVI_EINVAL,
+                 "kivi_gemv_v: group_size %d must be a positive multiple of %d", group_size, fpi);
+    KIVI_REQUIRE(D > 0 && D % fpi == 0 && D % group_size == 0, KIVI_EINVAL,
+                 "kivi_gemv_v: head_dim=%d must be a multiple of group_size=%d", D, group_size);
+    KIVI_REQUIRE(B > 0 && Tv >= 0, KIVI_EINVAL, "kivi_gemv_v: empty batch");
+    KIVI_REQUIRE((int64_t)B * nh < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_gemv_v: B*nh too large");
+    GemvVArgs a;
+    a.a = (const uint16_t*)av; a.a_sb = a_sb; a.a_sh = a_sh;
+    a.code = (const uint32_t*)code; a.code_sb = code_sb; a.code_sh = code_sh; a.code_sr = code_sr;
+    a.scale = (const uint16_t*)scale; a.mn = (const uint16_t*)mn;
+    a.sm_sb = sm_sb; a.sm_sh = sm_sh; a.sm_sr = sm_sr;
+    a.out = (uint16_t*)out; a.out_sb = out_sb; a.out_sh = out_sh;
+    a.nh = nh; a.ratio = nh / nh_kv; a.D = D; a.Tv = Tv;
+    a.units_per_b = nh;
+    // extents: exactly Tv token rows, so chunk tails past Tv read zeros (hardware bounds check)
+    const int64_t ce = Tv > 0 ? ((Tv - 1) * code_sr + D / fpi) * 4 : 0;
+    const int64_t se = Tv > 0 ? ((Tv - 1) * sm_sr + D / group_size) * 2 : 0;
+    const int64_t ae = Tv * 2;
+    a.code_extent = (ce > 0 && ce < (int64_t)0xFFFFFFFFll) ? (uint32_t)ce : 0;
+    a.sm_extent = (se > 0 && se < (int64_t)0xFFFFFFFFll) ? (uint32_t)se : 0;
+    a.a_extent = (ae > 0 && ae < (int64_t)0xFFFFFFFFll) ? (uint32_t)ae : 0;
+    return v_run(variant, a, B, group_size, bits, (hipStream_t)stream);
+}
+
+extern "C" int kivi_gemv_v(const void* av, int64_t a_sb, int64_t a_sh, const void* code, int64_t code_sb,
+                           int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
+                           int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                           int nh_kv, int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream) {
+    return kivi_gemv_v_variant(-1, av, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                               out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits, stream);
+}

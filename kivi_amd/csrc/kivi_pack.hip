@@ -1,0 +1,422 @@
+// Fused group-wise quantise + pack, unpack + dequantise (gfx950).
+//
+// Replaces triton_quantize_and_pack_along_last_dim (quant/new_pack.py:217-252:
+// _minmax_along_last_dim + five torch elementwise kernels + _pack_along_last_dim
+// and an int32 temporary 2x the input) with ONE pass: 2 B read, bits/8 + 4/g B
+// written per element.  Arithmetic is the reference's, op for op, so the
+// outputs are bit-identical:
+//   scale = fp16(fp16(mx - mn) / (2^bits - 1))
+//   code  = rint_half_even(clamp(fp16(fp16(x - mn) / scale), 0, 2^bits - 1))
+// every op evaluated in fp32 on fp16 operands and rounded to fp16 (innocuous
+// double rounding), with a correctly rounded fp32 division
+// (-fhip-fp32-correctly-rounded-divide-sqrt; never x * rcp(scale)).
+// A constant group has scale 0 -> 0/0 = NaN -> code 0 (the reference's CUDA
+// float->int conversion; its CPU run yields INT_MIN instead).
+#include "kivi_common.h"
+
+namespace {
+
+// Order-preserving fp16 -> u16 key, with -0 < +0 (what the oracle's h_lt does).
+__device__ __forceinline__ uint32_t h_key(uint32_t h) { return (h & 0x8000u) ? (h ^ 0xFFFFu) : (h | 0x8000u); }
+__device__ __forceinline__ uint32_t h_unkey(uint32_t k) { return (k & 0x8000u) ? (k ^ 0x8000u) : (k ^ 0xFFFFu); }
+
+struct GroupQ {
+    float fmn, fs, fmaxq;
+    uint16_t mn, scale;
+};
+
+__device__ __forceinline__ GroupQ make_group(uint32_t kmin, uint32_t kmax, int maxq) {
+    GroupQ g;
+    g.mn = (uint16_t)h_unkey(kmin);
+    const uint16_t mx = (uint16_t)h_unkey(kmax);
+    g.fmn = h2f_bits(g.mn);
+    const uint16_t range = f2h_bits(h2f_bits(mx) - g.fmn);        // new_pack.py:238 (mx - mn)
+    g.scale = f2h_bits(h2f_bits(range) / (float)maxq);            //                 / max_int
+    g.fs = h2f_bits(g.scale);
+    g.fmaxq = (float)maxq;
+    return g;
+}
+
+__device__ __forceinline__ uint32_t quant_one(uint16_t x, const GroupQ& g) {
+    const uint16_t d = f2h_bits(h2f_bits(x) - g.fmn);             // new_pack.py:239
+    const uint16_t q = f2h_bits(h2f_bits(d) / g.fs);              // :240, correctly rounded division
+    float fq = h2f_bits(q);
+    fq = __builtin_fmaxf(fq, 0.0f);                               // NaN -> 0 (fmax drops the NaN)
+    fq = __builtin_fminf(fq, g.fmaxq);                            // :241 clamp_
+    return (uint32_t)__builtin_rintf(fq);                         //      round_ (half to even), to(int32)
+}
+
+// One lane = 8 consecutive elements (16 B); LPG = g/8 lanes share a group.
+template <int BITS>
+__global__ __launch_bounds__(256) void quant_pack_lastdim_kernel(const uint16_t* __restrict__ x,
+                                                                 uint32_t* __restrict__ code,
+                                                                 uint16_t* __restrict__ scale,
+                                                                 uint16_t* __restrict__ mn, int64_t nchunk,
+                                                                 int lpg) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = c < nchunk;  // whole groups fall out together (nchunk % lpg == 0, lpg | 64)
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) v = __builtin_nontemporal_load((const u16x8*)(x + c * 8));
+    uint32_t kmin = 0xFFFFu, kmax = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t k = h_key(v[i]);
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+    }
+    for (int m = 1; m < lpg; m <<= 1) {
+        const uint32_t omin = __shfl_xor(kmin, m), omax = __shfl_xor(kmax, m);
+        kmin = omin < kmin ? omin : kmin;
+        kmax = omax > kmax ? omax : kmax;
+    }
+    const GroupQ g = make_group(kmin, kmax, (1 << BITS) - 1);
+    uint32_t q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = quant_one(v[i], g);
+    if constexpr (BITS == 2) {
+        uint32_t part = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) part |= q[i] << (2 * i);
+        const uint32_t other = __shfl_xor(part, 1);
+        if (valid && !(threadIdx.x & 1)) code[c >> 1] = part | (other << 16);
+    } else if constexpr (BITS == 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w |= q[i] << (4 * i);
+        if (valid) code[c] = w;
+    } else {
+        u32x2 w;
+        w[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+        w[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+        if (valid) *(u32x2*)(code + c * 2) = w;
+    }
+    if (valid && (c % lpg) == 0) {
+        scale[c / lpg] = g.scale;
+        mn[c / lpg] = g.mn;
+    }
+}
+
+// Any group size (multiple of fpi): one thread per group, scalar loops.
+template <int BITS>
+__global__ __launch_bounds__(256) void quant_pack_lastdim_generic(const uint16_t* x, uint32_t* code, uint16_t* scale,
+                                                                  uint16_t* mn, int64_t ngroups, int g) {
+    constexpr int FPI = 32 / BITS;
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const uint16_t* xp = x + gi * g;
+    uint32_t kmin = 0xFFFFu, kmax = 0u;
+    for (int i = 0; i < g; i++) {
+        const uint32_t k = h_key(xp[i]);
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+    }
+    const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+    for (int w = 0; w < g / FPI; w++) {
+        uint32_t word = 0;
+        for (int i = 0; i < FPI; i++) word |= quant_one(xp[w * FPI + i], gq) << (BITS * i);
+        code[gi * (g / FPI) + w] = word;
+    }
+    scale[gi] = gq.scale;
+    mn[gi] = gq.mn;
+}
+
+// Per-channel K straight from the un-transposed tensor: a lane owns two adjacent
+// channels (one 4-byte load per token, 256 B per wave-instruction) and the G tokens
+// of one group; codes of its channels are packed along t in registers.
+template <int BITS, int G>
+__global__ __launch_bounds__(64) void quant_pack_k_tmajor_kernel(const uint16_t* __restrict__ k, int64_t k_sb,
+                                                                 int64_t k_sh, int64_t k_st,
+                                                                 uint32_t* __restrict__ code, int64_t code_sb,
+                                                                 int64_t code_sh, int64_t code_sr, int64_t code_off,
+                                                                 uint16_t* __restrict__ scale,
+                                                                 uint16_t* __restrict__ mn, int64_t sm_sb,
+                                                                 int64_t sm_sh, int64_t sm_sr, int64_t sm_off, int nh,
+                                                                 int D, int64_t ngroups) {
+    constexpr int FPI = 32 / BITS;
+    constexpr int NW = G / FPI;
+    const int dpair = blockIdx.y * 64 + threadIdx.x;  // channels 2*dpair, 2*dpair+1
+    const int64_t gi = blockIdx.x % ngroups;
+    const int bh = (int)(blockIdx.x / ngroups);
+    const int b = bh / nh, h = bh - b * nh;
+    if (2 * dpair >= D) return;
+    const uint16_t* kp = k + b * k_sb + h * k_sh + gi * G * k_st + 2 * dpair;
+    uint32_t v[G];
+#pragma unroll
+    for (int t = 0; t < G; t++) v[t] = __builtin_nontemporal_load((const uint32_t*)(kp + t * k_st));
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        uint32_t kmin = 0xFFFFu, kmax = 0u;
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const uint32_t kk = h_key((v[t] >> (16 * ch)) & 0xFFFFu);
+            kmin = kk < kmin ? kk : kmin;
+            kmax = kk > kmax ? kk : kmax;
+        }
+        const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+        const int d = 2 * dpair + ch;
+        uint32_t* cp = code + b * code_sb + h * code_sh + (int64_t)d * code_sr + code_off + gi * NW;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int i = 0; i < FPI; i++)
+                word |= quant_one((uint16_t)((v[w * FPI + i] >> (16 * ch)) & 0xFFFFu), gq) << (BITS * i);
+            cp[w] = word;
+        }
+        const int64_t so = b * sm_sb + h * sm_sh + (int64_t)d * sm_sr + sm_off + gi;
+        scale[so] = gq.scale;
+        mn[so] = gq.mn;
+    }
+}
+
+// Any group size / odd D: one thread per (channel, group), strided scalar loads.
+template <int BITS>
+__global__ __launch_bounds__(64) void quant_pack_k_tmajor_generic(const uint16_t* k, int64_t k_sb, int64_t k_sh,
+                                                                  int64_t k_st, uint32_t* code, int64_t code_sb,
+                                                                  int64_t code_sh, int64_t code_sr, int64_t code_off,
+                                                                  uint16_t* scale, uint16_t* mn, int64_t sm_sb,
+                                                                  int64_t sm_sh, int64_t sm_sr, int64_t sm_off, int nh,
+                                                                  int D, int64_t ngroups, int g) {
+    constexpr int FPI = 32 / BITS;
+    const int d = blockIdx.y * 64 + threadIdx.x;
+    const int64_t gi = blockIdx.x % ngroups;
+    const int bh = (int)(blockIdx.x / ngroups);
+    const int b = bh / nh, h = bh - b * nh;
+    if (d >= D) return;
+    const uint16_t* kp = k + b * k_sb + h * k_sh + gi * g * k_st + d;
+    uint32_t kmin = 0xFFFFu, kmax = 0u;
+    for (int t = 0; t < g; t++) {
+        const uint32_t kk = h_key(kp[t * k_st]);
+        kmin = kk < kmin ? kk : kmin;
+        kmax = kk > kmax ? kk : kmax;
+    }
+    const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+    uint32_t* cp = code + b * code_sb + h * code_sh + (int64_t)d * code_sr + code_off + gi * (g / FPI);
+    for (int w = 0; w < g / FPI; w++) {
+        uint32_t word = 0;
+        for (int i = 0; i < FPI; i++) word |= quant_one(kp[(int64_t)(w * FPI + i) * k_st], gq) << (BITS * i);
+        cp[w] = word;
+    }
+    const int64_t so = b * sm_sb + h * sm_sh + (int64_t)d * sm_sr + sm_off + gi;
+    scale[so] = gq.scale;
+    mn[so] = gq.mn;
+}
+
+// out = fp16(fp16(fp16(q) * scale) + mn): one thread per packed word.
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_dequant_lastdim_kernel(const uint32_t* __restrict__ code,
+                                                                     const uint16_t* __restrict__ scale,
+                                                                     const uint16_t* __restrict__ mn,
+                                                                     uint16_t* __restrict__ out, int64_t nwords,
+                                                                     int64_t Tw, int64_t ng, int g) {
+    constexpr int FPI = 32 / BITS;
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nwords) return;
+    const int64_t row = wi / Tw, w = wi - row * Tw;
+    const int64_t gi = row * ng + (w * FPI) / g;
+    const float fs = h2f_bits(scale[gi]), fm = h2f_bits(mn[gi]);
+    const uint32_t word = code[wi];
+    uint16_t o[FPI];
+#pragma unroll
+    for (int i = 0; i < FPI; i++) {
+        const float q = (float)((word >> (BITS * i)) & ((1u << BITS) - 1u));  // exact in fp16
+        const uint16_t p = f2h_bits(q * fs);                                 // new_pack.py:82  data * scale
+        o[i] = f2h_bits(h2f_bits(p) + fm);                                   //                 + mn
+    }
+    uint16_t* op = out + wi * FPI;
+#pragma unroll
+    for (int i = 0; i < FPI; i += 4) {
+        typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+        u16x4 t = {o[i], o[i + 1], o[i + 2], o[i + 3]};
+        *(u16x4*)(op + i) = t;
+    }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_codes_lastdim_kernel(const uint32_t* __restrict__ code,
+                                                                   int16_t* __restrict__ out, int64_t nwords) {
+    constexpr int FPI = 32 / BITS;
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nwords) return;
+    const uint32_t word = code[wi];
+#pragma unroll
+    for (int i = 0; i < FPI; i++) out[wi * FPI + i] = (int16_t)((word >> (BITS * i)) & ((1u << BITS) - 1u));
+}
+
+// pack_tensor along the last dim (quant/new_pack.py:86-107, Triton twin :132-154):
+// word = OR_i data[j*fpi + i] << (bits*i) with int32 wrap-around, no masking (as the reference).
+template <int BITS>
+__global__ __launch_bounds__(256) void pack_codes_lastdim_kernel(const int32_t* __restrict__ data,
+                                                                 uint32_t* __restrict__ code, int64_t nwords) {
+    constexpr int FPI = 32 / BITS;
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nwords) return;
+    const int32_t* dp = data + wi * FPI;
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < FPI; i += 4) {
+        const u32x4 v = *(const u32x4*)(dp + i);
+#pragma unroll
+        for (int e = 0; e < 4; e++) word |= v[e] << (BITS * (i + e));
+    }
+    code[wi] = word;
+}
+
+bool bits_ok_pack(int bits) { return bits == 2 || bits == 4 || bits == 8; }
+
+}  // namespace
+
+extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, void* mn, int64_t rows, int64_t T,
+                                       int group_size, int bits, kivi_stream_t stream) {
+    KIVI_REQUIRE(bits_ok_pack(bits), KIVI_EINVAL, "kivi_quant_pack_lastdim: bits must be 2, 4 or 8 (new_pack.py:90), got %d",
+                 bits);
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(group_size > 0 && T % group_size == 0, KIVI_EINVAL,
+                 "kivi_quant_pack_lastdim: T=%lld not a multiple of group_size=%d (new_pack.py:222)", (long long)T,
+                 group_size);
+    KIVI_REQUIRE(T % fpi == 0 && group_size % fpi == 0, KIVI_EINVAL,
+                 "kivi_quant_pack_lastdim: T and group_size must be multiples of %d codes per word", fpi);
+    KIVI_REQUIRE(rows >= 0, KIVI_EINVAL, "kivi_quant_pack_lastdim: negative rows");
+    const int64_t n = rows * T;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int lpg = group_size / 8;
+    const bool fast = (group_size % 8 == 0) && lpg <= 64 && (lpg & (lpg - 1)) == 0 && ((uintptr_t)x % 16 == 0) &&
+                      ((uintptr_t)code % 8 == 0);
+    if (fast) {
+        const int64_t nchunk = n / 8;
+        dim3 grid((unsigned)((nchunk + 255) / 256));
+        if (bits == 2)
+            hipLaunchKernelGGL(quant_pack_lastdim_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)x, (uint32_t*)code,
+                               (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
+        else if (bits == 4)
+            hipLaunchKernelGGL(quant_pack_lastdim_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)x, (uint32_t*)code,
+                               (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
+        else
+            hipLaunchKernelGGL(quant_pack_lastdim_kernel<8>, grid, dim3(256), 0, s, (const uint16_t*)x, (uint32_t*)code,
+                               (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
+        return kivi_launch_status("quant_pack_lastdim");
+    }
+    const int64_t ngroups = n / group_size;
+    dim3 grid((unsigned)((ngroups + 255) / 256));
+    if (bits == 2)
+        hipLaunchKernelGGL(quant_pack_lastdim_generic<2>, grid, dim3(256), 0, s, (const uint16_t*)x, (uint32_t*)code,
+                           (uint16_t*)scale, (uint16_t*)mn, ngroups, group_size);
+    else if (bits == 4)
+        hipLaunchKernelGGL(quant_pack_lastdim_generic<4>, grid, dim3(256), 0, s, (const uint16_t*)x, (uint32_t*)code,
+                           (uint16_t*)scale, (uint16_t*)mn, ngroups, group_size);
+    else
+        hipLaunchKernelGGL(quant_pack_lastdim_generic<8>, grid, dim3(256), 0, s, (const uint16_t*)x, (uint32_t*)code,
+                           (uint16_t*)scale, (uint16_t*)mn, ngroups, group_size);
+    return kivi_launch_status("quant_pack_lastdim_generic");
+}
+
+#define KIVI_K_ARGS                                                                                                   \
+    (const uint16_t*)k, k_sb, k_sh, k_st, (uint32_t*)code, code_sb, code_sh, code_sr, code_off, (uint16_t*)scale,     \
+        (uint16_t*)mn, sm_sb, sm_sh, sm_sr, sm_off, nh, D, ngroups
+
+extern "C" int kivi_quant_pack_k_tmajor(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* code,
+                                        int64_t code_sb, int64_t code_sh, int64_t code_sr, int64_t code_off,
+                                        void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
+                                        int64_t sm_off, int B, int nh, int64_t T, int D, int group_size, int bits,
+                                        kivi_stream_t stream) {
+    KIVI_REQUIRE(bits_ok_pack(bits), KIVI_EINVAL, "kivi_quant_pack_k_tmajor: bits must be 2, 4 or 8, got %d", bits);
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(group_size > 0 && group_size % fpi == 0 && T % group_size == 0, KIVI_EINVAL,
+                 "kivi_quant_pack_k_tmajor: T=%lld must be a multiple of group_size=%d (new_pack.py:13), group_size of %d",
+                 (long long)T, group_size, fpi);
+    KIVI_REQUIRE(B > 0 && nh > 0 && D > 0 && T >= 0, KIVI_EINVAL, "kivi_quant_pack_k_tmajor: bad shape");
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ngroups = T / group_size;
+    const int64_t nblk = ngroups * B * nh;
+    KIVI_REQUIRE(nblk < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_quant_pack_k_tmajor: grid too large");
+    const bool fast = (D % 2 == 0) && (k_sb % 2 == 0) && (k_sh % 2 == 0) && (k_st % 2 == 0) && ((uintptr_t)k % 4 == 0) &&
+                      (group_size == 32 || group_size == 64 || group_size == 128) && bits != 8;
+    if (fast) {
+        dim3 grid((unsigned)nblk, (unsigned)((D / 2 + 63) / 64));
+#define KIVI_K_CASE(BITS, G)                                                                            \
+    if (bits == BITS && group_size == G) {                                                              \
+        hipLaunchKernelGGL((quant_pack_k_tmajor_kernel<BITS, G>), grid, dim3(64), 0, s, KIVI_K_ARGS);   \
+        return kivi_launch_status("quant_pack_k_tmajor");                                               \
+    }
+        KIVI_K_CASE(2, 32) KIVI_K_CASE(2, 64) KIVI_K_CASE(2, 128) KIVI_K_CASE(4, 32) KIVI_K_CASE(4, 64) KIVI_K_CASE(4, 128)
+#undef KIVI_K_CASE
+    }
+    dim3 grid((unsigned)nblk, (unsigned)((D + 63) / 64));
+    if (bits == 2)
+        hipLaunchKernelGGL(quant_pack_k_tmajor_generic<2>, grid, dim3(64), 0, s, KIVI_K_ARGS, group_size);
+    else if (bits == 4)
+        hipLaunchKernelGGL(quant_pack_k_tmajor_generic<4>, grid, dim3(64), 0, s, KIVI_K_ARGS, group_size);
+    else
+        hipLaunchKernelGGL(quant_pack_k_tmajor_generic<8>, grid, dim3(64), 0, s, KIVI_K_ARGS, group_size);
+    return kivi_launch_status("quant_pack_k_tmajor_generic");
+}
+
+extern "C" int kivi_unpack_dequant_lastdim(const void* code, const void* scale, const void* mn, void* out, int64_t rows,
+                                           int64_t T, int group_size, int bits, kivi_stream_t stream) {
+    KIVI_REQUIRE(bits_ok_pack(bits), KIVI_EINVAL, "kivi_unpack_dequant_lastdim: bits must be 2, 4 or 8 (new_pack.py:75)");
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(group_size > 0 && group_size % fpi == 0 && T % group_size == 0, KIVI_EINVAL,
+                 "kivi_unpack_dequant_lastdim: T=%lld must be a multiple of group_size=%d", (long long)T, group_size);
+    KIVI_REQUIRE((uintptr_t)out % 8 == 0, KIVI_EALIGN, "kivi_unpack_dequant_lastdim: out must be 8-byte aligned");
+    const int64_t nwords = rows * (T / fpi);
+    if (nwords == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((nwords + 255) / 256));
+    const int64_t Tw = T / fpi, ng = T / group_size;
+    if (bits == 2)
+        hipLaunchKernelGGL(unpack_dequant_lastdim_kernel<2>, grid, dim3(256), 0, s, (const uint32_t*)code,
+                           (const uint16_t*)scale, (const uint16_t*)mn, (uint16_t*)out, nwords, Tw, ng, group_size);
+    else if (bits == 4)
+        hipLaunchKernelGGL(unpack_dequant_lastdim_kernel<4>, grid, dim3(256), 0, s, (const uint32_t*)code,
+                           (const uint16_t*)scale, (const uint16_t*)mn, (uint16_t*)out, nwords, Tw, ng, group_size);
+    else
+        hipLaunchKernelGGL(unpack_dequant_lastdim_kernel<8>, grid, dim3(256), 0, s, (const uint32_t*)code,
+                           (const uint16_t*)scale, (const uint16_t*)mn, (uint16_t*)out, nwords, Tw, ng, group_size);
+    return kivi_launch_status("unpack_dequant_lastdim");
+}
+
+extern "C" int kivi_unpack_codes_lastdim(const void* code, void* out_i16, int64_t rows, int64_t T, int bits,
+                                         kivi_stream_t stream) {
+    KIVI_REQUIRE(bits_ok_pack(bits), KIVI_EINVAL, "kivi_unpack_codes_lastdim: bits must be 2, 4 or 8 (new_pack.py:113)");
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(T % fpi == 0, KIVI_EINVAL, "kivi_unpack_codes_lastdim: T must be a multiple of %d", fpi);
+    const int64_t nwords = rows * (T / fpi);
+    if (nwords == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((nwords + 255) / 256));
+    if (bits == 2)
+        hipLaunchKernelGGL(unpack_codes_lastdim_kernel<2>, grid, dim3(256), 0, s, (const uint32_t*)code, (int16_t*)out_i16,
+                           nwords);
+    else if (bits == 4)
+        hipLaunchKernelGGL(unpack_codes_lastdim_kernel<4>, grid, dim3(256), 0, s, (const uint32_t*)code, (int16_t*)out_i16,
+                           nwords);
+    else
+        hipLaunchKernelGGL(unpack_codes_lastdim_kernel<8>, grid, dim3(256), 0, s, (const uint32_t*)code, (int16_t*)out_i16,
+                           nwords);
+    return kivi_launch_status("unpack_codes_lastdim");
+}
+
+extern "C" int kivi_pack_codes_lastdim(const void* data_i32, void* code, int64_t rows, int64_t T, int bits,
+                                       kivi_stream_t stream) {
+    KIVI_REQUIRE(bits_ok_pack(bits), KIVI_EINVAL, "kivi_pack_codes_lastdim: only 2, 4, 8 bits are supported (new_pack.py:90)");
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(T % fpi == 0, KIVI_EINVAL,
+                 "kivi_pack_codes_lastdim: dimension length must be divisible by %d features per int (new_pack.py:91)", fpi);
+    KIVI_REQUIRE((uintptr_t)data_i32 % 16 == 0, KIVI_EALIGN, "kivi_pack_codes_lastdim: data must be 16-byte aligned");
+    const int64_t nwords = rows * (T / fpi);
+    if (nwords == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((nwords + 255) / 256));
+    if (bits == 2)
+        hipLaunchKernelGGL(pack_codes_lastdim_kernel<2>, grid, dim3(256), 0, s, (const int32_t*)data_i32, (uint32_t*)code,
+                           nwords);
+    else if (bits == 4)
+        hipLaunchKernelGGL(pack_codes_lastdim_kernel<4>, grid, dim3(256), 0, s, (const int32_t*)data_i32, (uint32_t*)code,
+                           nwords);
+    else
+        hipLaunchKernelGGL(pack_codes_lastdim_kernel<8>, grid, dim3(256), 0, s, (const int32_t*)data_i32, (uint32_t*)code,
+                           nwords);
+    return kivi_launch_status("pack_codes_lastdim");
+}

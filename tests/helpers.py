@@ -1,0 +1,60 @@
+"""Shared helpers for the parity tests."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def f16(arr: np.ndarray) -> torch.Tensor:
+    """uint16 bit pattern array -> fp16 tensor."""
+    return torch.from_numpy(arr.astype(np.uint16).view(np.int16).copy()).view(torch.float16)
+
+
+def bits(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().cpu().contiguous().view(torch.int16)
+
+
+def same_bits(a: torch.Tensor, b: torch.Tensor) -> bool:
+    a, b = a.detach().cpu(), b.detach().cpu()
+    if a.shape != b.shape:
+        return False
+    if a.dtype == torch.float16:
+        return bool((bits(a) == bits(b)).all())
+    return bool((a == b).all())
+
+
+def load_golden(prefix: str):
+    out = {}
+    for p in sorted(glob.glob(os.path.join(GOLD, prefix + "*.npz"))):
+        out[os.path.basename(p)[:-4]] = dict(np.load(p))
+    assert out, f"no golden fixtures match {prefix}"
+    return out
+
+
+def gemv_close(got: torch.Tensor, ref: torch.Tensor, rtol: float = 1e-3):
+    """north_star bar for the fp16 GEMV: |a-b| <= rtol * max(|ref|, rms(ref_row)).
+    Returns (ok, worst ratio)."""
+    g, r = got.detach().cpu().float(), ref.detach().cpu().float()
+    rms = r.pow(2).mean(dim=-1, keepdim=True).sqrt()
+    bound = rtol * torch.maximum(r.abs(), rms)
+    # an fp16 result cannot be closer than half an ulp of the reference: allow 1 ulp of slack on top
+    ulp = torch.finfo(torch.float16).eps * r.abs().clamp_min(2.0 ** -14)
+    ratio = ((g - r).abs() / (bound + ulp)).max().item() if r.numel() else 0.0
+    return ratio <= 1.0, ratio
+
+
+def make_kv(seed: int, B: int, nh_kv: int, T: int, D: int, kind: str = "randn"):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "randn":
+        return torch.randn((B, nh_kv, T, D), generator=g).half()
+    if kind == "int":
+        return torch.randint(10, (B, nh_kv, T, D), generator=g).half()
+    if kind == "outlier":  # a few large-magnitude channels, like real K caches (KIVI paper fig. 2)
+        x = torch.randn((B, nh_kv, T, D), generator=g)
+        x[..., ::17] *= 12.0
+        return x.half()
+    raise ValueError(kind)

@@ -1,0 +1,133 @@
+"""CPU: the oracle (oracle/kivi_oracle.c) against the fixtures minted from the REAL reference
+(oracle/pin_reference.py, run where /root/reference exists).  Nothing here touches the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import f16, load_golden, same_bits
+
+
+def test_half_conversion_exhaustive(oracle):
+    L = oracle.lib()
+    allh = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.float16)
+    f = allh.float()
+    # h2f over every half
+    ours = np.array([L.kivi_oracle_h2f(int(i)) for i in range(0, 65536, 1)], dtype=np.float32)
+    ref = f.numpy()
+    fin = np.isfinite(ref)
+    assert (ours[fin] == ref[fin]).all() and (np.isnan(ours) == np.isnan(ref)).all()
+    # f2h against torch's RNE conversion on a float sweep that includes every rounding boundary
+    g = torch.Generator().manual_seed(1)
+    xs = torch.cat([f[torch.isfinite(f)], f[torch.isfinite(f)] * (1 + 2 ** -12), f[torch.isfinite(f)] * (1 - 2 ** -12),
+                    torch.randn(20000, generator=g) * 70000, torch.randn(20000, generator=g) * 1e-6,
+                    torch.tensor([65504.0, 65519.9, 65520.0, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 0.0, -0.0])])
+    want = xs.half().view(torch.int16).numpy().view(np.uint16)
+    got = np.array([L.kivi_oracle_f2h(float(v)) for v in xs.numpy()], dtype=np.uint16)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("name,fx", sorted(load_golden("lastdim_").items()))
+def test_lastdim_pack_matches_reference(oracle, name, fx):
+    x = f16(fx["x"])
+    g, bits = int(fx["g"]), int(fx["bits"])
+    # the fixtures hold the reference's CPU outputs: NaN->int is INT_MIN there
+    code, scale, mn = oracle.quantize_and_pack_along_last_dim(x, g, bits, nan_mode=oracle.NAN_CPU)
+    assert same_bits(code, torch.from_numpy(fx["code"]))
+    assert same_bits(scale, f16(fx["scale"])) and same_bits(mn, f16(fx["mn"]))
+    deq = oracle.unpack_and_dequant_vcache(torch.from_numpy(fx["code"]), f16(fx["scale"]), f16(fx["mn"]), g, bits)
+    assert same_bits(deq, f16(fx["deq"]))
+    if not int(fx["has_nan"]):
+        # without constant groups the CUDA flavour (NaN -> 0) is identical
+        code2, _, _ = oracle.quantize_and_pack_along_last_dim(x, g, bits, nan_mode=oracle.NAN_CUDA)
+        assert same_bits(code2, code)
+
+
+def test_constant_group_modes(oracle):
+    """scale == 0 -> 0/0: reference on x86 packs INT_MIN (only element 0 of a word survives the shift),
+    the reference's CUDA conversion gives 0; the oracle restates both."""
+    x = torch.full((1, 1, 1, 64), 1.5, dtype=torch.float16)
+    x[..., 32:] = torch.arange(32).half()
+    c_cpu, s, m = oracle.quantize_and_pack_along_last_dim(x, 32, 2, nan_mode=oracle.NAN_CPU)
+    c_gpu, s2, m2 = oracle.quantize_and_pack_along_last_dim(x, 32, 2, nan_mode=oracle.NAN_CUDA)
+    assert c_cpu[0, 0, 0, 0].item() == -2147483648 and c_cpu[0, 0, 0, 1].item() == -2147483648
+    assert c_gpu[0, 0, 0, 0].item() == 0 and c_gpu[0, 0, 0, 1].item() == 0
+    assert same_bits(c_cpu[..., 2:], c_gpu[..., 2:]) and same_bits(s, s2) and same_bits(m, m2)
+    assert s[0, 0, 0, 0].item() == 0.0 and m[0, 0, 0, 0].item() == 1.5
+
+
+@pytest.mark.parametrize("name,fx", sorted(load_golden("kcache_").items()))
+def test_kcache_pack_matches_reference(oracle, name, fx):
+    k = f16(fx["k"])
+    g, bits = int(fx["g"]), int(fx["bits"])
+    code, scale, mn = oracle.quant_and_pack_kcache(k, g, bits, nan_mode=oracle.NAN_CPU)
+    assert same_bits(code, torch.from_numpy(fx["code"]))
+    assert same_bits(scale, f16(fx["scale"])) and same_bits(mn, f16(fx["mn"]))
+    deq = oracle.unpack_and_dequant_kcache(code, scale, mn, g, bits)
+    assert same_bits(deq, f16(fx["deq"]))
+    # hook identity (llama_kivi.py:345): last-dim packing of K^T == transpose of the T-major codes
+    c2, s2, m2 = oracle.quantize_and_pack_along_last_dim(k.transpose(2, 3).contiguous(), g, bits, nan_mode=oracle.NAN_CPU)
+    assert same_bits(c2, code.transpose(2, 3).contiguous())
+    assert same_bits(s2, scale.squeeze(3).transpose(2, 3).contiguous())
+    assert same_bits(m2, mn.squeeze(3).transpose(2, 3).contiguous())
+
+
+@pytest.mark.parametrize("name,fx", sorted(load_golden("packtensor_").items()))
+def test_pack_tensor_matches_reference(oracle, name, fx):
+    data = torch.from_numpy(fx["data"])
+    bits, pack_dim = int(fx["bits"]), int(fx["pack_dim"])
+    code = oracle.pack_tensor(data, bits, pack_dim)
+    assert same_bits(code, torch.from_numpy(fx["code"]))
+    assert bool((oracle.unpack_tensor(code, bits, pack_dim).int() == data).all())
+
+
+@pytest.mark.parametrize("name,fx", sorted(load_golden("gemvexact_").items()))
+def test_fused_gemv_indexing_matches_reference(oracle, name, fx):
+    """Exact-arithmetic cases: the reference's unpack_and_dequant_vcache + fp64 matmul is exact, so the
+    fused oracle (gemv_cuda.cu lane order) must agree bit for bit in both layouts and both fma modes."""
+    fA, qB = f16(fx["fA"]), torch.from_numpy(fx["qB"])
+    scales, zeros = f16(fx["scales"]), f16(fx["zeros"])
+    g, bits = int(fx["g"]), int(fx["bits"])
+    want = f16(fx["out"])
+    assert same_bits(oracle.bmm_fA_qB_outer(g, fA, qB, scales, zeros, bits), want)
+    assert same_bits(oracle.bmm_fA_qB_outer(g, fA, qB, scales, zeros, bits, use_fma=False), want)
+    assert same_bits(oracle.bmm_fA_qB_outer(g, fA, qB, scales, zeros, bits, fakequant=True), want)
+    B, nh, _, K = fA.shape
+    nh_kv = qB.shape[1]
+    fpi = 32 // bits
+    N = qB.shape[-1] * fpi
+    w_t = qB.reshape(-1, K, N // fpi).transpose(1, 2).contiguous()      # matmul.py:205
+    s_t = scales.reshape(-1, K, N // g).transpose(1, 2).contiguous()    # matmul.py:213
+    z_t = zeros.reshape(-1, K, N // g).transpose(1, 2).contiguous()     # matmul.py:214
+    got = oracle.gemv_forward_outer_dim(fA.reshape(B * nh, 1, K), w_t, s_t, z_t, bits, g, nh, nh_kv)
+    assert same_bits(got.view(B, nh, 1, N), want)
+
+
+def test_cfg1_fakequant_path(oracle):
+    """BASELINE config 1 (B=1,H=1,T=128,D=128,g=32, 2-bit): the reference's fake-quant qK procedure
+    (quant/test.py:187-195) reproduced by the oracle's fake-quant GEMV; fused arithmetic stays close."""
+    fx = load_golden("cfg1_fakequant_qk")["cfg1_fakequant_qk"]
+    q = f16(fx["q"])
+    code_T, scale_T, mn_T = torch.from_numpy(fx["code_T"]), f16(fx["scale_T"]), f16(fx["mn_T"])
+    want = f16(fx["out_fakequant"]).float()
+    rms = want.pow(2).mean().sqrt()
+    fq = oracle.bmm_fA_qB_outer(32, q, code_T, scale_T, mn_T, 2, fakequant=True).float()
+    assert (fq - want).abs().max() <= 2e-3 * rms
+    fused = oracle.bmm_fA_qB_outer(32, q, code_T, scale_T, mn_T, 2).float()
+    assert (fused - want).abs().max() <= 1e-2 * rms
+    # and the packed inputs themselves come out of the oracle's pack
+    k = f16(fx["k"])
+    c2, s2, m2 = oracle.quantize_and_pack_along_last_dim(k.transpose(2, 3).contiguous(), 32, 2)
+    assert same_bits(c2, code_T) and same_bits(s2, scale_T) and same_bits(m2, mn_T)
+
+
+def test_oracle_rejects_bad_arguments(oracle):
+    x = torch.zeros((1, 1, 2, 48), dtype=torch.float16)
+    with pytest.raises(ValueError):
+        oracle.quantize_and_pack_along_last_dim(x, 32, 2)        # T % group_size != 0 (new_pack.py:222)
+    with pytest.raises(ValueError):
+        oracle.quantize_and_pack_along_last_dim(torch.zeros((1, 1, 2, 64), dtype=torch.float16), 32, 3)
+    fA = torch.zeros((1, 3, 1, 32), dtype=torch.float16)
+    qB = torch.zeros((1, 2, 32, 2), dtype=torch.int32)
+    sz = torch.zeros((1, 2, 32, 1), dtype=torch.float16)
+    with pytest.raises(ValueError):
+        oracle.bmm_fA_qB_outer(32, fA, qB, sz, sz, 2)             # nh % nh_kv != 0 (matmul.py:216)
