@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- decode-step throughput of the KIVI KV-cache hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric: "decode-step tokens/sec + peak KV bytes, Llama-2-7B B=32 seq=4k, 2b/2b g=32"):
+one "step" = one decode step of the KIVI attention hot path for ALL 32 layers of a Llama-2-7B-shaped model at
+batch 32 per GPU over a 4096-token prompt cache, k_bits = v_bits = 2, group 32, residual 32 -- per layer:
+fused qK^T GEMV over the packed per-channel K cache + fp16 residual scores, fp32 softmax, fused sV GEMV over the
+packed per-token V cache + fp16 residual, and the in-place cache append / quantise (kivi_amd.attention
+.kivi_attention_decode, the reference's llama_kivi.py:314-399).  The dense projections / MLP are outside the
+hot path and are not run.  Inputs are synthetic (seeded randn), resident in HBM before the timed region.
+
+N > 1: one process per GPU (launched by torch.distributed.run), batch-sharded replicas -- the path has no
+exchange step, so there is no data-path collective; ranks only barrier and max-reduce the elapsed time.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_COPY_GBS = 6290.0  # same guide: float4 copy ceiling
+
+
+def kgemv_bytes(B, nh, nh_kv, D, T, g, bits):
+    """ALGORITHMIC bytes of one fused qK^T launch: codes + scale + zero + q + out."""
+    per_kv_head = D * T * bits // 8 + 2 * D * (T // g) * 2
+    return B * nh_kv * per_kv_head + B * nh * (D * 2 + T * 2)
+
+
+def vgemv_bytes(B, nh, nh_kv, D, Tv, g, bits):
+    per_kv_head = Tv * D * bits // 8 + 2 * Tv * (D // g) * 2
+    return B * nh_kv * per_kv_head + B * nh * (Tv * 2 + D * 2)
+
+
+def dist_setup(n_gpus: int):
+    """Returns (rank, world, local_rank, dist-or-None).  backend nccl (= RCCL) on GPUs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if n_gpus > 1 and world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} needs `python -m torch.distributed.run --nproc-per-node {n_gpus} bench.py ...` "
+                         f"(WORLD_SIZE={world})")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        return rank, world, local, dist
+    return 0, 1, local, None
+
+
+def max_over_ranks(seconds: float, dist, device) -> float:
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=15.0):
+    """The reference's pure-PyTorch fake-quant path (oracle/torch_fakequant.py port) on the host cores, on a bounded
+    sample of the same workload: ONE batch row of ONE layer (nh heads x T tokens), decode-equivalent work =
+    unpack+dequantise K and V + the two GEMVs (the cache is already packed in a decode step; pack is timed and
+    reported separately).  Extrapolated to tokens/s for `layers` layers."""
+    from oracle import torch_fakequant as TF
+    torch.manual_seed(0)
+    k = torch.randn((1, nh, T, D)).half()
+    v = torch.randn((1, nh, T, D)).half()
+    q = torch.randn((1, nh, 1, D)).half()
+    a = torch.softmax(torch.randn((1, nh, 1, T)), -1).half()
+    reps, dec_s, pack_s, t_start = 0, 0.0, 0.0, time.perf_counter()
+    while True:
+        _, _, st = TF.fakequant_decode_layer(q, a, k, v, g, bits)
+        reps += 1
+        dec_s += st["dequant_s"] + st["gemv_s"]
+        pack_s += st["pack_s"]
+        if time.perf_counter() - t_start > budget_s or reps >= 200:
+            break
+    per_layer_row = dec_s / reps
+    return {
+        "value": 1.0 / (per_layer_row * layers), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1 batch row x {nh} heads x T={T} x 1 layer, {reps} reps: unpack+dequant K,V + 2 matmuls "
+                  f"{per_layer_row * 1e3:.0f} ms/layer-row (pack of a full {T}-token prompt {pack_s / reps * 1e3:.0f} ms, "
+                  f"not in value); extrapolated x{layers} layers",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=32)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--prompt", type=int, default=4096)
+    ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--group", type=int, default=32)
+    ap.add_argument("--residual", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the K-GEMV launches with HIP events")
+    args = ap.parse_args()
+
+    rank, world, local, dist = dist_setup(args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    from kivi_amd.quant import matmul
+
+    B, L, nh, nh_kv, D = args.batch, args.layers, args.heads, args.kv_heads, args.head_dim
+    T0, g, bits, R = args.prompt, args.group, args.bits, args.residual
+    cfg = KiviConfig(bits, bits, g, R)
+    total_steps = args.warmup + args.steps
+    torch.manual_seed(1234 + rank)
+
+    # ---- build the per-layer caches (prefill with synthetic K/V), inputs resident in HBM
+    layers = []
+    for _ in range(L):
+        lc = KiviLayerCache(cfg, B, nh_kv, D, T0 + total_steps + 1, dev)
+        k = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
+        v = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
+        lc.prefill(k, v)
+        del k, v
+        layers.append(lc)
+    qs = [torch.randn((B, nh, 1, D), device=dev, dtype=torch.float16) for _ in range(L)]
+    ks = [torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16) for _ in range(L)]
+    vs = [torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16) for _ in range(L)]
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+
+    def step():
+        for i in range(L):
+            kivi_attention_decode(qs[i], ks[i], vs[i], layers[i])
+
+    for _ in range(args.warmup):
+        step()
+
+    # ---- HIP events around every qK^T launch of the timed region, on the launch stream (torch's current stream)
+    kev = []
+
+    def hook(phase, kind, info):
+        if kind != "k":
+            return
+        if phase == "pre":
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            kev.append([e0, None, kgemv_bytes(info["B"], info["nh"], info["nh_kv"], info["K"], info["N"],
+                                              info["group_size"], info["bits"])])
+        else:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            kev[-1][1] = e1
+
+    if not args.no_kernel_events:
+        matmul.launch_hook = hook
+
+    torch.cuda.synchronize()
+    barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier(dist)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    matmul.launch_hook = None
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    tokens_per_s = world * B * args.steps / elapsed
+
+    if rank == 0:
+        roof = None
+        if kev:
+            us = [a.elapsed_time(b) * 1e3 for a, b, _ in kev]
+            tot_bytes = sum(n for _, _, n in kev)
+            avg_us = sum(us) / len(us)
+            achieved = tot_bytes / (sum(us) * 1e-6) / 1e9
+            traffic = None
+            prof = os.path.join(ROOT, "profiles", "kgemv_pmc.json")
+            if os.path.exists(prof):
+                try:
+                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "gemv_k_kernel (fused int2 qK^T over packed K)", "launches": len(us),
+                    "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min(us), 2),
+                    "algorithmic_bytes_per_launch": tot_bytes // len(us),
+                    "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
+        kv_bytes = sum(lc.nbytes() for lc in layers)
+        fp16_bytes = 2 * L * B * nh_kv * layers[0].kv_seq_len * D * 2
+        out = {
+            "metric": "decode-step tokens/sec (KIVI attention hot path, Llama-2-7B shape, B=32/GPU, seq=4k, 2b/2b g=32)",
+            "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
+            "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
+                                   "residual + in-place KV append/quantise; 32 layers, no dense projections",
+                       "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
+                       "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
+                       "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)"},
+            "peak_kv_bytes": kv_bytes, "peak_kv_bytes_fp16_equivalent": fp16_bytes,
+            "kv_compression": round(fp16_bytes / kv_bytes, 3),
+            "allocator_peak_bytes": torch.cuda.max_memory_allocated(dev),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(B, nh, T0, D, g, bits, L)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

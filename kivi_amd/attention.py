@@ -1,0 +1,183 @@
+"""The KIVI attention hook: decode / prefill cache logic of the reference's
+LlamaFlashAttention_KIVI.forward (models/llama_kivi.py:265-466) on the HIP kernels.
+
+Same arithmetic sequence as the reference decode branch (:314-399):
+  scores  = cat([ fused qK^T over packed K , q @ K_residual^T ]) / sqrt(D)      (fp16)
+  weights = softmax(scores, fp32) -> fp16
+  out     = fused sV over packed V  +  weights[..., -L:] @ V_residual           (fp16)
+with the cache policy of cache.py.  What changed is data movement only: the fused GEMVs read the
+hook-state layout directly and write into a scores buffer (no torch.cat, no transposed copies), and
+the cache is appended in place.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .cache import KiviCacheTuple, KiviConfig, KiviLayerCache
+from .quant.matmul import cuda_bmm_fA_qB_outer
+
+__all__ = ["kivi_attention_decode", "kivi_attention_prefill", "LlamaAttention_KIVI", "LlamaFlashAttention_KIVI",
+           "KiviConfig", "KiviLayerCache"]
+
+
+def _scores_buffer(layer: KiviLayerCache, nh: int, kv_len: int) -> torch.Tensor:
+    """(B, nh, 1, kv_len) view of a per-layer fp16 buffer whose row pitch is a multiple of 8 halves
+    (16-byte stores of the fused GEMV)."""
+    pitch = ((layer.cap + 1 + 7) // 8) * 8
+    buf = getattr(layer, "_scores", None)
+    if buf is None or buf.shape[1] != nh:
+        buf = torch.empty((layer.B, nh, 1, pitch), dtype=torch.float16, device=layer.k_code.device)
+        layer._scores = buf
+    return buf[..., :kv_len]
+
+
+def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
+                          layer: KiviLayerCache, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decode step for one layer.  query (B, nh, 1, D), key/value (B, nh_kv, 1, D), RoPE already applied.
+    Mutates `layer` in place and returns attn_output (B, nh, 1, D) fp16 (before the o_proj transpose)."""
+    cfg = layer.cfg
+    B, nh, q_len, D = query_states.shape
+    assert q_len == 1, "decode branch: one new token (the reference kernel is q_len == 1 only)"
+    nh_kv = layer.nh_kv
+    rep = nh // nh_kv
+    kv_seq_len = layer.kv_seq_len + 1                                    # llama_kivi.py:307-309
+    g = cfg.group_size
+
+    # ---- scores over [quantised K prefix | fp16 K residual]  (:323-341)
+    Tq = layer.k_quant_len
+    layer.append_k(key_states)                                           # :333-336
+    scores = _scores_buffer(layer, nh, kv_seq_len)
+    if Tq:
+        kc, ks, km = layer.k_quant_views()
+        cuda_bmm_fA_qB_outer(g, query_states, kc, ks, km, cfg.k_bits, out=scores[..., :Tq])   # :324
+    k_full = layer.k_res_view()                                          # (B, nh_kv, L, D)
+    att_qkfull = torch.matmul(query_states.reshape(B, nh_kv, rep, D), k_full.transpose(2, 3))  # :337 (repeat_kv folded)
+    scores[..., Tq:].copy_(att_qkfull.view(B, nh, 1, -1))
+    attn_weights = scores / math.sqrt(D)                                  # :339, fp16 division like the reference
+    layer.maybe_flush_k()                                                 # :343-356
+
+    if attn_weights.size() != (B, nh, 1, kv_seq_len):
+        raise ValueError(f"Attention weights should be of size {(B, nh, 1, kv_seq_len)}, but is {attn_weights.size()}")
+    if attention_mask is not None:                                        # :364-372
+        if attention_mask.size() != (B, 1, 1, kv_seq_len):
+            raise ValueError(f"Attention mask should be of size {(B, 1, 1, kv_seq_len)}, but is {attention_mask.size()}")
+        attn_weights = attn_weights + attention_mask
+        attn_weights = torch.max(attn_weights, torch.tensor(torch.finfo(attn_weights.dtype).min, device=attn_weights.device))
+    attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)   # :375
+
+    # ---- output over [quantised V prefix | fp16 V window]  (:377-399)
+    layer.append_v(value_states)
+    Tv, Lv = layer.v_quant_len, layer.v_res_len
+    v_full = layer.v_res_view()
+    w_full = attn_weights[..., Tv:].reshape(B, nh_kv, rep, Lv)
+    if Tv == 0:
+        attn_output = torch.matmul(w_full, v_full).view(B, nh, 1, D)     # :380
+    else:
+        vc, vs, vm = layer.v_quant_views()
+        attn_output = cuda_bmm_fA_qB_outer(g, attn_weights[..., :Tv], vc, vs, vm, cfg.v_bits)   # :382 (strided slice, no copy)
+        attn_output += torch.matmul(w_full, v_full).view(B, nh, 1, D)    # :384
+    layer.maybe_flush_v()                                                 # :386-399
+    layer.kv_seq_len = kv_seq_len
+    return attn_output
+
+
+def kivi_attention_prefill(query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
+                           layer: KiviLayerCache) -> torch.Tensor:
+    """Prompt pass (:401-452): causal attention over fp16 q/k/v (the reference uses flash-attn with its mask
+    argument hard-wired to None, :420-423; here torch SDPA, outside the quantised hot path), then split K/V into
+    the quantised prefix and the fp16 residual."""
+    B, nh, T, D = query_states.shape
+    rep = nh // layer.nh_kv
+    k, v = key_states, value_states
+    if rep > 1:
+        k = k.repeat_interleave(rep, dim=1)
+        v = v.repeat_interleave(rep, dim=1)
+    attn_output = F.scaled_dot_product_attention(query_states, k, v, is_causal=True)
+    layer.prefill(key_states, value_states)
+    return attn_output
+
+
+# --------------------------------------------------------------------------- module hook
+
+def _rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+class LlamaAttention_KIVI(nn.Module):
+    """Self-contained Llama attention block with the KIVI cache hook (reference: LlamaFlashAttention_KIVI,
+    models/llama_kivi.py:264-466; constructor fields :22-61).
+
+    `config` needs hidden_size, num_attention_heads, num_key_value_heads, max_position_embeddings, rope_theta and
+    the four KIVI fields the reference monkey-patches onto the HF config (README.md:72-75): k_bits, v_bits,
+    group_size, residual_length.  forward() keeps the reference signature and returns
+    (attn_output, None, past_key_value) with past_key_value the 9-tuple of :454-455.
+    """
+
+    def __init__(self, config, layer_idx: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.layer_idx = layer_idx
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = getattr(config, "num_key_value_heads", self.num_heads)
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.max_position_embeddings = getattr(config, "max_position_embeddings", 4096)
+        self.rope_theta = getattr(config, "rope_theta", 10000.0)
+        self.kivi = KiviConfig(config.k_bits, config.v_bits, config.group_size, config.residual_length)
+        self.k_bits, self.v_bits = config.k_bits, config.v_bits
+        self.group_size, self.residual_length = config.group_size, config.residual_length
+        if self.head_dim * self.num_heads != self.hidden_size:
+            raise ValueError("hidden_size must be divisible by num_heads")
+        bias = getattr(config, "attention_bias", False)
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=bias)
+        inv_freq = 1.0 / (self.rope_theta ** (torch.arange(0, self.head_dim, 2, dtype=torch.float32) / self.head_dim))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+
+    def _rope(self, q, k, position_ids):
+        freqs = position_ids[:, :, None].float() * self.inv_freq[None, None, :].float()   # (B, T, D/2)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        cos, sin = emb.cos()[:, None].to(q.dtype), emb.sin()[:, None].to(q.dtype)        # (B, 1, T, D)
+        return q * cos + _rotate_half(q) * sin, k * cos + _rotate_half(k) * sin
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.LongTensor] = None, past_key_value=None, output_attentions: bool = False,
+                use_cache: bool = False, **kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[tuple]]:
+        bsz, q_len, _ = hidden_states.size()
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim).transpose(1, 2)
+        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        past_len = 0 if past_key_value is None else int(past_key_value[-1])
+        if position_ids is None:
+            position_ids = torch.arange(past_len, past_len + q_len, device=hidden_states.device)[None].expand(bsz, -1)
+        q, k = self._rope(q, k, position_ids)
+
+        if past_key_value is not None:
+            if isinstance(past_key_value, KiviCacheTuple):
+                layer = past_key_value.layer
+            else:  # a plain reference-style tuple: adopt it once
+                layer = KiviLayerCache.from_tuple(self.kivi, past_key_value, self._capacity(past_len + 1))
+            attn_output = kivi_attention_decode(q, k, v, layer, attention_mask)
+        else:
+            layer = KiviLayerCache(self.kivi, bsz, self.num_key_value_heads, self.head_dim, self._capacity(q_len),
+                                   hidden_states.device, q.dtype)
+            attn_output = kivi_attention_prefill(q, k, v, layer)
+        past = layer.as_tuple() if use_cache else None                                     # :454-455
+        attn_output = attn_output.transpose(1, 2).reshape(bsz, q_len, self.num_heads * self.head_dim)
+        return self.o_proj(attn_output), None, past
+
+    def _capacity(self, needed: int) -> int:
+        return max(needed, getattr(self.config, "kivi_max_cache_len", self.max_position_embeddings))
+
+
+# The reference has an eager and a flash class with identical cache logic; both names resolve here.
+LlamaFlashAttention_KIVI = LlamaAttention_KIVI

@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "_build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []

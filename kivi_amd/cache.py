@@ -1,0 +1,213 @@
+"""Per-layer KIVI KV-cache state: the reference's 9-tuple, held in pre-allocated buffers.
+
+Reference contract (models/llama_kivi.py:454-455, read back at :315-322):
+    (K_code_T, K_full, K_scale_T, K_mn_T, V_code, V_full, V_scale, V_mn, kv_seq_len)
+      K_code_T (B, nh_kv, D, Tq/fpi) int32     K_scale_T, K_mn_T (B, nh_kv, D, Tq/g) fp16
+      K_full   (B, nh_kv, 0..R-1, D) fp16 or None
+      V_code   (B, nh_kv, Tv, D/fpi) int32     V_scale, V_mn (B, nh_kv, Tv, D/g) fp16
+      V_full   (B, nh_kv, <=R, D) fp16
+The reference grows every member with torch.cat -- packed V + scale + mn are re-copied EVERY step
+(llama_kivi.py:393-395), packed K every R steps (:350-352).  Here the same tensors are views of
+capacity-sized buffers that are appended in place, so a decode step moves only the new token(s).
+`as_tuple()` hands out the 9-tuple (views, same shapes/dtypes as the reference's) for callers that
+index it the reference way (`past[0][-1]` is the running kv length, :698, :916).
+
+Cache policy (llama_kivi.py:343-356, 386-399, 425-452):
+  K: residual grows; when it holds exactly R tokens all R are quantised at once (per channel, groups of g tokens).
+  V: sliding fp16 window of R tokens; when it holds R+1 the OLDEST token is quantised (per token, groups of g channels).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .quant import new_pack
+
+
+class KiviCacheTuple(tuple):
+    """The reference's 9-tuple, plus a back-pointer to the in-place buffers that own the views."""
+    layer: "KiviLayerCache"
+
+    def __new__(cls, items, layer):
+        t = super().__new__(cls, items)
+        t.layer = layer
+        return t
+
+
+@dataclass
+class KiviConfig:
+    k_bits: int = 2
+    v_bits: int = 2
+    group_size: int = 32
+    residual_length: int = 32
+
+    def __post_init__(self):
+        assert self.k_bits in (2, 4) and self.v_bits in (2, 4), "the fused GEMV supports 2 and 4 bits (matmul.py:215)"
+        assert self.residual_length % self.group_size == 0  # llama_kivi.py:344
+
+
+class KiviLayerCache:
+    """One layer's quantised KV cache with capacity `max_len` tokens, appended in place."""
+
+    def __init__(self, cfg: KiviConfig, batch: int, num_kv_heads: int, head_dim: int, max_len: int,
+                 device, dtype=torch.float16):
+        assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
+        self.cfg = cfg
+        R, g = cfg.residual_length, cfg.group_size
+        self.B, self.nh_kv, self.D = batch, num_kv_heads, head_dim
+        assert head_dim % g == 0 and head_dim % (32 // cfg.v_bits) == 0
+        self.cap = ((max_len + R - 1) // R) * R
+        kf, vf = 32 // cfg.k_bits, 32 // cfg.v_bits
+        dev = device
+        self.k_code = torch.empty((batch, num_kv_heads, head_dim, self.cap // kf), dtype=torch.int32, device=dev)
+        self.k_scale = torch.empty((batch, num_kv_heads, head_dim, self.cap // g), dtype=dtype, device=dev)
+        self.k_mn = torch.empty_like(self.k_scale)
+        self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=dev)
+        self.v_code = torch.empty((batch, num_kv_heads, self.cap, head_dim // vf), dtype=torch.int32, device=dev)
+        self.v_scale = torch.empty((batch, num_kv_heads, self.cap, head_dim // g), dtype=dtype, device=dev)
+        self.v_mn = torch.empty_like(self.v_scale)
+        # fp16 V window: R (+1 transient) live tokens inside a 2R+1 buffer, compacted every R steps
+        self.v_res = torch.empty((batch, num_kv_heads, 2 * R + 1, head_dim), dtype=dtype, device=dev)
+        self.k_quant_len = 0   # tokens in the packed K prefix (multiple of R)
+        self.k_res_len = 0     # tokens in the fp16 K residual (< R between steps)
+        self.v_quant_len = 0   # tokens in the packed V prefix
+        self.v_res_start = 0
+        self.v_res_len = 0     # tokens in the fp16 V window (<= R between steps)
+        self.kv_seq_len = 0
+
+    # ------------------------------------------------------------------ views (the 9-tuple)
+    def k_quant_views(self):
+        if self.k_quant_len == 0:
+            return None, None, None
+        kf, g = 32 // self.cfg.k_bits, self.cfg.group_size
+        return (self.k_code[..., : self.k_quant_len // kf], self.k_scale[..., : self.k_quant_len // g],
+                self.k_mn[..., : self.k_quant_len // g])
+
+    def v_quant_views(self):
+        if self.v_quant_len == 0:
+            return None, None, None
+        n = self.v_quant_len
+        return self.v_code[:, :, :n], self.v_scale[:, :, :n], self.v_mn[:, :, :n]
+
+    def k_res_view(self) -> Optional[torch.Tensor]:
+        return self.k_res[:, :, : self.k_res_len] if self.k_res_len else None
+
+    def v_res_view(self) -> torch.Tensor:
+        return self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len]
+
+    def as_tuple(self) -> KiviCacheTuple:
+        kc, ks, km = self.k_quant_views()
+        vc, vs, vm = self.v_quant_views()
+        return KiviCacheTuple((kc, self.k_res_view(), ks, km, vc, self.v_res_view(), vs, vm, self.kv_seq_len), self)
+
+    def nbytes(self) -> int:
+        """Resident cache bytes (capacity-independent: what the 9-tuple's tensors span)."""
+        t = self.as_tuple()
+        return sum(x.numel() * x.element_size() for x in t[:8] if x is not None)
+
+    def allocated_bytes(self) -> int:
+        return sum(x.numel() * x.element_size() for x in (self.k_code, self.k_scale, self.k_mn, self.k_res, self.v_code,
+                                                          self.v_scale, self.v_mn, self.v_res))
+
+    # ------------------------------------------------------------------ prefill (llama_kivi.py:425-452)
+    def prefill(self, key_states: torch.Tensor, value_states: torch.Tensor) -> None:
+        """key/value_states (B, nh_kv, T, D) fp16 (any strides with a contiguous last dim)."""
+        cfg = self.cfg
+        R, g = cfg.residual_length, cfg.group_size
+        T = key_states.shape[2]
+        assert T <= self.cap, f"prompt of {T} tokens exceeds the cache capacity {self.cap}"
+        nq = (T // R) * R                      # quantised K prefix, fp16 remainder T % R
+        if nq:
+            new_pack.quantize_and_pack_k_tmajor(key_states[:, :, :nq], g, cfg.k_bits,
+                                                out=(self.k_code, self.k_scale, self.k_mn), token_offset=0)
+        self.k_quant_len = nq
+        self.k_res_len = T - nq
+        if self.k_res_len:
+            self.k_res[:, :, : self.k_res_len].copy_(key_states[:, :, nq:])
+        nv = max(T - R, 0)                     # quantised V prefix, last min(T, R) tokens stay fp16
+        if nv:
+            code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(value_states[:, :, :nv].contiguous(), g,
+                                                                                cfg.v_bits)
+            self.v_code[:, :, :nv].copy_(code)
+            self.v_scale[:, :, :nv].copy_(scale)
+            self.v_mn[:, :, :nv].copy_(mn)
+        self.v_quant_len = nv
+        self.v_res_start = 0
+        self.v_res_len = T - nv
+        self.v_res[:, :, : self.v_res_len].copy_(value_states[:, :, nv:])
+        self.kv_seq_len = T
+
+    # ------------------------------------------------------------------ decode-step mutations
+    def append_k(self, key_states: torch.Tensor) -> None:
+        """llama_kivi.py:333-336: K residual += the new token (B, nh_kv, 1, D)."""
+        assert key_states.shape[2] == 1
+        assert self.k_quant_len + self.k_res_len + 1 <= self.cap, "cache capacity exceeded"
+        self.k_res[:, :, self.k_res_len: self.k_res_len + 1].copy_(key_states)
+        self.k_res_len += 1
+
+    def maybe_flush_k(self) -> None:
+        """llama_kivi.py:343-356: when the residual holds exactly R tokens, quantise all of them in place."""
+        R = self.cfg.residual_length
+        if self.k_res_len == R:
+            new_pack.quantize_and_pack_k_tmajor(self.k_res, self.cfg.group_size, self.cfg.k_bits,
+                                                out=(self.k_code, self.k_scale, self.k_mn),
+                                                token_offset=self.k_quant_len)
+            self.k_quant_len += R
+            self.k_res_len = 0
+
+    def append_v(self, value_states: torch.Tensor) -> None:
+        """llama_kivi.py:377: V window += the new token."""
+        assert value_states.shape[2] == 1
+        R = self.cfg.residual_length
+        if self.v_res_start + self.v_res_len + 1 > self.v_res.shape[2]:
+            live = self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len].clone()
+            self.v_res[:, :, : self.v_res_len].copy_(live)
+            self.v_res_start = 0
+        pos = self.v_res_start + self.v_res_len
+        self.v_res[:, :, pos: pos + 1].copy_(value_states)
+        self.v_res_len += 1
+        assert self.v_res_len <= R + 1
+
+    def maybe_flush_v(self) -> None:
+        """llama_kivi.py:386-399: when the window holds R+1 tokens, quantise the oldest one in place."""
+        R, g = self.cfg.residual_length, self.cfg.group_size
+        if self.v_res_len > R:
+            assert self.v_res_len == R + 1 and self.v_quant_len + 1 <= self.cap
+            oldest = self.v_res[:, :, self.v_res_start: self.v_res_start + 1]
+            code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(oldest.contiguous(), g, self.cfg.v_bits)
+            n = self.v_quant_len
+            self.v_code[:, :, n: n + 1].copy_(code)
+            self.v_scale[:, :, n: n + 1].copy_(scale)
+            self.v_mn[:, :, n: n + 1].copy_(mn)
+            self.v_quant_len += 1
+            self.v_res_start += 1
+            self.v_res_len -= 1
+
+    # ------------------------------------------------------------------ import of a plain reference tuple
+    @classmethod
+    def from_tuple(cls, cfg: KiviConfig, past, max_len: int) -> "KiviLayerCache":
+        """Adopt a plain 9-tuple produced elsewhere (copies it into capacity buffers once)."""
+        kc, kfull, ks, km, vc, vfull, vs, vm, kv_len = past
+        ref = vfull if vfull is not None else kfull
+        B, nh_kv, _, D = ref.shape
+        self = cls(cfg, B, nh_kv, D, max_len, ref.device, ref.dtype)
+        kf = 32 // cfg.k_bits
+        if kc is not None:
+            self.k_quant_len = kc.shape[-1] * kf
+            self.k_code[..., : kc.shape[-1]].copy_(kc)
+            self.k_scale[..., : ks.shape[-1]].copy_(ks)
+            self.k_mn[..., : km.shape[-1]].copy_(km)
+        if kfull is not None:
+            self.k_res_len = kfull.shape[2]
+            self.k_res[:, :, : self.k_res_len].copy_(kfull)
+        if vc is not None:
+            self.v_quant_len = vc.shape[2]
+            self.v_code[:, :, : self.v_quant_len].copy_(vc)
+            self.v_scale[:, :, : self.v_quant_len].copy_(vs)
+            self.v_mn[:, :, : self.v_quant_len].copy_(vm)
+        self.v_res_len = vfull.shape[2]
+        self.v_res[:, :, : self.v_res_len].copy_(vfull)
+        self.kv_seq_len = int(kv_len)
+        return self

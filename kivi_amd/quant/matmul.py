@@ -15,6 +15,10 @@ __all__ = ["cuda_bmm_fA_qB_outer", "triton_bmm_fA_qB_outer", "bmm_variants", "bm
 
 _V_DIMS = {2: (64, 128, 256), 4: (32, 64, 128, 256)}
 
+# Optional instrumentation (bench.py): called as hook("pre"|"post", kind, info) around each launch on the
+# launch stream.  None in normal use.
+launch_hook = None
+
 
 def _prep(group_size, fA, qB, scales, zeros, bits):
     assert len(fA.shape) == 4 and len(qB.shape) == 4
@@ -47,9 +51,13 @@ def _prep(group_size, fA, qB, scales, zeros, bits):
     return fA, qB, scales, zeros, B, nh, nh_kv, K, N
 
 
-def _run(group_size, fA, qB, scales, zeros, bits, variant=None):
+def _run(group_size, fA, qB, scales, zeros, bits, variant=None, out=None):
     fA, qB, scales, zeros, B, nh, nh_kv, K, N = _prep(group_size, fA, qB, scales, zeros, bits)
-    out = torch.empty((B, nh, 1, N), dtype=torch.float16, device=fA.device)
+    if out is None:
+        out = torch.empty((B, nh, 1, N), dtype=torch.float16, device=fA.device)
+    else:
+        # in-place destination, e.g. the [..., :Tq] slice of a scores buffer (replaces the reference's torch.cat, :339)
+        assert out.shape == (B, nh, 1, N) and out.dtype == torch.float16 and out.stride(3) == 1 and out.is_cuda
     lib = _lib.load()
     common = (_lib.ptr(fA), fA.stride(0), fA.stride(1),
               _lib.ptr(qB), qB.stride(0), qB.stride(1), qB.stride(2),
@@ -64,23 +72,30 @@ def _run(group_size, fA, qB, scales, zeros, bits, variant=None):
         vid = -1
     else:
         kind, vid = variant
+    hook = launch_hook
+    if hook is not None:
+        info = dict(B=B, nh=nh, nh_kv=nh_kv, K=K, N=N, bits=bits, group_size=group_size)
+        hook("pre", kind, info)
     if kind == "k":
         _lib.check(lib.kivi_gemv_k_variant(vid, *common, B, nh, nh_kv, K, N, group_size, bits, stream), "kivi_gemv_k")
     else:
         _lib.check(lib.kivi_gemv_v_variant(vid, *common, B, nh, nh_kv, K, N, group_size, bits, stream), "kivi_gemv_v")
+    if hook is not None:
+        hook("post", kind, info)
     return out
 
 
 def cuda_bmm_fA_qB_outer(group_size: int, fA: torch.Tensor, qB: torch.Tensor, scales: torch.Tensor,
-                         zeros: torch.Tensor, bits: int) -> torch.Tensor:
+                         zeros: torch.Tensor, bits: int, out: torch.Tensor = None) -> torch.Tensor:
     """C = fA x dequant(qB) with groups along the OUTER (packed) dim (reference matmul.py:178-219).
 
     fA (B, nh, 1, K) fp16, qB (B, nh_kv, K, N // fpi) int32, scales / zeros (B, nh_kv, K, N // group_size) fp16
     -> (B, nh, 1, N) fp16.  C[b,h,0,n] = sum_k fA[b,h,0,k] * (scales[b,hk,k,n//g] * code[b,hk,k,n] + zeros[b,hk,k,n//g]),
     hk = h // (nh // nh_kv); fp32 arithmetic, one rounding to fp16.
-    fA may be a last-dim-contiguous slice (llama_kivi.py:382); no copy is made.
+    fA may be a last-dim-contiguous slice (llama_kivi.py:382); no copy is made.  `out` (optional, not in the
+    reference signature) is a pre-allocated (B, nh, 1, N) destination view.
     """
-    return _run(group_size, fA, qB, scales, zeros, bits)
+    return _run(group_size, fA, qB, scales, zeros, bits, out=out)
 
 
 def triton_bmm_fA_qB_outer(group_size: int, fA: torch.Tensor, qB: torch.Tensor, scales: torch.Tensor,
