@@ -158,21 +158,20 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # ---- HIP events around every qK^T launch of the timed region, on the launch stream (torch's current stream)
+    # ---- HIP events on every qK^T dispatch of the timed region: the library launches the kernel with
+    # hipExtLaunchKernelGGL(start, stop) on torch's current stream, so the pair brackets exactly that dispatch
+    # (what rocprofv3 reports as the kernel duration).
+    from kivi_amd import _lib
+    klib = _lib.load()
     kev = []
 
     def hook(phase, kind, info):
-        if kind != "k":
+        if kind != "k" or phase != "pre":
             return
-        if phase == "pre":
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            kev.append([e0, None, kgemv_bytes(info["B"], info["nh"], info["nh_kv"], info["K"], info["N"],
-                                              info["group_size"], info["bits"])])
-        else:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            kev[-1][1] = e1
+        e0, e1 = klib.kivi_event_create(), klib.kivi_event_create()
+        klib.kivi_set_launch_events(e0, e1)
+        kev.append((e0, e1, kgemv_bytes(info["B"], info["nh"], info["nh_kv"], info["K"], info["N"], info["group_size"],
+                                        info["bits"])))
 
     if not args.no_kernel_events:
         matmul.launch_hook = hook
@@ -193,7 +192,7 @@ def main():
     if rank == 0:
         roof = None
         if kev:
-            us = [a.elapsed_time(b) * 1e3 for a, b, _ in kev]
+            us = [klib.kivi_event_elapsed_us(a, b) for a, b, _ in kev]
             tot_bytes = sum(n for _, _, n in kev)
             avg_us = sum(us) / len(us)
             achieved = tot_bytes / (sum(us) * 1e-6) / 1e9

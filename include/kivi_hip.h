@@ -104,6 +104,21 @@ int kivi_gemv_k(const void* q, int64_t q_sb, int64_t q_sh, const void* code, int
                 int group_size, int bits, kivi_stream_t stream);
 
 /*
+ * Same product over PAGED per-channel K storage (what an in-place, appendable cache needs: with the plain
+ * (B, nh_kv, D, capacity) layout every channel row is strided by the capacity and HBM efficiency collapses,
+ * see DESIGN.md).  A page holds `page_tokens` tokens of all D channels as its own contiguous block:
+ *   code  (B, nh_kv, P, D, page_tokens/fpi)   strides code_sb, code_sh, code_sp (page), code_sr (channel row)
+ *   scale (B, nh_kv, P, D, page_tokens/g)     strides sm_sb,   sm_sh,   sm_sp,          sm_sr
+ * Token t lives in page t / page_tokens.  `variant` = -1 picks the default kernel.  No reference twin: the
+ * reference re-allocates the whole packed K with torch.cat instead (models/llama_kivi.py:350-352).
+ */
+int kivi_gemv_k_paged(int variant, int64_t page_tokens, int64_t code_sp, int64_t sm_sp, const void* q, int64_t q_sb,
+                      int64_t q_sh, const void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
+                      const void* scale, const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out,
+                      int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
+                      int bits, kivi_stream_t stream);
+
+/*
  * sV over the packed per-token V cache:
  *   out[b, h, d] = fp16( sum_t a[b,h,t] * (scale[b,hk,t,d/g] * code[b,hk,t,d] + mn[b,hk,t,d/g]) )
  * Replaces the same reference chain at the call site models/llama_kivi.py:382
@@ -145,6 +160,14 @@ int kivi_gemv_v_variant(int variant, const void* a, int64_t a_sb, int64_t a_sh, 
                         int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
                         int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
                         int nh_kv, int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream);
+
+/* Per-dispatch timing: the NEXT fused-GEMV launch issued by this thread stamps `start` / `stop` (hipEvent_t
+ * from kivi_event_create) with the dispatch's own begin / end (hipExtLaunchKernelGGL), i.e. what a profiler
+ * reports as the kernel duration.  kivi_event_elapsed_us synchronises on `stop`. */
+void* kivi_event_create(void);
+void kivi_event_destroy(void* event);
+void kivi_set_launch_events(void* start, void* stop);
+float kivi_event_elapsed_us(void* start, void* stop);
 
 #ifdef __cplusplus
 }

@@ -34,12 +34,17 @@ SIGNATURES = {
     "kivi_gemv_k": (_i32, _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "kivi_gemv_v": (_i32, _GEMV_ARGS + [_i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "kivi_gemv_outer_dim": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "kivi_gemv_k_paged": (_i32, [_i32, _i64, _i64, _i64] + _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),
     "kivi_gemv_k_variant": (_i32, [_i32] + _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "kivi_gemv_v_num_variants": (_i32, []),
     "kivi_gemv_v_variant_name": (ctypes.c_char_p, [_i32]),
     "kivi_gemv_v_variant": (_i32, [_i32] + _GEMV_ARGS + [_i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_event_create": (_vp, []),
+    "kivi_event_destroy": (None, [_vp]),
+    "kivi_set_launch_events": (None, [_vp, _vp]),
+    "kivi_event_elapsed_us": (ctypes.c_float, [_vp, _vp]),
 }
 
 _lib = None

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .cache import KiviCacheTuple, KiviConfig, KiviLayerCache
-from .quant.matmul import cuda_bmm_fA_qB_outer
+from .quant.matmul import cuda_bmm_fA_qB_outer, gemv_k_paged
 
 __all__ = ["kivi_attention_decode", "kivi_attention_prefill", "LlamaAttention_KIVI", "LlamaFlashAttention_KIVI",
            "KiviConfig", "KiviLayerCache"]
@@ -52,9 +52,8 @@ def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, 
     Tq = layer.k_quant_len
     layer.append_k(key_states)                                           # :333-336
     scores = _scores_buffer(layer, nh, kv_seq_len)
-    if Tq:
-        kc, ks, km = layer.k_quant_views()
-        cuda_bmm_fA_qB_outer(g, query_states, kc, ks, km, cfg.k_bits, out=scores[..., :Tq])   # :324
+    if Tq:   # :324, reading the K pages in place and writing straight into the scores buffer
+        gemv_k_paged(g, query_states, layer.k_code, layer.k_scale, layer.k_mn, Tq, cfg.k_bits, out=scores[..., :Tq])
     k_full = layer.k_res_view()                                          # (B, nh_kv, L, D)
     att_qkfull = torch.matmul(query_states.reshape(B, nh_kv, rep, D), k_full.transpose(2, 3))  # :337 (repeat_kv folded)
     scores[..., Tq:].copy_(att_qkfull.view(B, nh, 1, -1))

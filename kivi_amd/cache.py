@@ -1,4 +1,4 @@
-"""Per-layer KIVI KV-cache state: the reference's 9-tuple, held in pre-allocated buffers.
+"""Per-layer KIVI KV-cache state: the reference's 9-tuple, held in pre-allocated, in-place-appended buffers.
 
 Reference contract (models/llama_kivi.py:454-455, read back at :315-322):
     (K_code_T, K_full, K_scale_T, K_mn_T, V_code, V_full, V_scale, V_mn, kv_seq_len)
@@ -7,10 +7,15 @@ Reference contract (models/llama_kivi.py:454-455, read back at :315-322):
       V_code   (B, nh_kv, Tv, D/fpi) int32     V_scale, V_mn (B, nh_kv, Tv, D/g) fp16
       V_full   (B, nh_kv, <=R, D) fp16
 The reference grows every member with torch.cat -- packed V + scale + mn are re-copied EVERY step
-(llama_kivi.py:393-395), packed K every R steps (:350-352).  Here the same tensors are views of
-capacity-sized buffers that are appended in place, so a decode step moves only the new token(s).
-`as_tuple()` hands out the 9-tuple (views, same shapes/dtypes as the reference's) for callers that
-index it the reference way (`past[0][-1]` is the running kv length, :698, :916).
+(llama_kivi.py:393-395), packed K every R steps (:350-352).  Here a decode step moves only the new token(s):
+
+  * V (per token) is stored exactly in the reference layout with spare rows at the end; appending a token
+    writes one row and the 9-tuple members are plain views.
+  * K (per channel) cannot be appended in the reference layout without striding every channel row by the
+    capacity, which costs ~35 % of HBM efficiency on MI355X (profiles/).  It is stored in PAGES of
+    `page_tokens` tokens, each page a contiguous (D, page_tokens/fpi) block = the reference layout of that token
+    range; the fused GEMV reads pages directly (kivi_gemv_k_paged).  The reference-layout K members of the
+    9-tuple are materialised (one copy) only if somebody actually indexes them.
 
 Cache policy (llama_kivi.py:343-356, 386-399, 425-452):
   K: residual grows; when it holds exactly R tokens all R are quantised at once (per channel, groups of g tokens).
@@ -25,15 +30,31 @@ import torch
 
 from .quant import new_pack
 
+PAGE_TOKENS = 2048   # = the tile of the default qK^T kernels (64 lanes x 2 words x 16 codes; 4-bit: 4 words x 8)
+
 
 class KiviCacheTuple(tuple):
-    """The reference's 9-tuple, plus a back-pointer to the in-place buffers that own the views."""
-    layer: "KiviLayerCache"
+    """The reference's 9-tuple.  `t[-1]` / `t[8]` (running kv length, what HF's generate loop reads,
+    llama_kivi.py:698, :916) is free; tensor members are built from the live cache on first access."""
 
-    def __new__(cls, items, layer):
-        t = super().__new__(cls, items)
+    def __new__(cls, layer: "KiviLayerCache"):
+        t = super().__new__(cls, (None,) * 8 + (layer.kv_seq_len,))
         t.layer = layer
+        t._items = None
         return t
+
+    def _materialise(self):
+        if self._items is None:
+            self._items = self.layer._tuple_members() + (tuple.__getitem__(self, 8),)
+        return self._items
+
+    def __getitem__(self, i):
+        if isinstance(i, int) and i in (8, -1):
+            return tuple.__getitem__(self, 8)
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
 
 
 @dataclass
@@ -52,17 +73,21 @@ class KiviLayerCache:
     """One layer's quantised KV cache with capacity `max_len` tokens, appended in place."""
 
     def __init__(self, cfg: KiviConfig, batch: int, num_kv_heads: int, head_dim: int, max_len: int,
-                 device, dtype=torch.float16):
+                 device, dtype=torch.float16, page_tokens: int = PAGE_TOKENS):
         assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
         self.cfg = cfg
         R, g = cfg.residual_length, cfg.group_size
         self.B, self.nh_kv, self.D = batch, num_kv_heads, head_dim
         assert head_dim % g == 0 and head_dim % (32 // cfg.v_bits) == 0
+        assert page_tokens % R == 0 and page_tokens % g == 0, "a K flush of R tokens must not straddle pages"
+        self.page_tokens = page_tokens
         self.cap = ((max_len + R - 1) // R) * R
+        self.n_pages = (self.cap + page_tokens - 1) // page_tokens
         kf, vf = 32 // cfg.k_bits, 32 // cfg.v_bits
         dev = device
-        self.k_code = torch.empty((batch, num_kv_heads, head_dim, self.cap // kf), dtype=torch.int32, device=dev)
-        self.k_scale = torch.empty((batch, num_kv_heads, head_dim, self.cap // g), dtype=dtype, device=dev)
+        self.k_code = torch.empty((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // kf), dtype=torch.int32,
+                                  device=dev)
+        self.k_scale = torch.empty((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // g), dtype=dtype, device=dev)
         self.k_mn = torch.empty_like(self.k_scale)
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=dev)
         self.v_code = torch.empty((batch, num_kv_heads, self.cap, head_dim // vf), dtype=torch.int32, device=dev)
@@ -77,13 +102,19 @@ class KiviLayerCache:
         self.v_res_len = 0     # tokens in the fp16 V window (<= R between steps)
         self.kv_seq_len = 0
 
-    # ------------------------------------------------------------------ views (the 9-tuple)
-    def k_quant_views(self):
+    # ------------------------------------------------------------------ the 9-tuple
+    def k_quant_reference_layout(self):
+        """(K_code_T, K_scale_T, K_mn_T) in the reference layout (B, nh_kv, D, Tq/...): gathers the pages (a copy)."""
         if self.k_quant_len == 0:
             return None, None, None
         kf, g = 32 // self.cfg.k_bits, self.cfg.group_size
-        return (self.k_code[..., : self.k_quant_len // kf], self.k_scale[..., : self.k_quant_len // g],
-                self.k_mn[..., : self.k_quant_len // g])
+        npg = (self.k_quant_len + self.page_tokens - 1) // self.page_tokens
+        B, h, D = self.B, self.nh_kv, self.D
+
+        def gather(x, per_tok):
+            y = x[:, :, :npg].permute(0, 1, 3, 2, 4).reshape(B, h, D, -1)
+            return y[..., : self.k_quant_len // per_tok].contiguous()
+        return gather(self.k_code, kf), gather(self.k_scale, g), gather(self.k_mn, g)
 
     def v_quant_views(self):
         if self.v_quant_len == 0:
@@ -97,19 +128,41 @@ class KiviLayerCache:
     def v_res_view(self) -> torch.Tensor:
         return self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len]
 
-    def as_tuple(self) -> KiviCacheTuple:
-        kc, ks, km = self.k_quant_views()
+    def _tuple_members(self):
+        kc, ks, km = self.k_quant_reference_layout()
         vc, vs, vm = self.v_quant_views()
-        return KiviCacheTuple((kc, self.k_res_view(), ks, km, vc, self.v_res_view(), vs, vm, self.kv_seq_len), self)
+        return (kc, self.k_res_view(), ks, km, vc, self.v_res_view(), vs, vm)
+
+    def as_tuple(self) -> KiviCacheTuple:
+        return KiviCacheTuple(self)
 
     def nbytes(self) -> int:
-        """Resident cache bytes (capacity-independent: what the 9-tuple's tensors span)."""
-        t = self.as_tuple()
-        return sum(x.numel() * x.element_size() for x in t[:8] if x is not None)
+        """Resident cache bytes = what the reference's 9-tuple tensors would hold for the same state."""
+        c = self.cfg
+        per_k = self.D * self.k_quant_len * c.k_bits // 8 + 2 * self.D * (self.k_quant_len // c.group_size) * 2
+        per_v = self.v_quant_len * self.D * c.v_bits // 8 + 2 * self.v_quant_len * (self.D // c.group_size) * 2
+        res = (self.k_res_len + self.v_res_len) * self.D * 2
+        return self.B * self.nh_kv * (per_k + per_v + res)
 
     def allocated_bytes(self) -> int:
         return sum(x.numel() * x.element_size() for x in (self.k_code, self.k_scale, self.k_mn, self.k_res, self.v_code,
                                                           self.v_scale, self.v_mn, self.v_res))
+
+    # ------------------------------------------------------------------ K pages
+    def _k_page(self, p: int):
+        return self.k_code[:, :, p], self.k_scale[:, :, p], self.k_mn[:, :, p]
+
+    def _quantise_k(self, key_states: torch.Tensor, t0: int) -> None:
+        """Quantise tokens key_states (B, nh_kv, n, D), n % g == 0, into the packed prefix starting at token t0."""
+        P, g = self.page_tokens, self.cfg.group_size
+        n = key_states.shape[2]
+        done = 0
+        while done < n:
+            p, off = divmod(t0 + done, P)
+            take = min(n - done, P - off)
+            new_pack.quantize_and_pack_k_tmajor(key_states[:, :, done: done + take], g, self.cfg.k_bits,
+                                                out=self._k_page(p), token_offset=off)
+            done += take
 
     # ------------------------------------------------------------------ prefill (llama_kivi.py:425-452)
     def prefill(self, key_states: torch.Tensor, value_states: torch.Tensor) -> None:
@@ -120,8 +173,7 @@ class KiviLayerCache:
         assert T <= self.cap, f"prompt of {T} tokens exceeds the cache capacity {self.cap}"
         nq = (T // R) * R                      # quantised K prefix, fp16 remainder T % R
         if nq:
-            new_pack.quantize_and_pack_k_tmajor(key_states[:, :, :nq], g, cfg.k_bits,
-                                                out=(self.k_code, self.k_scale, self.k_mn), token_offset=0)
+            self._quantise_k(key_states[:, :, :nq], 0)
         self.k_quant_len = nq
         self.k_res_len = T - nq
         if self.k_res_len:
@@ -151,9 +203,7 @@ class KiviLayerCache:
         """llama_kivi.py:343-356: when the residual holds exactly R tokens, quantise all of them in place."""
         R = self.cfg.residual_length
         if self.k_res_len == R:
-            new_pack.quantize_and_pack_k_tmajor(self.k_res, self.cfg.group_size, self.cfg.k_bits,
-                                                out=(self.k_code, self.k_scale, self.k_mn),
-                                                token_offset=self.k_quant_len)
+            self._quantise_k(self.k_res, self.k_quant_len)
             self.k_quant_len += R
             self.k_res_len = 0
 
@@ -188,17 +238,19 @@ class KiviLayerCache:
     # ------------------------------------------------------------------ import of a plain reference tuple
     @classmethod
     def from_tuple(cls, cfg: KiviConfig, past, max_len: int) -> "KiviLayerCache":
-        """Adopt a plain 9-tuple produced elsewhere (copies it into capacity buffers once)."""
+        """Adopt a plain 9-tuple produced elsewhere (copies it into the in-place buffers once)."""
         kc, kfull, ks, km, vc, vfull, vs, vm, kv_len = past
         ref = vfull if vfull is not None else kfull
         B, nh_kv, _, D = ref.shape
         self = cls(cfg, B, nh_kv, D, max_len, ref.device, ref.dtype)
-        kf = 32 // cfg.k_bits
+        kf, g, P = 32 // cfg.k_bits, cfg.group_size, self.page_tokens
         if kc is not None:
             self.k_quant_len = kc.shape[-1] * kf
-            self.k_code[..., : kc.shape[-1]].copy_(kc)
-            self.k_scale[..., : ks.shape[-1]].copy_(ks)
-            self.k_mn[..., : km.shape[-1]].copy_(km)
+            for p in range((self.k_quant_len + P - 1) // P):
+                n = min(P, self.k_quant_len - p * P)
+                self.k_code[:, :, p, :, : n // kf].copy_(kc[..., p * P // kf: (p * P + n) // kf])
+                self.k_scale[:, :, p, :, : n // g].copy_(ks[..., p * P // g: (p * P + n) // g])
+                self.k_mn[:, :, p, :, : n // g].copy_(km[..., p * P // g: (p * P + n) // g])
         if kfull is not None:
             self.k_res_len = kfull.shape[2]
             self.k_res[:, :, : self.k_res_len].copy_(kfull)

@@ -15,3 +15,32 @@ void kivi_set_error(const char* fmt, ...) {
 
 extern "C" int kivi_abi_version(void) { return KIVI_ABI_VERSION; }
 extern "C" const char* kivi_last_error(void) { return g_err; }
+
+// ---- per-dispatch timing events (instrumentation for bench.py / tools; not on the drop-in surface)
+static thread_local KiviLaunchEvents g_events = {nullptr, nullptr};
+
+KiviLaunchEvents kivi_take_launch_events() {
+    KiviLaunchEvents e = g_events;
+    g_events.start = nullptr;
+    g_events.stop = nullptr;
+    return e;
+}
+
+extern "C" void* kivi_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+extern "C" void kivi_event_destroy(void* e) {
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+extern "C" void kivi_set_launch_events(void* start, void* stop) {
+    g_events.start = (hipEvent_t)start;
+    g_events.stop = (hipEvent_t)stop;
+}
+extern "C" float kivi_event_elapsed_us(void* start, void* stop) {
+    float ms = -1.0f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
+    return ms * 1000.0f;
+}

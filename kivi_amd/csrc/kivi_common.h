@@ -1,5 +1,6 @@
 // Shared device helpers for the KIVI gfx950 kernels (wave64, CDNA4 only).
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,6 +33,22 @@ static inline int kivi_launch_status(const char* what) {
     }
     return 0;
 }
+
+// ---- launch with optional per-dispatch timing events (kivi_set_launch_events, bench instrumentation):
+// hipExtLaunchKernelGGL stamps the events with the dispatch's own begin / end, like a profiler does.
+struct KiviLaunchEvents {
+    hipEvent_t start, stop;
+};
+KiviLaunchEvents kivi_take_launch_events();
+
+#define KIVI_LAUNCH(kernel, grid, block, stream, ...)                                                    \
+    do {                                                                                                 \
+        KiviLaunchEvents ev__ = kivi_take_launch_events();                                               \
+        if (ev__.start || ev__.stop)                                                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev__.start, ev__.stop, 0, __VA_ARGS__); \
+        else                                                                                             \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                             \
+    } while (0)
 
 // ---- device helpers -------------------------------------------------------
 template <typename T, bool NT>
@@ -79,20 +96,57 @@ __device__ __forceinline__ float fma_mix_hi(uint32_t m, float b, float c) {
     return d;
 }
 
+// f32(half `qhi` of the SGPR pair-word `q`) * f32(half `vhi` of v) [+ c]: exact fp16 x fp16 product
+// (22 significand bits) in one VOP3P instruction, no separate conversions.  `qhi` / `vhi` must fold to
+// constants at the call site (they select the asm string).
+__device__ __forceinline__ float mul_hh_s(uint32_t q, bool qhi, uint32_t v, bool vhi) {
+    float d;
+    if (!qhi && !vhi) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v));
+    else if (qhi && !vhi) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v));
+    else if (!qhi && vhi) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v));
+    return d;
+}
+__device__ __forceinline__ float fma_hh_s(uint32_t q, bool qhi, uint32_t v, bool vhi, float c) {
+    float d;
+    if (!qhi && !vhi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v), "v"(c));
+    else if (qhi && !vhi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v), "v"(c));
+    else if (!qhi && vhi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(v), "v"(c));
+    return d;
+}
+// same with a per-lane (VGPR) half operand
+__device__ __forceinline__ float mul_hh_vv(uint32_t a_lo, uint32_t v, bool hi) {
+    float d;
+    if (hi) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a_lo), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a_lo), "v"(v));
+    return d;
+}
+__device__ __forceinline__ float fma_hh_vv(uint32_t a_lo, uint32_t v, float c, bool hi) {
+    float d;
+    if (hi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a_lo), "v"(v), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a_lo), "v"(v), "v"(c));
+    return d;
+}
+
 // Unpack strategies for the fused GEMV inner loop (see DESIGN.md "VALU budget").
 enum : int {
     KIVI_UNPACK_BFE = 0,    // v_bfe_u32 + v_cvt_f32_u32 + v_fma_f32            (3 op / code)
     KIVI_UNPACK_UBYTE = 1,  // byte-plane mask + v_cvt_f32_ubyteN + v_fma_f32    (2.25 op / code)
     KIVI_UNPACK_MIX = 2,    // half-plane mask + v_fma_mix_f32 on fp16 subnormals (1.56 op / code)
+    KIVI_UNPACK_NONE = 3,   // DIAGNOSTIC ONLY (wrong results): one xor per word, shows the memory-side ceiling
+    KIVI_UNPACK_DEN32 = 4,  // in-place mask read as an fp32 SUBNORMAL + v_fmac_f32 (two 2-cycle ops / code)
 };
 
 // Accumulate one packed word `w` (FPI = 32/BITS codes) into acc[FPI]:
 //   acc[p] += code_p * POSTINV[p] * qs          (POSTINV = power of two, undone by post_scale)
-// qs must be pre-multiplied by 2^24 in MIX mode (qs_factor()).
+// qs must carry qs_factor<MODE>().
 template <int BITS, int MODE>
 __device__ __forceinline__ void accum_word(uint32_t w, float qs, float* acc) {
     constexpr int FPI = 32 / BITS;
-    if constexpr (MODE == KIVI_UNPACK_BFE) {
+    if constexpr (MODE == KIVI_UNPACK_NONE) {
+        acc[0] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, acc[0]) ^ w) & 0x3FFFFFFFu) + qs;
+    } else if constexpr (MODE == KIVI_UNPACK_BFE) {
 #pragma unroll
         for (int p = 0; p < FPI; p++) {
             float c = (float)((w >> (BITS * p)) & ((1u << BITS) - 1u));
@@ -109,6 +163,22 @@ __device__ __forceinline__ void accum_word(uint32_t w, float qs, float* acc) {
                 float c = (float)((mb >> (8 * b)) & 0xFFu);  // v_cvt_f32_ubyte{b}: code * 2^(BITS*k)
                 acc[b * PER_BYTE + k] = __builtin_fmaf(c, qs, acc[b * PER_BYTE + k]);
             }
+        }
+    } else if constexpr (MODE == KIVI_UNPACK_DEN32) {
+        // fp32 mantissa = bits 0..22: 11 two-bit (5 four-bit) fields readable in place as subnormals
+        constexpr int INPLACE = (BITS == 2) ? 11 : 5;
+        constexpr int SHIFT = (BITS == 2) ? 10 : 12;
+        constexpr uint32_t M0 = (1u << BITS) - 1u;
+#pragma unroll
+        for (int p = 0; p < INPLACE; p++) {
+            const float c = __builtin_bit_cast(float, w & (M0 << (BITS * p)));
+            acc[p] = __builtin_fmaf(c, qs, acc[p]);
+        }
+        const uint32_t ws = w >> SHIFT;
+#pragma unroll
+        for (int p = INPLACE; p < FPI; p++) {
+            const float c = __builtin_bit_cast(float, ws & (M0 << (BITS * p - SHIFT)));
+            acc[p] = __builtin_fmaf(c, qs, acc[p]);
         }
     } else {
         // fp16 mantissa = bits 0..9 of each half: 5 two-bit fields (or 2 four-bit fields) are
@@ -139,24 +209,32 @@ __device__ __forceinline__ void accum_word(uint32_t w, float qs, float* acc) {
 template <int BITS, int MODE>
 __device__ __forceinline__ constexpr float post_scale(int p) {
     constexpr int FPI = 32 / BITS;
-    if constexpr (MODE == KIVI_UNPACK_BFE) {
+    if constexpr (MODE == KIVI_UNPACK_BFE || MODE == KIVI_UNPACK_NONE) {
         return 1.0f;
     } else if constexpr (MODE == KIVI_UNPACK_UBYTE) {
         constexpr int PER_BYTE = 8 / BITS;
         int k = p % PER_BYTE;
         return 1.0f / (float)(1u << (BITS * k));
+    } else if constexpr (MODE == KIVI_UNPACK_DEN32) {
+        // value read = code * 2^(bit position) * 2^-149, qs carries 2^100 (qs_factor): undo 2^-49 * 2^pos
+        constexpr int INPLACE = (BITS == 2) ? 11 : 5;
+        constexpr int SHIFT = (BITS == 2) ? 10 : 12;
+        const int pos = (p < INPLACE) ? BITS * p : BITS * p - SHIFT;
+        return 562949953421312.0f / (float)(1u << pos);  // 2^49 / 2^pos
     } else {
+        // value read = code * 2^(bit position in the half) * 2^-24 (fp16 subnormal): undo both
         constexpr int HALF = FPI / 2;
         constexpr int INPLACE = (BITS == 2) ? 5 : 2;
         constexpr int K0 = (BITS == 2) ? 2 : 0;
         int k = p % HALF;
         int field = (k < INPLACE) ? k : (k - INPLACE + K0);
-        return 1.0f / (float)(1u << (BITS * field));
+        return 16777216.0f / (float)(1u << (BITS * field));
     }
 }
 
-// qs pre-factor: MIX reads masked codes as fp16 subnormals (x 2^-24).
+// qs pre-factor.  MIX needs none (products of an fp16 subnormal and qs stay normal in fp32; the 2^24 is
+// undone in post_scale).  DEN32 reads fp32 subnormals (x 2^-149): qs carries 2^100 so products stay normal.
 template <int MODE>
 __device__ __forceinline__ constexpr float qs_factor() {
-    return MODE == KIVI_UNPACK_MIX ? 16777216.0f : 1.0f;
+    return MODE == KIVI_UNPACK_DEN32 ? 1.2676506002282294e30f : 1.0f;
 }

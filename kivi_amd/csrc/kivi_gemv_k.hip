@@ -33,7 +33,10 @@ struct GemvKArgs {
     int64_t T, Tw;
     int units_per_b;   // nh / R
     int tile_blocks;   // blocks per (b, head unit)
-    uint32_t code_extent, sm_extent;  // bytes spanned by one (b, kv head) slab
+    // paged K storage (kivi_gemv_k_paged): a page = page_tokens tokens of every channel, stored as its own
+    // contiguous (D, page_tokens/fpi) block.  page_words == 0: plain hook-state layout (one "page").
+    int64_t page_words, page_groups;   // words / quant groups of one channel row inside a page
+    int64_t code_sp, sm_sp;            // page strides
 };
 
 template <int N> struct WordVec;
@@ -47,7 +50,7 @@ __device__ __forceinline__ uint32_t vec_get(const V& v, int j) {
     else return v[j];
 }
 
-constexpr int KQ_MAXD = 256;
+constexpr int KQ_MAXD = 1 << 20;  // head_dim bound of the tuned kernels (q is read row by row)
 
 template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
 __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
@@ -63,7 +66,6 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
     typedef typename WordVec<WPL>::type WV;
     typedef typename std::conditional<NGL == 1, uint16_t, uint32_t>::type SV;
 
-    __shared__ float q_lds[R][KQ_MAXD];
     // cross-wave exchange: every wave keeps 1/DSPLIT of its accumulators and hands the rest over
     __shared__ float red[DSPLIT > 1 ? 4 * (DSPLIT - 1) * R * Q * 64 : 1];
 
@@ -79,28 +81,33 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
     const int tib = wave / DSPLIT;                    // tile index inside the block
     const int dpart = wave % DSPLIT;
 
-    // stage q (R heads x D) as fp32 in LDS: uniform-address reads in the row loop
-    for (int i = threadIdx.x; i < R * a.D; i += 256) {
-        int r = i / a.D, d = i - r * a.D;
-        q_lds[r][d] = h2f_bits(a.q[b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + d]);
-    }
-    __syncthreads();
-
-    const int64_t word0 = ((int64_t)tile * 64 + lane) * WPL;
+    constexpr int TILE_W = 64 * WPL;                  // words of one channel row covered by a wave
+    const int64_t tile_w0 = (int64_t)tile * TILE_W;    // first word (global token order) of the tile
+    const int64_t word0 = tile_w0 + lane * WPL;
     const bool valid = word0 < a.Tw;
-    const int64_t g0 = (word0 * FPI) / G;
+    // where the tile's first word lives: page index + word offset inside the page row
+    const int64_t page = a.page_words ? tile_w0 / a.page_words : 0;
+    const int64_t win = a.page_words ? tile_w0 - page * a.page_words : tile_w0;
+    const int64_t left = a.Tw - tile_w0;               // words of the row that exist from here on
+    const uint32_t tile_words = (uint32_t)(left < TILE_W ? (left > 0 ? left : 0) : TILE_W);
 
     const int DP = (a.D + DSPLIT - 1) / DSPLIT;
     const int d0 = dpart * DP;
     const int d1 = (d0 + DP < a.D) ? d0 + DP : a.D;
+    const int nrows = d1 - d0;
 
     // wave-uniform buffer descriptors over this (b, kv head) slab; per-row scalar offsets,
     // 32-bit per-lane byte offsets.  Lanes past the row end are masked by `valid`.
-    const rsrc_t rc = make_rsrc(a.code + b * a.code_sb + hk * a.code_sh, a.code_extent);
-    const rsrc_t rs = make_rsrc(a.scale + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
-    const rsrc_t rm = make_rsrc(a.mn + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
-    const uint32_t coff = (uint32_t)(word0 * 4);
-    const uint32_t soff = (uint32_t)(g0 * 2);
+    // descriptors start at the tile's first word of channel 0 and span its D rows
+    const uint32_t tile_groups = (tile_words * FPI + G - 1) / G;
+    const uint32_t c_ext = (uint32_t)(((int64_t)(a.D - 1) * a.code_sr + tile_words) * 4);
+    const uint32_t s_ext = (uint32_t)(((int64_t)(a.D - 1) * a.sm_sr + tile_groups) * 2);
+    const int64_t sm_base = b * a.sm_sb + hk * a.sm_sh + page * a.sm_sp + (win * FPI) / G;
+    const rsrc_t rc = make_rsrc(a.code + b * a.code_sb + hk * a.code_sh + page * a.code_sp + win, c_ext);
+    const rsrc_t rs = make_rsrc(a.scale + sm_base, s_ext);
+    const rsrc_t rm = make_rsrc(a.mn + sm_base, s_ext);
+    const uint32_t coff = (uint32_t)(lane * WPL * 4);
+    const uint32_t soff = (uint32_t)(((lane * WPL * FPI) / G) * 2);
     const uint32_t cstep = (uint32_t)(a.code_sr * 4), sstep = (uint32_t)(a.sm_sr * 2);
 
     float acc[R][NACC];
@@ -113,25 +120,29 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
         for (int g = 0; g < NGL; g++) zacc[r][g] = 0.f;
     }
 
-    auto row = [&](int d, const WV& w, SV sraw, SV mraw) {
-        float scf[NGL], mz[NGL];
-        if constexpr (NGL == 1) {
-            scf[0] = h2f_bits(sraw) * qs_factor<MODE>();
-            mz[0] = h2f_bits(mraw);
-        } else {
-            scf[0] = h2f_bits((uint16_t)(sraw & 0xFFFFu)) * qs_factor<MODE>();
-            scf[1] = h2f_bits((uint16_t)(sraw >> 16)) * qs_factor<MODE>();
-            mz[0] = h2f_bits((uint16_t)(mraw & 0xFFFFu));
-            mz[1] = h2f_bits((uint16_t)(mraw >> 16));
-        }
+    // q is wave-uniform per row: it is read with SCALAR loads, two channels (one dword) at a time, and
+    // enters the arithmetic as an SGPR fp16 operand of v_fma_mix_f32 -- no LDS, no block barrier, no VGPRs.
+    const uint32_t* qrow[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        qrow[r] = (const uint32_t*)(a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh);   // 4-byte aligned (k_variant_fits)
+
+    // channel d: w = packed codes, sraw/mraw = raw fp16 scale / zero-point bits; `odd` = d & 1 (folds to a
+    // constant in the unrolled batches)
+    auto row = [&](int d, bool odd, const WV& w, SV sraw, SV mraw) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float qd = q_lds[r][d];
+            const uint32_t qb = qrow[r][d >> 1];                 // s_load_dword: fp16 pair (q[d & ~1], q[d | 1])
             float qs[NGL];
+            qs[0] = mul_hh_s(qb, odd, (uint32_t)sraw, false);
+            zacc[r][0] = fma_hh_s(qb, odd, (uint32_t)mraw, false, zacc[r][0]);
+            if constexpr (NGL == 2) {
+                qs[1] = mul_hh_s(qb, odd, (uint32_t)sraw, true);
+                zacc[r][1] = fma_hh_s(qb, odd, (uint32_t)mraw, true, zacc[r][1]);
+            }
+            if constexpr (qs_factor<MODE>() != 1.0f) {
 #pragma unroll
-            for (int g = 0; g < NGL; g++) {
-                qs[g] = qd * scf[g];
-                zacc[r][g] = __builtin_fmaf(qd, mz[g], zacc[r][g]);
+                for (int g = 0; g < NGL; g++) qs[g] *= qs_factor<MODE>();
             }
 #pragma unroll
             for (int j = 0; j < WPL; j++) {
@@ -140,40 +151,41 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
             }
         }
     };
-    // batch `bi` = rows d0 + bi*U .. +U-1
-    auto load_batch = [&](int bi, WV* wb, SV* sb, SV* mb) {
-        const uint32_t dr = (uint32_t)(d0 + bi * U);
+    // batch = U consecutive channels starting at `dr` (even: d0 and U are even)
+    auto load_batch = [&](int dr, WV* wb, SV* sb, SV* mb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            wb[u] = buf_load<WV, NT>(rc, coff, (dr + u) * cstep);
-            sb[u] = buf_load<SV, NT>(rs, soff, (dr + u) * sstep);
-            mb[u] = buf_load<SV, NT>(rm, soff, (dr + u) * sstep);
+            wb[u] = buf_load<WV, NT>(rc, coff, (uint32_t)(dr + u) * cstep);
+            sb[u] = buf_load<SV, NT>(rs, soff, (uint32_t)(dr + u) * sstep);
+            mb[u] = buf_load<SV, NT>(rm, soff, (uint32_t)(dr + u) * sstep);
         }
     };
-    auto compute_batch = [&](int bi, const WV* wb, const SV* sb, const SV* mb) {
+    auto compute_batch = [&](int dr, const WV* wb, const SV* sb, const SV* mb) {
 #pragma unroll
-        for (int u = 0; u < U; u++) row(d0 + bi * U + u, wb[u], sb[u], mb[u]);
+        for (int u = 0; u < U; u++) row(dr + u, (u & 1) != 0, wb[u], sb[u], mb[u]);
     };
+    static_assert(U % 2 == 0, "batches start on even channels");
 
     if (valid) {
         // ping-pong register buffers: batch n+1 is in flight while batch n is consumed
         WV wA[U], wB[U];
         SV sA[U], sB[U], mA[U], mB[U];
-        const int nfull = (d1 - d0) / U;
-        if (nfull > 0) load_batch(0, wA, sA, mA);
+        const int nfull = nrows / U;
+        if (nfull > 0) load_batch(d0, wA, sA, mA);
         int it = 0;
         for (; it + 2 <= nfull; it += 2) {
-            load_batch(it + 1, wB, sB, mB);
-            compute_batch(it, wA, sA, mA);
-            if (it + 2 < nfull) load_batch(it + 2, wA, sA, mA);
-            compute_batch(it + 1, wB, sB, mB);
+            load_batch(d0 + (it + 1) * U, wB, sB, mB);
+            compute_batch(d0 + it * U, wA, sA, mA);
+            if (it + 2 < nfull) load_batch(d0 + (it + 2) * U, wA, sA, mA);
+            compute_batch(d0 + (it + 1) * U, wB, sB, mB);
         }
-        if (it < nfull) compute_batch(it, wA, sA, mA);
-        for (int d = d0 + nfull * U; d < d1; d++) {  // channel tail (D/DSPLIT not a multiple of U)
+        if (it < nfull) compute_batch(d0 + it * U, wA, sA, mA);
+        for (int d = d0 + nfull * U; d < d1; d++) {   // channel tail (rows per wave not a multiple of U)
             WV w = buf_load<WV, NT>(rc, coff, (uint32_t)d * cstep);
             SV sv = buf_load<SV, NT>(rs, soff, (uint32_t)d * sstep);
             SV mv = buf_load<SV, NT>(rm, soff, (uint32_t)d * sstep);
-            row(d, w, sv, mv);
+            if (d & 1) row(d, true, w, sv, mv);
+            else row(d, false, w, sv, mv);
         }
     }
 
@@ -263,10 +275,12 @@ __global__ __launch_bounds__(256) void gemv_k_generic(const GemvKArgs a, int G) 
     const int b = bh / a.nh, h = bh - b * a.nh;
     const int hk = h / a.ratio;
     if (w >= a.Tw) return;
-    const int64_t g = (w * FPI) / G;
-    const uint32_t* cp = a.code + b * a.code_sb + hk * a.code_sh + w;
-    const uint16_t* sp = a.scale + b * a.sm_sb + hk * a.sm_sh + g;
-    const uint16_t* mp = a.mn + b * a.sm_sb + hk * a.sm_sh + g;
+    const int64_t page = a.page_words ? w / a.page_words : 0;
+    const int64_t win = a.page_words ? w - page * a.page_words : w;
+    const int64_t g = (win * FPI) / G;
+    const uint32_t* cp = a.code + b * a.code_sb + hk * a.code_sh + page * a.code_sp + win;
+    const uint16_t* sp = a.scale + b * a.sm_sb + hk * a.sm_sh + page * a.sm_sp + g;
+    const uint16_t* mp = a.mn + b * a.sm_sb + hk * a.sm_sh + page * a.sm_sp + g;
     const uint16_t* qp = a.q + b * a.q_sb + (int64_t)h * a.q_sh;
     float acc[FPI];
 #pragma unroll
@@ -289,7 +303,7 @@ typedef void (*KLaunch)(const GemvKArgs&, dim3, hipStream_t);
 
 template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
 void launch_k(const GemvKArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((gemv_k_kernel<BITS, G, WPL, DSPLIT, R, U, MODE, NT>), grid, dim3(256), 0, s, a);
+    KIVI_LAUNCH((gemv_k_kernel<BITS, G, WPL, DSPLIT, R, U, MODE, NT>), grid, dim3(256), s, a);
 }
 
 struct KVariant {
@@ -303,7 +317,8 @@ struct KVariant {
      MODE, NT, launch_k<BITS, G, WPL, DS, R, U, MODE, (NT != 0)>}
 
 const KVariant k_variants[] = {
-    // ---- 2-bit, g=32, MHA: the north-star shape.  First entry = default.
+    // ---- 2-bit, g=32, MHA: the north-star shape.  Table order = dispatch preference (measured, profiles/).
+    KV(2, 32, 2, 4, 1, 4, 2, 1),
     KV(2, 32, 4, 2, 1, 4, 2, 0),
     KV(2, 32, 4, 2, 1, 4, 2, 1),
     KV(2, 32, 4, 2, 1, 8, 2, 0),
@@ -315,7 +330,6 @@ const KVariant k_variants[] = {
     KV(2, 32, 4, 4, 1, 4, 2, 0),
     KV(2, 32, 4, 4, 1, 8, 2, 1),
     KV(2, 32, 2, 4, 1, 4, 2, 0),
-    KV(2, 32, 2, 4, 1, 4, 2, 1),
     KV(2, 32, 2, 4, 1, 8, 2, 0),
     KV(2, 32, 2, 4, 1, 8, 2, 1),
     KV(2, 32, 2, 2, 1, 8, 2, 0),
@@ -323,42 +337,71 @@ const KVariant k_variants[] = {
     KV(2, 32, 2, 1, 1, 8, 2, 0),
     KV(2, 32, 2, 1, 1, 8, 2, 1),
     KV(2, 32, 2, 1, 1, 16, 2, 1),
+    KV(2, 32, 2, 4, 1, 2, 2, 1),
+    KV(2, 32, 2, 4, 1, 4, 4, 1),
+    KV(2, 32, 2, 4, 1, 2, 4, 1),
+    KV(2, 32, 4, 4, 1, 2, 2, 1),
+    KV(2, 32, 4, 2, 1, 2, 2, 1),
+    KV(2, 32, 4, 2, 1, 4, 4, 1),
+    KV(2, 32, 2, 2, 1, 4, 2, 1),
     // unpack-strategy A/B on two geometries
     KV(2, 32, 4, 2, 1, 4, 0, 0),
     KV(2, 32, 4, 2, 1, 4, 1, 0),
     KV(2, 32, 2, 4, 1, 4, 0, 0),
     KV(2, 32, 2, 4, 1, 4, 1, 0),
+    // memory-side ceiling of each geometry (diagnostic, excluded from dispatch and parity tests)
+    KV(2, 32, 2, 4, 1, 4, 3, 1),
+    KV(2, 32, 2, 2, 1, 8, 3, 1),
+    KV(2, 32, 2, 1, 1, 8, 3, 1),
+    KV(2, 32, 4, 4, 1, 4, 3, 1),
+    KV(2, 32, 4, 2, 1, 4, 3, 1),
+    KV(2, 32, 4, 1, 1, 8, 3, 1),
     // ---- 2-bit, other group sizes
+    KV(2, 64, 2, 4, 1, 4, 2, 1),
     KV(2, 64, 4, 2, 1, 4, 2, 0),
-    KV(2, 64, 2, 4, 1, 4, 2, 0),
+    KV(2, 128, 2, 4, 1, 4, 2, 1),
     KV(2, 128, 4, 2, 1, 4, 2, 0),
-    KV(2, 128, 2, 4, 1, 4, 2, 0),
-    // ---- 4-bit
-    KV(4, 32, 4, 2, 1, 4, 2, 0),
-    KV(4, 32, 4, 4, 1, 4, 2, 0),
-    KV(4, 32, 2, 4, 1, 4, 2, 0),
-    KV(4, 64, 4, 2, 1, 4, 2, 0),
-    KV(4, 64, 2, 4, 1, 4, 2, 0),
-    KV(4, 128, 4, 2, 1, 4, 2, 0),
-    KV(4, 128, 2, 4, 1, 4, 2, 0),
+    // ---- 4-bit (fpi = 8: four words per lane give the same 32 tokens per lane as 2-bit w2)
+    KV(4, 32, 4, 4, 1, 4, 2, 1),
+    KV(4, 32, 2, 4, 1, 4, 2, 1),
+    KV(4, 32, 4, 2, 1, 4, 2, 1),
+    KV(4, 64, 4, 4, 1, 4, 2, 1),
+    KV(4, 64, 2, 4, 1, 4, 2, 1),
+    KV(4, 128, 4, 4, 1, 4, 2, 1),
+    KV(4, 128, 2, 4, 1, 4, 2, 1),
     KV(4, 32, 4, 2, 1, 4, 0, 0),
-    // ---- GQA: R query heads share every unpacked code (no channel split: R*TPL accumulators)
-    KV(2, 32, 2, 1, 4, 4, 2, 0),
-    KV(2, 32, 1, 1, 4, 8, 2, 0),
-    KV(2, 32, 1, 2, 4, 8, 2, 0),
-    KV(2, 32, 2, 1, 2, 4, 2, 0),
-    KV(2, 32, 1, 1, 8, 8, 2, 0),
-    KV(4, 32, 2, 1, 4, 4, 2, 0),
-    KV(2, 64, 2, 1, 4, 4, 2, 0),
-    KV(2, 128, 2, 1, 4, 4, 2, 0),
+    // ---- GQA: R query heads share every unpacked code (R*TPL accumulators per lane)
+    KV(2, 32, 1, 1, 4, 4, 2, 1),
+    KV(2, 32, 1, 2, 4, 4, 2, 1),
+    KV(2, 32, 2, 2, 2, 4, 2, 1),
+    KV(2, 32, 2, 4, 2, 4, 2, 1),
+    KV(2, 32, 1, 1, 8, 4, 2, 1),
+    KV(2, 32, 1, 1, 2, 8, 2, 1),
+    KV(4, 32, 2, 2, 4, 4, 2, 1),
+    KV(4, 32, 2, 2, 2, 4, 2, 1),
+    KV(2, 64, 1, 2, 4, 4, 2, 1),
+    KV(2, 128, 1, 2, 4, 4, 2, 1),
+    KV(2, 64, 2, 2, 2, 4, 2, 1),
 };
 constexpr int k_nvariants = sizeof(k_variants) / sizeof(k_variants[0]);
+
+int ngl_of(const KVariant& v, int bits, int G) {
+    const int tpl = v.wpl * (32 / bits);
+    return tpl >= G ? tpl / G : 1;
+}
 
 bool k_variant_fits(const KVariant& v, const GemvKArgs& a, int bits, int G) {
     if (v.bits != bits || v.G != G) return false;
     if (a.ratio % v.R != 0 && !(v.R == 1)) return false;
     if (a.D > KQ_MAXD) return false;
-    if (a.code_extent == 0 || a.sm_extent == 0) return false;  // slab too large for a buffer descriptor
+    // one tile's D rows must fit a 32-bit buffer descriptor
+    if ((int64_t)a.D * a.code_sr * 4 >= ((int64_t)1 << 31) || (int64_t)a.D * a.sm_sr * 2 >= ((int64_t)1 << 31)) return false;
+    if (a.page_words) {   // pages are whole tiles, aligned like rows
+        if (a.page_words % (64 * v.wpl)) return false;
+        if ((a.code_sp % v.wpl) || (a.sm_sp % ngl_of(v, bits, G))) return false;
+    }
+    // q is read as aligned fp16 pairs with scalar loads; every wave's channel range starts on an even channel
+    if ((a.D % (2 * v.dsplit)) || (a.q_sh % 2) || (a.q_sb % 2) || ((uintptr_t)a.q % 4)) return false;
     const int fpi = 32 / bits;
     const int tpl = v.wpl * fpi;
     const int ngl = tpl >= G ? tpl / G : 1;
@@ -393,7 +436,7 @@ int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream
     int best = -1;
     for (int i = 0; i < k_nvariants; i++) {
         const KVariant& v = k_variants[i];
-        if (v.mode != KIVI_UNPACK_MIX) continue;
+        if (v.mode != KIVI_UNPACK_MIX) continue;   // production unpack; the other modes are A/B references
         if (!k_variant_fits(v, a, bits, G)) continue;
         if (a.ratio % v.R) continue;
         if (best < 0 || v.R > k_variants[best].R) best = i;
@@ -427,10 +470,7 @@ int k_check_and_fill(GemvKArgs& a, const void* q, int64_t q_sb, int64_t q_sh, co
     a.out = (uint16_t*)out; a.out_sb = out_sb; a.out_sh = out_sh;
     a.nh = nh; a.ratio = nh / nh_kv; a.D = D; a.T = T; a.Tw = T / fpi;
     a.units_per_b = nh; a.tile_blocks = 1;
-    const int64_t ce = ((int64_t)(D - 1) * code_sr + a.Tw) * 4;
-    const int64_t se = ((int64_t)(D - 1) * sm_sr + T / group_size) * 2;
-    a.code_extent = (ce > 0 && ce < (int64_t)0xFFFFFFFFll) ? (uint32_t)ce : 0;
-    a.sm_extent = (se > 0 && se < (int64_t)0xFFFFFFFFll) ? (uint32_t)se : 0;
+    a.page_words = 0; a.page_groups = 0; a.code_sp = 0; a.sm_sp = 0;
     return 0;
 }
 
@@ -441,23 +481,52 @@ extern "C" const char* kivi_gemv_k_variant_name(int v) {
     return (v >= 0 && v < k_nvariants) ? k_variants[v].name : "";
 }
 
+static int k_entry(int variant, int64_t page_tokens, int64_t code_sp, int64_t sm_sp, const void* q, int64_t q_sb,
+                   int64_t q_sh, const void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
+                   const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb,
+                   int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size, int bits,
+                   kivi_stream_t stream) {
+    GemvKArgs a;
+    int rc = k_check_and_fill(a, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                              out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits);
+    if (rc) return rc;
+    if (page_tokens) {
+        const int fpi = 32 / bits;
+        KIVI_REQUIRE(page_tokens > 0 && page_tokens % group_size == 0 && page_tokens % fpi == 0, KIVI_EINVAL,
+                     "kivi_gemv_k_paged: page_tokens=%lld must be a multiple of group_size=%d", (long long)page_tokens,
+                     group_size);
+        a.page_words = page_tokens / fpi;
+        a.page_groups = page_tokens / group_size;
+        a.code_sp = code_sp;
+        a.sm_sp = sm_sp;
+    }
+    if (T == 0) return 0;
+    return k_run(variant, a, B, nh_kv, group_size, bits, (hipStream_t)stream);
+}
+
 extern "C" int kivi_gemv_k_variant(int variant, const void* q, int64_t q_sb, int64_t q_sh, const void* code,
                                    int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
                                    const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out,
                                    int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T,
                                    int group_size, int bits, kivi_stream_t stream) {
-    GemvKArgs a;
-    int rc = k_check_and_fill(a, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
-                              out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits);
-    if (rc) return rc;
-    if (T == 0) return 0;
-    return k_run(variant, a, B, nh_kv, group_size, bits, (hipStream_t)stream);
+    return k_entry(variant, 0, 0, 0, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                   out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits, stream);
 }
 
 extern "C" int kivi_gemv_k(const void* q, int64_t q_sb, int64_t q_sh, const void* code, int64_t code_sb,
                            int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
                            int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
                            int nh_kv, int D, int64_t T, int group_size, int bits, kivi_stream_t stream) {
-    return kivi_gemv_k_variant(-1, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr,
-                               out, out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits, stream);
+    return k_entry(-1, 0, 0, 0, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                   out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits, stream);
+}
+
+extern "C" int kivi_gemv_k_paged(int variant, int64_t page_tokens, int64_t code_sp, int64_t sm_sp, const void* q,
+                                 int64_t q_sb, int64_t q_sh, const void* code, int64_t code_sb, int64_t code_sh,
+                                 int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb, int64_t sm_sh,
+                                 int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv,
+                                 int D, int64_t T, int group_size, int bits, kivi_stream_t stream) {
+    KIVI_REQUIRE(page_tokens > 0, KIVI_EINVAL, "kivi_gemv_k_paged: page_tokens must be positive");
+    return k_entry(variant, page_tokens, code_sp, sm_sp, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb,
+                   sm_sh, sm_sr, out, out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits, stream);
 }

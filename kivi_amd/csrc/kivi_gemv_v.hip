@@ -87,24 +87,19 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     }
 
     auto tok = [&](const WV& w, SV sraw, SV mraw, const uint16_t* av) {
-        float scf[NGL], mz[NGL];
-        if constexpr (NGL == 1) {
-            scf[0] = h2f_bits(sraw) * qs_factor<MODE>();
-            mz[0] = h2f_bits(mraw);
-        } else {
-            scf[0] = h2f_bits((uint16_t)(sraw & 0xFFFFu)) * qs_factor<MODE>();
-            scf[1] = h2f_bits((uint16_t)(sraw >> 16)) * qs_factor<MODE>();
-            mz[0] = h2f_bits((uint16_t)(mraw & 0xFFFFu));
-            mz[1] = h2f_bits((uint16_t)(mraw >> 16));
-        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float ar = h2f_bits(av[r]);
+            const uint32_t ab = av[r];                      // fp16 bits of a[t] for this lane's token
             float as[NGL];
+            as[0] = mul_hh_vv(ab, (uint32_t)sraw, false);   // exact fp16 x fp16 product, one instruction
+            zacc[r][0] = fma_hh_vv(ab, (uint32_t)mraw, zacc[r][0], false);
+            if constexpr (NGL == 2) {
+                as[1] = mul_hh_vv(ab, (uint32_t)sraw, true);
+                zacc[r][1] = fma_hh_vv(ab, (uint32_t)mraw, zacc[r][1], true);
+            }
+            if constexpr (qs_factor<MODE>() != 1.0f) {
 #pragma unroll
-            for (int g = 0; g < NGL; g++) {
-                as[g] = ar * scf[g];
-                zacc[r][g] = __builtin_fmaf(ar, mz[g], zacc[r][g]);
+                for (int g = 0; g < NGL; g++) as[g] *= qs_factor<MODE>();
             }
 #pragma unroll
             for (int j = 0; j < WPL; j++) {
@@ -238,7 +233,7 @@ typedef void (*VLaunch)(const GemvVArgs&, dim3, hipStream_t);
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
 void launch_v(const GemvVArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT>), grid, dim3(256), 0, s, a);
+    KIVI_LAUNCH((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT>), grid, dim3(256), s, a);
 }
 
 struct VVariant {
@@ -252,7 +247,8 @@ struct VVariant {
      NT, launch_v<BITS, G, DW, WPL, R, U, MODE, (NT != 0)>}
 
 const VVariant v_variants[] = {
-    // ---- 2-bit, D=128 (DW=8), g=32, MHA: first entry = default
+    // ---- 2-bit, D=128 (DW=8), g=32, MHA: table order = dispatch preference (measured, profiles/)
+    VV(2, 32, 8, 2, 1, 4, 2, 1),
     VV(2, 32, 8, 4, 1, 2, 2, 0),
     VV(2, 32, 8, 4, 1, 2, 2, 1),
     VV(2, 32, 8, 4, 1, 4, 2, 0),
@@ -260,11 +256,16 @@ const VVariant v_variants[] = {
     VV(2, 32, 8, 4, 1, 1, 2, 0),
     VV(2, 32, 8, 4, 1, 1, 2, 1),
     VV(2, 32, 8, 2, 1, 4, 2, 0),
-    VV(2, 32, 8, 2, 1, 4, 2, 1),
     VV(2, 32, 8, 2, 1, 8, 2, 1),
     VV(2, 32, 8, 4, 1, 2, 0, 0),
     VV(2, 32, 8, 4, 1, 2, 1, 0),
+    VV(2, 32, 8, 4, 1, 2, 4, 1),
+    VV(2, 32, 8, 2, 1, 4, 4, 1),
+    VV(2, 32, 8, 4, 1, 2, 3, 1),   // diagnostic: memory-side ceiling
+    VV(2, 32, 8, 2, 1, 4, 3, 1),
     // other group sizes / head dims
+    VV(2, 64, 8, 2, 1, 4, 2, 1),
+    VV(2, 128, 8, 2, 1, 4, 2, 1),
     VV(2, 64, 8, 4, 1, 2, 2, 0),
     VV(2, 128, 8, 4, 1, 2, 2, 0),
     VV(2, 32, 4, 4, 1, 2, 2, 0),
@@ -273,11 +274,11 @@ const VVariant v_variants[] = {
     VV(2, 64, 16, 4, 1, 2, 2, 0),
     VV(2, 128, 16, 4, 1, 2, 2, 0),
     // ---- 4-bit (D=128 -> DW=16; D=64 -> DW=8)
-    VV(4, 32, 16, 4, 1, 4, 2, 0),
-    VV(4, 64, 16, 4, 1, 4, 2, 0),
-    VV(4, 128, 16, 4, 1, 4, 2, 0),
-    VV(4, 32, 8, 4, 1, 4, 2, 0),
-    VV(4, 64, 8, 4, 1, 4, 2, 0),
+    VV(4, 32, 16, 4, 1, 4, 2, 1),
+    VV(4, 64, 16, 4, 1, 4, 2, 1),
+    VV(4, 128, 16, 4, 1, 4, 2, 1),
+    VV(4, 32, 8, 4, 1, 4, 2, 1),
+    VV(4, 64, 8, 4, 1, 4, 2, 1),
     VV(4, 32, 16, 4, 1, 4, 0, 0),
     // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
     VV(2, 32, 8, 2, 4, 2, 2, 0),

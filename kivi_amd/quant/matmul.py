@@ -11,7 +11,7 @@ import torch
 
 from .. import _lib
 
-__all__ = ["cuda_bmm_fA_qB_outer", "triton_bmm_fA_qB_outer", "bmm_variants", "bmm_fA_qB_outer_variant"]
+__all__ = ["cuda_bmm_fA_qB_outer", "triton_bmm_fA_qB_outer", "gemv_k_paged", "bmm_variants", "bmm_fA_qB_outer_variant"]
 
 _V_DIMS = {2: (64, 128, 256), 4: (32, 64, 128, 256)}
 
@@ -105,12 +105,54 @@ def triton_bmm_fA_qB_outer(group_size: int, fA: torch.Tensor, qB: torch.Tensor, 
     return _run(group_size, fA, qB, scales, zeros, bits)
 
 
-def bmm_variants():
-    """[(kind, id, name)] of every compiled kernel variant (bench / parity sweeps)."""
+def gemv_k_paged(group_size: int, q: torch.Tensor, code_pages: torch.Tensor, scale_pages: torch.Tensor,
+                 mn_pages: torch.Tensor, T: int, bits: int, out: torch.Tensor = None, variant: int = -1) -> torch.Tensor:
+    """qK^T over PAGED per-channel K storage (kivi_amd.cache): code_pages (B, nh_kv, P, D, page_tokens // fpi) int32,
+    scale_pages / mn_pages (B, nh_kv, P, D, page_tokens // group_size) fp16, first T tokens valid.
+    Same arithmetic as cuda_bmm_fA_qB_outer on the equivalent (B, nh_kv, D, T // fpi) tensor."""
+    for t, n in ((q, "q"), (code_pages, "code_pages"), (scale_pages, "scale_pages"), (mn_pages, "mn_pages")):
+        _lib.require_gpu(t, n)
+    assert bits in [2, 4]
+    B, nh, M, D = q.shape
+    if M != 1:
+        raise NotImplementedError("fused GEMV supports q_len == 1 (decode) only, like the reference kernel")
+    nh_kv = code_pages.shape[1]
+    assert nh % nh_kv == 0
+    fpi = 32 // bits
+    page_tokens = code_pages.shape[4] * fpi
+    assert code_pages.dim() == 5 and code_pages.shape[3] == D and code_pages.stride(4) == 1
+    assert scale_pages.shape == mn_pages.shape and scale_pages.stride() == mn_pages.stride() and scale_pages.stride(4) == 1
+    assert scale_pages.shape[4] * group_size == page_tokens and T <= code_pages.shape[2] * page_tokens
+    if q.stride(3) != 1:
+        q = q.contiguous()
+    if out is None:
+        out = torch.empty((B, nh, 1, T), dtype=torch.float16, device=q.device)
+    else:
+        assert out.shape == (B, nh, 1, T) and out.dtype == torch.float16 and out.stride(3) == 1 and out.is_cuda
+    lib = _lib.load()
+    hook = launch_hook
+    if hook is not None:
+        info = dict(B=B, nh=nh, nh_kv=nh_kv, K=D, N=T, bits=bits, group_size=group_size)
+        hook("pre", "k", info)
+    _lib.check(lib.kivi_gemv_k_paged(
+        variant, page_tokens, code_pages.stride(2), scale_pages.stride(2),
+        _lib.ptr(q), q.stride(0), q.stride(1),
+        _lib.ptr(code_pages), code_pages.stride(0), code_pages.stride(1), code_pages.stride(3),
+        _lib.ptr(scale_pages), _lib.ptr(mn_pages), scale_pages.stride(0), scale_pages.stride(1), scale_pages.stride(3),
+        _lib.ptr(out), out.stride(0), out.stride(1), B, nh, nh_kv, D, T, group_size, bits, _lib.stream_ptr(q)),
+        "kivi_gemv_k_paged")
+    if hook is not None:
+        hook("post", "k", info)
+    return out
+
+
+def bmm_variants(include_diagnostic: bool = False):
+    """[(kind, id, name)] of every compiled kernel variant (bench / parity sweeps).  Variants named *_m3_* are
+    memory-ceiling diagnostics that skip the unpack (wrong results) and are hidden unless asked for."""
     lib = _lib.load()
     out = [("k", i, lib.kivi_gemv_k_variant_name(i).decode()) for i in range(lib.kivi_gemv_k_num_variants())]
     out += [("v", i, lib.kivi_gemv_v_variant_name(i).decode()) for i in range(lib.kivi_gemv_v_num_variants())]
-    return out
+    return [v for v in out if include_diagnostic or "_m3_" not in v[2]]
 
 
 def bmm_fA_qB_outer_variant(kind: str, vid: int, group_size, fA, qB, scales, zeros, bits):

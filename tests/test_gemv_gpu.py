@@ -41,7 +41,7 @@ def test_exact_fixtures_all_variants(mods, name, fx):
             continue  # variant compiled for another (bits, group, head_dim, ratio)
         assert same_bits(got, want), vname
         ran += 1
-    assert ran >= 2
+    assert ran >= 1
     # reference kernel-input layout through the kivi_gemv twin (matmul.py:205,213-214 transposes)
     B, nh, _, K = fA.shape
     nh_kv, fpi = qB.shape[1], 32 // bits
@@ -140,6 +140,45 @@ def test_sv_vs_oracle(mods, oracle, B, nh, nh_kv, Tv, D, g, bits):
             continue
         ok, ratio = gemv_close(gv, ref)
         assert ok, f"{vname}: worst error / bound = {ratio:.3f}"
+
+
+@pytest.mark.parametrize("B,nh,nh_kv,T,D,g,bits,page", [
+    (2, 4, 4, 4096, 128, 32, 2, 2048), (1, 2, 2, 4128, 128, 32, 2, 2048), (1, 8, 2, 2080, 128, 32, 2, 2048),
+    (1, 2, 2, 96, 128, 32, 2, 2048), (1, 2, 2, 3072, 128, 64, 4, 2048), (1, 2, 2, 5000 // 32 * 32, 128, 32, 2, 4096),
+    (1, 2, 2, 1056, 64, 32, 2, 1024),
+])
+def test_paged_k_matches_reference_layout(mods, oracle, B, nh, nh_kv, T, D, g, bits, page):
+    """kivi_gemv_k_paged on (B, nh_kv, P, D, page/fpi) pages == the same kernel on the reference (B, nh_kv, D, T/fpi)
+    layout (bit for bit), and both match the oracle."""
+    new_pack, matmul, _ = mods
+    fpi = 32 // bits
+    k = make_kv(61, B, nh_kv, T, D)
+    q = make_kv(62, B, nh, 1, D).cuda()
+    code_T, scale_T, mn_T = _pack_k(new_pack, k, g, bits)
+    P = (T + page - 1) // page
+    cp = torch.zeros((B, nh_kv, P, D, page // fpi), dtype=torch.int32, device="cuda")
+    sp = torch.full((B, nh_kv, P, D, page // g), float("nan"), dtype=torch.float16, device="cuda")  # poison the tail
+    mp = torch.full_like(sp, float("nan"))
+    for p in range(P):
+        n = min(page, T - p * page)
+        cp[:, :, p, :, : n // fpi] = code_T[..., p * page // fpi: (p * page + n) // fpi]
+        sp[:, :, p, :, : n // g] = scale_T[..., p * page // g: (p * page + n) // g]
+        mp[:, :, p, :, : n // g] = mn_T[..., p * page // g: (p * page + n) // g]
+    flat = matmul.cuda_bmm_fA_qB_outer(g, q, code_T, scale_T, mn_T, bits)
+    paged = matmul.gemv_k_paged(g, q, cp, sp, mp, T, bits)
+    ref = oracle.bmm_fA_qB_outer(g, q.cpu(), code_T.cpu(), scale_T.cpu(), mn_T.cpu(), bits)
+    ok, ratio = gemv_close(paged, ref)
+    assert ok, ratio
+    assert torch.isfinite(paged).all()
+    if page == 2048:   # same kernel variant on both layouts -> identical summation order
+        assert same_bits(paged, flat)
+    else:
+        ok, ratio = gemv_close(paged, flat.cpu())
+        assert ok, ratio
+    # in-place destination with a padded row pitch (the scores buffer of the hook)
+    buf = torch.zeros((B, nh, 1, ((T + 40) // 8) * 8), dtype=torch.float16, device="cuda")
+    matmul.gemv_k_paged(g, q, cp, sp, mp, T, bits, out=buf[..., :T])
+    assert same_bits(buf[..., :T], paged) and bool((buf[..., T:] == 0).all())
 
 
 def test_integer_inputs_like_reference_test(mods, oracle):

@@ -36,10 +36,11 @@ def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits):
         kn, vn = make_kv(200 + s, B, nh_kv, 1, D), make_kv(300 + s, B, nh_kv, 1, D)
         out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer)
         ref, past = H.decode_step(q, kn, vn, past, bits, bits, g, R)
-        ok, ratio = gemv_close(out, ref, rtol=2e-3)   # softmax + two fp16 partial sums on top of the GEMV bar
+        ok, ratio = gemv_close(out, ref, rtol=3e-3)   # fp32 softmax (GPU exp vs libm) + two fp16 partial sums on top of the GEMV bar
         assert ok, (s, ratio)
         _cmp_cache(layer.as_tuple(), past)             # cache contents are bit-identical at every step
     assert layer.nbytes() == sum(x.numel() * x.element_size() for x in past[:8] if x is not None)
+    assert layer.as_tuple()[-1] == past[8] and len(layer.as_tuple()) == 9
 
 
 def test_module_hook_prefill_then_decode():

@@ -32,6 +32,25 @@ def time_launches(fn, nbuf, iters, warm=3):
     return ts[len(ts) // 2], ts[0], ts[-1]
 
 
+def time_dispatches(fn, nbuf, iters, warm=3):
+    """Per-dispatch kernel durations (hipExtLaunchKernelGGL start/stop events): what rocprofv3 reports."""
+    from kivi_amd import _lib
+    lib = _lib.load()
+    for i in range(warm):
+        fn(i % nbuf)
+    torch.cuda.synchronize()
+    evs = [(lib.kivi_event_create(), lib.kivi_event_create()) for _ in range(iters)]
+    for i in range(iters):
+        lib.kivi_set_launch_events(evs[i][0], evs[i][1])
+        fn(i % nbuf)
+    torch.cuda.synchronize()
+    ts = sorted(lib.kivi_event_elapsed_us(a, b) for a, b in evs)
+    for a, b in evs:
+        lib.kivi_event_destroy(a)
+        lib.kivi_event_destroy(b)
+    return ts[len(ts) // 2], ts[0], ts[-1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=32)
@@ -41,10 +60,11 @@ def main():
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--g", type=int, default=32)
     ap.add_argument("--bits", type=int, default=2)
-    ap.add_argument("--nbuf", type=int, default=8)
+    ap.add_argument("--nbuf", type=int, default=24)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--skip_pack", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--kcap", type=int, default=0, help="allocate K buffers with this token capacity (row stride) > T")
     args = ap.parse_args()
     B, nh, nh_kv, T, D, g, bits = args.B, args.nh, args.nh_kv, args.T, args.D, args.g, args.bits
     fpi = 32 // bits
@@ -59,11 +79,26 @@ def main():
     k = torch.randn((B, nh_kv, T, D), device=dev, dtype=torch.float16)
     kc, ks, km = new_pack.quantize_and_pack_k_tmajor(k, g, bits)
     vc, vs, vm = new_pack.triton_quantize_and_pack_along_last_dim(k, g, bits)  # same tensor as V
+    if args.kcap:
+        cap = args.kcap
+        kc2 = torch.zeros((B, nh_kv, D, cap // fpi), device=dev, dtype=torch.int32)
+        ks2 = torch.zeros((B, nh_kv, D, cap // g), device=dev, dtype=torch.float16)
+        km2 = torch.zeros_like(ks2)
+        kc2[..., : T // fpi] = kc
+        ks2[..., : T // g] = ks
+        km2[..., : T // g] = km
+        kc, ks, km = kc2[..., : T // fpi], ks2[..., : T // g], km2[..., : T // g]
+        print("K row strides:", kc.stride(), ks.stride())
     Kbufs, Vbufs = [(kc, ks, km)], [(vc, vs, vm)]
     for i in range(1, args.nbuf):
-        c = torch.randint(-2**31, 2**31 - 1, kc.shape, device=dev, dtype=torch.int32)
-        s = (torch.rand(ks.shape, device=dev) + 0.5).half()
-        m = torch.randn(km.shape, device=dev).half()
+        if args.kcap:
+            c = torch.randint(-2**31, 2**31 - 1, (B, nh_kv, D, args.kcap // fpi), device=dev, dtype=torch.int32)[..., : T // fpi]
+            s = (torch.rand((B, nh_kv, D, args.kcap // g), device=dev) + 0.5).half()[..., : T // g]
+            m = torch.randn((B, nh_kv, D, args.kcap // g), device=dev).half()[..., : T // g]
+        else:
+            c = torch.randint(-2**31, 2**31 - 1, kc.shape, device=dev, dtype=torch.int32)
+            s = (torch.rand(ks.shape, device=dev) + 0.5).half()
+            m = torch.randn(km.shape, device=dev).half()
         Kbufs.append((c, s, m))
         c = torch.randint(-2**31, 2**31 - 1, vc.shape, device=dev, dtype=torch.int32)
         s = (torch.rand(vs.shape, device=dev) + 0.5).half()
@@ -87,7 +122,7 @@ def main():
     del src, dsts
 
     # ---- reference outputs from the generic-most variant for cross-checking
-    names = matmul.bmm_variants()
+    names = matmul.bmm_variants(include_diagnostic=True)
     ref_k = None
     ref_v = None
     for kind, vid, name in names:
@@ -108,16 +143,16 @@ def main():
                 ref_v = out0.float()
             ref = ref_v
         rms = ref.pow(2).mean(-1, keepdim=True).sqrt()
-        err = ((out0.float() - ref).abs() / torch.maximum(ref.abs(), rms)).max().item()
-        med, mn_, mx_ = time_launches(lambda i: matmul.bmm_fA_qB_outer_variant(kind, vid, g, x, *bufs[i], bits),
-                                      args.nbuf, args.iters)
+        err = ((out0.float() - ref).abs() / torch.maximum(ref.abs(), rms)).max().item() if "_m3_" not in name else -1.0
+        med, mn_, mx_ = time_dispatches(lambda i: matmul.bmm_fA_qB_outer_variant(kind, vid, g, x, *bufs[i], bits),
+                                        args.nbuf, args.iters)
         tbs = nbytes / med / 1e6
         print(f"{name:38s} median {med:8.1f} us  min {mn_:8.1f}  max {mx_:8.1f}  {tbs:6.2f} TB/s  "
               f"{100 * tbs / 8.0:5.1f}% of 8TB/s  relerr-vs-first {err:.2e}")
         res[key].append(dict(name=name, median_us=med, min_us=mn_, max_us=mx_, tbps=tbs, err_vs_first=err))
     # default dispatch
     for label, x, bufs, nbytes in (("default qK", q, Kbufs, kbytes), ("default sV", a, Vbufs, vbytes)):
-        med, mn_, mx_ = time_launches(lambda i: matmul.cuda_bmm_fA_qB_outer(g, x, *bufs[i], bits), args.nbuf, args.iters)
+        med, mn_, mx_ = time_dispatches(lambda i: matmul.cuda_bmm_fA_qB_outer(g, x, *bufs[i], bits), args.nbuf, args.iters)
         print(f"{label:38s} median {med:8.1f} us  min {mn_:8.1f}  {nbytes / med / 1e6:6.2f} TB/s")
         res[label.replace(" ", "_")] = dict(median_us=med, min_us=mn_, tbps=nbytes / med / 1e6)
 
