@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--group", type=int, default=32)
     ap.add_argument("--residual", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="reference-style composition (one launch per reference op)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the K-GEMV launches with HIP events")
     args = ap.parse_args()
 
@@ -153,7 +154,7 @@ def main():
 
     def step():
         for i in range(L):
-            kivi_attention_decode(qs[i], ks[i], vs[i], layers[i])
+            kivi_attention_decode(qs[i], ks[i], vs[i], layers[i], fused_kernels=not args.unfused)
 
     for _ in range(args.warmup):
         step()
@@ -218,6 +219,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
+                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (3, +1 every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
                        "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)"},

@@ -143,6 +143,37 @@ int kivi_gemv_outer_dim(const void* in, const void* kernel, const void* scale, c
                         int64_t BS, int64_t IC, int64_t OC, int bit, int group_size, int nh, int nh_kv,
                         kivi_stream_t stream);
 
+/* --------------------------------------------------- fused decode step --- */
+
+/*
+ * The three launches of one decode step of the attention hook (models/llama_kivi.py:314-399) for one layer.
+ * Together they replace ~20 kernels of the reference sequence with identical roundings:
+ *
+ * kivi_decode_scores: out[b,h,:T] = fused qK^T over the packed K pages (as kivi_gemv_k_paged) and
+ *   out[b,h,T:T+res_len+1] = q . k for the fp16 residual keys plus the new one (:333-337); also appends `knew`
+ *   to the residual buffer at index res_len (the torch.cat of :334).  `out` is the pre-scale score row (:339 cat).
+ * kivi_softmax_scaled: probs = softmax_fp32(fp16(scores * inv_scale) [+ mask, clamped at fp16 min]) -> fp16
+ *   (:339 division, :364-372 mask, :375 softmax).  rows = B*nh, row pitches in halves, mask (B,1,1,n) or NULL.
+ * kivi_decode_output: out[b,h,:] = fp16( fp16(fused sV over the packed V) + fp16(probs[..., Tv:] @ V_window) )
+ *   (:382-384; window = rows [win_start, win_start+res_len) of `vres` plus `vnew`), appends `vnew` to the window
+ *   (:377) and, if `flush`, quantises the oldest window row into cache row Tv (:386-399), bit-identical to
+ *   kivi_quant_pack_lastdim.  The caller advances its lengths afterwards.
+ * Return KIVI_EUNSUPPORTED when no tuned kernel covers the shape (callers then compose the unfused entry points).
+ */
+int kivi_decode_scores(int64_t page_tokens, int64_t code_sp, int64_t sm_sp, const void* q, int64_t q_sb, int64_t q_sh,
+                       const void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
+                       const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* kres, int64_t kres_sb,
+                       int64_t kres_sh, int64_t kres_st, const void* knew, int64_t knew_sb, int64_t knew_sh, int res_len,
+                       void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T,
+                       int group_size, int bits, kivi_stream_t stream);
+int kivi_softmax_scaled(const void* scores, void* probs, int64_t rows, int64_t n, int64_t s_pitch, int64_t p_pitch,
+                        float inv_scale, const void* mask, int64_t mask_sb, int nh, kivi_stream_t stream);
+int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb, int64_t code_sh,
+                       int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* vres,
+                       int64_t vres_sb, int64_t vres_sh, int64_t vres_st, int win_start, int res_len, const void* vnew,
+                       int64_t vnew_sb, int64_t vnew_sh, int flush, void* out, int64_t out_sb, int64_t out_sh, int B,
+                       int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream);
+
 /* ------------------------------------------------- tuning / bench hooks --- */
 
 /* Kernel variants of kivi_gemv_k (same arguments + variant id; -1 = the default heuristic).

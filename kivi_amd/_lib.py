@@ -35,6 +35,13 @@ SIGNATURES = {
     "kivi_gemv_v": (_i32, _GEMV_ARGS + [_i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "kivi_gemv_outer_dim": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "kivi_gemv_k_paged": (_i32, [_i32, _i64, _i64, _i64] + _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "kivi_decode_scores": (_i32, [_i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
+                                  _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64,
+                                  _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "kivi_softmax_scaled": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _vp, _i64, _i32, _vp]),
+    "kivi_decode_output": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
+                                  _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64,
+                                  _i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),
     "kivi_gemv_k_variant": (_i32, [_i32] + _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
@@ -51,7 +58,11 @@ _lib = None
 
 
 class KiviHipError(RuntimeError):
-    pass
+    rc = None
+
+
+class KiviUnsupported(KiviHipError):
+    """KIVI_EUNSUPPORTED: valid request, no tuned kernel for this shape (callers may compose the unfused ops)."""
 
 
 def load() -> ctypes.CDLL:
@@ -77,7 +88,9 @@ def load() -> ctypes.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().kivi_last_error().decode(errors="replace")
-        raise KiviHipError(f"{what} failed (rc={rc}): {msg}")
+        err = (KiviUnsupported if rc == -3 else KiviHipError)(f"{what} failed (rc={rc}): {msg}")
+        err.rc = rc
+        raise err
 
 
 def stream_ptr(t: torch.Tensor) -> ctypes.c_void_p:

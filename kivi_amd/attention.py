@@ -18,31 +18,72 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._lib import KiviUnsupported
 from .cache import KiviCacheTuple, KiviConfig, KiviLayerCache
+from .quant import fused
 from .quant.matmul import cuda_bmm_fA_qB_outer, gemv_k_paged
 
 __all__ = ["kivi_attention_decode", "kivi_attention_prefill", "LlamaAttention_KIVI", "LlamaFlashAttention_KIVI",
            "KiviConfig", "KiviLayerCache"]
 
 
-def _scores_buffer(layer: KiviLayerCache, nh: int, kv_len: int) -> torch.Tensor:
-    """(B, nh, 1, kv_len) view of a per-layer fp16 buffer whose row pitch is a multiple of 8 halves
+def _row_buffer(layer: KiviLayerCache, name: str, nh: int) -> torch.Tensor:
+    """(B, nh, 1, pitch) per-layer fp16 scratch row buffer, pitch = a multiple of 8 halves >= capacity + 1
     (16-byte stores of the fused GEMV)."""
     pitch = ((layer.cap + 1 + 7) // 8) * 8
-    buf = getattr(layer, "_scores", None)
+    buf = getattr(layer, name, None)
     if buf is None or buf.shape[1] != nh:
         buf = torch.empty((layer.B, nh, 1, pitch), dtype=torch.float16, device=layer.k_code.device)
-        layer._scores = buf
-    return buf[..., :kv_len]
+        setattr(layer, name, buf)
+    return buf
+
+
+def _scores_buffer(layer: KiviLayerCache, nh: int, kv_len: int) -> torch.Tensor:
+    return _row_buffer(layer, "_scores", nh)[..., :kv_len]
+
+
+def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask) -> torch.Tensor:
+    """The decode step in three launches (+1 when the K residual fills up): same arithmetic and roundings as the
+    composed path below.  Raises KiviUnsupported when no tuned kernel covers the shape."""
+    cfg = layer.cfg
+    B, nh, _, D = query_states.shape
+    kv_seq_len = layer.kv_seq_len + 1
+    scores = _row_buffer(layer, "_scores", nh)
+    probs = _row_buffer(layer, "_probs", nh)
+    if attention_mask is not None and attention_mask.size() != (B, 1, 1, kv_seq_len):
+        raise ValueError(f"Attention mask should be of size {(B, 1, 1, kv_seq_len)}, but is {attention_mask.size()}")
+    assert layer.k_quant_len + layer.k_res_len + 1 <= layer.cap, "cache capacity exceeded"
+    fused.decode_scores(layer, query_states, key_states, scores)          # :323-337 (+ the K append of :333-336)
+    layer.k_res_len += 1
+    fused.softmax_scaled(scores, probs, kv_seq_len, 1.0 / math.sqrt(D), attention_mask)   # :339, :364-375
+    layer.maybe_flush_k()                                                  # :343-356
+    if layer.v_res_start + layer.v_res_len + 1 > layer.v_res.shape[2]:     # make room in the window buffer
+        layer.compact_v_window()
+    out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=query_states.device)
+    flushed = fused.decode_output(layer, probs, value_states, out)         # :377-399
+    layer.v_res_len += 1
+    if flushed:
+        layer.v_quant_len += 1
+        layer.v_res_start += 1
+        layer.v_res_len -= 1
+    layer.kv_seq_len = kv_seq_len
+    return out
 
 
 def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
-                          layer: KiviLayerCache, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          layer: KiviLayerCache, attention_mask: Optional[torch.Tensor] = None,
+                          fused_kernels: bool = True) -> torch.Tensor:
     """One decode step for one layer.  query (B, nh, 1, D), key/value (B, nh_kv, 1, D), RoPE already applied.
-    Mutates `layer` in place and returns attn_output (B, nh, 1, D) fp16 (before the o_proj transpose)."""
+    Mutates `layer` in place and returns attn_output (B, nh, 1, D) fp16 (before the o_proj transpose).
+    `fused_kernels=False` forces the reference-style composition (one launch per reference op)."""
     cfg = layer.cfg
     B, nh, q_len, D = query_states.shape
     assert q_len == 1, "decode branch: one new token (the reference kernel is q_len == 1 only)"
+    if fused_kernels and not getattr(layer, "_fused_unsupported", False):
+        try:
+            return _decode_fused(query_states, key_states, value_states, layer, attention_mask)
+        except KiviUnsupported:
+            layer._fused_unsupported = True   # shape without a tuned kernel: compose the unfused ops from now on
     nh_kv = layer.nh_kv
     rep = nh // nh_kv
     kv_seq_len = layer.kv_seq_len + 1                                    # llama_kivi.py:307-309

@@ -207,14 +207,18 @@ class KiviLayerCache:
             self.k_quant_len += R
             self.k_res_len = 0
 
+    def compact_v_window(self) -> None:
+        """Move the live window rows to the front of the 2R+1 buffer (once every ~R steps)."""
+        live = self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len].clone()
+        self.v_res[:, :, : self.v_res_len].copy_(live)
+        self.v_res_start = 0
+
     def append_v(self, value_states: torch.Tensor) -> None:
         """llama_kivi.py:377: V window += the new token."""
         assert value_states.shape[2] == 1
         R = self.cfg.residual_length
         if self.v_res_start + self.v_res_len + 1 > self.v_res.shape[2]:
-            live = self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len].clone()
-            self.v_res[:, :, : self.v_res_len].copy_(live)
-            self.v_res_start = 0
+            self.compact_v_window()
         pos = self.v_res_start + self.v_res_len
         self.v_res[:, :, pos: pos + 1].copy_(value_states)
         self.v_res_len += 1

@@ -37,6 +37,16 @@ struct GemvKArgs {
     // contiguous (D, page_tokens/fpi) block.  page_words == 0: plain hook-state layout (one "page").
     int64_t page_words, page_groups;   // words / quant groups of one channel row inside a page
     int64_t code_sp, sm_sp;            // page strides
+    // fused decode step (kivi_decode_scores): blocks >= main_blocks score the fp16 K residual
+    // (models/llama_kivi.py:333-337) and append the new token to it.
+    int main_blocks;                   // >= 0: fused decode step (residual role on); -1 = plain GEMV
+    int res_blocks;                    // the FIRST res_blocks blocks of the grid do the residual (they are short and
+                                       // latency-bound: started first, they hide under the streaming blocks)
+    const uint16_t* kres;              // (B, nh_kv, R, D) fp16 residual buffer
+    int64_t kres_sb, kres_sh, kres_st;
+    const uint16_t* knew;              // (B, nh_kv, D) the new key
+    int64_t knew_sb, knew_sh;
+    int res_len;                       // tokens already in the residual; the new one becomes index res_len
 };
 
 template <int N> struct WordVec;
@@ -51,6 +61,46 @@ __device__ __forceinline__ uint32_t vec_get(const V& v, int j) {
 }
 
 constexpr int KQ_MAXD = 1 << 20;  // head_dim bound of the tuned kernels (q is read row by row)
+
+// Residual role of the fused decode step: one block per (b, head unit) computes q . k for the <= R fp16
+// residual keys plus the new one (out[b, h, T + t], fp32 accumulate, one rounding: what the reference's fp16
+// torch.matmul does at llama_kivi.py:337) and the first unit of every kv head appends the new key (:333-336).
+template <int R>
+__device__ __forceinline__ void k_residual_role(const GemvKArgs& a, int unit) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = unit / a.units_per_b;
+    const int hu = unit - b * a.units_per_b;
+    const int h0 = hu * R;
+    const int hk = h0 / a.ratio;
+    const int L = a.res_len + 1;
+    const uint16_t* knew = a.knew + b * a.knew_sb + hk * a.knew_sh;
+    const uint16_t* kres = a.kres + b * a.kres_sb + hk * a.kres_sh;
+    for (int t = wave; t < L; t += 4) {
+        const uint16_t* krow = (t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew;
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) s[r] = 0.f;
+        for (int d = lane * 2; d < a.D; d += 128) {
+            const uint32_t kk = *(const uint32_t*)(krow + d);
+            const float k0 = h2f_bits((uint16_t)(kk & 0xFFFFu)), k1 = h2f_bits((uint16_t)(kk >> 16));
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t qq = *(const uint32_t*)(a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + d);
+                s[r] = __builtin_fmaf(h2f_bits((uint16_t)(qq & 0xFFFFu)), k0, s[r]);
+                s[r] = __builtin_fmaf(h2f_bits((uint16_t)(qq >> 16)), k1, s[r]);
+            }
+            if (t == a.res_len && (h0 % a.ratio) == 0)   // append: this block owns the kv head's write
+                *(uint32_t*)(const_cast<uint16_t*>(kres) + (int64_t)t * a.kres_st + d) = kk;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) s[r] += __shfl_xor(s[r], m);
+            if (lane == 0) a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.T + t] = f2h_bits(s[r]);
+        }
+    }
+}
 
 template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
 __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
@@ -69,10 +119,15 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
     // cross-wave exchange: every wave keeps 1/DSPLIT of its accumulators and hands the rest over
     __shared__ float red[DSPLIT > 1 ? 4 * (DSPLIT - 1) * R * Q * 64 : 1];
 
+    if ((int)blockIdx.x < a.res_blocks) {   // block-uniform role switch
+        k_residual_role<R>(a, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.res_blocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
-    const int unit = blockIdx.x / a.tile_blocks;     // (b, head unit)
-    const int tb = blockIdx.x - unit * a.tile_blocks;
+    const int unit = bid / a.tile_blocks;            // (b, head unit)
+    const int tb = bid - unit * a.tile_blocks;
     const int b = unit / a.units_per_b;
     const int hu = unit - b * a.units_per_b;
     const int h0 = hu * R;                            // first query head of the unit
@@ -429,7 +484,14 @@ int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream
         const int tpb = 4 / v.dsplit;
         a.units_per_b = a.nh / v.R;
         a.tile_blocks = (tiles + tpb - 1) / tpb;
-        v.fn(a, dim3((unsigned)((int64_t)B * a.units_per_b * a.tile_blocks)), s);
+        int64_t blocks = (int64_t)B * a.units_per_b * a.tile_blocks;
+        a.res_blocks = 0;
+        if (a.main_blocks >= 0) {   // fused decode step: one residual block per (b, head unit), scheduled first
+            a.main_blocks = (int)blocks;
+            a.res_blocks = B * a.units_per_b;
+            blocks += a.res_blocks;
+        }
+        v.fn(a, dim3((unsigned)blocks), s);
         return kivi_launch_status(v.name);
     }
     // heuristic: first fitting variant with the largest usable R; table order = preference
@@ -442,6 +504,9 @@ int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream
         if (best < 0 || v.R > k_variants[best].R) best = i;
     }
     if (best >= 0) return k_run(best, a, B, nh_kv, G, bits, s);
+    KIVI_REQUIRE(a.main_blocks < 0, KIVI_EUNSUPPORTED,
+                 "kivi_decode_scores: no tuned kernel for this shape (bits=%d g=%d D=%d); use the unfused path", bits, G,
+                 a.D);
     // generic fallback
     dim3 grid((unsigned)(((a.Tw + 255) / 256) * (int64_t)B * a.nh));
     if (bits == 2) hipLaunchKernelGGL(gemv_k_generic<2>, grid, dim3(256), 0, s, a, G);
@@ -471,6 +536,8 @@ int k_check_and_fill(GemvKArgs& a, const void* q, int64_t q_sb, int64_t q_sh, co
     a.nh = nh; a.ratio = nh / nh_kv; a.D = D; a.T = T; a.Tw = T / fpi;
     a.units_per_b = nh; a.tile_blocks = 1;
     a.page_words = 0; a.page_groups = 0; a.code_sp = 0; a.sm_sp = 0;
+    a.main_blocks = -1; a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
+    a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     return 0;
 }
 
@@ -529,4 +596,34 @@ extern "C" int kivi_gemv_k_paged(int variant, int64_t page_tokens, int64_t code_
     KIVI_REQUIRE(page_tokens > 0, KIVI_EINVAL, "kivi_gemv_k_paged: page_tokens must be positive");
     return k_entry(variant, page_tokens, code_sp, sm_sp, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb,
                    sm_sh, sm_sr, out, out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits, stream);
+}
+
+extern "C" int kivi_decode_scores(int64_t page_tokens, int64_t code_sp, int64_t sm_sp, const void* q, int64_t q_sb,
+                                  int64_t q_sh, const void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
+                                  const void* scale, const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
+                                  void* kres, int64_t kres_sb, int64_t kres_sh, int64_t kres_st, const void* knew,
+                                  int64_t knew_sb, int64_t knew_sh, int res_len, void* out, int64_t out_sb,
+                                  int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size, int bits,
+                                  kivi_stream_t stream) {
+    GemvKArgs a;
+    int rc = k_check_and_fill(a, q, q_sb, q_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                              out_sb, out_sh, B, nh, nh_kv, D, T, group_size, bits);
+    if (rc) return rc;
+    const int fpi = 32 / bits;
+    KIVI_REQUIRE(page_tokens > 0 && page_tokens % group_size == 0 && page_tokens % fpi == 0, KIVI_EINVAL,
+                 "kivi_decode_scores: page_tokens=%lld must be a positive multiple of group_size=%d", (long long)page_tokens,
+                 group_size);
+    KIVI_REQUIRE(res_len >= 0 && kres && knew, KIVI_EINVAL, "kivi_decode_scores: residual buffers missing");
+    KIVI_REQUIRE(D % 2 == 0 && kres_sb % 2 == 0 && kres_sh % 2 == 0 && kres_st % 2 == 0 && knew_sb % 2 == 0 &&
+                     knew_sh % 2 == 0 && (uintptr_t)kres % 4 == 0 && (uintptr_t)knew % 4 == 0,
+                 KIVI_EALIGN, "kivi_decode_scores: residual rows must be 4-byte aligned");
+    a.page_words = page_tokens / fpi;
+    a.page_groups = page_tokens / group_size;
+    a.code_sp = code_sp;
+    a.sm_sp = sm_sp;
+    a.main_blocks = 0;
+    a.kres = (const uint16_t*)kres; a.kres_sb = kres_sb; a.kres_sh = kres_sh; a.kres_st = kres_st;
+    a.knew = (const uint16_t*)knew; a.knew_sb = knew_sb; a.knew_sh = knew_sh;
+    a.res_len = res_len;
+    return k_run(-1, a, B, nh_kv, group_size, bits, (hipStream_t)stream);
 }

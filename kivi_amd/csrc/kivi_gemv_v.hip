@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "kivi_common.h"
+#include "kivi_quant.h"
 
 namespace {
 
@@ -32,6 +33,15 @@ struct GemvVArgs {
     int64_t Tv;
     int units_per_b;
     uint32_t code_extent, sm_extent, a_extent;
+    bool extents_ok;
+    // fused decode step (kivi_decode_output): fp16 V window (llama_kivi.py:377-399)
+    int fused;                         // 0 = plain GEMV
+    uint16_t* vres;                    // (B, nh_kv, W, D) window buffer
+    int64_t vres_sb, vres_sh, vres_st;
+    int win_start, res_len;            // live rows [win_start, win_start + res_len); the new token goes right after
+    const uint16_t* vnew;              // (B, nh_kv, D) the new value
+    int64_t vnew_sb, vnew_sh;
+    int flush;                         // quantise the oldest window row into cache row Tv
 };
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
@@ -191,10 +201,64 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             red[wave][r][lr * EPL + e] = acc[r][i] + z;
         }
     __syncthreads();
+    const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
     for (int i = threadIdx.x; i < R * D; i += 256) {
         const int r = i / D, d = i - r * D;
         const float s = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
-        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = f2h_bits(s);
+        uint16_t o = f2h_bits(s);
+        if (a.fused) {
+            // + probs[..., -L:] @ V_window  (llama_kivi.py:384; :380 when nothing is quantised yet)
+            const uint16_t* arow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv;
+            const uint16_t* vr = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + d;
+            float res = 0.f;
+            for (int t = 0; t < a.res_len; t++) res = __builtin_fmaf(h2f_bits(arow[t]), h2f_bits(vr[(int64_t)t * a.vres_st]), res);
+            const uint16_t vn = a.vnew[b * a.vnew_sb + hk * a.vnew_sh + d];
+            res = __builtin_fmaf(h2f_bits(arow[a.res_len]), h2f_bits(vn), res);
+            o = (a.Tv > 0) ? f2h_bits(h2f_bits(o) + h2f_bits(f2h_bits(res))) : f2h_bits(res);
+            if (r == 0 && owner)   // append the new token to the window (:377)
+                a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)(a.win_start + a.res_len) * a.vres_st + d] = vn;
+        }
+        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
+    }
+    if (a.fused && a.flush && owner) {
+        // the window now holds R+1 tokens: quantise the OLDEST one into cache row Tv (:386-399), bit-identical
+        // to the stand-alone pack kernel (shared quantiser)
+        __syncthreads();
+        uint32_t* lds = reinterpret_cast<uint32_t*>(&red[0][0][0]);   // D keys, then D codes
+        const int d = threadIdx.x;
+        uint16_t x = 0;
+        if (d < D) {
+            x = a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + d];
+            lds[d] = h_key(x);
+        }
+        __syncthreads();
+        GroupQ gq;
+        uint32_t c = 0;
+        if (d < D) {
+            uint32_t kmin = 0xFFFFu, kmax = 0u;
+            const int g0 = (d / G) * G;
+            for (int i = 0; i < G; i++) {
+                const uint32_t k = lds[g0 + i];
+                kmin = k < kmin ? k : kmin;
+                kmax = k > kmax ? k : kmax;
+            }
+            gq = make_group(kmin, kmax, (1 << BITS) - 1);
+            c = quant_one(x, gq);
+        }
+        __syncthreads();
+        if (d < D) lds[d] = c;
+        __syncthreads();
+        if (d < DW) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int i = 0; i < FPI; i++) word |= lds[d * FPI + i] << (BITS * i);
+            const_cast<uint32_t*>(a.code)[b * a.code_sb + hk * a.code_sh + a.Tv * a.code_sr + d] = word;
+        }
+        if (d < D && (d % G) == 0) {
+            const int64_t so = b * a.sm_sb + hk * a.sm_sh + a.Tv * a.sm_sr + d / G;
+            const_cast<uint16_t*>(a.scale)[so] = gq.scale;
+            const_cast<uint16_t*>(a.mn)[so] = gq.mn;
+        }
     }
 }
 
@@ -295,7 +359,8 @@ bool v_variant_fits(const VVariant& v, const GemvVArgs& a, int bits, int G) {
     const int fpi = 32 / bits;
     if (a.D != v.dw * fpi) return false;
     if (a.ratio % v.R) return false;
-    if (a.code_extent == 0 || a.sm_extent == 0 || a.a_extent == 0) return false;
+    if (!a.extents_ok) return false;
+    if (!a.fused && a.Tv == 0) return false;
     const int epl = v.wpl * fpi;
     const int ngl = epl >= G ? epl / G : 1;
     if ((a.code_sr % v.wpl) || (a.code_sh % v.wpl) || (a.code_sb % v.wpl) || ((uintptr_t)a.code % (4 * v.wpl)))
@@ -326,6 +391,8 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         if (best < 0 || v.R > v_variants[best].R) best = i;
     }
     if (best >= 0) return v_run(best, a, B, G, bits, s);
+    KIVI_REQUIRE(!a.fused, KIVI_EUNSUPPORTED,
+                 "kivi_decode_output: no tuned kernel for this shape (bits=%d g=%d D=%d); use the unfused path", bits, G, a.D);
     const int fpi = 32 / bits;
     const int Dw = a.D / fpi;
     dim3 grid((unsigned)(B * a.nh), (unsigned)((Dw + 63) / 64));
@@ -341,22 +408,20 @@ extern "C" const char* kivi_gemv_v_variant_name(int v) {
     return (v >= 0 && v < v_nvariants) ? v_variants[v].name : "";
 }
 
-extern "C" int kivi_gemv_v_variant(int variant, const void* av, int64_t a_sb, int64_t a_sh, const void* code,
-                                   int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
-                                   const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out,
-                                   int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D,
-                                   int group_size, int bits, kivi_stream_t stream) {
-    KIVI_REQUIRE(bits == 2 || bits == 4, KIVI_EINVAL, "kivi_gemv_v: bits must be 2 or 4 (matmul.py:215), got %d", bits);
-    KIVI_REQUIRE(nh_kv > 0 && nh > 0 && nh % nh_kv == 0, KIVI_EINVAL,
-                 "kivi_gemv_v: nh %% nh_kv != 0 (matmul.py:216): nh=%d nh_kv=%d", nh, nh_kv);
+static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, int64_t a_sh, const void* code,
+                  int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale, const void* mn, int64_t sm_sb,
+                  int64_t sm_sh, int64_t sm_sr, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv,
+                  int64_t Tv, int D, int group_size, int bits) {
+    KIVI_REQUIRE(bits == 2 || bits == 4, KIVI_EINVAL, "%s: bits must be 2 or 4 (matmul.py:215), got %d", who, bits);
+    KIVI_REQUIRE(nh_kv > 0 && nh > 0 && nh % nh_kv == 0, KIVI_EINVAL, "%s: nh %% nh_kv != 0 (matmul.py:216): nh=%d nh_kv=%d",
+                 who, nh, nh_kv);
     const int fpi = 32 / bits;
-    KIVI_REQUIRE(group_size > 0 && group_size % fpi == 0, KIVI_EINVAL,
-                 "kivi_gemv_v: group_size %d must be a positive multiple of %d", group_size, fpi);
+    KIVI_REQUIRE(group_size > 0 && group_size % fpi == 0, KIVI_EINVAL, "%s: group_size %d must be a positive multiple of %d",
+                 who, group_size, fpi);
     KIVI_REQUIRE(D > 0 && D % fpi == 0 && D % group_size == 0, KIVI_EINVAL,
-                 "kivi_gemv_v: head_dim=%d must be a multiple of group_size=%d", D, group_size);
-    KIVI_REQUIRE(B > 0 && Tv >= 0, KIVI_EINVAL, "kivi_gemv_v: empty batch");
-    KIVI_REQUIRE((int64_t)B * nh < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_gemv_v: B*nh too large");
-    GemvVArgs a;
+                 "%s: head_dim=%d must be a multiple of group_size=%d", who, D, group_size);
+    KIVI_REQUIRE(B > 0 && Tv >= 0, KIVI_EINVAL, "%s: empty batch", who);
+    KIVI_REQUIRE((int64_t)B * nh < ((int64_t)1 << 31), KIVI_EINVAL, "%s: B*nh too large", who);
     a.a = (const uint16_t*)av; a.a_sb = a_sb; a.a_sh = a_sh;
     a.code = (const uint32_t*)code; a.code_sb = code_sb; a.code_sh = code_sh; a.code_sr = code_sr;
     a.scale = (const uint16_t*)scale; a.mn = (const uint16_t*)mn;
@@ -368,9 +433,24 @@ extern "C" int kivi_gemv_v_variant(int variant, const void* av, int64_t a_sb, in
     const int64_t ce = Tv > 0 ? ((Tv - 1) * code_sr + D / fpi) * 4 : 0;
     const int64_t se = Tv > 0 ? ((Tv - 1) * sm_sr + D / group_size) * 2 : 0;
     const int64_t ae = Tv * 2;
-    a.code_extent = (ce > 0 && ce < (int64_t)0xFFFFFFFFll) ? (uint32_t)ce : 0;
-    a.sm_extent = (se > 0 && se < (int64_t)0xFFFFFFFFll) ? (uint32_t)se : 0;
-    a.a_extent = (ae > 0 && ae < (int64_t)0xFFFFFFFFll) ? (uint32_t)ae : 0;
+    a.extents_ok = ce < (int64_t)0xFFFFFFFFll && se < (int64_t)0xFFFFFFFFll && ae < (int64_t)0xFFFFFFFFll;
+    a.code_extent = (uint32_t)(a.extents_ok ? ce : 0);
+    a.sm_extent = (uint32_t)(a.extents_ok ? se : 0);
+    a.a_extent = (uint32_t)(a.extents_ok ? ae : 0);
+    a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
+    a.vres_sb = a.vres_sh = a.vres_st = a.vnew_sb = a.vnew_sh = 0;
+    return 0;
+}
+
+extern "C" int kivi_gemv_v_variant(int variant, const void* av, int64_t a_sb, int64_t a_sh, const void* code,
+                                   int64_t code_sb, int64_t code_sh, int64_t code_sr, const void* scale,
+                                   const void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* out,
+                                   int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D,
+                                   int group_size, int bits, kivi_stream_t stream) {
+    GemvVArgs a;
+    int rc = v_fill(a, "kivi_gemv_v", av, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
+                    out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits);
+    if (rc) return rc;
     return v_run(variant, a, B, group_size, bits, (hipStream_t)stream);
 }
 
@@ -380,4 +460,24 @@ extern "C" int kivi_gemv_v(const void* av, int64_t a_sb, int64_t a_sh, const voi
                            int nh_kv, int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream) {
     return kivi_gemv_v_variant(-1, av, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
                                out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits, stream);
+}
+
+extern "C" int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb,
+                                  int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh,
+                                  int64_t sm_sr, void* vres, int64_t vres_sb, int64_t vres_sh, int64_t vres_st,
+                                  int win_start, int res_len, const void* vnew, int64_t vnew_sb, int64_t vnew_sh,
+                                  int flush, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv,
+                                  int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream) {
+    GemvVArgs a;
+    int rc = v_fill(a, "kivi_decode_output", probs, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh,
+                    sm_sr, out, out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits);
+    if (rc) return rc;
+    KIVI_REQUIRE(vres && vnew && res_len >= 0 && win_start >= 0, KIVI_EINVAL, "kivi_decode_output: window buffers missing");
+    KIVI_REQUIRE(D <= 256, KIVI_EUNSUPPORTED, "kivi_decode_output: head_dim %d > 256", D);
+    a.fused = 1;
+    a.vres = (uint16_t*)vres; a.vres_sb = vres_sb; a.vres_sh = vres_sh; a.vres_st = vres_st;
+    a.win_start = win_start; a.res_len = res_len;
+    a.vnew = (const uint16_t*)vnew; a.vnew_sb = vnew_sb; a.vnew_sh = vnew_sh;
+    a.flush = flush ? 1 : 0;
+    return v_run(-1, a, B, group_size, bits, (hipStream_t)stream);
 }

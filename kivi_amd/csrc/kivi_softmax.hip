@@ -1,0 +1,140 @@
+// Scale + (mask) + softmax over one row of attention scores, one launch.
+//
+// Replaces three torch kernels of the reference decode branch (models/llama_kivi.py):
+//   attn_weights = cat([...]) / math.sqrt(head_dim)                     :339   fp16 result
+//   attn_weights = max(attn_weights + attention_mask, finfo.min)        :364-372 (optional)
+//   softmax(attn_weights, dim=-1, dtype=float32).to(fp16)               :375
+// with the same roundings: the scaled score is rounded to fp16 (torch's CUDA/HIP division by a Python scalar
+// multiplies by the fp32 reciprocal -- proven equal to true division for every finite half and the divisors
+// used here in oracle/pin_reference.py), the mask add is rounded to fp16, the softmax runs in fp32 and the
+// probabilities are rounded once.  One 256-thread block per (b, h) row; the row lives in registers.
+#include "kivi_common.h"
+
+namespace {
+
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* lds) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float o = __shfl_xor(v, m);
+        v = is_max ? __builtin_fmaxf(v, o) : v + o;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();   // previous use of lds is over
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    const float a = lds[0], b = lds[1], c = lds[2], d = lds[3];
+    return is_max ? __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+// CHUNKS x 1024 elements per row are held in registers (4 halves per thread per chunk).
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void softmax_scaled_kernel(const uint16_t* __restrict__ scores, uint16_t* __restrict__ probs,
+                                                             int64_t n, int64_t s_pitch, int64_t p_pitch, float inv_scale,
+                                                             const uint16_t* __restrict__ mask, int64_t mask_sb, int nh) {
+    __shared__ float lds[4];
+    const int64_t row = blockIdx.x;
+    const uint16_t* srow = scores + row * s_pitch;
+    uint16_t* prow = probs + row * p_pitch;
+    const uint16_t* mrow = mask ? mask + (row / nh) * mask_sb : nullptr;
+    float x[CHUNKS][4];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        const int64_t j0 = (int64_t)c * 1024 + threadIdx.x * 4;
+        u16x4 raw = {0, 0, 0, 0};
+        if (j0 + 4 <= n) raw = *(const u16x4*)(srow + j0);
+        else
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (j0 + e < n) raw[e] = srow[j0 + e];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float v = -__builtin_inff();
+            if (j0 + e < n) {
+                uint16_t h = f2h_bits(h2f_bits(raw[e]) * inv_scale);                  // :339, fp16 result
+                if (mrow) {
+                    h = f2h_bits(h2f_bits(h) + h2f_bits(mrow[j0 + e]));              // :368
+                    if (h2f_bits(h) < -65504.0f) h = 0xFBFFu;                        // :369-371 max(., finfo.min)
+                }
+                v = h2f_bits(h);
+            }
+            x[c][e] = v;
+            mx = __builtin_fmaxf(mx, v);
+        }
+    }
+    mx = block_reduce(mx, true, lds);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            x[c][e] = __builtin_expf(x[c][e] - mx);   // exp(-inf) = 0 for the padding lanes
+            sum += x[c][e];
+        }
+    sum = block_reduce(sum, false, lds);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        const int64_t j0 = (int64_t)c * 1024 + threadIdx.x * 4;
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] / sum);
+        if (j0 + 4 <= n) *(u16x4*)(prow + j0) = o;
+        else
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (j0 + e < n) prow[j0 + e] = o[e];
+    }
+}
+
+// Any row length: three passes over the (L2-resident) row.
+__global__ __launch_bounds__(256) void softmax_scaled_generic(const uint16_t* __restrict__ scores, uint16_t* __restrict__ probs,
+                                                              int64_t n, int64_t s_pitch, int64_t p_pitch, float inv_scale,
+                                                              const uint16_t* __restrict__ mask, int64_t mask_sb, int nh) {
+    __shared__ float lds[4];
+    const int64_t row = blockIdx.x;
+    const uint16_t* srow = scores + row * s_pitch;
+    uint16_t* prow = probs + row * p_pitch;
+    const uint16_t* mrow = mask ? mask + (row / nh) * mask_sb : nullptr;
+    auto val = [&](int64_t j) {
+        uint16_t h = f2h_bits(h2f_bits(srow[j]) * inv_scale);
+        if (mrow) {
+            h = f2h_bits(h2f_bits(h) + h2f_bits(mrow[j]));
+            if (h2f_bits(h) < -65504.0f) h = 0xFBFFu;
+        }
+        return h2f_bits(h);
+    };
+    float mx = -__builtin_inff();
+    for (int64_t j = threadIdx.x; j < n; j += 256) mx = __builtin_fmaxf(mx, val(j));
+    mx = block_reduce(mx, true, lds);
+    float sum = 0.f;
+    for (int64_t j = threadIdx.x; j < n; j += 256) sum += __builtin_expf(val(j) - mx);
+    sum = block_reduce(sum, false, lds);
+    for (int64_t j = threadIdx.x; j < n; j += 256) prow[j] = f2h_bits(__builtin_expf(val(j) - mx) / sum);
+}
+
+}  // namespace
+
+extern "C" int kivi_softmax_scaled(const void* scores, void* probs, int64_t rows, int64_t n, int64_t s_pitch,
+                                   int64_t p_pitch, float inv_scale, const void* mask, int64_t mask_sb, int nh,
+                                   kivi_stream_t stream) {
+    KIVI_REQUIRE(rows >= 0 && n >= 0 && nh > 0, KIVI_EINVAL, "kivi_softmax_scaled: bad shape");
+    KIVI_REQUIRE(scores != probs || s_pitch == p_pitch, KIVI_EINVAL, "kivi_softmax_scaled: in-place needs equal pitches");
+    if (rows == 0 || n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (s_pitch % 4 == 0) && (p_pitch % 4 == 0) && ((uintptr_t)scores % 8 == 0) && ((uintptr_t)probs % 8 == 0);
+    dim3 grid((unsigned)rows);
+#define KIVI_SM_CASE(C)                                                                                              \
+    if (vec && n <= (C) * 1024) {                                                                                    \
+        hipLaunchKernelGGL(softmax_scaled_kernel<C>, grid, dim3(256), 0, s, (const uint16_t*)scores, (uint16_t*)probs, \
+                           n, s_pitch, p_pitch, inv_scale, (const uint16_t*)mask, mask_sb, nh);                      \
+        return kivi_launch_status("softmax_scaled");                                                                \
+    }
+    KIVI_SM_CASE(1) KIVI_SM_CASE(2) KIVI_SM_CASE(4) KIVI_SM_CASE(5) KIVI_SM_CASE(8) KIVI_SM_CASE(16)
+#undef KIVI_SM_CASE
+    KIVI_REQUIRE(scores != probs, KIVI_EINVAL, "kivi_softmax_scaled: rows longer than 16384 cannot be in place");
+    hipLaunchKernelGGL(softmax_scaled_generic, grid, dim3(256), 0, s, (const uint16_t*)scores, (uint16_t*)probs, n,
+                       s_pitch, p_pitch, inv_scale, (const uint16_t*)mask, mask_sb, nh);
+    return kivi_launch_status("softmax_scaled_generic");
+}

@@ -18,9 +18,10 @@ def _cmp_cache(t_gpu, t_ref):
     assert t_gpu[8] == t_ref[8]
 
 
+@pytest.mark.parametrize("fused_kernels", [True, False])
 @pytest.mark.parametrize("nh,nh_kv,T0,R,g,bits", [(4, 4, 70, 32, 32, 2), (8, 2, 33, 32, 32, 2), (4, 2, 5, 32, 32, 2),
-                                                   (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2)])
-def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits):
+                                                   (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2), (6, 2, 40, 32, 32, 2)])
+def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits, fused_kernels):
     from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
     from oracle import hook_ref as H
     B, D = 2, 128
@@ -34,7 +35,7 @@ def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits):
     for s in range(steps):
         q = make_kv(100 + s, B, nh, 1, D)
         kn, vn = make_kv(200 + s, B, nh_kv, 1, D), make_kv(300 + s, B, nh_kv, 1, D)
-        out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer)
+        out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer, fused_kernels=fused_kernels)
         ref, past = H.decode_step(q, kn, vn, past, bits, bits, g, R)
         ok, ratio = gemv_close(out, ref, rtol=3e-3)   # fp32 softmax (GPU exp vs libm) + two fp16 partial sums on top of the GEMV bar
         assert ok, (s, ratio)
@@ -69,3 +70,50 @@ def test_module_hook_prefill_then_decode():
         outs.append(o)
         assert cur[-1] == 48 and torch.isfinite(o).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_fused_and_composed_paths_agree_with_mask():
+    """Same inputs through the 3-launch fused step and the reference-style composition: identical cache contents,
+    outputs within fp16 rounding of each other -- including the additive attention mask branch (llama_kivi.py:364-372)."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    B, nh, nh_kv, D, T0, R = 2, 8, 4, 128, 100, 32
+    cfg = KiviConfig(2, 2, 32, R)
+    k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
+    la = KiviLayerCache(cfg, B, nh_kv, D, 256, "cuda")
+    lb = KiviLayerCache(cfg, B, nh_kv, D, 256, "cuda")
+    for lc in (la, lb):
+        lc.prefill(k0.cuda(), v0.cuda())
+    for s in range(40):
+        q = make_kv(100 + s, B, nh, 1, D).cuda()
+        kn, vn = make_kv(200 + s, B, nh_kv, 1, D).cuda(), make_kv(300 + s, B, nh_kv, 1, D).cuda()
+        mask = torch.zeros((B, 1, 1, T0 + s + 1), dtype=torch.float16, device="cuda")
+        mask[0, :, :, : 7 + s] = torch.finfo(torch.float16).min      # left padding of sequence 0
+        oa = kivi_attention_decode(q, kn, vn, la, attention_mask=mask, fused_kernels=True)
+        ob = kivi_attention_decode(q, kn, vn, lb, attention_mask=mask, fused_kernels=False)
+        assert not getattr(la, "_fused_unsupported", False)
+        ok, ratio = gemv_close(oa, ob.cpu(), rtol=2e-3)
+        assert ok, (s, ratio)
+        for x, y in zip(la.as_tuple()[:8], lb.as_tuple()[:8]):
+            assert (x is None) == (y is None) and (x is None or same_bits(x, y))
+
+
+@pytest.mark.parametrize("n,pitch", [(33, 40), (1024, 1024), (4109, 4136), (5000, 5000), (16384, 16384), (20001, 20008)])
+def test_softmax_scaled_kernel(n, pitch):
+    from kivi_amd.quant import fused
+    torch.manual_seed(n)
+    B, nh = 2, 3
+    scores = torch.zeros((B, nh, 1, pitch), dtype=torch.float16, device="cuda")
+    scores[..., :n] = (torch.randn((B, nh, 1, n), device="cuda") * 20).half()
+    probs = torch.full_like(scores, 7.0)
+    inv = 1.0 / (128 ** 0.5)
+    for mask in (None, torch.where(torch.rand((B, 1, 1, n), device="cuda") < 0.2, torch.finfo(torch.float16).min, 0.0).half()):
+        fused.softmax_scaled(scores, probs, n, inv, mask)
+        x = scores[..., :n] / (128 ** 0.5)                     # reference op sequence on torch (llama_kivi.py:339-375)
+        if mask is not None:
+            x = torch.max(x + mask, torch.tensor(torch.finfo(torch.float16).min, device="cuda"))
+        ref = torch.softmax(x, dim=-1, dtype=torch.float32).half()
+        got = probs[..., :n]
+        assert torch.isfinite(got).all() and bool((probs[..., n:] == 7.0).all())
+        err = (got.float() - ref.float()).abs()
+        assert bool((err <= 1.5e-3 * ref.float() + 1e-7).all()), err.max().item()
+        assert abs(got.float().sum(-1) - 1).max().item() < 2e-3
