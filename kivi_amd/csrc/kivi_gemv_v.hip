@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     typedef typename std::conditional<NGL == 1, uint16_t, uint32_t>::type SV;
 
     __shared__ float red[4][R][D];
+    __shared__ float resl[4][R][D];   // fused decode step: per-wave partial sums over the fp16 V window
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,6 +158,53 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
         if (it < nbatch) compute_batch(wA, sA, mA, aA);
     }
 
+    const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
+    if (a.fused) {
+        // probs[..., -L:] @ V_window (llama_kivi.py:384): the <= R+1 fp16 window tokens (the last one is the new
+        // value, appended here, :377) are spread over the 4 waves, a lane owns channel pairs; all loads of a
+        // wave are independent, so this costs one L2 round trip instead of L serial ones.
+        constexpr int NP = (D / 2 + 63) / 64;            // channel pairs per lane
+        float racc[R][NP][2];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < NP; c++) racc[r][c][0] = racc[r][c][1] = 0.f;
+        const int L = a.res_len + 1;
+        const uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+        for (int t = wave; t < L; t += 4) {
+            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+            float at[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) at[r] = h2f_bits(a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]);
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const int p = lane + 64 * c;
+                if (p < D / 2) {
+                    const uint32_t vv = *(const uint32_t*)(vrow + 2 * p);
+                    const float v0 = h2f_bits((uint16_t)(vv & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv >> 16));
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        racc[r][c][0] = __builtin_fmaf(at[r], v0, racc[r][c][0]);
+                        racc[r][c][1] = __builtin_fmaf(at[r], v1, racc[r][c][1]);
+                    }
+                    if (t == a.res_len && owner)
+                        *(uint32_t*)(a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)(a.win_start + t) * a.vres_st + 2 * p) = vv;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const int p = lane + 64 * c;
+                if (p < D / 2) {
+                    resl[wave][r][2 * p] = racc[r][c][0];
+                    resl[wave][r][2 * p + 1] = racc[r][c][1];
+                }
+            }
+    }
+
     // undo the positional power-of-two factors, then combine the TPI lanes that share `lr`
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -201,22 +249,15 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             red[wave][r][lr * EPL + e] = acc[r][i] + z;
         }
     __syncthreads();
-    const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
     for (int i = threadIdx.x; i < R * D; i += 256) {
         const int r = i / D, d = i - r * D;
         const float s = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
         uint16_t o = f2h_bits(s);
         if (a.fused) {
-            // + probs[..., -L:] @ V_window  (llama_kivi.py:384; :380 when nothing is quantised yet)
-            const uint16_t* arow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv;
-            const uint16_t* vr = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + d;
-            float res = 0.f;
-            for (int t = 0; t < a.res_len; t++) res = __builtin_fmaf(h2f_bits(arow[t]), h2f_bits(vr[(int64_t)t * a.vres_st]), res);
-            const uint16_t vn = a.vnew[b * a.vnew_sb + hk * a.vnew_sh + d];
-            res = __builtin_fmaf(h2f_bits(arow[a.res_len]), h2f_bits(vn), res);
+            const float res = (resl[0][r][d] + resl[1][r][d]) + (resl[2][r][d] + resl[3][r][d]);
+            // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (:382-384);
+            // only the window part exists before anything is quantised (:380)
             o = (a.Tv > 0) ? f2h_bits(h2f_bits(o) + h2f_bits(f2h_bits(res))) : f2h_bits(res);
-            if (r == 0 && owner)   // append the new token to the window (:377)
-                a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)(a.win_start + a.res_len) * a.vres_st + d] = vn;
         }
         a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
     }
@@ -473,6 +514,9 @@ extern "C" int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh,
                     sm_sr, out, out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits);
     if (rc) return rc;
     KIVI_REQUIRE(vres && vnew && res_len >= 0 && win_start >= 0, KIVI_EINVAL, "kivi_decode_output: window buffers missing");
+    KIVI_REQUIRE(D % 2 == 0 && vres_sb % 2 == 0 && vres_sh % 2 == 0 && vres_st % 2 == 0 && vnew_sb % 2 == 0 &&
+                     vnew_sh % 2 == 0 && (uintptr_t)vres % 4 == 0 && (uintptr_t)vnew % 4 == 0,
+                 KIVI_EALIGN, "kivi_decode_output: window rows must be 4-byte aligned");
     KIVI_REQUIRE(D <= 256, KIVI_EUNSUPPORTED, "kivi_decode_output: head_dim %d > 256", D);
     a.fused = 1;
     a.vres = (uint16_t*)vres; a.vres_sb = vres_sb; a.vres_sh = vres_sh; a.vres_st = vres_st;
