@@ -42,6 +42,25 @@ def _scores_buffer(layer: KiviLayerCache, nh: int, kv_len: int) -> torch.Tensor:
     return _row_buffer(layer, "_scores", nh)[..., :kv_len]
 
 
+def _composed_output(attn_weights: torch.Tensor, value_states: torch.Tensor, layer: KiviLayerCache, nh: int) -> torch.Tensor:
+    """Output over [quantised V prefix | fp16 V window], one launch per reference op (llama_kivi.py:377-399)."""
+    cfg = layer.cfg
+    B, nh_kv, D = layer.B, layer.nh_kv, layer.D
+    rep = nh // nh_kv
+    layer.append_v(value_states)
+    Tv, Lv = layer.v_quant_len, layer.v_res_len
+    v_full = layer.v_res_view()
+    w_full = attn_weights[..., Tv:].reshape(B, nh_kv, rep, Lv)
+    if Tv == 0:
+        attn_output = torch.matmul(w_full, v_full).view(B, nh, 1, D)     # :380
+    else:
+        vc, vs, vm = layer.v_quant_views()
+        attn_output = cuda_bmm_fA_qB_outer(cfg.group_size, attn_weights[..., :Tv], vc, vs, vm, cfg.v_bits)   # :382
+        attn_output += torch.matmul(w_full, v_full).view(B, nh, 1, D)    # :384
+    layer.maybe_flush_v()                                                 # :386-399
+    return attn_output
+
+
 def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask) -> torch.Tensor:
     """The decode step in three launches (+1 when the K residual fills up): same arithmetic and roundings as the
     composed path below.  Raises KiviUnsupported when no tuned kernel covers the shape."""
@@ -55,12 +74,25 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
     assert layer.k_quant_len + layer.k_res_len + 1 <= layer.cap, "cache capacity exceeded"
     fused.decode_scores(layer, query_states, key_states, scores)          # :323-337 (+ the K append of :333-336)
     layer.k_res_len += 1
-    fused.softmax_scaled(scores, probs, kv_seq_len, 1.0 / math.sqrt(D), attention_mask)   # :339, :364-375
     layer.maybe_flush_k()                                                  # :343-356
     if layer.v_res_start + layer.v_res_len + 1 > layer.v_res.shape[2]:     # make room in the window buffer
         layer.compact_v_window()
     out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=query_states.device)
-    flushed = fused.decode_output(layer, probs, value_states, out)         # :377-399
+    inv = 1.0 / math.sqrt(D)
+    flushed = None
+    if not getattr(layer, "_softmax_unfusable", False):
+        try:   # scale + mask + softmax (:339, :364-375) inside the sV launch (:377-399)
+            flushed = fused.decode_output(layer, scores, value_states, out, softmax_inv_scale=inv, mask=attention_mask)
+        except KiviUnsupported:
+            layer._softmax_unfusable = True      # rows too long for the LDS: keep the softmax as its own launch
+    if flushed is None:
+        fused.softmax_scaled(scores, probs, kv_seq_len, inv, attention_mask)
+        try:
+            flushed = fused.decode_output(layer, probs, value_states, out)
+        except KiviUnsupported:   # no tuned sV kernel for this head_dim / group: compose the output part
+            out = _composed_output(probs[..., :kv_seq_len], value_states, layer, nh)
+            layer.kv_seq_len = kv_seq_len
+            return out
     layer.v_res_len += 1
     if flushed:
         layer.v_quant_len += 1
@@ -110,18 +142,7 @@ def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, 
         attn_weights = torch.max(attn_weights, torch.tensor(torch.finfo(attn_weights.dtype).min, device=attn_weights.device))
     attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)   # :375
 
-    # ---- output over [quantised V prefix | fp16 V window]  (:377-399)
-    layer.append_v(value_states)
-    Tv, Lv = layer.v_quant_len, layer.v_res_len
-    v_full = layer.v_res_view()
-    w_full = attn_weights[..., Tv:].reshape(B, nh_kv, rep, Lv)
-    if Tv == 0:
-        attn_output = torch.matmul(w_full, v_full).view(B, nh, 1, D)     # :380
-    else:
-        vc, vs, vm = layer.v_quant_views()
-        attn_output = cuda_bmm_fA_qB_outer(g, attn_weights[..., :Tv], vc, vs, vm, cfg.v_bits)   # :382 (strided slice, no copy)
-        attn_output += torch.matmul(w_full, v_full).view(B, nh, 1, D)    # :384
-    layer.maybe_flush_v()                                                 # :386-399
+    attn_output = _composed_output(attn_weights, value_states, layer, nh)    # :377-399
     layer.kv_seq_len = kv_seq_len
     return attn_output
 

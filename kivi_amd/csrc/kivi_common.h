@@ -41,14 +41,42 @@ struct KiviLaunchEvents {
 };
 KiviLaunchEvents kivi_take_launch_events();
 
-#define KIVI_LAUNCH(kernel, grid, block, stream, ...)                                                    \
-    do {                                                                                                 \
-        KiviLaunchEvents ev__ = kivi_take_launch_events();                                               \
-        if (ev__.start || ev__.stop)                                                                     \
-            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev__.start, ev__.stop, 0, __VA_ARGS__); \
-        else                                                                                             \
-            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                             \
+#define KIVI_LAUNCH_LDS(kernel, grid, block, lds, stream, ...)                                              \
+    do {                                                                                                   \
+        KiviLaunchEvents ev__ = kivi_take_launch_events();                                                 \
+        if (ev__.start || ev__.stop)                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev__.start, ev__.stop, 0, __VA_ARGS__); \
+        else                                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                             \
     } while (0)
+#define KIVI_LAUNCH(kernel, grid, block, stream, ...) KIVI_LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)
+
+// max / sum over the 256 threads of a block through 4 floats of LDS (same tree in every kernel that uses it,
+// so the stand-alone softmax and the one fused into the sV kernel round identically)
+__device__ __forceinline__ float kivi_block_reduce(float v, bool is_max, float* lds) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float o = __shfl_xor(v, m);
+        v = is_max ? __builtin_fmaxf(v, o) : v + o;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();   // previous use of lds is over
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    const float a = lds[0], b = lds[1], c = lds[2], d = lds[3];
+    return is_max ? __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+// One attention score -> the fp16 value the reference feeds its softmax (llama_kivi.py:339, :364-372):
+// fp16(s * inv_scale) [then fp16(+ mask) clamped at the fp16 minimum].
+__device__ __forceinline__ uint16_t kivi_scaled_score(uint16_t s, float inv_scale, bool has_mask, uint16_t m) {
+    uint16_t h = __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, s) * inv_scale));
+    if (has_mask) {
+        h = __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, h) + (float)__builtin_bit_cast(_Float16, m)));
+        if ((float)__builtin_bit_cast(_Float16, h) < -65504.0f) h = 0xFBFFu;
+    }
+    return h;
+}
 
 // ---- device helpers -------------------------------------------------------
 template <typename T, bool NT>

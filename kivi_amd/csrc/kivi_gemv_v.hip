@@ -42,6 +42,13 @@ struct GemvVArgs {
     const uint16_t* vnew;              // (B, nh_kv, D) the new value
     int64_t vnew_sb, vnew_sh;
     int flush;                         // quantise the oldest window row into cache row Tv
+    // softmax folded into this launch (kivi_decode_softmax_output): `a` then points at the PRE-softmax score rows
+    // written by kivi_decode_scores; every block turns its R rows into fp16 probabilities in LDS first.
+    int softmax;
+    int n_scores, n_pad;               // row length kv_len, LDS pitch (halves)
+    float inv_scale;
+    const uint16_t* mask;              // (B, 1, 1, n) additive fp16 mask or null
+    int64_t mask_sb;
 };
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
@@ -61,6 +68,8 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 
     __shared__ float red[4][R][D];
     __shared__ float resl[4][R][D];   // fused decode step: per-wave partial sums over the fp16 V window
+    __shared__ float sm_lds[4];
+    extern __shared__ uint16_t pl[];  // [R][n_pad] fp16 probabilities when the softmax is folded in
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,6 +87,69 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     rsrc_t ra[R];
 #pragma unroll
     for (int r = 0; r < R; r++) ra[r] = make_rsrc(a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh, a.a_extent);
+
+    if (a.softmax) {
+        // scale + mask + softmax of this block's R score rows, the arithmetic of kivi_softmax_scaled (same element ->
+        // thread assignment and reduction tree, so the probabilities are bit-identical to the stand-alone kernel).
+        // The whole row (<= 8192 scores) is fetched with up to 8 independent 8-byte loads per thread: one L2 round trip.
+        typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+        constexpr int SMC = 8;
+        const int n = a.n_scores;
+        const int nch = (n + 1023) / 1024;
+        const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb : nullptr;
+#pragma unroll 1
+        for (int r = 0; r < R; r++) {
+            const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
+            uint16_t* prow = pl + (size_t)r * a.n_pad;
+            u16x4 raw[SMC];
+#pragma unroll
+            for (int c = 0; c < SMC; c++) {
+                const int j0 = c * 1024 + (int)threadIdx.x * 4;
+                raw[c] = u16x4{0, 0, 0, 0};
+                if (c < nch) {
+                    if (j0 + 4 <= n) raw[c] = *(const u16x4*)(srow + j0);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (j0 + e < n) raw[c][e] = srow[j0 + e];
+                }
+            }
+            float x[SMC][4];
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int c = 0; c < SMC; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int j = c * 1024 + (int)threadIdx.x * 4 + e;
+                    float v = -__builtin_inff();
+                    if (c < nch && j < n)
+                        v = h2f_bits(kivi_scaled_score(raw[c][e], a.inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
+                    x[c][e] = v;
+                    mx = __builtin_fmaxf(mx, v);
+                }
+            mx = kivi_block_reduce(mx, true, sm_lds);
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < SMC; c++)
+                if (c < nch)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        x[c][e] = __builtin_expf(x[c][e] - mx);
+                        sum += x[c][e];
+                    }
+            sum = kivi_block_reduce(sum, false, sm_lds);
+#pragma unroll
+            for (int c = 0; c < SMC; c++)
+                if (c < nch) {
+                    const int j0 = c * 1024 + (int)threadIdx.x * 4;
+                    u16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] / sum);
+                    if (j0 < a.n_pad) *(u16x4*)(prow + j0) = o;   // n_pad is a multiple of 8: whole vectors stay inside the row
+                }
+        }
+        __syncthreads();
+    }
 
     const int gi0 = (lr * EPL) / G;             // first group index of this lane inside a row
     const uint32_t coff = (uint32_t)(((int64_t)lt * a.code_sr + lr * WPL) * 4);
@@ -135,7 +207,14 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             sb[u] = buf_load<SV, NT>(rs, soff + c * sstep, 0);
             mb[u] = buf_load<SV, NT>(rm, soff + c * sstep, 0);
 #pragma unroll
-            for (int r = 0; r < R; r++) ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
+            for (int r = 0; r < R; r++) {
+                if (a.softmax) {
+                    const int64_t t = (int64_t)c * TPI + lt;
+                    ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
+                } else {
+                    ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
+                }
+            }
         }
     };
     auto compute_batch = [&](const WV* wb, const SV* sb, const SV* mb, const uint16_t (*ab)[R]) {
@@ -176,7 +255,9 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
             float at[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) at[r] = h2f_bits(a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]);
+            for (int r = 0; r < R; r++)
+                at[r] = h2f_bits(a.softmax ? pl[(size_t)r * a.n_pad + a.Tv + t]
+                                           : a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]);
 #pragma unroll
             for (int c = 0; c < NP; c++) {
                 const int p = lane + 64 * c;
@@ -338,7 +419,8 @@ typedef void (*VLaunch)(const GemvVArgs&, dim3, hipStream_t);
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
 void launch_v(const GemvVArgs& a, dim3 grid, hipStream_t s) {
-    KIVI_LAUNCH((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT>), grid, dim3(256), s, a);
+    const size_t lds = a.softmax ? (size_t)R * a.n_pad * sizeof(uint16_t) : 0;
+    KIVI_LAUNCH_LDS((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT>), grid, dim3(256), lds, s, a);
 }
 
 struct VVariant {
@@ -402,6 +484,10 @@ bool v_variant_fits(const VVariant& v, const GemvVArgs& a, int bits, int G) {
     if (a.ratio % v.R) return false;
     if (!a.extents_ok) return false;
     if (!a.fused && a.Tv == 0) return false;
+    if (a.softmax) {   // rows live in registers (<= 8192 scores) and in LDS; vector loads need aligned rows
+        if (a.n_scores > 8192 || (size_t)v.R * a.n_pad * 2 > 96 * 1024) return false;
+        if ((a.a_sh % 4) || (a.a_sb % 4) || ((uintptr_t)a.a % 8)) return false;
+    }
     const int epl = v.wpl * fpi;
     const int ngl = epl >= G ? epl / G : 1;
     if ((a.code_sr % v.wpl) || (a.code_sh % v.wpl) || (a.code_sb % v.wpl) || ((uintptr_t)a.code % (4 * v.wpl)))
@@ -478,6 +564,7 @@ static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, i
     a.code_extent = (uint32_t)(a.extents_ok ? ce : 0);
     a.sm_extent = (uint32_t)(a.extents_ok ? se : 0);
     a.a_extent = (uint32_t)(a.extents_ok ? ae : 0);
+    a.softmax = 0; a.n_scores = 0; a.n_pad = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
     a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
     a.vres_sb = a.vres_sh = a.vres_st = a.vnew_sb = a.vnew_sh = 0;
     return 0;
@@ -503,12 +590,45 @@ extern "C" int kivi_gemv_v(const void* av, int64_t a_sb, int64_t a_sh, const voi
                                out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits, stream);
 }
 
+static int decode_output_impl(int softmax, float inv_scale, const void* mask, int64_t mask_sb, const void* probs,
+                              int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
+                              void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* vres,
+                              int64_t vres_sb, int64_t vres_sh, int64_t vres_st, int win_start, int res_len,
+                              const void* vnew, int64_t vnew_sb, int64_t vnew_sh, int flush, void* out, int64_t out_sb,
+                              int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits,
+                              kivi_stream_t stream);
+
 extern "C" int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb,
                                   int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh,
                                   int64_t sm_sr, void* vres, int64_t vres_sb, int64_t vres_sh, int64_t vres_st,
                                   int win_start, int res_len, const void* vnew, int64_t vnew_sb, int64_t vnew_sh,
                                   int flush, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv,
                                   int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream) {
+    return decode_output_impl(0, 1.0f, nullptr, 0, probs, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh,
+                              sm_sr, vres, vres_sb, vres_sh, vres_st, win_start, res_len, vnew, vnew_sb, vnew_sh, flush,
+                              out, out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits, stream);
+}
+
+extern "C" int kivi_decode_softmax_output(const void* scores, int64_t a_sb, int64_t a_sh, float inv_scale,
+                                          const void* mask, int64_t mask_sb, void* code, int64_t code_sb,
+                                          int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb,
+                                          int64_t sm_sh, int64_t sm_sr, void* vres, int64_t vres_sb, int64_t vres_sh,
+                                          int64_t vres_st, int win_start, int res_len, const void* vnew, int64_t vnew_sb,
+                                          int64_t vnew_sh, int flush, void* out, int64_t out_sb, int64_t out_sh, int B,
+                                          int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits,
+                                          kivi_stream_t stream) {
+    return decode_output_impl(1, inv_scale, mask, mask_sb, scores, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn,
+                              sm_sb, sm_sh, sm_sr, vres, vres_sb, vres_sh, vres_st, win_start, res_len, vnew, vnew_sb,
+                              vnew_sh, flush, out, out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits, stream);
+}
+
+static int decode_output_impl(int softmax, float inv_scale, const void* mask, int64_t mask_sb, const void* probs,
+                              int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
+                              void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* vres,
+                              int64_t vres_sb, int64_t vres_sh, int64_t vres_st, int win_start, int res_len,
+                              const void* vnew, int64_t vnew_sb, int64_t vnew_sh, int flush, void* out, int64_t out_sb,
+                              int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits,
+                              kivi_stream_t stream) {
     GemvVArgs a;
     int rc = v_fill(a, "kivi_decode_output", probs, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh,
                     sm_sr, out, out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits);
@@ -523,5 +643,15 @@ extern "C" int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh,
     a.win_start = win_start; a.res_len = res_len;
     a.vnew = (const uint16_t*)vnew; a.vnew_sb = vnew_sb; a.vnew_sh = vnew_sh;
     a.flush = flush ? 1 : 0;
+    if (softmax) {
+        const int64_t n = Tv + res_len + 1;
+        KIVI_REQUIRE(n < ((int64_t)1 << 30), KIVI_EINVAL, "kivi_decode_softmax_output: row too long");
+        a.softmax = 1;
+        a.n_scores = (int)n;
+        a.n_pad = (int)((n + 7) / 8 * 8);
+        a.inv_scale = inv_scale;
+        a.mask = (const uint16_t*)mask;
+        a.mask_sb = mask_sb;
+    }
     return v_run(-1, a, B, group_size, bits, (hipStream_t)stream);
 }

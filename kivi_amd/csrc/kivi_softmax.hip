@@ -14,20 +14,6 @@ namespace {
 
 typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float block_reduce(float v, bool is_max, float* lds) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const float o = __shfl_xor(v, m);
-        v = is_max ? __builtin_fmaxf(v, o) : v + o;
-    }
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();   // previous use of lds is over
-    if ((threadIdx.x & 63) == 0) lds[wave] = v;
-    __syncthreads();
-    const float a = lds[0], b = lds[1], c = lds[2], d = lds[3];
-    return is_max ? __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)) : (a + b) + (c + d);
-}
-
 // CHUNKS x 1024 elements per row are held in registers (4 halves per thread per chunk).
 template <int CHUNKS>
 __global__ __launch_bounds__(256) void softmax_scaled_kernel(const uint16_t* __restrict__ scores, uint16_t* __restrict__ probs,
@@ -53,18 +39,13 @@ __global__ __launch_bounds__(256) void softmax_scaled_kernel(const uint16_t* __r
         for (int e = 0; e < 4; e++) {
             float v = -__builtin_inff();
             if (j0 + e < n) {
-                uint16_t h = f2h_bits(h2f_bits(raw[e]) * inv_scale);                  // :339, fp16 result
-                if (mrow) {
-                    h = f2h_bits(h2f_bits(h) + h2f_bits(mrow[j0 + e]));              // :368
-                    if (h2f_bits(h) < -65504.0f) h = 0xFBFFu;                        // :369-371 max(., finfo.min)
-                }
-                v = h2f_bits(h);
+                v = h2f_bits(kivi_scaled_score(raw[e], inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
             }
             x[c][e] = v;
             mx = __builtin_fmaxf(mx, v);
         }
     }
-    mx = block_reduce(mx, true, lds);
+    mx = kivi_block_reduce(mx, true, lds);
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++)
@@ -73,7 +54,7 @@ __global__ __launch_bounds__(256) void softmax_scaled_kernel(const uint16_t* __r
             x[c][e] = __builtin_expf(x[c][e] - mx);   // exp(-inf) = 0 for the padding lanes
             sum += x[c][e];
         }
-    sum = block_reduce(sum, false, lds);
+    sum = kivi_block_reduce(sum, false, lds);
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++) {
         const int64_t j0 = (int64_t)c * 1024 + threadIdx.x * 4;
@@ -98,19 +79,14 @@ __global__ __launch_bounds__(256) void softmax_scaled_generic(const uint16_t* __
     uint16_t* prow = probs + row * p_pitch;
     const uint16_t* mrow = mask ? mask + (row / nh) * mask_sb : nullptr;
     auto val = [&](int64_t j) {
-        uint16_t h = f2h_bits(h2f_bits(srow[j]) * inv_scale);
-        if (mrow) {
-            h = f2h_bits(h2f_bits(h) + h2f_bits(mrow[j]));
-            if (h2f_bits(h) < -65504.0f) h = 0xFBFFu;
-        }
-        return h2f_bits(h);
+        return h2f_bits(kivi_scaled_score(srow[j], inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
     };
     float mx = -__builtin_inff();
     for (int64_t j = threadIdx.x; j < n; j += 256) mx = __builtin_fmaxf(mx, val(j));
-    mx = block_reduce(mx, true, lds);
+    mx = kivi_block_reduce(mx, true, lds);
     float sum = 0.f;
     for (int64_t j = threadIdx.x; j < n; j += 256) sum += __builtin_expf(val(j) - mx);
-    sum = block_reduce(sum, false, lds);
+    sum = kivi_block_reduce(sum, false, lds);
     for (int64_t j = threadIdx.x; j < n; j += 256) prow[j] = f2h_bits(__builtin_expf(val(j) - mx) / sum);
 }
 

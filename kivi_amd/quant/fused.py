@@ -50,16 +50,32 @@ def softmax_scaled(scores: torch.Tensor, probs: torch.Tensor, n: int, inv_scale:
                "kivi_softmax_scaled")
 
 
-def decode_output(layer, probs: torch.Tensor, value_states: torch.Tensor, out: torch.Tensor) -> bool:
+def decode_output(layer, probs: torch.Tensor, value_states: torch.Tensor, out: torch.Tensor,
+                  softmax_inv_scale: float = None, mask: torch.Tensor = None) -> bool:
     """out (B, nh, 1, D) <- fused sV over the packed V + probs[..., Tv:] @ [fp16 V window | new value]; the new value is
     appended to the window and, when the window then exceeds R tokens, its oldest token is quantised into the cache.
-    Returns True if that flush happened (the caller updates the lengths)."""
+    Returns True if that flush happened (the caller updates the lengths).
+    With `softmax_inv_scale`, `probs` holds the PRE-softmax scores and scale + mask + softmax run inside the same launch."""
     cfg = layer.cfg
     B, nh = probs.shape[0], probs.shape[1]
     v = value_states if value_states.stride(3) == 1 else value_states.contiguous()
     vc, vs, vm, vr = layer.v_code, layer.v_scale, layer.v_mn, layer.v_res
     flush = layer.v_res_len + 1 > cfg.residual_length
     lib = _lib.load()
+    if softmax_inv_scale is not None:
+        if mask is not None:
+            assert mask.dtype == torch.float16 and mask.stride(3) == 1
+        _lib.check(lib.kivi_decode_softmax_output(
+            _lib.ptr(probs), probs.stride(0), probs.stride(1), float(softmax_inv_scale),
+            _lib.ptr(mask) if mask is not None else None, mask.stride(0) if mask is not None else 0,
+            _lib.ptr(vc), vc.stride(0), vc.stride(1), vc.stride(2),
+            _lib.ptr(vs), _lib.ptr(vm), vs.stride(0), vs.stride(1), vs.stride(2),
+            _lib.ptr(vr), vr.stride(0), vr.stride(1), vr.stride(2), layer.v_res_start, layer.v_res_len,
+            _lib.ptr(v), v.stride(0), v.stride(1), int(flush),
+            _lib.ptr(out), out.stride(0), out.stride(1),
+            B, nh, layer.nh_kv, layer.v_quant_len, layer.D, cfg.group_size, cfg.v_bits, _lib.stream_ptr(probs)),
+            "kivi_decode_softmax_output")
+        return flush
     _lib.check(lib.kivi_decode_output(
         _lib.ptr(probs), probs.stride(0), probs.stride(1),
         _lib.ptr(vc), vc.stride(0), vc.stride(1), vc.stride(2),

@@ -7,6 +7,27 @@ from helpers import gemv_close, make_kv, same_bits
 pytestmark = pytest.mark.gpu
 
 
+def test_fused_step_partial_support():
+    """head_dim 96: the qK^T kernel is tuned, the sV kernel is not -> the step mixes fused scores with a composed output
+    and must still match the reference logic and keep the cache consistent."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    from oracle import hook_ref as H
+    B, nh, nh_kv, D, T0, R = 1, 4, 2, 96, 40, 32
+    cfg = KiviConfig(2, 2, 32, R)
+    k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
+    layer = KiviLayerCache(cfg, B, nh_kv, D, 128, "cuda")
+    layer.prefill(k0.cuda(), v0.cuda())
+    past = H.prefill_cache(k0, v0, 2, 2, 32, R)
+    for s in range(30):
+        q = make_kv(100 + s, B, nh, 1, D)
+        kn, vn = make_kv(200 + s, B, nh_kv, 1, D), make_kv(300 + s, B, nh_kv, 1, D)
+        out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer)
+        ref, past = H.decode_step(q, kn, vn, past, 2, 2, 32, R)
+        ok, ratio = gemv_close(out, ref, rtol=3e-3)
+        assert ok, (s, ratio)
+        _cmp_cache(layer.as_tuple(), past)
+
+
 def _cmp_cache(t_gpu, t_ref):
     names = ["K_code_T", "K_full", "K_scale_T", "K_mn_T", "V_code", "V_full", "V_scale", "V_mn"]
     for n, a, b in zip(names, t_gpu[:8], t_ref[:8]):
