@@ -219,7 +219,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
-                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (3, +1 every R steps)",
+                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (2: scores; softmax+output; +1 K flush every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
                        "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)"},

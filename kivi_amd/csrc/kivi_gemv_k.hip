@@ -13,6 +13,8 @@
 // scale is folded into q once per (row, group) and the zero-point term
 // sum_d q[d]*mn[d,G] is hoisted out of the per-token work (one fma per group).
 // DSPLIT waves of a block split the channel range and combine through LDS.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "kivi_common.h"
@@ -62,11 +64,15 @@ __device__ __forceinline__ uint32_t vec_get(const V& v, int j) {
 
 constexpr int KQ_MAXD = 1 << 20;  // head_dim bound of the tuned kernels (q is read row by row)
 
-// Residual role of the fused decode step: one block per (b, head unit) computes q . k for the <= R fp16
-// residual keys plus the new one (out[b, h, T + t], fp32 accumulate, one rounding: what the reference's fp16
-// torch.matmul does at llama_kivi.py:337) and the first unit of every kv head appends the new key (:333-336).
+// Residual role of the fused decode step: one block per (b, head unit) computes q . k for the <= R fp16 residual
+// keys plus the new one (out[b, h, T + t], fp32 accumulate, one rounding: what the reference's fp16 torch.matmul
+// does at llama_kivi.py:337) and the first unit of every kv head appends the new key (:333-336).  Pure latency
+// work on L2-resident data: q is loaded once, a wave takes 4 tokens per pass with all their loads in flight
+// together, and these blocks are scheduled FIRST so they hide under the streaming blocks.
 template <int R>
 __device__ __forceinline__ void k_residual_role(const GemvKArgs& a, int unit) {
+    constexpr int TB = 4;                      // tokens per wave per pass
+    constexpr int NC = 2;                      // channel pairs per lane: D <= 256
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = unit / a.units_per_b;
@@ -74,30 +80,63 @@ __device__ __forceinline__ void k_residual_role(const GemvKArgs& a, int unit) {
     const int h0 = hu * R;
     const int hk = h0 / a.ratio;
     const int L = a.res_len + 1;
+    const bool owner = (h0 % a.ratio) == 0;
     const uint16_t* knew = a.knew + b * a.knew_sb + hk * a.knew_sh;
-    const uint16_t* kres = a.kres + b * a.kres_sb + hk * a.kres_sh;
-    for (int t = wave; t < L; t += 4) {
-        const uint16_t* krow = (t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew;
-        float s[R];
+    uint16_t* kres = const_cast<uint16_t*>(a.kres) + b * a.kres_sb + hk * a.kres_sh;
+    float q0[R][NC], q1[R][NC];
 #pragma unroll
-        for (int r = 0; r < R; r++) s[r] = 0.f;
-        for (int d = lane * 2; d < a.D; d += 128) {
-            const uint32_t kk = *(const uint32_t*)(krow + d);
-            const float k0 = h2f_bits((uint16_t)(kk & 0xFFFFu)), k1 = h2f_bits((uint16_t)(kk >> 16));
+    for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint32_t qq = *(const uint32_t*)(a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + d);
-                s[r] = __builtin_fmaf(h2f_bits((uint16_t)(qq & 0xFFFFu)), k0, s[r]);
-                s[r] = __builtin_fmaf(h2f_bits((uint16_t)(qq >> 16)), k1, s[r]);
+        for (int c = 0; c < NC; c++) {
+            const int d = lane * 2 + 128 * c;
+            uint32_t qq = 0;
+            if (d < a.D) qq = *(const uint32_t*)(a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + d);
+            q0[r][c] = h2f_bits((uint16_t)(qq & 0xFFFFu));
+            q1[r][c] = h2f_bits((uint16_t)(qq >> 16));
+        }
+    for (int t0 = wave; t0 < L; t0 += 4 * TB) {
+        uint32_t kk[TB][NC];
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const int t = t0 + 4 * u;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int d = lane * 2 + 128 * c;
+                kk[u][c] = 0;
+                if (t < L && d < a.D) {
+                    const uint16_t* krow = (t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew;
+                    kk[u][c] = *(const uint32_t*)(krow + d);
+                }
             }
-            if (t == a.res_len && (h0 % a.ratio) == 0)   // append: this block owns the kv head's write
-                *(uint32_t*)(const_cast<uint16_t*>(kres) + (int64_t)t * a.kres_st + d) = kk;
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int u = 0; u < TB; u++) {
+            const int t = t0 + 4 * u;
+            float s[R];
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) s[r] += __shfl_xor(s[r], m);
-            if (lane == 0) a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.T + t] = f2h_bits(s[r]);
+            for (int r = 0; r < R; r++) {
+                s[r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    s[r] = __builtin_fmaf(q0[r][c], h2f_bits((uint16_t)(kk[u][c] & 0xFFFFu)), s[r]);
+                    s[r] = __builtin_fmaf(q1[r][c], h2f_bits((uint16_t)(kk[u][c] >> 16)), s[r]);
+                }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) s[r] += __shfl_xor(s[r], m);
+            }
+            if (t < L) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.T + t] = f2h_bits(s[r]);
+                }
+                if (t == a.res_len && owner) {   // append the new key (:333-336)
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const int d = lane * 2 + 128 * c;
+                        if (d < a.D) *(uint32_t*)(kres + (int64_t)t * a.kres_st + d) = kk[u][c];
+                    }
+                }
+            }
         }
     }
 }
@@ -614,6 +653,7 @@ extern "C" int kivi_decode_scores(int64_t page_tokens, int64_t code_sp, int64_t 
                  "kivi_decode_scores: page_tokens=%lld must be a positive multiple of group_size=%d", (long long)page_tokens,
                  group_size);
     KIVI_REQUIRE(res_len >= 0 && kres && knew, KIVI_EINVAL, "kivi_decode_scores: residual buffers missing");
+    KIVI_REQUIRE(D <= 256, KIVI_EUNSUPPORTED, "kivi_decode_scores: head_dim %d > 256", D);
     KIVI_REQUIRE(D % 2 == 0 && kres_sb % 2 == 0 && kres_sh % 2 == 0 && kres_st % 2 == 0 && knew_sb % 2 == 0 &&
                      knew_sh % 2 == 0 && (uintptr_t)kres % 4 == 0 && (uintptr_t)knew % 4 == 0,
                  KIVI_EALIGN, "kivi_decode_scores: residual rows must be 4-byte aligned");

@@ -88,6 +88,89 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) ra[r] = make_rsrc(a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh, a.a_extent);
 
+    const int gi0 = (lr * EPL) / G;             // first group index of this lane inside a row
+    const uint32_t coff = (uint32_t)(((int64_t)lt * a.code_sr + lr * WPL) * 4);
+    const uint32_t soff = (uint32_t)(((int64_t)lt * a.sm_sr + gi0) * 2);
+    const uint32_t aoff = (uint32_t)(lt * 2);
+    const uint32_t cstep = (uint32_t)(a.code_sr * 4 * TPI);  // bytes per chunk of TPI tokens
+    const uint32_t sstep = (uint32_t)(a.sm_sr * 2 * TPI);
+    const uint32_t astep = (uint32_t)(2 * TPI);
+
+    float acc[R][EPL];
+    float zacc[R][NGL];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int i = 0; i < EPL; i++) acc[r][i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NGL; g++) zacc[r][g] = 0.f;
+    }
+
+    auto tok = [&](const WV& w, SV sraw, SV mraw, const uint16_t* av) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t ab = av[r];                      // fp16 bits of a[t] for this lane's token
+            float as[NGL];
+            as[0] = mul_hh_vv(ab, (uint32_t)sraw, false);   // exact fp16 x fp16 product, one instruction
+            zacc[r][0] = fma_hh_vv(ab, (uint32_t)mraw, zacc[r][0], false);
+            if constexpr (NGL == 2) {
+                as[1] = mul_hh_vv(ab, (uint32_t)sraw, true);
+                zacc[r][1] = fma_hh_vv(ab, (uint32_t)mraw, zacc[r][1], true);
+            }
+            if constexpr (qs_factor<MODE>() != 1.0f) {
+#pragma unroll
+                for (int g = 0; g < NGL; g++) as[g] *= qs_factor<MODE>();
+            }
+#pragma unroll
+            for (int j = 0; j < WPL; j++) {
+                const int g = (NGL == 1) ? 0 : (j * FPI) / G;
+                accum_word<BITS, MODE>(w[j], as[g], &acc[r][j * FPI]);
+            }
+        }
+    };
+
+    // chunk c = TPI tokens; wave w owns chunks w, w+4, ...; batch = U chunks of this wave
+    const int nchunk = (int)((a.Tv + TPI - 1) / TPI);
+    const int my_chunks = (nchunk > wave) ? (nchunk - wave + 3) / 4 : 0;
+    const int nbatch = (my_chunks + U - 1) / U;  // out-of-range chunks read zeros (bounds check)
+
+    // The chunk offset goes into the (bounds-checked) per-lane voffset: soffset is excluded
+    // from the hardware range check, and the tail relies on out-of-range rows reading 0.
+    auto load_wsm = [&](int bi, WV* wb, SV* sb, SV* mb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = (uint32_t)((bi * U + u) * 4 + wave);
+            wb[u] = buf_load<WV, NT>(rc, coff + c * cstep, 0);
+            sb[u] = buf_load<SV, NT>(rs, soff + c * sstep, 0);
+            mb[u] = buf_load<SV, NT>(rm, soff + c * sstep, 0);
+        }
+    };
+    auto load_a = [&](int bi, uint16_t (*ab)[R]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = (uint32_t)((bi * U + u) * 4 + wave);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (a.softmax) {   // probabilities produced by this block, in LDS
+                    const int64_t t = (int64_t)c * TPI + lt;
+                    ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
+                } else {
+                    ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
+                }
+            }
+        }
+    };
+    auto compute_batch = [&](const WV* wb, const SV* sb, const SV* mb, const uint16_t (*ab)[R]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) tok(wb[u], sb[u], mb[u], ab[u]);
+    };
+
+    WV wA[U], wB[U];
+    SV sA[U], sB[U], mA[U], mB[U];
+    uint16_t aA[U][R], aB[U][R];
+    // the first batch of packed V is requested before the softmax phase so the stream is already moving
+    if (nbatch > 0) load_wsm(0, wA, sA, mA);
+
     if (a.softmax) {
         // scale + mask + softmax of this block's R score rows, the arithmetic of kivi_softmax_scaled (same element ->
         // thread assignment and reduction tree, so the probabilities are bit-identical to the stand-alone kernel).
@@ -151,87 +234,17 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
         __syncthreads();
     }
 
-    const int gi0 = (lr * EPL) / G;             // first group index of this lane inside a row
-    const uint32_t coff = (uint32_t)(((int64_t)lt * a.code_sr + lr * WPL) * 4);
-    const uint32_t soff = (uint32_t)(((int64_t)lt * a.sm_sr + gi0) * 2);
-    const uint32_t aoff = (uint32_t)(lt * 2);
-    const uint32_t cstep = (uint32_t)(a.code_sr * 4 * TPI);  // bytes per chunk of TPI tokens
-    const uint32_t sstep = (uint32_t)(a.sm_sr * 2 * TPI);
-    const uint32_t astep = (uint32_t)(2 * TPI);
-
-    float acc[R][EPL];
-    float zacc[R][NGL];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-#pragma unroll
-        for (int i = 0; i < EPL; i++) acc[r][i] = 0.f;
-#pragma unroll
-        for (int g = 0; g < NGL; g++) zacc[r][g] = 0.f;
-    }
-
-    auto tok = [&](const WV& w, SV sraw, SV mraw, const uint16_t* av) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const uint32_t ab = av[r];                      // fp16 bits of a[t] for this lane's token
-            float as[NGL];
-            as[0] = mul_hh_vv(ab, (uint32_t)sraw, false);   // exact fp16 x fp16 product, one instruction
-            zacc[r][0] = fma_hh_vv(ab, (uint32_t)mraw, zacc[r][0], false);
-            if constexpr (NGL == 2) {
-                as[1] = mul_hh_vv(ab, (uint32_t)sraw, true);
-                zacc[r][1] = fma_hh_vv(ab, (uint32_t)mraw, zacc[r][1], true);
-            }
-            if constexpr (qs_factor<MODE>() != 1.0f) {
-#pragma unroll
-                for (int g = 0; g < NGL; g++) as[g] *= qs_factor<MODE>();
-            }
-#pragma unroll
-            for (int j = 0; j < WPL; j++) {
-                const int g = (NGL == 1) ? 0 : (j * FPI) / G;
-                accum_word<BITS, MODE>(w[j], as[g], &acc[r][j * FPI]);
-            }
-        }
-    };
-
-    // chunk c = TPI tokens; wave w owns chunks w, w+4, ...; batch = U chunks of this wave
-    const int nchunk = (int)((a.Tv + TPI - 1) / TPI);
-    const int my_chunks = (nchunk > wave) ? (nchunk - wave + 3) / 4 : 0;
-    const int nbatch = (my_chunks + U - 1) / U;  // out-of-range chunks read zeros (bounds check)
-
-    // The chunk offset goes into the (bounds-checked) per-lane voffset: soffset is excluded
-    // from the hardware range check, and the tail relies on out-of-range rows reading 0.
-    auto load_batch = [&](int bi, WV* wb, SV* sb, SV* mb, uint16_t (*ab)[R]) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t c = (uint32_t)((bi * U + u) * 4 + wave);
-            wb[u] = buf_load<WV, NT>(rc, coff + c * cstep, 0);
-            sb[u] = buf_load<SV, NT>(rs, soff + c * sstep, 0);
-            mb[u] = buf_load<SV, NT>(rm, soff + c * sstep, 0);
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (a.softmax) {
-                    const int64_t t = (int64_t)c * TPI + lt;
-                    ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
-                } else {
-                    ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
-                }
-            }
-        }
-    };
-    auto compute_batch = [&](const WV* wb, const SV* sb, const SV* mb, const uint16_t (*ab)[R]) {
-#pragma unroll
-        for (int u = 0; u < U; u++) tok(wb[u], sb[u], mb[u], ab[u]);
-    };
-
     {
-        WV wA[U], wB[U];
-        SV sA[U], sB[U], mA[U], mB[U];
-        uint16_t aA[U][R], aB[U][R];
-        if (nbatch > 0) load_batch(0, wA, sA, mA, aA);
+        if (nbatch > 0) load_a(0, aA);
         int it = 0;
         for (; it + 2 <= nbatch; it += 2) {
-            load_batch(it + 1, wB, sB, mB, aB);
+            load_wsm(it + 1, wB, sB, mB);
+            load_a(it + 1, aB);
             compute_batch(wA, sA, mA, aA);
-            if (it + 2 < nbatch) load_batch(it + 2, wA, sA, mA, aA);
+            if (it + 2 < nbatch) {
+                load_wsm(it + 2, wA, sA, mA);
+                load_a(it + 2, aA);
+            }
             compute_batch(wB, sB, mB, aB);
         }
         if (it < nbatch) compute_batch(wA, sA, mA, aA);

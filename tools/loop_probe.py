@@ -33,6 +33,9 @@ attn_c = torch.softmax(torch.randn((B, nh, 1, 4064), device=dev), -1).half()
 big = torch.randn((B, nh, 1, kv), device=dev, dtype=torch.float16)
 
 
+KVAR = -1
+
+
 def run(pattern, reps=3):
     evk, evv = [], []
     for _ in range(reps):
@@ -41,7 +44,7 @@ def run(pattern, reps=3):
                 if op == "k":
                     e = (lib.kivi_event_create(), lib.kivi_event_create())
                     lib.kivi_set_launch_events(*e)
-                    matmul.gemv_k_paged(32, q, lc.k_code, lc.k_scale, lc.k_mn, lc.k_quant_len, 2, out=scores[..., :lc.k_quant_len])
+                    matmul.gemv_k_paged(32, q, lc.k_code, lc.k_scale, lc.k_mn, lc.k_quant_len, 2, out=scores[..., :lc.k_quant_len], variant=KVAR)
                     evk.append(e)
                 elif op in ("v", "vc"):
                     e = (lib.kivi_event_create(), lib.kivi_event_create())
@@ -63,6 +66,10 @@ def run(pattern, reps=3):
     print(f"pattern {''.join(pattern):10s}  K: {stats(evk):48s}  V: {stats(evv)}")
 
 
-for pat in (["k"], ["v"], ["vc"], ["k", "v"], ["k", "s", "v"], ["k", "m", "s", "v", "s", "m"], ["s", "k"], ["m", "k"]):
-    run(pat)
-    run(pat)
+names = {n: i for k, i, n in matmul.bmm_variants() if k == "k"}
+for vn in sys.argv[1:] or ["k_b2_g32_w2_ds4_r1_u4_m2_nt1"]:
+    KVAR = names[vn]
+    print("==", vn)
+    for pat in (["k"], ["s", "k"], ["m", "s", "k"]):
+        run(pat)
+        run(pat)
