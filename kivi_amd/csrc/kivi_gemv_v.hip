@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                 kmax = k > kmax ? k : kmax;
             }
             gq = make_group(kmin, kmax, (1 << BITS) - 1);
-            c = quant_one(x, gq);
+            c = quant_one<BITS>(x, gq);
         }
         __syncthreads();
         if (d < D) lds[d] = c;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim_kernel(const uint16_t*
     const GroupQ g = make_group(kmin, kmax, (1 << BITS) - 1);
     uint32_t q[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) q[i] = quant_one(v[i], g);
+    for (int i = 0; i < 8; i++) q[i] = quant_one<BITS>(v[i], g);
     if constexpr (BITS == 2) {
         uint32_t part = 0;
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim_generic(const uint16_t
     const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
     for (int w = 0; w < g / FPI; w++) {
         uint32_t word = 0;
-        for (int i = 0; i < FPI; i++) word |= quant_one(xp[w * FPI + i], gq) << (BITS * i);
+        for (int i = 0; i < FPI; i++) word |= quant_one<BITS>(xp[w * FPI + i], gq) << (BITS * i);
         code[gi * (g / FPI) + w] = word;
     }
     scale[gi] = gq.scale;
@@ -131,12 +131,84 @@ __global__ __launch_bounds__(64) void quant_pack_k_tmajor_kernel(const uint16_t*
             uint32_t word = 0;
 #pragma unroll
             for (int i = 0; i < FPI; i++)
-                word |= quant_one((uint16_t)((v[w * FPI + i] >> (16 * ch)) & 0xFFFFu), gq) << (BITS * i);
+                word |= quant_one<BITS>((uint16_t)((v[w * FPI + i] >> (16 * ch)) & 0xFFFFu), gq) << (BITS * i);
             cp[w] = word;
         }
         const int64_t so = b * sm_sb + h * sm_sh + (int64_t)d * sm_sr + sm_off + gi;
         scale[so] = gq.scale;
         mn[so] = gq.mn;
+    }
+}
+
+// Same arithmetic, tiled for the store side: a 256-thread block takes NG = 16 consecutive groups (512 tokens at
+// g = 32) of one (b, h); each wave quantises 4 of them exactly like the kernel above, but the packed words and the
+// scale / mn go through an LDS tile so that every channel row is written as one contiguous 128-byte (codes) and
+// 32-byte (scale, mn) segment instead of 64 scattered 8-byte stores.  D <= 128 per block column (blockIdx.y).
+template <int BITS, int G>
+__global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t* __restrict__ k, int64_t k_sb, int64_t k_sh,
+                                                                 int64_t k_st, uint32_t* __restrict__ code,
+                                                                 int64_t code_sb, int64_t code_sh, int64_t code_sr,
+                                                                 int64_t code_off, uint16_t* __restrict__ scale,
+                                                                 uint16_t* __restrict__ mn, int64_t sm_sb, int64_t sm_sh,
+                                                                 int64_t sm_sr, int64_t sm_off, int nh, int D,
+                                                                 int64_t ngroups, int64_t nchunks) {
+    constexpr int FPI = 32 / BITS;
+    constexpr int NW = G / FPI;          // words per group per channel
+    constexpr int NG = 16;               // groups per block
+    constexpr int CP = NG * NW + 1;      // LDS row pitch (words), +1 against bank conflicts
+    __shared__ uint32_t codeL[128 * CP];
+    __shared__ uint16_t scaleL[128 * NG], mnL[128 * NG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = blockIdx.x % nchunks;
+    const int bh = (int)(blockIdx.x / nchunks);
+    const int b = bh / nh, h = bh - b * nh;
+    const int d0 = blockIdx.y * 128;     // first channel of this block column
+    const int dl = 2 * lane;             // this lane's channel pair inside the column
+    const int64_t g_first = chunk * NG;
+    const int ng_here = (int)((ngroups - g_first) < NG ? (ngroups - g_first) : NG);
+    if (d0 + dl < D) {
+        for (int gl = wave; gl < ng_here; gl += 4) {
+            const uint16_t* kp = k + b * k_sb + h * k_sh + (g_first + gl) * G * k_st + d0 + dl;
+            uint32_t v[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) v[t] = __builtin_nontemporal_load((const uint32_t*)(kp + t * k_st));
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint32_t kmin = 0xFFFFu, kmax = 0u;
+#pragma unroll
+                for (int t = 0; t < G; t++) {
+                    const uint32_t kk = h_key((v[t] >> (16 * ch)) & 0xFFFFu);
+                    kmin = kk < kmin ? kk : kmin;
+                    kmax = kk > kmax ? kk : kmax;
+                }
+                const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int i = 0; i < FPI; i++)
+                        word |= quant_one<BITS>((uint16_t)((v[w * FPI + i] >> (16 * ch)) & 0xFFFFu), gq) << (BITS * i);
+                    codeL[(dl + ch) * CP + gl * NW + w] = word;
+                }
+                scaleL[(dl + ch) * NG + gl] = gq.scale;
+                mnL[(dl + ch) * NG + gl] = gq.mn;
+            }
+        }
+    }
+    __syncthreads();
+    // cooperative row stores: two threads per channel row, each a contiguous half
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    if (d0 + row < D) {
+        const int nwords = ng_here * NW;
+        uint32_t* cp = code + b * code_sb + h * code_sh + (int64_t)(d0 + row) * code_sr + code_off + g_first * NW;
+        const int w0 = half * (NG * NW / 2);
+        for (int w = w0; w < w0 + NG * NW / 2 && w < nwords; w++) cp[w] = codeL[row * CP + w];
+        const int64_t so = b * sm_sb + h * sm_sh + (int64_t)(d0 + row) * sm_sr + sm_off + g_first;
+        const int s0 = half * (NG / 2);
+        for (int gq_ = s0; gq_ < s0 + NG / 2 && gq_ < ng_here; gq_++) {
+            scale[so + gq_] = scaleL[row * NG + gq_];
+            mn[so + gq_] = mnL[row * NG + gq_];
+        }
     }
 }
 
@@ -165,7 +237,7 @@ __global__ __launch_bounds__(64) void quant_pack_k_tmajor_generic(const uint16_t
     uint32_t* cp = code + b * code_sb + h * code_sh + (int64_t)d * code_sr + code_off + gi * (g / FPI);
     for (int w = 0; w < g / FPI; w++) {
         uint32_t word = 0;
-        for (int i = 0; i < FPI; i++) word |= quant_one(kp[(int64_t)(w * FPI + i) * k_st], gq) << (BITS * i);
+        for (int i = 0; i < FPI; i++) word |= quant_one<BITS>(kp[(int64_t)(w * FPI + i) * k_st], gq) << (BITS * i);
         cp[w] = word;
     }
     const int64_t so = b * sm_sb + h * sm_sh + (int64_t)d * sm_sr + sm_off + gi;
@@ -304,6 +376,17 @@ extern "C" int kivi_quant_pack_k_tmajor(const void* k, int64_t k_sb, int64_t k_s
     KIVI_REQUIRE(nblk < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_quant_pack_k_tmajor: grid too large");
     const bool fast = (D % 2 == 0) && (k_sb % 2 == 0) && (k_sh % 2 == 0) && (k_st % 2 == 0) && ((uintptr_t)k % 4 == 0) &&
                       (group_size == 32 || group_size == 64 || group_size == 128) && bits != 8;
+    if (fast && ngroups >= 8) {   // store-coalescing tile kernel (prefill-sized calls)
+        const int64_t nchunks = (ngroups + 15) / 16;
+        dim3 grid((unsigned)(nchunks * B * nh), (unsigned)((D + 127) / 128));
+#define KIVI_KT_CASE(BITS, G)                                                                                   \
+    if (bits == BITS && group_size == G) {                                                                      \
+        hipLaunchKernelGGL((quant_pack_k_tmajor_tiled<BITS, G>), grid, dim3(256), 0, s, KIVI_K_ARGS, nchunks);  \
+        return kivi_launch_status("quant_pack_k_tmajor_tiled");                                                 \
+    }
+        KIVI_KT_CASE(2, 32) KIVI_KT_CASE(2, 64) KIVI_KT_CASE(4, 32) KIVI_KT_CASE(4, 64)
+#undef KIVI_KT_CASE
+    }
     if (fast) {
         dim3 grid((unsigned)nblk, (unsigned)((D / 2 + 63) / 64));
 #define KIVI_K_CASE(BITS, G)                                                                            \

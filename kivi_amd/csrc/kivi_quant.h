@@ -9,6 +9,7 @@ __device__ __forceinline__ uint32_t h_unkey(uint32_t k) { return (k & 0x8000u) ?
 
 struct GroupQ {
     float fmn, fs, fmaxq;
+    float th[3];   // 2-bit decision thresholds tau_k * scale (exact fp32 products)
     uint16_t mn, scale;
 };
 
@@ -21,11 +22,28 @@ __device__ __forceinline__ GroupQ make_group(uint32_t kmin, uint32_t kmax, int m
     g.scale = f2h_bits(h2f_bits(range) / (float)maxq);            //                 / max_int
     g.fs = h2f_bits(g.scale);
     g.fmaxq = (float)maxq;
+    // 2-bit fast path (quant_one<2>): code = #{k : d > tau_k * scale} with
+    //   tau_0 = 0.5 + 2^-12, tau_1 = 1.5 - 2^-11 (>=), tau_2 = 2.5 + 2^-10
+    // = the fp16 rounding boundaries of d/scale around k + 0.5 combined with round-half-even of the quotient.
+    // tau (12 bits) x scale (11 bits) is exact in fp32, so the comparison is exact and the result is identical to
+    // rint(clamp(fp16(d / scale))): checked against the division for every scale and every d within 3 ulps of a
+    // boundary (and 4e7 random pairs) -- tests/test_oracle_golden.py::test_threshold_quantiser_equals_division.
+    // scale 0 (constant group: 0/0) and scale inf (range overflow: x/inf or inf/inf) quantise to code 0 in the
+    // reference's CUDA path; NaN thresholds make every comparison false.
+    const float fsx = (g.fs > 0.0f && g.fs < __builtin_inff()) ? g.fs : __builtin_nanf("");
+    g.th[0] = 0.500244140625f * fsx;
+    g.th[1] = 1.49951171875f * fsx;
+    g.th[2] = 2.5009765625f * fsx;
     return g;
 }
 
+template <int BITS>
 __device__ __forceinline__ uint32_t quant_one(uint16_t x, const GroupQ& g) {
     const uint16_t d = f2h_bits(h2f_bits(x) - g.fmn);             // new_pack.py:239
+    if constexpr (BITS == 2) {
+        const float fd = h2f_bits(d);
+        return (uint32_t)(fd > g.th[0]) + (uint32_t)(fd >= g.th[1]) + (uint32_t)(fd > g.th[2]);
+    }
     const uint16_t q = f2h_bits(h2f_bits(d) / g.fs);              // :240, correctly rounded division
     float fq = h2f_bits(q);
     fq = __builtin_fmaxf(fq, 0.0f);                               // NaN -> 0 (fmax drops the NaN)

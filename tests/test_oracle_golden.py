@@ -131,3 +131,48 @@ def test_oracle_rejects_bad_arguments(oracle):
     sz = torch.zeros((1, 2, 32, 1), dtype=torch.float16)
     with pytest.raises(ValueError):
         oracle.bmm_fA_qB_outer(32, fA, qB, sz, sz, 2)             # nh % nh_kv != 0 (matmul.py:216)
+
+
+def test_threshold_quantiser_equals_division():
+    """The 2-bit kernels count thresholds instead of dividing (kivi_quant.h): code = [d > t0*s] + [d >= t1*s] + [d > t2*s].
+    For EVERY positive fp16 scale and every d within 3 ulps of a decision boundary (plus random pairs) this equals the
+    reference's rint(clamp(fp16(d / s))) with the division done in fp32 and rounded to fp16 (new_pack.py:240-241)."""
+    allh = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16)
+    s_all = allh[1:]
+    taus = np.array([0.5 + 2 ** -12, 1.5 - 2 ** -11, 2.5 + 2 ** -10], dtype=np.float32)
+    strict = [True, False, True]
+
+    def ref_code(d, s):
+        with np.errstate(over="ignore"):
+            q = (d.astype(np.float32) / s.astype(np.float32)).astype(np.float16).astype(np.float32)
+        return np.rint(np.clip(q, 0, 3)).astype(np.int32)
+
+    def thr_code(d, s):
+        df, sf = d.astype(np.float32), s.astype(np.float32)
+        sf = np.where((sf > 0) & np.isfinite(sf), sf, np.float32(np.nan))   # scale 0 / inf -> code 0 (kivi_quant.h)
+        c = np.zeros(d.shape, np.int32)
+        for t, st in zip(taus, strict):
+            with np.errstate(invalid="ignore"):
+                th = t * sf
+            ok = np.isfinite(sf)
+            assert (th[ok].astype(np.float64) == np.float64(t) * sf[ok].astype(np.float64)).all()   # the product is exact
+            c += (df > th) if st else (df >= th)
+        return c
+
+    for k in range(3):
+        with np.errstate(over="ignore"):
+            bits = (taus[k] * s_all.astype(np.float32)).astype(np.float16).view(np.uint16).astype(np.int32)
+        for off in range(-3, 4):
+            d = np.clip(bits + off, 0, 0x7BFF).astype(np.uint16).view(np.float16)
+            assert (ref_code(d, s_all) == thr_code(d, s_all)).all(), (k, off)
+    rng = np.random.default_rng(0)
+    d = allh[rng.integers(0, allh.size, 2_000_000)]
+    s = s_all[rng.integers(0, s_all.size, 2_000_000)]
+    assert (ref_code(d, s) == thr_code(d, s)).all()
+    # degenerate scales: 0/0 and x/inf, inf/inf -> NaN or 0 -> code 0 (CUDA float->int of NaN)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for sv, dv in ((0.0, 0.0), (np.inf, 1.0), (np.inf, np.inf), (np.inf, 0.0)):
+            d1, s1 = np.array([dv], np.float16), np.array([sv], np.float16)
+            q = (d1.astype(np.float32) / s1.astype(np.float32)).astype(np.float16).astype(np.float32)
+            ref = 0 if np.isnan(q[0]) else int(np.rint(np.clip(q, 0, 3))[0])
+            assert thr_code(d1, s1)[0] == ref == 0
