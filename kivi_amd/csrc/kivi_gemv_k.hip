@@ -464,7 +464,16 @@ const KVariant k_variants[] = {
     KV(4, 128, 4, 4, 1, 4, 2, 1),
     KV(4, 128, 2, 4, 1, 4, 2, 1),
     KV(4, 32, 4, 2, 1, 4, 0, 0),
-    // ---- GQA: R query heads share every unpacked code (R*TPL accumulators per lane)
+    // ---- GQA: R query heads share every unpacked code (R*TPL accumulators per lane).  The unpack is R FMAs per
+    // code, so the cheaper-per-FMA fp32-subnormal form (mask + R x v_fmac_f32) beats the FMA-mix form here.
+    KV(2, 32, 1, 2, 4, 4, 4, 1),
+    KV(2, 32, 1, 1, 4, 4, 4, 1),
+    KV(2, 32, 2, 2, 2, 4, 4, 1),
+    KV(2, 32, 1, 1, 8, 4, 4, 1),
+    KV(2, 32, 2, 1, 4, 2, 4, 1),
+    KV(4, 32, 2, 2, 4, 4, 4, 1),
+    KV(2, 64, 1, 2, 4, 4, 4, 1),
+    KV(2, 128, 1, 2, 4, 4, 4, 1),
     KV(2, 32, 1, 1, 4, 4, 2, 1),
     KV(2, 32, 1, 2, 4, 4, 2, 1),
     KV(2, 32, 2, 2, 2, 4, 2, 1),
@@ -537,7 +546,8 @@ int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream
     int best = -1;
     for (int i = 0; i < k_nvariants; i++) {
         const KVariant& v = k_variants[i];
-        if (v.mode != KIVI_UNPACK_MIX) continue;   // production unpack; the other modes are A/B references
+        // production unpacks: FMA-mix, and the fp32-subnormal form for GQA units; the others are A/B references
+        if (!(v.mode == KIVI_UNPACK_MIX || (v.mode == KIVI_UNPACK_DEN32 && v.R > 1))) continue;
         if (!k_variant_fits(v, a, bits, G)) continue;
         if (a.ratio % v.R) continue;
         if (best < 0 || v.R > k_variants[best].R) best = i;

@@ -481,6 +481,11 @@ const VVariant v_variants[] = {
     VV(4, 64, 8, 4, 1, 4, 2, 1),
     VV(4, 32, 16, 4, 1, 4, 0, 0),
     // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
+    VV(2, 32, 8, 2, 4, 2, 4, 1),
+    VV(2, 32, 8, 2, 2, 4, 4, 1),
+    VV(2, 64, 8, 2, 4, 2, 4, 1),
+    VV(2, 128, 8, 2, 4, 2, 4, 1),
+    VV(4, 32, 16, 4, 4, 2, 4, 1),
     VV(2, 32, 8, 2, 4, 2, 2, 0),
     VV(2, 32, 8, 2, 2, 4, 2, 0),
     VV(2, 64, 8, 2, 4, 2, 2, 0),
@@ -526,7 +531,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
     int best = -1;
     for (int i = 0; i < v_nvariants; i++) {
         const VVariant& v = v_variants[i];
-        if (v.mode != KIVI_UNPACK_MIX) continue;
+        if (!(v.mode == KIVI_UNPACK_MIX || (v.mode == KIVI_UNPACK_DEN32 && v.R > 1))) continue;
         if (!v_variant_fits(v, a, bits, G)) continue;
         if (best < 0 || v.R > v_variants[best].R) best = i;
     }
