@@ -143,6 +143,15 @@ int kivi_gemv_outer_dim(const void* in, const void* kernel, const void* scale, c
                         int64_t BS, int64_t IC, int64_t OC, int bit, int group_size, int nh, int nh_kv,
                         kivi_stream_t stream);
 
+/*
+ * ABI twin of the reference's second native entry point, the legacy AWQ-style inner-dim 4-bit GEMV
+ * (torch::Tensor gemv_forward_cuda, quant/csrc/gemv_cuda.h:4-10, gemv_cuda.cu:60-246): in (B, IC) fp16,
+ * kernel (OC, IC/8) int32 packed along IC, scale / zeros (OC, sz_pitch >= IC/g) fp16, out (B, OC) fp16;
+ * bit must be 4 and group_size 64 or 128 like the reference.  Off the KV-cache path (surface parity only).
+ */
+int kivi_gemv_awq(const void* in, const void* kernel, const void* scale, const void* zeros, void* out, int64_t B,
+                  int64_t IC, int64_t OC, int bit, int group_size, int64_t sz_pitch, kivi_stream_t stream);
+
 /* --------------------------------------------------- fused decode step --- */
 
 /*

@@ -45,6 +45,7 @@ SIGNATURES = {
     "kivi_decode_softmax_output": (_i32, [_vp, _i64, _i64, ctypes.c_float, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64,
                                           _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64,
                                           _i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),
     "kivi_gemv_k_variant": (_i32, [_i32] + _GEMV_ARGS + [_i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),

@@ -72,7 +72,63 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_kernel(const uint16_t* __r
     }
 }
 
+// Legacy AWQ-style INNER-dim grouped 4-bit GEMV (gemv_kernel_g64 / gemv_kernel_g128, gemv_cuda.cu:60-184):
+//   out[b, oc] = fp16( sum_ic (scale[oc, ic/g] * code[oc, ic] + zero[oc, ic/g]) * in[b, ic] )
+// weight (OC, IC/8) int32 packed along IC, scale / zeros (OC, >= IC/g) fp16 with row pitch `sz_pitch`.
+// Not on the KV-cache path (only the reference's disabled scripts call it, quant/gemv.py:188,225); kept for surface
+// parity, written for clarity: one wave per (b, oc), 32 codes per lane per pass.
+__global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t* __restrict__ in, const uint32_t* __restrict__ weight,
+                                                       const uint16_t* __restrict__ scale,
+                                                       const uint16_t* __restrict__ zeros, uint16_t* __restrict__ out,
+                                                       int64_t IC, int64_t OC, int g, int64_t sz_pitch) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t oc = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t b = blockIdx.y;
+    if (oc >= OC) return;
+    const int64_t ww = IC / 8;
+    const uint32_t* wrow = weight + oc * ww;
+    const uint16_t* xrow = in + b * IC;
+    float psum = 0.f;
+    for (int64_t w0 = (int64_t)lane * 4; w0 < ww; w0 += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t w = w0 + j;
+            if (w < ww) {
+                uint32_t word = wrow[w];
+                const int64_t gi = (w * 8) / g;
+                const float sc = h2f_bits(scale[oc * sz_pitch + gi]), zp = h2f_bits(zeros[oc * sz_pitch + gi]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float dq = __builtin_fmaf(sc, (float)(word & 0xFu), zp);   // gemv_cuda.cu:101
+                    psum = __builtin_fmaf(dq, h2f_bits(xrow[w * 8 + i]), psum);      // :103
+                    word >>= 4;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) psum += __shfl_xor(psum, m);
+    if (lane == 0) out[b * OC + oc] = f2h_bits(psum);
+}
+
 }  // namespace
+
+extern "C" int kivi_gemv_awq(const void* in, const void* kernel, const void* scale, const void* zeros, void* out, int64_t B,
+                             int64_t IC, int64_t OC, int bit, int group_size, int64_t sz_pitch, kivi_stream_t stream) {
+    KIVI_REQUIRE(bit == 4, KIVI_EINVAL, "kivi_gemv_awq: the reference kernels are 4-bit only (PACK_FACTOR 8), got %d", bit);
+    KIVI_REQUIRE(group_size == 64 || group_size == 128, KIVI_EINVAL,
+                 "kivi_gemv_awq: group_size must be 64 or 128 (gemv_cuda.cu:227-244), got %d", group_size);
+    KIVI_REQUIRE(IC > 0 && IC % group_size == 0 && OC >= 0 && B >= 0 && sz_pitch >= IC / group_size, KIVI_EINVAL,
+                 "kivi_gemv_awq: IC=%lld must be a multiple of group_size=%d", (long long)IC, group_size);
+    KIVI_REQUIRE(B < 65536, KIVI_EINVAL, "kivi_gemv_awq: batch too large");
+    if (B == 0 || OC == 0) return 0;
+    dim3 grid((unsigned)((OC + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL(gemv_awq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in,
+                       (const uint32_t*)kernel, (const uint16_t*)scale, (const uint16_t*)zeros, (uint16_t*)out, IC, OC,
+                       group_size, sz_pitch);
+    return kivi_launch_status("gemv_awq");
+}
 
 extern "C" int kivi_gemv_outer_dim(const void* in, const void* kernel, const void* scale, const void* zeros, void* out,
                                    int64_t BS, int64_t IC, int64_t OC, int bit, int group_size, int nh, int nh_kv,

@@ -34,8 +34,27 @@ def gemv_forward_cuda_outer_dim(in_feats: torch.Tensor, kernel: torch.Tensor, sc
     return out
 
 
-def gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, bit: int, group_size: int):
-    """Reference gemv_cuda.cu:201-246 (AWQ-style inner-dim 4-bit GEMV, g64/g128).  Legacy: only the
-    reference's disabled test scripts call it (quant/gemv.py:188,225); not on the KV-cache path."""
-    raise NotImplementedError("AWQ inner-dim GEMV (gemv_forward_cuda) is outside the KV-cache hot path; "
-                              "see DESIGN.md 'out of scope'")
+def gemv_forward_cuda(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors: torch.Tensor, zeros: torch.Tensor,
+                      bit: int, group_size: int) -> torch.Tensor:
+    """Reference gemv_cuda.cu:201-246: legacy AWQ-style INNER-dim 4-bit GEMV (g64 / g128).
+    in_feats (B, IC) fp16, kernel (OC, IC // 8) int32 packed along IC, scaling_factors / zeros (OC, >= IC // g) fp16
+    ("zeros" is the fp16 group minimum, quant/gemv.py:188) -> (B, OC) fp16.  Only the reference's disabled test
+    scripts call it; kept for surface parity."""
+    for t, n in ((in_feats, "in_feats"), (kernel, "kernel"), (scaling_factors, "scaling_factors"), (zeros, "zeros")):
+        _lib.require_gpu(t, n)
+    if in_feats.dtype != torch.float16 or scaling_factors.dtype != torch.float16 or zeros.dtype != torch.float16:
+        raise TypeError("in_feats, scaling_factors and zeros must be float16")
+    if kernel.dtype != torch.int32:
+        raise TypeError("kernel must be int32")
+    B, IC = in_feats.shape
+    OC = kernel.shape[0]
+    x, w = in_feats.contiguous(), kernel.contiguous()
+    s = scaling_factors if scaling_factors.stride(1) == 1 else scaling_factors.contiguous()
+    z = zeros if (zeros.stride() == s.stride()) else zeros.contiguous()
+    if z.stride() != s.stride():
+        s = s.contiguous()
+    out = torch.empty((B, OC), dtype=torch.float16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.kivi_gemv_awq(_lib.ptr(x), _lib.ptr(w), _lib.ptr(s), _lib.ptr(z), _lib.ptr(out), B, IC, OC, bit,
+                                 group_size, s.stride(0), _lib.stream_ptr(x)), "kivi_gemv_awq")
+    return out

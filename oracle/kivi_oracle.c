@@ -425,3 +425,44 @@ int kivi_oracle_fakequant_bmm(const uint16_t* fA, int64_t fa_stride, const int32
     free(acc);
     return 0;
 }
+
+/*
+ * gemv_forward_cuda -> gemv_kernel_g64 / gemv_kernel_g128 (gemv_cuda.cu:60-246): legacy AWQ-style inner-dim
+ * 4-bit GEMV.  32 lanes, each pass covers 1024 input channels: lane l owns words 4l..4l+3 (32 codes) of the pass
+ * (:81, :153), scale / zero index = pass * (1024/g) + l / (g/32) (:84-85, :156-157), fp32 fma accumulation in
+ * (pass, ic_0, ic_1) order, shuffle-down tree, one RN rounding.  Scale rows use the caller's pitch (the reference
+ * hard-codes a padded pitch that equals IC/g whenever IC is a multiple of 1024).
+ */
+int kivi_oracle_gemv_awq(const uint16_t* in, const int32_t* kernel, const uint16_t* scale, const uint16_t* zeros,
+                         uint16_t* out, int64_t B, int64_t IC, int64_t OC, int g, int64_t sz_pitch, int use_fma) {
+    if (!(g == 64 || g == 128) || IC % g) return -1;
+    const int64_t ww = IC / 8;
+    const int64_t npass = (IC + 1023) / 1024;
+    const int lanes_per_group = g / 32;
+    for (int64_t b = 0; b < B; b++)
+        for (int64_t oc = 0; oc < OC; oc++) {
+            float psum[32];
+            for (int l = 0; l < 32; l++) psum[l] = 0.0f;
+            for (int64_t p = 0; p < npass; p++)
+                for (int l = 0; l < 32; l++) {
+                    const int64_t gi = p * (1024 / g) + l / lanes_per_group;
+                    for (int i0 = 0; i0 < 4; i0++) {
+                        const int64_t w = p * 128 + l * 4 + i0;
+                        if (w >= ww) continue; /* inputs guard (:93, :165) */
+                        uint32_t word = (uint32_t)kernel[oc * ww + w];
+                        const float cs = h2f(scale[oc * sz_pitch + gi]), cz = h2f(zeros[oc * sz_pitch + gi]);
+                        for (int i1 = 0; i1 < 8; i1++) {
+                            const float wf = (float)(word & 0xFu);
+                            const float x = h2f(in[b * IC + w * 8 + i1]);
+                            if (use_fma) psum[l] = fmaf(fmaf(cs, wf, cz), x, psum[l]);
+                            else psum[l] = psum[l] + (cs * wf + cz) * x;
+                            word >>= 4;
+                        }
+                    }
+                }
+            for (int off = 16; off >= 1; off >>= 1)
+                for (int l = 0; l + off < 32; l++) psum[l] += psum[l + off];
+            out[b * OC + oc] = f2h(psum[0]);
+        }
+    return 0;
+}

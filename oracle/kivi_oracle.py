@@ -55,6 +55,7 @@ def lib() -> ctypes.CDLL:
         L.kivi_oracle_bmm_fA_qB_outer.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32,
                                                   i32, i32]
         L.kivi_oracle_fakequant_bmm.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32]
+        L.kivi_oracle_gemv_awq.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i64, i32]
         _lib = L
     return _lib
 
@@ -206,4 +207,19 @@ def bmm_fA_qB_outer(group_size: int, fA, qB, scales, zeros, bits: int, use_fma: 
         rc = lib().kivi_oracle_bmm_fA_qB_outer(_p(a), K, _p(w), _p(s), _p(z), _p(out), B * nh, K, N, bits,
                                                group_size, nh, nh_kv, int(use_fma))
     _chk(rc, "bmm_fA_qB_outer")
+    return out
+
+
+def gemv_forward_awq(in_feats, kernel, scaling_factors, zeros, bit: int, group_size: int, use_fma: bool = True):
+    """gemv_cuda.cu:201-246 (legacy inner-dim 4-bit GEMV)."""
+    assert bit == 4
+    x = _c(in_feats, torch.float16)
+    B, IC = x.shape
+    w = _c(kernel, torch.int32)
+    OC = w.shape[0]
+    s = _c(scaling_factors, torch.float16)
+    z = _c(zeros, torch.float16)
+    out = torch.empty((B, OC), dtype=torch.float16)
+    _chk(lib().kivi_oracle_gemv_awq(_p(x), _p(w), _p(s), _p(z), _p(out), B, IC, OC, group_size, s.shape[1], int(use_fma)),
+         "gemv_awq")
     return out

@@ -231,8 +231,14 @@ def test_errors_like_reference(mods):
         matmul.cuda_bmm_fA_qB_outer(32, fA[:, :2], qB, sz, sz, 8)   # bits in [2, 4] (matmul.py:215)
     with pytest.raises(NotImplementedError):
         matmul.cuda_bmm_fA_qB_outer(32, torch.zeros(1, 2, 2, 64, device="cuda", dtype=torch.float16), qB, sz, sz, 2)
-    with pytest.raises(NotImplementedError):
-        kivi_gemv.gemv_forward_cuda(None, None, None, None, 4, 64)
+    from kivi_amd._lib import KiviHipError
+    x = torch.zeros(2, 128, device="cuda", dtype=torch.float16)
+    w = torch.zeros(4, 16, device="cuda", dtype=torch.int32)
+    sz = torch.zeros(4, 2, device="cuda", dtype=torch.float16)
+    with pytest.raises(KiviHipError):
+        kivi_gemv.gemv_forward_cuda(x, w, sz, sz, 2, 64)             # the reference kernels are 4-bit only
+    with pytest.raises(KiviHipError):
+        kivi_gemv.gemv_forward_cuda(x, w, sz, sz, 4, 32)             # g64 / g128 only (gemv_cuda.cu:227-244)
 
 
 def test_full_size_qk_properties(mods, oracle):
@@ -268,3 +274,23 @@ def test_full_size_qk_properties(mods, oracle):
     assert ok, ratio
     ok, ratio = gemv_close(s1, b_.cpu())
     assert ok, ratio
+
+
+@pytest.mark.parametrize("B,IC,OC,GS", [(3, 2048, 64, 64), (1, 1024, 33, 128), (2, 4096, 16, 128), (2, 640, 8, 64)])
+def test_legacy_awq_gemv(mods, oracle, B, IC, OC, GS):
+    """kivi_gemv.gemv_forward_cuda (quant/gemv.py:168-195 procedure): inner-dim grouped 4-bit GEMV vs the oracle that
+    restates gemv_kernel_g64/g128, and vs the dequantised matmul the reference script compares with."""
+    new_pack, _, kivi_gemv = mods
+    g = torch.Generator().manual_seed(3)
+    inp = torch.randn((B, IC), generator=g).half()
+    wt = torch.randn((OC, IC), generator=g).half()
+    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(wt.view(1, 1, OC, IC).cuda(), GS, 4)
+    qweight, scale, mn = code.view(OC, IC // 8), scale.view(OC, IC // GS), mn.view(OC, IC // GS)
+    got = kivi_gemv.gemv_forward_cuda(inp.cuda(), qweight, scale, mn, 4, GS)
+    ref = oracle.gemv_forward_awq(inp, qweight.cpu(), scale.cpu(), mn.cpu(), 4, GS)
+    ok, ratio = gemv_close(got, ref)
+    assert ok, ratio
+    deq = new_pack.unpack_and_dequant_vcache(qweight.view(1, 1, OC, -1), scale.view(1, 1, OC, -1, 1), mn.view(1, 1, OC, -1, 1),
+                                             GS, 4).view(OC, IC)
+    full = inp.cuda().float() @ deq.float().T
+    assert ((got.float() - full).abs() <= 5e-3 * full.pow(2).mean().sqrt() + 5e-3 * full.abs()).all()
