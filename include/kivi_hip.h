@@ -195,6 +195,26 @@ int kivi_decode_softmax_output(const void* scores, int64_t a_sb, int64_t a_sh, f
                                int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits,
                                kivi_stream_t stream);
 
+/* Everything of the decode step that follows the packed qK^T GEMV, in ONE launch: residual scores
+ * q . [fp16 K residual | new key] (+ append of the new key), scale + mask + softmax, packed sV + fp16 V window
+ * (+ append of the new value, + quantisation of the oldest window token).  A layer's decode step is then
+ * kivi_gemv_k_paged (scores[..., :Tq]) followed by this call.  `scores` rows have length Tq + k_res_len + 1 ==
+ * Tv + v_res_len + 1.  KIVI_EUNSUPPORTED when a shape / alignment requirement is not met (use the finer entry points). */
+typedef struct kivi_decode_attend_args {
+    const void* q; int64_t q_sb, q_sh;                           /* (B, nh, D) queries */
+    void* kres; int64_t kres_sb, kres_sh, kres_st;               /* (B, nh_kv, R, D) fp16 K residual buffer */
+    const void* knew; int64_t knew_sb, knew_sh; int k_res_len;   /* (B, nh_kv, D) new key; keys already in kres */
+    void* scores; int64_t s_sb, s_sh;                            /* (B, nh, >= n) pre-softmax score rows */
+    float inv_scale; const void* mask; int64_t mask_sb;          /* 1/sqrt(D); additive (B,1,1,n) fp16 mask or NULL */
+    void* v_code; int64_t vc_sb, vc_sh, vc_sr;                   /* packed V (B, nh_kv, >=Tv+1, D/fpi) */
+    void* v_scale; void* v_mn; int64_t vs_sb, vs_sh, vs_sr;
+    void* vres; int64_t vres_sb, vres_sh, vres_st; int v_win_start, v_res_len;   /* fp16 V window buffer */
+    const void* vnew; int64_t vnew_sb, vnew_sh; int v_flush;     /* new value; quantise the oldest window token */
+    void* out; int64_t out_sb, out_sh;                           /* (B, nh, D) attention output */
+    int B, nh, nh_kv, D, group_size, v_bits; int64_t Tq, Tv;
+} kivi_decode_attend_args;
+int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream);
+
 /* ------------------------------------------------- tuning / bench hooks --- */
 
 /* Kernel variants of kivi_gemv_k (same arguments + variant id; -1 = the default heuristic).

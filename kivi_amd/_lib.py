@@ -21,6 +21,24 @@ _GEMV_ARGS = [_vp, _i64, _i64,            # q / a + strides
               _vp, _vp, _i64, _i64, _i64,  # scale, mn + strides
               _vp, _i64, _i64]            # out + strides
 
+class DecodeAttendArgs(ctypes.Structure):
+    """kivi_decode_attend_args (include/kivi_hip.h), field for field."""
+    _fields_ = [
+        ("q", _vp), ("q_sb", _i64), ("q_sh", _i64),
+        ("kres", _vp), ("kres_sb", _i64), ("kres_sh", _i64), ("kres_st", _i64),
+        ("knew", _vp), ("knew_sb", _i64), ("knew_sh", _i64), ("k_res_len", _i32),
+        ("scores", _vp), ("s_sb", _i64), ("s_sh", _i64),
+        ("inv_scale", ctypes.c_float), ("mask", _vp), ("mask_sb", _i64),
+        ("v_code", _vp), ("vc_sb", _i64), ("vc_sh", _i64), ("vc_sr", _i64),
+        ("v_scale", _vp), ("v_mn", _vp), ("vs_sb", _i64), ("vs_sh", _i64), ("vs_sr", _i64),
+        ("vres", _vp), ("vres_sb", _i64), ("vres_sh", _i64), ("vres_st", _i64), ("v_win_start", _i32), ("v_res_len", _i32),
+        ("vnew", _vp), ("vnew_sb", _i64), ("vnew_sh", _i64), ("v_flush", _i32),
+        ("out", _vp), ("out_sb", _i64), ("out_sh", _i64),
+        ("B", _i32), ("nh", _i32), ("nh_kv", _i32), ("D", _i32), ("group_size", _i32), ("v_bits", _i32),
+        ("Tq", _i64), ("Tv", _i64),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/kivi_hip.h declares
 SIGNATURES = {
     "kivi_abi_version": (_i32, []),
@@ -45,6 +63,7 @@ SIGNATURES = {
     "kivi_decode_softmax_output": (_i32, [_vp, _i64, _i64, ctypes.c_float, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64,
                                           _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64,
                                           _i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_decode_attend": (_i32, [ctypes.POINTER(DecodeAttendArgs), _vp]),
     "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),

@@ -72,19 +72,31 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
     if attention_mask is not None and attention_mask.size() != (B, 1, 1, kv_seq_len):
         raise ValueError(f"Attention mask should be of size {(B, 1, 1, kv_seq_len)}, but is {attention_mask.size()}")
     assert layer.k_quant_len + layer.k_res_len + 1 <= layer.cap, "cache capacity exceeded"
-    fused.decode_scores(layer, query_states, key_states, scores)          # :323-337 (+ the K append of :333-336)
-    layer.k_res_len += 1
-    layer.maybe_flush_k()                                                  # :343-356
     if layer.v_res_start + layer.v_res_len + 1 > layer.v_res.shape[2]:     # make room in the window buffer
         layer.compact_v_window()
     out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=query_states.device)
     inv = 1.0 / math.sqrt(D)
     flushed = None
-    if not getattr(layer, "_softmax_unfusable", False):
-        try:   # scale + mask + softmax (:339, :364-375) inside the sV launch (:377-399)
-            flushed = fused.decode_output(layer, scores, value_states, out, softmax_inv_scale=inv, mask=attention_mask)
+    if not getattr(layer, "_attend_unfusable", False):
+        # two launches: packed qK^T GEMV (:324), then residual scores + K append + softmax + output + V append/flush
+        try:
+            if layer.k_quant_len:
+                gemv_k_paged(cfg.group_size, query_states, layer.k_code, layer.k_scale, layer.k_mn, layer.k_quant_len,
+                             cfg.k_bits, out=scores[..., : layer.k_quant_len])
+            flushed = fused.decode_attend(layer, query_states, key_states, value_states, scores, out, inv, attention_mask)
+            layer.k_res_len += 1
+            layer.maybe_flush_k()                                          # :343-356
         except KiviUnsupported:
-            layer._softmax_unfusable = True      # rows too long for the LDS: keep the softmax as its own launch
+            layer._attend_unfusable = True       # e.g. rows too long for the LDS: use the three-launch form below
+    if flushed is None:
+        fused.decode_scores(layer, query_states, key_states, scores)      # :323-337 (+ the K append of :333-336)
+        layer.k_res_len += 1
+        layer.maybe_flush_k()                                              # :343-356
+        if not getattr(layer, "_softmax_unfusable", False):
+            try:   # scale + mask + softmax (:339, :364-375) inside the sV launch (:377-399)
+                flushed = fused.decode_output(layer, scores, value_states, out, softmax_inv_scale=inv, mask=attention_mask)
+            except KiviUnsupported:
+                layer._softmax_unfusable = True  # keep the softmax as its own launch
     if flushed is None:
         fused.softmax_scaled(scores, probs, kv_seq_len, inv, attention_mask)
         try:

@@ -49,6 +49,16 @@ struct GemvVArgs {
     float inv_scale;
     const uint16_t* mask;              // (B, 1, 1, n) additive fp16 mask or null
     int64_t mask_sb;
+    // residual scores folded in as well (kivi_decode_attend): q . [fp16 K residual | new key] is computed by the
+    // block that owns the row, written at a[..., Tq:] and fed to the softmax; the new key is appended (:333-337)
+    const uint16_t* rq;                // (B, nh, D) queries, null = scores are already complete
+    int64_t rq_sb, rq_sh;
+    uint16_t* rkres;                   // (B, nh_kv, R_k, D) fp16 K residual buffer
+    int64_t rk_sb, rk_sh, rk_st;
+    const uint16_t* rknew;             // (B, nh_kv, D) the new key
+    int64_t rkn_sb, rkn_sh;
+    int rk_len;                        // keys already in the residual
+    int Tq;                            // packed K length = offset of the residual scores in a row
 };
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
@@ -70,6 +80,8 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     __shared__ float resl[4][R][D];   // fused decode step: per-wave partial sums over the fp16 V window
     __shared__ float sm_lds[4];
     extern __shared__ uint16_t pl[];  // [R][n_pad] fp16 probabilities when the softmax is folded in
+    constexpr int RSMAX = 136;        // residual keys per row handled in LDS (R_k <= 128, + the new one)
+    __shared__ uint16_t rs_lds[R][RSMAX];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -180,6 +192,42 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
         const int n = a.n_scores;
         const int nch = (n + 1023) / 1024;
         const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb : nullptr;
+        const bool owner_k = (h0 % a.ratio) == 0;
+        if (a.rq) {
+            // q . k over the fp16 residual keys and the new key: one thread per (head, key), 16-byte loads,
+            // fp32 accumulate, one rounding (the reference's fp16 torch.matmul, :337); kept in LDS for the softmax and
+            // also written to the score row
+            const int L = a.rk_len + 1;
+            const uint16_t* knew = a.rknew + b * a.rkn_sb + hk * a.rkn_sh;
+            uint16_t* kres = a.rkres + b * a.rk_sb + hk * a.rk_sh;
+            // 8 lanes per (head, key): each takes D/8 channels with 16-byte loads, then a 3-step shuffle reduction
+            constexpr int CPL = D / 8;                       // channels per lane (D % 64 == 0)
+            for (int idx = threadIdx.x; idx < R * L * 8; idx += 256) {
+                const int sub = idx & 7, rt = idx >> 3;
+                const int r = rt / L, t = rt - r * L;
+                const uint16_t* krow = ((t < a.rk_len) ? kres + (int64_t)t * a.rk_st : knew) + sub * CPL;
+                const uint16_t* qrow = a.rq + b * a.rq_sb + (int64_t)(h0 + r) * a.rq_sh + sub * CPL;
+                const bool append = (t == a.rk_len) && owner_k && r == 0;
+                float sc = 0.f;
+#pragma unroll
+                for (int d = 0; d < CPL; d += 8) {
+                    const u16x8 kv = *(const u16x8*)(krow + d);
+                    const u16x8 qv = *(const u16x8*)(qrow + d);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qv[e]), h2f_bits(kv[e]), sc);
+                    if (append) *(u16x8*)(kres + (int64_t)t * a.rk_st + sub * CPL + d) = kv;
+                }
+                sc += __shfl_xor(sc, 1);
+                sc += __shfl_xor(sc, 2);
+                sc += __shfl_xor(sc, 4);
+                if (sub == 0) {
+                    const uint16_t hs = f2h_bits(sc);
+                    rs_lds[r][t] = hs;
+                    const_cast<uint16_t*>(a.a)[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tq + t] = hs;
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
             const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
@@ -190,11 +238,17 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                 const int j0 = c * 1024 + (int)threadIdx.x * 4;
                 raw[c] = u16x4{0, 0, 0, 0};
                 if (c < nch) {
-                    if (j0 + 4 <= n) raw[c] = *(const u16x4*)(srow + j0);
-                    else
+                    if (a.rq && j0 + 4 > a.Tq) {   // (part of) the vector lies in the residual range: take it from LDS
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (j0 + e < n) raw[c][e] = (j0 + e >= a.Tq) ? rs_lds[r][j0 + e - a.Tq] : srow[j0 + e];
+                    } else if (j0 + 4 <= n) {
+                        raw[c] = *(const u16x4*)(srow + j0);
+                    } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
                             if (j0 + e < n) raw[c][e] = srow[j0 + e];
+                    }
                 }
             }
             float x[SMC][4];
@@ -583,6 +637,8 @@ static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, i
     a.sm_extent = (uint32_t)(a.extents_ok ? se : 0);
     a.a_extent = (uint32_t)(a.extents_ok ? ae : 0);
     a.softmax = 0; a.n_scores = 0; a.n_pad = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
+    a.rq = nullptr; a.rkres = nullptr; a.rknew = nullptr; a.rk_len = 0; a.Tq = 0;
+    a.rq_sb = a.rq_sh = a.rk_sb = a.rk_sh = a.rk_st = a.rkn_sb = a.rkn_sh = 0;
     a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
     a.vres_sb = a.vres_sh = a.vres_st = a.vnew_sb = a.vnew_sh = 0;
     return 0;
@@ -607,6 +663,18 @@ extern "C" int kivi_gemv_v(const void* av, int64_t a_sb, int64_t a_sh, const voi
     return kivi_gemv_v_variant(-1, av, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh, sm_sr, out,
                                out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits, stream);
 }
+
+struct ResidualK {
+    const void* q;
+    int64_t q_sb, q_sh;
+    void* kres;
+    int64_t kres_sb, kres_sh, kres_st;
+    const void* knew;
+    int64_t knew_sb, knew_sh;
+    int res_len;
+    int64_t Tq;
+};
+static thread_local const ResidualK* g_residual_k = nullptr;   // set only for the duration of kivi_decode_attend (same thread)
 
 static int decode_output_impl(int softmax, float inv_scale, const void* mask, int64_t mask_sb, const void* probs,
                               int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
@@ -670,6 +738,34 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
         a.inv_scale = inv_scale;
         a.mask = (const uint16_t*)mask;
         a.mask_sb = mask_sb;
+        if (g_residual_k) {
+            const ResidualK& rk = *g_residual_k;
+            KIVI_REQUIRE(rk.res_len + 1 <= 136 && rk.Tq + rk.res_len + 1 == n, KIVI_EUNSUPPORTED,
+                         "kivi_decode_attend: residual of %d keys does not fit / lengths disagree", rk.res_len);
+            KIVI_REQUIRE(D % 64 == 0 && rk.q_sb % 8 == 0 && rk.q_sh % 8 == 0 && rk.kres_sb % 8 == 0 && rk.kres_sh % 8 == 0 &&
+                             rk.kres_st % 8 == 0 && rk.knew_sb % 8 == 0 && rk.knew_sh % 8 == 0 &&
+                             (uintptr_t)rk.q % 16 == 0 && (uintptr_t)rk.kres % 16 == 0 && (uintptr_t)rk.knew % 16 == 0,
+                         KIVI_EUNSUPPORTED, "kivi_decode_attend: rows are not 16-byte aligned");
+            a.rq = (const uint16_t*)rk.q; a.rq_sb = rk.q_sb; a.rq_sh = rk.q_sh;
+            a.rkres = (uint16_t*)rk.kres; a.rk_sb = rk.kres_sb; a.rk_sh = rk.kres_sh; a.rk_st = rk.kres_st;
+            a.rknew = (const uint16_t*)rk.knew; a.rkn_sb = rk.knew_sb; a.rkn_sh = rk.knew_sh;
+            a.rk_len = rk.res_len;
+            a.Tq = (int)rk.Tq;
+        }
     }
     return v_run(-1, a, B, group_size, bits, (hipStream_t)stream);
+}
+
+extern "C" int kivi_decode_attend(const kivi_decode_attend_args* p, kivi_stream_t stream) {
+    KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_decode_attend: null arguments");
+    ResidualK rk = {p->q, p->q_sb, p->q_sh, p->kres, p->kres_sb, p->kres_sh, p->kres_st, p->knew, p->knew_sb, p->knew_sh,
+                    p->k_res_len, p->Tq};
+    g_residual_k = &rk;
+    const int rc = decode_output_impl(1, p->inv_scale, p->mask, p->mask_sb, p->scores, p->s_sb, p->s_sh, p->v_code, p->vc_sb,
+                                      p->vc_sh, p->vc_sr, p->v_scale, p->v_mn, p->vs_sb, p->vs_sh, p->vs_sr, p->vres,
+                                      p->vres_sb, p->vres_sh, p->vres_st, p->v_win_start, p->v_res_len, p->vnew, p->vnew_sb,
+                                      p->vnew_sh, p->v_flush, p->out, p->out_sb, p->out_sh, p->B, p->nh, p->nh_kv, p->Tv, p->D,
+                                      p->group_size, p->v_bits, stream);
+    g_residual_k = nullptr;
+    return rc;
 }

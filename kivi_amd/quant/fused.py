@@ -6,6 +6,8 @@ the shape and falls back to the reference-style composition (quant.matmul + torc
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -85,4 +87,38 @@ def decode_output(layer, probs: torch.Tensor, value_states: torch.Tensor, out: t
         _lib.ptr(out), out.stride(0), out.stride(1),
         B, nh, layer.nh_kv, layer.v_quant_len, layer.D, cfg.group_size, cfg.v_bits, _lib.stream_ptr(probs)),
         "kivi_decode_output")
+    return flush
+
+
+def decode_attend(layer, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
+                  scores: torch.Tensor, out: torch.Tensor, inv_scale: float, mask: torch.Tensor = None) -> bool:
+    """Everything after the packed qK^T GEMV in one launch (kivi_decode_attend): residual scores + K append,
+    scale + mask + softmax, packed sV + V window + V append (+ flush of the oldest window token).
+    `scores[..., :Tq]` must already hold the packed part.  Returns True if the V flush happened."""
+    cfg = layer.cfg
+    B, nh, _, D = query_states.shape
+    q = query_states if query_states.stride(3) == 1 else query_states.contiguous()
+    k = key_states if key_states.stride(3) == 1 else key_states.contiguous()
+    v = value_states if value_states.stride(3) == 1 else value_states.contiguous()
+    vc, vs, vm, vr, kr = layer.v_code, layer.v_scale, layer.v_mn, layer.v_res, layer.k_res
+    flush = layer.v_res_len + 1 > cfg.residual_length
+    if mask is not None:
+        assert mask.dtype == torch.float16 and mask.stride(3) == 1
+    a = _lib.DecodeAttendArgs(
+        q=q.data_ptr(), q_sb=q.stride(0), q_sh=q.stride(1),
+        kres=kr.data_ptr(), kres_sb=kr.stride(0), kres_sh=kr.stride(1), kres_st=kr.stride(2),
+        knew=k.data_ptr(), knew_sb=k.stride(0), knew_sh=k.stride(1), k_res_len=layer.k_res_len,
+        scores=scores.data_ptr(), s_sb=scores.stride(0), s_sh=scores.stride(1),
+        inv_scale=float(inv_scale), mask=mask.data_ptr() if mask is not None else None,
+        mask_sb=mask.stride(0) if mask is not None else 0,
+        v_code=vc.data_ptr(), vc_sb=vc.stride(0), vc_sh=vc.stride(1), vc_sr=vc.stride(2),
+        v_scale=vs.data_ptr(), v_mn=vm.data_ptr(), vs_sb=vs.stride(0), vs_sh=vs.stride(1), vs_sr=vs.stride(2),
+        vres=vr.data_ptr(), vres_sb=vr.stride(0), vres_sh=vr.stride(1), vres_st=vr.stride(2),
+        v_win_start=layer.v_res_start, v_res_len=layer.v_res_len,
+        vnew=v.data_ptr(), vnew_sb=v.stride(0), vnew_sh=v.stride(1), v_flush=int(flush),
+        out=out.data_ptr(), out_sb=out.stride(0), out_sh=out.stride(1),
+        B=B, nh=nh, nh_kv=layer.nh_kv, D=D, group_size=cfg.group_size, v_bits=cfg.v_bits,
+        Tq=layer.k_quant_len, Tv=layer.v_quant_len)
+    lib = _lib.load()
+    _lib.check(lib.kivi_decode_attend(ctypes.byref(a), _lib.stream_ptr(q)), "kivi_decode_attend")
     return flush
