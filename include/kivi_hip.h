@@ -212,6 +212,9 @@ typedef struct kivi_decode_attend_args {
     const void* vnew; int64_t vnew_sb, vnew_sh; int v_flush;     /* new value; quantise the oldest window token */
     void* out; int64_t out_sb, out_sh;                           /* (B, nh, D) attention output */
     int B, nh, nh_kv, D, group_size, v_bits; int64_t Tq, Tv;
+    void* workspace; int64_t workspace_bytes;                    /* optional (may be NULL): zero-initialised device
+        scratch, >= 4096 + 4 * B*nh*D*65 bytes.  With it, rows are split over several blocks when B*nh_kv is too
+        small to fill the GPU (long context, small batch); counters in it are left at zero after every call. */
 } kivi_decode_attend_args;
 int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream);
 

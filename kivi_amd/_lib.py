@@ -36,6 +36,7 @@ class DecodeAttendArgs(ctypes.Structure):
         ("out", _vp), ("out_sb", _i64), ("out_sh", _i64),
         ("B", _i32), ("nh", _i32), ("nh_kv", _i32), ("D", _i32), ("group_size", _i32), ("v_bits", _i32),
         ("Tq", _i64), ("Tv", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64),
     ]
 
 

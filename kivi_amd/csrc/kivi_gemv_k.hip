@@ -14,6 +14,7 @@
 // sum_d q[d]*mn[d,G] is hoisted out of the per-token work (one fma per group).
 // DSPLIT waves of a block split the channel range and combine through LDS.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -544,6 +545,11 @@ int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream
     }
     // heuristic: first fitting variant with the largest usable R; table order = preference
     int best = -1;
+    static const char* forced = getenv("KIVI_GEMV_K_VARIANT");   // tuning aid: force a variant by name if it fits
+    if (forced)
+        for (int i = 0; i < k_nvariants; i++)
+            if (!strcmp(forced, k_variants[i].name) && k_variant_fits(k_variants[i], a, bits, G))
+                return k_run(i, a, B, nh_kv, G, bits, s);
     for (int i = 0; i < k_nvariants; i++) {
         const KVariant& v = k_variants[i];
         // production unpacks: FMA-mix, and the fp32-subnormal form for GQA units; the others are A/B references

@@ -12,6 +12,9 @@
 // (token, group), zero-point term hoisted), then the 64/LPR lanes that own the
 // same channels are combined with a halving butterfly (EPL-EPL/TPI shuffles
 // instead of EPL*log2(TPI)) and the 4 waves of the block through LDS.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
 #include "kivi_common.h"
@@ -59,14 +62,21 @@ struct GemvVArgs {
     int64_t rkn_sb, rkn_sh;
     int rk_len;                        // keys already in the residual
     int Tq;                            // packed K length = offset of the residual scores in a row
+    // split-T (SPLIT kernels): nsplit blocks share one (b, head unit); partial sums meet in `ws`
+    int nsplit, cps;                   // blocks per unit, chunks (of TPI tokens) per block
+    int sm_loop;                       // rows longer than 8192: softmax by passes (always the case in SPLIT kernels)
+    const float* stats;                // SPLIT: (max, sum) of every (b, h) row from softmax_rowstats_kernel, or null
+    float* ws;                         // [units][nsplit + 1][R * D] fp32 partials (+1: the window part)
+    int* counters;                     // [units] arrival counters, zero between launches
+    size_t ws_bytes;                   // bytes available at ws
 };
 
-template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
+template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT>
 __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     constexpr int FPI = 32 / BITS;
     constexpr int LPR = DW / WPL;               // lanes per token row
     static_assert(LPR >= 1 && LPR <= 16 && (LPR & (LPR - 1)) == 0, "D/fpi must be 4, 8, 16 or 32 words");
-    typedef typename std::conditional<WPL == 4, u32x4, u32x2>::type WV;
+    typedef typename std::conditional<WPL == 4, u32x4, typename std::conditional<WPL == 2, u32x2, uint32_t>::type>::type WV;
     constexpr int TPI = 64 / LPR;               // tokens per wave-iteration
     constexpr int EPL = WPL * FPI;              // channels per lane
     constexpr int D = DW * FPI;
@@ -82,10 +92,16 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     extern __shared__ uint16_t pl[];  // [R][n_pad] fp16 probabilities when the softmax is folded in
     constexpr int RSMAX = 136;        // residual keys per row handled in LDS (R_k <= 128, + the new one)
     __shared__ uint16_t rs_lds[R][RSMAX];
+    __shared__ uint16_t pw[R][RSMAX];  // loop-path softmax: probabilities of the fp16-window tokens (block `split == 0`)
+    __shared__ int last_flag;
+    const bool sm_loop = SPLIT || a.sm_loop;   // softmax by passes over the row instead of the register-resident form
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = blockIdx.x;
+    // SPLIT: nsplit consecutive blocks share a (b, head unit), each takes a contiguous range of token chunks
+    const int nsplit = SPLIT ? a.nsplit : 1;
+    const int unit = SPLIT ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
+    const int split = SPLIT ? (int)blockIdx.x - unit * nsplit : 0;
     const int b = unit / a.units_per_b;
     const int hu = unit - b * a.units_per_b;
     const int h0 = hu * R;
@@ -136,14 +152,21 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 #pragma unroll
             for (int j = 0; j < WPL; j++) {
                 const int g = (NGL == 1) ? 0 : (j * FPI) / G;
-                accum_word<BITS, MODE>(w[j], as[g], &acc[r][j * FPI]);
+                uint32_t wj;
+                if constexpr (WPL == 1) wj = w;
+                else wj = w[j];
+                accum_word<BITS, MODE>(wj, as[g], &acc[r][j * FPI]);
             }
         }
     };
 
     // chunk c = TPI tokens; wave w owns chunks w, w+4, ...; batch = U chunks of this wave
     const int nchunk = (int)((a.Tv + TPI - 1) / TPI);
-    const int my_chunks = (nchunk > wave) ? (nchunk - wave + 3) / 4 : 0;
+    const int c_begin = SPLIT ? split * a.cps : 0;                              // this block's chunk range
+    const int c_end = SPLIT ? ((c_begin + a.cps < nchunk) ? c_begin + a.cps : nchunk) : nchunk;
+    const int nloc = c_end > c_begin ? c_end - c_begin : 0;
+    const int64_t t_begin = (int64_t)c_begin * TPI;                             // first token of the range
+    const int my_chunks = (nloc > wave) ? (nloc - wave + 3) / 4 : 0;
     const int nbatch = (my_chunks + U - 1) / U;  // out-of-range chunks read zeros (bounds check)
 
     // The chunk offset goes into the (bounds-checked) per-lane voffset: soffset is excluded
@@ -151,7 +174,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     auto load_wsm = [&](int bi, WV* wb, SV* sb, SV* mb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t c = (uint32_t)((bi * U + u) * 4 + wave);
+            const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * 4 + wave);
             wb[u] = buf_load<WV, NT>(rc, coff + c * cstep, 0);
             sb[u] = buf_load<SV, NT>(rs, soff + c * sstep, 0);
             mb[u] = buf_load<SV, NT>(rm, soff + c * sstep, 0);
@@ -160,14 +183,16 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     auto load_a = [&](int bi, uint16_t (*ab)[R]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t c = (uint32_t)((bi * U + u) * 4 + wave);
+            const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * 4 + wave);
+            const bool mine = !SPLIT || (int)c < c_end;   // chunks past the range belong to the next block
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                if (a.softmax) {   // probabilities produced by this block, in LDS
+                if (a.softmax) {   // probabilities produced by this block, in LDS (indexed from the range start)
                     const int64_t t = (int64_t)c * TPI + lt;
-                    ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
+                    ab[u][r] = (mine && t < a.Tv) ? pl[(size_t)r * a.n_pad + (t - t_begin)] : (uint16_t)0;
                 } else {
-                    ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
+                    const uint16_t av = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
+                    ab[u][r] = mine ? av : (uint16_t)0;
                 }
             }
         }
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                 const int r = rt / L, t = rt - r * L;
                 const uint16_t* krow = ((t < a.rk_len) ? kres + (int64_t)t * a.rk_st : knew) + sub * CPL;
                 const uint16_t* qrow = a.rq + b * a.rq_sb + (int64_t)(h0 + r) * a.rq_sh + sub * CPL;
-                const bool append = (t == a.rk_len) && owner_k && r == 0;
+                const bool append = (t == a.rk_len) && owner_k && r == 0 && split == 0;
                 float sc = 0.f;
 #pragma unroll
                 for (int d = 0; d < CPL; d += 8) {
@@ -228,6 +253,77 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             }
             __syncthreads();
         }
+        if (sm_loop) {
+            // rows of any length / one block of several per row: two passes over the (L2-resident) row for max and
+            // sum, then only this block's token range (and, in block 0, the window tokens) is normalised into LDS.
+            // Same per-thread element order and reduction tree as the register-resident form below.
+            const int64_t t_end = ((int64_t)c_end * TPI < a.Tv) ? (int64_t)c_end * TPI : a.Tv;
+#pragma unroll 1
+            for (int r = 0; r < R; r++) {
+                const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
+                auto sval = [&](int j) {
+                    const uint16_t raw1 = (a.rq && j >= a.Tq) ? rs_lds[r][j - a.Tq] : srow[j];
+                    return h2f_bits(kivi_scaled_score(raw1, a.inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
+                };
+                const int nvec = a.rq ? (a.Tq & ~3) : (n & ~3);   // scores below this index come straight from memory
+                float mx = -__builtin_inff();
+                float sum = 0.f;
+                if (a.stats) {   // row statistics were computed once per row by the row-stats launch
+                    mx = a.stats[2 * ((int64_t)b * a.nh + h0 + r)];
+                    sum = a.stats[2 * ((int64_t)b * a.nh + h0 + r) + 1];
+                } else {
+                for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
+                    if (j0 + 4 <= nvec) {
+                        const u16x4 v4 = *(const u16x4*)(srow + j0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            mx = __builtin_fmaxf(mx, h2f_bits(kivi_scaled_score(v4[e], a.inv_scale, mrow != nullptr,
+                                                                                 mrow ? mrow[j0 + e] : 0)));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (j0 + e < n) mx = __builtin_fmaxf(mx, sval(j0 + e));
+                    }
+                }
+                mx = kivi_block_reduce(mx, true, sm_lds);
+                for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
+                    if (j0 + 4 <= nvec) {
+                        const u16x4 v4 = *(const u16x4*)(srow + j0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            sum += __builtin_expf(h2f_bits(kivi_scaled_score(v4[e], a.inv_scale, mrow != nullptr,
+                                                                             mrow ? mrow[j0 + e] : 0)) - mx);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (j0 + e < n) sum += __builtin_expf(sval(j0 + e) - mx);
+                    }
+                }
+                sum = kivi_block_reduce(sum, false, sm_lds);
+                }
+                // normalise this block's own token range into LDS: 8-byte loads, several in flight
+                uint16_t* prow = pl + (size_t)r * a.n_pad;
+#pragma unroll 4
+                for (int64_t j0 = t_begin + threadIdx.x * 4; j0 < t_end; j0 += 1024) {
+                    if (j0 + 4 <= t_end && j0 + 4 <= nvec) {
+                        const u16x4 v4 = *(const u16x4*)(srow + j0);
+                        u16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            o[e] = f2h_bits(__builtin_expf(h2f_bits(kivi_scaled_score(v4[e], a.inv_scale, mrow != nullptr,
+                                                                                     mrow ? mrow[j0 + e] : 0)) - mx) / sum);
+                        *(u16x4*)(prow + (j0 - t_begin)) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (j0 + e < t_end) prow[j0 + e - t_begin] = f2h_bits(__builtin_expf(sval((int)(j0 + e)) - mx) / sum);
+                    }
+                }
+                if (a.fused && split == 0)
+                    for (int t = threadIdx.x; t < n - (int)a.Tv && t < RSMAX; t += 256)
+                        pw[r][t] = f2h_bits(__builtin_expf(sval((int)a.Tv + t) - mx) / sum);
+            }
+        } else {
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
             const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
@@ -285,6 +381,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                     if (j0 < a.n_pad) *(u16x4*)(prow + j0) = o;   // n_pad is a multiple of 8: whole vectors stay inside the row
                 }
         }
+        }
         __syncthreads();
     }
 
@@ -305,7 +402,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     }
 
     const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
-    if (a.fused) {
+    if (a.fused && split == 0) {
         // probs[..., -L:] @ V_window (llama_kivi.py:384): the <= R+1 fp16 window tokens (the last one is the new
         // value, appended here, :377) are spread over the 4 waves, a lane owns channel pairs; all loads of a
         // wave are independent, so this costs one L2 round trip instead of L serial ones.
@@ -323,8 +420,8 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             float at[R];
 #pragma unroll
             for (int r = 0; r < R; r++)
-                at[r] = h2f_bits(a.softmax ? pl[(size_t)r * a.n_pad + a.Tv + t]
-                                           : a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]);
+                at[r] = h2f_bits(!a.softmax ? a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]
+                                 : (sm_loop ? pw[r][t] : pl[(size_t)r * a.n_pad + a.Tv + t]));
 #pragma unroll
             for (int c = 0; c < NP; c++) {
                 const int p = lane + 64 * c;
@@ -397,19 +494,63 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             red[wave][r][lr * EPL + e] = acc[r][i] + z;
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < R * D; i += 256) {
-        const int r = i / D, d = i - r * D;
-        const float s = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
-        uint16_t o = f2h_bits(s);
-        if (a.fused) {
-            const float res = (resl[0][r][d] + resl[1][r][d]) + (resl[2][r][d] + resl[3][r][d]);
-            // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (:382-384);
-            // only the window part exists before anything is quantised (:380)
-            o = (a.Tv > 0) ? f2h_bits(h2f_bits(o) + h2f_bits(f2h_bits(res))) : f2h_bits(res);
+    if constexpr (!SPLIT) {
+        for (int i = threadIdx.x; i < R * D; i += 256) {
+            const int r = i / D, d = i - r * D;
+            const float s = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+            uint16_t o = f2h_bits(s);
+            if (a.fused) {
+                const float res = (resl[0][r][d] + resl[1][r][d]) + (resl[2][r][d] + resl[3][r][d]);
+                // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (:382-384);
+                // only the window part exists before anything is quantised (:380)
+                o = (a.Tv > 0) ? f2h_bits(h2f_bits(o) + h2f_bits(f2h_bits(res))) : f2h_bits(res);
+            }
+            a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
         }
-        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
+    } else {
+        // partial sums of this block -> workspace; the block that arrives last adds them up in split order and
+        // writes the row.  Hand-off without fences (cdna_hip_programming.md G16, "write-through payload"): the partials
+        // are stored write-through (agent-scope relaxed atomic stores = sc1), every wave drains its stores, one lane
+        // bumps the arrival counter; the last arriver reads them with agent-scope (sc1, L1-bypassing) loads.
+        uint32_t* part = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * (nsplit + 1) + split) * (R * D));
+        uint32_t* winp = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * (nsplit + 1) + nsplit) * (R * D));
+        for (int i = threadIdx.x; i < R * D; i += 256) {
+            const int r = i / D, d = i - r * D;
+            const float qs = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+            __hip_atomic_store(part + i, __builtin_bit_cast(uint32_t, qs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.fused && split == 0) {
+                const float ws_ = (resl[0][r][d] + resl[1][r][d]) + (resl[2][r][d] + resl[3][r][d]);
+                __hip_atomic_store(winp + i, __builtin_bit_cast(uint32_t, ws_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == nsplit - 1);
+            if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+            last_flag = last;
+        }
+        __syncthreads();
+        if (last_flag) {
+            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * (nsplit + 1) * (R * D));
+            for (int i = threadIdx.x; i < R * D; i += 256) {
+                const int r = i / D, d = i - r * D;
+                float s = 0.f;
+                for (int sp = 0; sp < nsplit; sp++)
+                    s += __builtin_bit_cast(float, __hip_atomic_load(p0 + (size_t)sp * (R * D) + i, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT));
+                uint16_t o = f2h_bits(s);
+                if (a.fused) {
+                    const float res = __builtin_bit_cast(float, __hip_atomic_load(p0 + (size_t)nsplit * (R * D) + i,
+                                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    o = (a.Tv > 0) ? f2h_bits(h2f_bits(o) + h2f_bits(f2h_bits(res))) : f2h_bits(res);
+                }
+                a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
+            }
+        }
     }
-    if (a.fused && a.flush && owner) {
+    if (a.fused && a.flush && owner && split == 0) {
         // the window now holds R+1 tokens: quantise the OLDEST one into cache row Tv (:386-399), bit-identical
         // to the stand-alone pack kernel (shared quantiser)
         __syncthreads();
@@ -451,6 +592,104 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     }
 }
 
+// Row statistics for the split-T decode step: one block per (b, h) score row computes the residual scores
+// q . [fp16 K residual | new key] (+ the K append), then max and sum(exp) of the scaled / masked row with exactly the
+// element order and reduction tree of kivi_softmax_scaled.  The sV blocks of the row then normalise their own ranges.
+struct RowStatsArgs {
+    uint16_t* scores;
+    int64_t s_sb, s_sh;
+    int n, Tq;
+    float inv_scale;
+    const uint16_t* mask;
+    int64_t mask_sb;
+    const uint16_t* q;
+    int64_t q_sb, q_sh;
+    uint16_t* kres;
+    int64_t k_sb, k_sh, k_st;
+    const uint16_t* knew;
+    int64_t kn_sb, kn_sh;
+    int rk_len, ratio, nh, D;
+    float* stats;
+};
+
+__global__ __launch_bounds__(256) void softmax_rowstats_kernel(const RowStatsArgs p) {
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    __shared__ float sm_lds[4];
+    __shared__ uint16_t rs_lds[136];
+    const int row = blockIdx.x;
+    const int b = row / p.nh, h = row - b * p.nh;
+    const int hk = h / p.ratio;
+    uint16_t* srow = p.scores + b * p.s_sb + (int64_t)h * p.s_sh;
+    const uint16_t* mrow = p.mask ? p.mask + b * p.mask_sb : nullptr;
+    const int L = p.rk_len + 1;
+    {
+        const uint16_t* knew = p.knew + b * p.kn_sb + hk * p.kn_sh;
+        uint16_t* kres = p.kres + b * p.k_sb + hk * p.k_sh;
+        const int cpl = p.D / 8;
+        for (int idx = threadIdx.x; idx < L * 8; idx += 256) {
+            const int sub = idx & 7, t = idx >> 3;
+            const uint16_t* krow = ((t < p.rk_len) ? kres + (int64_t)t * p.k_st : knew) + sub * cpl;
+            const uint16_t* qrow = p.q + b * p.q_sb + (int64_t)h * p.q_sh + sub * cpl;
+            const bool append = (t == p.rk_len) && (h % p.ratio) == 0;
+            float sc = 0.f;
+            for (int d = 0; d < cpl; d += 8) {
+                const u16x8 kv = *(const u16x8*)(krow + d);
+                const u16x8 qv = *(const u16x8*)(qrow + d);
+#pragma unroll
+                for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qv[e]), h2f_bits(kv[e]), sc);
+                if (append) *(u16x8*)(kres + (int64_t)t * p.k_st + sub * cpl + d) = kv;
+            }
+            sc += __shfl_xor(sc, 1);
+            sc += __shfl_xor(sc, 2);
+            sc += __shfl_xor(sc, 4);
+            if (sub == 0) {
+                const uint16_t hs = f2h_bits(sc);
+                rs_lds[t] = hs;
+                srow[p.Tq + t] = hs;
+            }
+        }
+        __syncthreads();
+    }
+    const int n = p.n;
+    auto sval = [&](int j) {
+        const uint16_t raw1 = (j >= p.Tq) ? rs_lds[j - p.Tq] : srow[j];
+        return h2f_bits(kivi_scaled_score(raw1, p.inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
+    };
+    const int nvec = p.Tq & ~3;
+    float mx = -__builtin_inff();
+    for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
+        if (j0 + 4 <= nvec) {
+            const u16x4 v4 = *(const u16x4*)(srow + j0);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                mx = __builtin_fmaxf(mx, h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (j0 + e < n) mx = __builtin_fmaxf(mx, sval(j0 + e));
+        }
+    }
+    mx = kivi_block_reduce(mx, true, sm_lds);
+    float sum = 0.f;
+    for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
+        if (j0 + 4 <= nvec) {
+            const u16x4 v4 = *(const u16x4*)(srow + j0);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                sum += __builtin_expf(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)) - mx);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (j0 + e < n) sum += __builtin_expf(sval(j0 + e) - mx);
+        }
+    }
+    sum = kivi_block_reduce(sum, false, sm_lds);
+    if (threadIdx.x == 0) {
+        p.stats[2 * row] = mx;
+        p.stats[2 * row + 1] = sum;
+    }
+}
+
 // Shape-agnostic fallback: one thread per output word (fpi channels), loops over tokens.
 template <int BITS>
 __global__ __launch_bounds__(64) void gemv_v_generic(const GemvVArgs a, int G, int Dw) {
@@ -487,7 +726,10 @@ typedef void (*VLaunch)(const GemvVArgs&, dim3, hipStream_t);
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT>
 void launch_v(const GemvVArgs& a, dim3 grid, hipStream_t s) {
     const size_t lds = a.softmax ? (size_t)R * a.n_pad * sizeof(uint16_t) : 0;
-    KIVI_LAUNCH_LDS((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT>), grid, dim3(256), lds, s, a);
+    if (a.nsplit > 1)
+        KIVI_LAUNCH_LDS((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT, true>), grid, dim3(256), lds, s, a);
+    else
+        KIVI_LAUNCH_LDS((gemv_v_kernel<BITS, G, DW, WPL, R, U, MODE, NT, false>), grid, dim3(256), lds, s, a);
 }
 
 struct VVariant {
@@ -502,13 +744,13 @@ struct VVariant {
 
 const VVariant v_variants[] = {
     // ---- 2-bit, D=128 (DW=8), g=32, MHA: table order = dispatch preference (measured, profiles/)
+    VV(2, 32, 8, 4, 1, 1, 2, 1),
     VV(2, 32, 8, 2, 1, 4, 2, 1),
     VV(2, 32, 8, 4, 1, 2, 2, 0),
     VV(2, 32, 8, 4, 1, 2, 2, 1),
     VV(2, 32, 8, 4, 1, 4, 2, 0),
     VV(2, 32, 8, 4, 1, 4, 2, 1),
     VV(2, 32, 8, 4, 1, 1, 2, 0),
-    VV(2, 32, 8, 4, 1, 1, 2, 1),
     VV(2, 32, 8, 2, 1, 4, 2, 0),
     VV(2, 32, 8, 2, 1, 8, 2, 1),
     VV(2, 32, 8, 4, 1, 2, 0, 0),
@@ -535,6 +777,9 @@ const VVariant v_variants[] = {
     VV(4, 64, 8, 4, 1, 4, 2, 1),
     VV(4, 32, 16, 4, 1, 4, 0, 0),
     // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
+    VV(2, 32, 8, 1, 4, 4, 4, 1),
+    VV(2, 32, 8, 1, 8, 4, 4, 1),
+    VV(2, 32, 8, 1, 4, 8, 4, 1),
     VV(2, 32, 8, 2, 4, 2, 4, 1),
     VV(2, 32, 8, 2, 2, 4, 4, 1),
     VV(2, 64, 8, 2, 4, 2, 4, 1),
@@ -556,8 +801,7 @@ bool v_variant_fits(const VVariant& v, const GemvVArgs& a, int bits, int G) {
     if (a.ratio % v.R) return false;
     if (!a.extents_ok) return false;
     if (!a.fused && a.Tv == 0) return false;
-    if (a.softmax) {   // rows live in registers (<= 8192 scores) and in LDS; vector loads need aligned rows
-        if (a.n_scores > 8192 || (size_t)v.R * a.n_pad * 2 > 96 * 1024) return false;
+    if (a.softmax) {   // vector loads of the score rows need aligned rows; the LDS budget is checked in v_run
         if ((a.a_sh % 4) || (a.a_sb % 4) || ((uintptr_t)a.a % 8)) return false;
     }
     const int epl = v.wpl * fpi;
@@ -579,16 +823,72 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
                      "kivi_gemv_v_variant: %s does not fit this problem (bits=%d g=%d D=%d ratio=%d)", v.name, bits, G,
                      a.D, a.ratio);
         a.units_per_b = a.nh / v.R;
-        v.fn(a, dim3((unsigned)((int64_t)B * a.units_per_b)), s);
+        const int64_t units = (int64_t)B * a.units_per_b;
+        const int tpi = 64 / (v.dw / v.wpl);
+        const int64_t nchunk = (a.Tv + tpi - 1) / tpi;
+        // split-T: with few (b, head unit) rows a block per row cannot fill 256 CUs; S blocks share a row and meet in
+        // the caller's workspace.  Only when a workspace was supplied (kivi_decode_attend).
+        int S = 1;
+        if (a.ws && units < 512 && nchunk >= 32) {
+            // ~3 blocks per CU in total: enough to fill the chip, few enough that the per-block prologue/epilogue
+            // (range normalisation, butterfly, workspace hand-off) stays small next to the streamed range
+            S = (int)((768 + units - 1) / units);
+            if (S > nchunk / 32) S = (int)(nchunk / 32);
+            if (S > 64) S = 64;
+            const size_t need = (size_t)units * (S + 1) * v.R * a.D * sizeof(float);
+            if (S < 2 || need > a.ws_bytes) S = 1;
+        }
+        if (S > 1 && a.rq) {   // the row statistics (and the residual scores / K append) get their own launch
+            const size_t stats_bytes = ((size_t)B * a.nh * 2 * sizeof(float) + 255) / 256 * 256;
+            if (stats_bytes + (size_t)units * (S + 1) * v.R * a.D * sizeof(float) > a.ws_bytes) {
+                S = 1;
+            } else {
+                RowStatsArgs rp;
+                rp.scores = const_cast<uint16_t*>(a.a); rp.s_sb = a.a_sb; rp.s_sh = a.a_sh;
+                rp.n = a.n_scores; rp.Tq = a.Tq; rp.inv_scale = a.inv_scale; rp.mask = a.mask; rp.mask_sb = a.mask_sb;
+                rp.q = a.rq; rp.q_sb = a.rq_sb; rp.q_sh = a.rq_sh;
+                rp.kres = a.rkres; rp.k_sb = a.rk_sb; rp.k_sh = a.rk_sh; rp.k_st = a.rk_st;
+                rp.knew = a.rknew; rp.kn_sb = a.rkn_sb; rp.kn_sh = a.rkn_sh;
+                rp.rk_len = a.rk_len; rp.ratio = a.ratio; rp.nh = a.nh; rp.D = a.D;
+                rp.stats = a.ws;
+                hipLaunchKernelGGL(softmax_rowstats_kernel, dim3((unsigned)((int64_t)B * a.nh)), dim3(256), 0, s, rp);
+                a.stats = a.ws;
+                a.ws = (float*)((char*)a.ws + stats_bytes);
+                a.ws_bytes -= stats_bytes;
+                a.rq = nullptr;    // the sV blocks read the completed score rows
+            }
+        }
+        a.nsplit = S;
+        a.cps = (int)((nchunk + S - 1) / S);
+        if (a.softmax) {
+            const int64_t range = (S > 1) ? (int64_t)a.cps * tpi : (int64_t)a.n_scores;
+            a.n_pad = (int)((range + 7) / 8 * 8);
+            a.sm_loop = (S > 1 || a.n_scores > 8192) ? 1 : 0;
+            KIVI_REQUIRE((size_t)v.R * a.n_pad * 2 <= 96 * 1024, KIVI_EUNSUPPORTED,
+                         "kivi_decode_attend: %d probability rows of %d do not fit the LDS", v.R, a.n_pad);
+        }
+        v.fn(a, dim3((unsigned)(units * S)), s);
         return kivi_launch_status(v.name);
     }
     int best = -1;
-    for (int i = 0; i < v_nvariants; i++) {
-        const VVariant& v = v_variants[i];
-        if (!(v.mode == KIVI_UNPACK_MIX || (v.mode == KIVI_UNPACK_DEN32 && v.R > 1))) continue;
-        if (!v_variant_fits(v, a, bits, G)) continue;
-        if (best < 0 || v.R > v_variants[best].R) best = i;
-    }
+    static const char* forced = getenv("KIVI_GEMV_V_VARIANT");   // tuning aid: force a variant by name if it fits
+    if (forced)
+        for (int i = 0; i < v_nvariants; i++)
+            if (!strcmp(forced, v_variants[i].name) && v_variant_fits(v_variants[i], a, bits, G)) return v_run(i, a, B, G, bits, s);
+    // GQA: unlike qK^T, sharing the unpack between the query heads of a kv head does not pay here (the R x EPL
+    // accumulators cut the occupancy, and the re-reads of a kv head by its other query heads hit the Infinity Cache):
+    // measured at B=64/nh_kv=8/T=8k and B=16/nh_kv=8/T=32k, one head per block wins with >= 1024 rows, two heads per
+    // block below that.  Table order decides among equals.
+    const int want_r = (a.ratio % 2 == 0 && (int64_t)B * a.nh < 1024) ? 2 : 1;
+    for (int pass = 0; pass < 2 && best < 0; pass++)
+        for (int i = 0; i < v_nvariants; i++) {
+            const VVariant& v = v_variants[i];
+            if (!(v.mode == KIVI_UNPACK_MIX || (v.mode == KIVI_UNPACK_DEN32 && v.R > 1))) continue;
+            if (pass == 0 && v.R != want_r) continue;
+            if (!v_variant_fits(v, a, bits, G)) continue;
+            best = i;
+            break;
+        }
     if (best >= 0) return v_run(best, a, B, G, bits, s);
     KIVI_REQUIRE(!a.fused, KIVI_EUNSUPPORTED,
                  "kivi_decode_output: no tuned kernel for this shape (bits=%d g=%d D=%d); use the unfused path", bits, G, a.D);
@@ -637,6 +937,8 @@ static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, i
     a.sm_extent = (uint32_t)(a.extents_ok ? se : 0);
     a.a_extent = (uint32_t)(a.extents_ok ? ae : 0);
     a.softmax = 0; a.n_scores = 0; a.n_pad = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
+    a.stats = nullptr;
+    a.nsplit = 1; a.cps = 0; a.sm_loop = 0; a.ws = nullptr; a.counters = nullptr; a.ws_bytes = 0;
     a.rq = nullptr; a.rkres = nullptr; a.rknew = nullptr; a.rk_len = 0; a.Tq = 0;
     a.rq_sb = a.rq_sh = a.rk_sb = a.rk_sh = a.rk_st = a.rkn_sb = a.rkn_sh = 0;
     a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
@@ -673,6 +975,8 @@ struct ResidualK {
     int64_t knew_sb, knew_sh;
     int res_len;
     int64_t Tq;
+    void* workspace;
+    size_t workspace_bytes;
 };
 static thread_local const ResidualK* g_residual_k = nullptr;   // set only for the duration of kivi_decode_attend (same thread)
 
@@ -751,6 +1055,11 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
             a.rknew = (const uint16_t*)rk.knew; a.rkn_sb = rk.knew_sb; a.rkn_sh = rk.knew_sh;
             a.rk_len = rk.res_len;
             a.Tq = (int)rk.Tq;
+            if (rk.workspace && rk.workspace_bytes > 4096) {   // first 4 KiB: arrival counters; rest: fp32 partials
+                a.counters = (int*)rk.workspace;
+                a.ws = (float*)((char*)rk.workspace + 4096);
+                a.ws_bytes = rk.workspace_bytes - 4096;
+            }
         }
     }
     return v_run(-1, a, B, group_size, bits, (hipStream_t)stream);
@@ -759,7 +1068,7 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
 extern "C" int kivi_decode_attend(const kivi_decode_attend_args* p, kivi_stream_t stream) {
     KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_decode_attend: null arguments");
     ResidualK rk = {p->q, p->q_sb, p->q_sh, p->kres, p->kres_sb, p->kres_sh, p->kres_st, p->knew, p->knew_sb, p->knew_sh,
-                    p->k_res_len, p->Tq};
+                    p->k_res_len, p->Tq, p->workspace, (size_t)p->workspace_bytes};
     g_residual_k = &rk;
     const int rc = decode_output_impl(1, p->inv_scale, p->mask, p->mask_sb, p->scores, p->s_sb, p->s_sh, p->v_code, p->vc_sb,
                                       p->vc_sh, p->vc_sr, p->v_scale, p->v_mn, p->vs_sb, p->vs_sh, p->vs_sr, p->vres,

@@ -90,6 +90,20 @@ def decode_output(layer, probs: torch.Tensor, value_states: torch.Tensor, out: t
     return flush
 
 
+_WS = {}
+
+
+def _workspace(device, row_floats: int) -> torch.Tensor:
+    """Zero-initialised scratch shared by every layer on a device (launches are stream-ordered): 4 KiB of arrival
+    counters + fp32 partials for up to 64 + 1 blocks per row (kivi_decode_attend, split-T)."""
+    need = 4096 + 4096 + 8 * row_floats // 64 + 4 * row_floats * 65
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _WS[device] = ws
+    return ws
+
+
 def decode_attend(layer, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
                   scores: torch.Tensor, out: torch.Tensor, inv_scale: float, mask: torch.Tensor = None) -> bool:
     """Everything after the packed qK^T GEMV in one launch (kivi_decode_attend): residual scores + K append,
@@ -104,6 +118,7 @@ def decode_attend(layer, query_states: torch.Tensor, key_states: torch.Tensor, v
     flush = layer.v_res_len + 1 > cfg.residual_length
     if mask is not None:
         assert mask.dtype == torch.float16 and mask.stride(3) == 1
+    ws = _workspace(q.device, B * nh * D)
     a = _lib.DecodeAttendArgs(
         q=q.data_ptr(), q_sb=q.stride(0), q_sh=q.stride(1),
         kres=kr.data_ptr(), kres_sb=kr.stride(0), kres_sh=kr.stride(1), kres_st=kr.stride(2),
@@ -118,7 +133,8 @@ def decode_attend(layer, query_states: torch.Tensor, key_states: torch.Tensor, v
         vnew=v.data_ptr(), vnew_sb=v.stride(0), vnew_sh=v.stride(1), v_flush=int(flush),
         out=out.data_ptr(), out_sb=out.stride(0), out_sh=out.stride(1),
         B=B, nh=nh, nh_kv=layer.nh_kv, D=D, group_size=cfg.group_size, v_bits=cfg.v_bits,
-        Tq=layer.k_quant_len, Tv=layer.v_quant_len)
+        Tq=layer.k_quant_len, Tv=layer.v_quant_len,
+        workspace=ws.data_ptr(), workspace_bytes=ws.numel() * ws.element_size())
     lib = _lib.load()
     _lib.check(lib.kivi_decode_attend(ctypes.byref(a), _lib.stream_ptr(q)), "kivi_decode_attend")
     return flush

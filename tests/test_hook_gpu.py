@@ -7,6 +7,29 @@ from helpers import gemv_close, make_kv, same_bits
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("nh,nh_kv,T0,R", [(4, 4, 2100, 32), (8, 2, 4200, 128), (2, 1, 9000, 32)])
+def test_long_context_small_batch_split_rows(oracle, nh, nh_kv, T0, R):
+    """Few (b, kv head) rows and a long context: the sV launch splits every row over several blocks that meet in a
+    workspace (and rows > 8192 use the multi-pass softmax).  Must match the reference logic like any other shape."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    from oracle import hook_ref as H
+    B, D, g = 1, 128, 32
+    cfg = KiviConfig(2, 2, g, R)
+    k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
+    layer = KiviLayerCache(cfg, B, nh_kv, D, T0 + 16, "cuda")
+    layer.prefill(k0.cuda(), v0.cuda())
+    past = H.prefill_cache(k0, v0, 2, 2, g, R)
+    for s in range(5):
+        q = make_kv(100 + s, B, nh, 1, D)
+        kn, vn = make_kv(200 + s, B, nh_kv, 1, D), make_kv(300 + s, B, nh_kv, 1, D)
+        out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer)
+        assert not getattr(layer, "_attend_unfusable", False) and not getattr(layer, "_fused_unsupported", False)
+        ref, past = H.decode_step(q, kn, vn, past, 2, 2, g, R)
+        ok, ratio = gemv_close(out, ref, rtol=3e-3)
+        assert ok, (s, ratio)
+    _cmp_cache(layer.as_tuple(), past)
+
+
 def test_fused_step_partial_support():
     """head_dim 96: the qK^T kernel is tuned, the sV kernel is not -> the step mixes fused scores with a composed output
     and must still match the reference logic and keep the cache consistent."""
