@@ -62,7 +62,7 @@ def _composed_output(attn_weights: torch.Tensor, value_states: torch.Tensor, lay
 
 
 def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask) -> torch.Tensor:
-    """The decode step in three launches (+1 when the K residual fills up): same arithmetic and roundings as the
+    """The decode step in two launches (three when only the separate softmax fits; +1 when the K residual fills up): same arithmetic and roundings as the
     composed path below.  Raises KiviUnsupported when no tuned kernel covers the shape."""
     cfg = layer.cfg
     B, nh, _, D = query_states.shape
