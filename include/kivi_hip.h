@@ -204,7 +204,8 @@ typedef struct kivi_decode_attend_args {
     const void* q; int64_t q_sb, q_sh;                           /* (B, nh, D) queries */
     void* kres; int64_t kres_sb, kres_sh, kres_st;               /* (B, nh_kv, R, D) fp16 K residual buffer */
     const void* knew; int64_t knew_sb, knew_sh; int k_res_len;   /* (B, nh_kv, D) new key; keys already in kres */
-    void* scores; int64_t s_sb, s_sh;                            /* (B, nh, >= n) pre-softmax score rows */
+    void* scores; int64_t s_sb, s_sh;                            /* (B, nh, >= n) pre-softmax score rows; scratch:
+        on return the rows may hold the probabilities instead */
     float inv_scale; const void* mask; int64_t mask_sb;          /* 1/sqrt(D); additive (B,1,1,n) fp16 mask or NULL */
     void* v_code; int64_t vc_sb, vc_sh, vc_sr;                   /* packed V (B, nh_kv, >=Tv+1, D/fpi) */
     void* v_scale; void* v_mn; int64_t vs_sb, vs_sh, vs_sr;
@@ -213,8 +214,9 @@ typedef struct kivi_decode_attend_args {
     void* out; int64_t out_sb, out_sh;                           /* (B, nh, D) attention output */
     int B, nh, nh_kv, D, group_size, v_bits; int64_t Tq, Tv;
     void* workspace; int64_t workspace_bytes;                    /* optional (may be NULL): zero-initialised device
-        scratch, >= 4096 + 4 * B*nh*D*65 bytes.  With it, rows are split over several blocks when B*nh_kv is too
-        small to fill the GPU (long context, small batch); counters in it are left at zero after every call. */
+        scratch, >= 65536 + 4096 + B*nh*8 + 4 * B*nh*D*65 bytes.  With it, rows are split over several blocks when
+        B*nh_kv is too small to fill the GPU (long context, small batch) or the probabilities of a block's rows would
+        not fit a small LDS budget (grouped queries, long rows); counters in it are left at zero after every call. */
 } kivi_decode_attend_args;
 int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream);
 

@@ -13,6 +13,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkivi_hip.so")
+# tuning aid (A/B of two builds inside one GPU session): KIVI_HIP_LIB=/path/to/other/libkivi_hip.so
+LIB_PATH = os.environ.get("KIVI_HIP_LIB", LIB_PATH)
 
 _i64, _i32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 

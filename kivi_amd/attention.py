@@ -12,6 +12,7 @@ the cache is appended in place.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -61,6 +62,19 @@ def _composed_output(attn_weights: torch.Tensor, value_states: torch.Tensor, lay
     return attn_output
 
 
+_FUSION_ENV = os.environ.get("KIVI_DECODE_FUSION")   # tuning aid: "attend" (2 launches), "softmax" (3), "separate" (4)
+
+
+def _fusion_level(layer, nh: int, kv_len: int) -> int:
+    """How much of the decode step goes into the sV launch: 2 = everything after the packed qK^T (kivi_decode_attend),
+    1 = softmax + output, 0 = output only (softmax as its own launch).  Level 2 covers every tuned shape: for short
+    MHA rows the block that owns a row does the row's softmax before it starts streaming; for grouped queries / long
+    rows the library splits rows over blocks and adds a row-statistics launch (kivi_gemv_v.hip, v_run)."""
+    if _FUSION_ENV:
+        return {"attend": 2, "softmax": 1, "separate": 0}[_FUSION_ENV]
+    return 2
+
+
 def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask) -> torch.Tensor:
     """The decode step in two launches (three when only the separate softmax fits; +1 when the K residual fills up): same arithmetic and roundings as the
     composed path below.  Raises KiviUnsupported when no tuned kernel covers the shape."""
@@ -77,6 +91,11 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
     out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=query_states.device)
     inv = 1.0 / math.sqrt(D)
     flushed = None
+    level = _fusion_level(layer, nh, kv_seq_len)
+    if level < 2:
+        layer._attend_unfusable = True
+    if level < 1:
+        layer._softmax_unfusable = True
     if not getattr(layer, "_attend_unfusable", False):
         # two launches: packed qK^T GEMV (:324), then residual scores + K append + softmax + output + V append/flush
         try:

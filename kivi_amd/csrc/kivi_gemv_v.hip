@@ -22,6 +22,8 @@
 
 namespace {
 
+constexpr int64_t KIVI_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per row unit)
+
 struct GemvVArgs {
     const uint16_t* a;
     int64_t a_sb, a_sh;
@@ -64,8 +66,6 @@ struct GemvVArgs {
     int Tq;                            // packed K length = offset of the residual scores in a row
     // split-T (SPLIT kernels): nsplit blocks share one (b, head unit); partial sums meet in `ws`
     int nsplit, cps;                   // blocks per unit, chunks (of TPI tokens) per block
-    int sm_loop;                       // rows longer than 8192: softmax by passes (always the case in SPLIT kernels)
-    const float* stats;                // SPLIT: (max, sum) of every (b, h) row from softmax_rowstats_kernel, or null
     float* ws;                         // [units][nsplit + 1][R * D] fp32 partials (+1: the window part)
     int* counters;                     // [units] arrival counters, zero between launches
     size_t ws_bytes;                   // bytes available at ws
@@ -92,9 +92,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     extern __shared__ uint16_t pl[];  // [R][n_pad] fp16 probabilities when the softmax is folded in
     constexpr int RSMAX = 136;        // residual keys per row handled in LDS (R_k <= 128, + the new one)
     __shared__ uint16_t rs_lds[R][RSMAX];
-    __shared__ uint16_t pw[R][RSMAX];  // loop-path softmax: probabilities of the fp16-window tokens (block `split == 0`)
     __shared__ int last_flag;
-    const bool sm_loop = SPLIT || a.sm_loop;   // softmax by passes over the row instead of the register-resident form
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,9 +110,18 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     const rsrc_t rc = make_rsrc(a.code + b * a.code_sb + hk * a.code_sh, a.code_extent);
     const rsrc_t rs = make_rsrc(a.scale + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
     const rsrc_t rm = make_rsrc(a.mn + b * a.sm_sb + hk * a.sm_sh, a.sm_extent);
+    // chunk c = TPI tokens; a SPLIT block owns chunks [c_begin, c_end) of its row
+    const int nchunk = (int)((a.Tv + TPI - 1) / TPI);
+    const int c_begin = SPLIT ? split * a.cps : 0;
+    const int c_end = SPLIT ? ((c_begin + a.cps < nchunk) ? c_begin + a.cps : nchunk) : nchunk;
+    // the probability rows are bounded at the END OF THIS BLOCK'S RANGE: a wave's last batch may reach into the next
+    // block's chunks, those tokens then read probability 0 (hardware range check) and contribute nothing
+    const uint32_t a_ext = SPLIT ? (uint32_t)__builtin_amdgcn_readfirstlane(
+                                       (int)(((int64_t)c_end * TPI * 2 < (int64_t)a.a_extent) ? (int64_t)c_end * TPI * 2 : (int64_t)a.a_extent))
+                                 : a.a_extent;
     rsrc_t ra[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) ra[r] = make_rsrc(a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh, a.a_extent);
+    for (int r = 0; r < R; r++) ra[r] = make_rsrc(a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh, a_ext);
 
     const int gi0 = (lr * EPL) / G;             // first group index of this lane inside a row
     const uint32_t coff = (uint32_t)(((int64_t)lt * a.code_sr + lr * WPL) * 4);
@@ -160,12 +167,8 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
         }
     };
 
-    // chunk c = TPI tokens; wave w owns chunks w, w+4, ...; batch = U chunks of this wave
-    const int nchunk = (int)((a.Tv + TPI - 1) / TPI);
-    const int c_begin = SPLIT ? split * a.cps : 0;                              // this block's chunk range
-    const int c_end = SPLIT ? ((c_begin + a.cps < nchunk) ? c_begin + a.cps : nchunk) : nchunk;
+    // wave w owns chunks w, w+4, ... of the block's range; batch = U chunks of this wave
     const int nloc = c_end > c_begin ? c_end - c_begin : 0;
-    const int64_t t_begin = (int64_t)c_begin * TPI;                             // first token of the range
     const int my_chunks = (nloc > wave) ? (nloc - wave + 3) / 4 : 0;
     const int nbatch = (my_chunks + U - 1) / U;  // out-of-range chunks read zeros (bounds check)
 
@@ -184,15 +187,13 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * 4 + wave);
-            const bool mine = !SPLIT || (int)c < c_end;   // chunks past the range belong to the next block
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                if (a.softmax) {   // probabilities produced by this block, in LDS (indexed from the range start)
+                if (!SPLIT && a.softmax) {   // probabilities produced by this block, in LDS
                     const int64_t t = (int64_t)c * TPI + lt;
-                    ab[u][r] = (mine && t < a.Tv) ? pl[(size_t)r * a.n_pad + (t - t_begin)] : (uint16_t)0;
+                    ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
                 } else {
-                    const uint16_t av = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
-                    ab[u][r] = mine ? av : (uint16_t)0;
+                    ab[u][r] = buf_load<uint16_t, false>(ra[r], aoff + c * astep, 0);
                 }
             }
         }
@@ -205,19 +206,72 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     WV wA[U], wB[U];
     SV sA[U], sB[U], mA[U], mB[U];
     uint16_t aA[U][R], aB[U][R];
-    // the first batch of packed V is requested before the softmax phase so the stream is already moving
-    if (nbatch > 0) load_wsm(0, wA, sA, mA);
+
+    // Everything small that the step needs besides the packed stream is REQUESTED first, in one go, so that none of
+    // it waits behind the stream's own loads (the memory system is saturated once the stream runs, a dependent
+    // round trip then costs several us): the score row(s), the fp16 V window, the window token about to be
+    // quantised.  The consumers come later, in the order the data is needed.
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    constexpr int SMC = 8;
+    const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
+    const bool do_win = a.fused && split == 0;
+    const bool do_flush = do_win && a.flush && owner;
+    const bool reg_softmax = a.softmax;
+    const int n_sc = a.n_scores;
+    const int nch_sc = (n_sc + 1023) / 1024;
+    // (a) row 0 of the register-resident softmax: the part of the score row that is already in memory
+    auto load_raw = [&](int r, u16x4* raw) {
+        const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
+        const int lim = a.rq ? (a.Tq < n_sc ? a.Tq : n_sc) : n_sc;   // scores from `lim` on are produced by this block
+#pragma unroll
+        for (int c = 0; c < SMC; c++) {
+            const int j0 = c * 1024 + (int)threadIdx.x * 4;
+            raw[c] = u16x4{0, 0, 0, 0};
+            if (c < nch_sc) {
+                if (j0 + 4 <= lim) {
+                    raw[c] = *(const u16x4*)(srow + j0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (j0 + e < lim) raw[c][e] = srow[j0 + e];
+                }
+            }
+        }
+    };
+    u16x4 raw0[SMC];
+    if (reg_softmax) load_raw(0, raw0);
+    // (b) the first PWT window tokens of this wave (covers a window of 4*PWT-1 = 35 tokens; longer ones loop below)
+    constexpr int NP = (D / 2 + 63) / 64;            // channel pairs per lane
+    constexpr int PWT = 9;
+    const int Lw = a.res_len + 1;
+    uint32_t vpre[PWT][NP];
+    if (do_win) {
+        const uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+#pragma unroll
+        for (int k = 0; k < PWT; k++) {
+            const int t = wave + 4 * k;
+            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const int p = lane + 64 * c;
+                vpre[k][c] = (t < Lw && p < D / 2) ? *(const uint32_t*)(vrow + 2 * p) : 0u;
+            }
+        }
+    }
+    // (c) the oldest window token, quantised below
+    uint16_t xflush = 0;
+    if (do_flush && (int)threadIdx.x < D)
+        xflush = a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + threadIdx.x];
 
     if (a.softmax) {
         // scale + mask + softmax of this block's R score rows, the arithmetic of kivi_softmax_scaled (same element ->
         // thread assignment and reduction tree, so the probabilities are bit-identical to the stand-alone kernel).
         // The whole row (<= 8192 scores) is fetched with up to 8 independent 8-byte loads per thread: one L2 round trip.
-        typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-        constexpr int SMC = 8;
-        const int n = a.n_scores;
-        const int nch = (n + 1023) / 1024;
+        const int n = n_sc;
+        const int nch = nch_sc;
         const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb : nullptr;
-        const bool owner_k = (h0 % a.ratio) == 0;
+        const bool owner_k = owner;
         if (a.rq) {
             // q . k over the fp16 residual keys and the new key: one thread per (head, key), 16-byte loads,
             // fp32 accumulate, one rounding (the reference's fp16 torch.matmul, :337); kept in LDS for the softmax and
@@ -251,99 +305,29 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                     const_cast<uint16_t*>(a.a)[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tq + t] = hs;
                 }
             }
-            __syncthreads();
         }
-        if (sm_loop) {
-            // rows of any length / one block of several per row: two passes over the (L2-resident) row for max and
-            // sum, then only this block's token range (and, in block 0, the window tokens) is normalised into LDS.
-            // Same per-thread element order and reduction tree as the register-resident form below.
-            const int64_t t_end = ((int64_t)c_end * TPI < a.Tv) ? (int64_t)c_end * TPI : a.Tv;
-#pragma unroll 1
-            for (int r = 0; r < R; r++) {
-                const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
-                auto sval = [&](int j) {
-                    const uint16_t raw1 = (a.rq && j >= a.Tq) ? rs_lds[r][j - a.Tq] : srow[j];
-                    return h2f_bits(kivi_scaled_score(raw1, a.inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
-                };
-                const int nvec = a.rq ? (a.Tq & ~3) : (n & ~3);   // scores below this index come straight from memory
-                float mx = -__builtin_inff();
-                float sum = 0.f;
-                if (a.stats) {   // row statistics were computed once per row by the row-stats launch
-                    mx = a.stats[2 * ((int64_t)b * a.nh + h0 + r)];
-                    sum = a.stats[2 * ((int64_t)b * a.nh + h0 + r) + 1];
-                } else {
-                for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
-                    if (j0 + 4 <= nvec) {
-                        const u16x4 v4 = *(const u16x4*)(srow + j0);
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            mx = __builtin_fmaxf(mx, h2f_bits(kivi_scaled_score(v4[e], a.inv_scale, mrow != nullptr,
-                                                                                 mrow ? mrow[j0 + e] : 0)));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (j0 + e < n) mx = __builtin_fmaxf(mx, sval(j0 + e));
-                    }
-                }
-                mx = kivi_block_reduce(mx, true, sm_lds);
-                for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
-                    if (j0 + 4 <= nvec) {
-                        const u16x4 v4 = *(const u16x4*)(srow + j0);
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            sum += __builtin_expf(h2f_bits(kivi_scaled_score(v4[e], a.inv_scale, mrow != nullptr,
-                                                                             mrow ? mrow[j0 + e] : 0)) - mx);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (j0 + e < n) sum += __builtin_expf(sval(j0 + e) - mx);
-                    }
-                }
-                sum = kivi_block_reduce(sum, false, sm_lds);
-                }
-                // normalise this block's own token range into LDS: 8-byte loads, several in flight
-                uint16_t* prow = pl + (size_t)r * a.n_pad;
-#pragma unroll 4
-                for (int64_t j0 = t_begin + threadIdx.x * 4; j0 < t_end; j0 += 1024) {
-                    if (j0 + 4 <= t_end && j0 + 4 <= nvec) {
-                        const u16x4 v4 = *(const u16x4*)(srow + j0);
-                        u16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            o[e] = f2h_bits(__builtin_expf(h2f_bits(kivi_scaled_score(v4[e], a.inv_scale, mrow != nullptr,
-                                                                                     mrow ? mrow[j0 + e] : 0)) - mx) / sum);
-                        *(u16x4*)(prow + (j0 - t_begin)) = o;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (j0 + e < t_end) prow[j0 + e - t_begin] = f2h_bits(__builtin_expf(sval((int)(j0 + e)) - mx) / sum);
-                    }
-                }
-                if (a.fused && split == 0)
-                    for (int t = threadIdx.x; t < n - (int)a.Tv && t < RSMAX; t += 256)
-                        pw[r][t] = f2h_bits(__builtin_expf(sval((int)a.Tv + t) - mx) / sum);
-            }
-        } else {
+        // the first batch of packed V is requested before the softmax arithmetic so the stream is already moving
+        if (nbatch > 0) load_wsm(0, wA, sA, mA);
+        if (a.rq) __syncthreads();
+        {
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
-            const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
             uint16_t* prow = pl + (size_t)r * a.n_pad;
             u16x4 raw[SMC];
+            if (r == 0) {
 #pragma unroll
-            for (int c = 0; c < SMC; c++) {
-                const int j0 = c * 1024 + (int)threadIdx.x * 4;
-                raw[c] = u16x4{0, 0, 0, 0};
-                if (c < nch) {
-                    if (a.rq && j0 + 4 > a.Tq) {   // (part of) the vector lies in the residual range: take it from LDS
+                for (int c = 0; c < SMC; c++) raw[c] = raw0[c];
+            } else {
+                load_raw(r, raw);
+            }
+            if (a.rq) {   // the residual range was produced by this block: take it from LDS
+#pragma unroll
+                for (int c = 0; c < SMC; c++) {
+                    const int j0 = c * 1024 + (int)threadIdx.x * 4;
+                    if (c < nch && j0 + 4 > a.Tq) {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
-                            if (j0 + e < n) raw[c][e] = (j0 + e >= a.Tq) ? rs_lds[r][j0 + e - a.Tq] : srow[j0 + e];
-                    } else if (j0 + 4 <= n) {
-                        raw[c] = *(const u16x4*)(srow + j0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (j0 + e < n) raw[c][e] = srow[j0 + e];
+                            if (j0 + e >= a.Tq && j0 + e < n) raw[c][e] = rs_lds[r][j0 + e - a.Tq];
                     }
                 }
             }
@@ -383,6 +367,129 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
         }
         }
         __syncthreads();
+    } else {
+        if (nbatch > 0) load_wsm(0, wA, sA, mA);
+    }
+
+    if (do_win) {
+        // probs[..., -L:] @ V_window (llama_kivi.py:384): the <= R+1 fp16 window tokens (the last one is the new
+        // value, appended here, :377) are spread over the 4 waves, a lane owns channel pairs.  Done BEFORE the
+        // stream from the rows requested at the top, so nothing but the packed sum is left for the tail.
+        float racc[R][NP][2];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < NP; c++) racc[r][c][0] = racc[r][c][1] = 0.f;
+        const uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+        auto win_tok = [&](int t, const uint32_t* vv_c) {
+            float at[R];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                at[r] = h2f_bits(!a.softmax ? a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]
+                                 : pl[(size_t)r * a.n_pad + a.Tv + t]);
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const int p = lane + 64 * c;
+                if (p < D / 2) {
+                    const uint32_t vv = vv_c[c];
+                    const float v0 = h2f_bits((uint16_t)(vv & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv >> 16));
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        racc[r][c][0] = __builtin_fmaf(at[r], v0, racc[r][c][0]);
+                        racc[r][c][1] = __builtin_fmaf(at[r], v1, racc[r][c][1]);
+                    }
+                    if (t == a.res_len && owner)
+                        *(uint32_t*)(a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)(a.win_start + t) * a.vres_st + 2 * p) = vv;
+                }
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < PWT; k++) {
+            const int t = wave + 4 * k;
+            if (t < Lw) win_tok(t, vpre[k]);
+        }
+        for (int t = wave + 4 * PWT; t < Lw; t += 4) {
+            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+            uint32_t vv_c[NP];
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const int p = lane + 64 * c;
+                vv_c[c] = (p < D / 2) ? *(const uint32_t*)(vrow + 2 * p) : 0u;
+            }
+            win_tok(t, vv_c);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const int p = lane + 64 * c;
+                if (p < D / 2) {
+                    resl[wave][r][2 * p] = racc[r][c][0];
+                    resl[wave][r][2 * p + 1] = racc[r][c][1];
+                }
+            }
+    }
+    if (do_flush) {
+        // the window now holds R+1 tokens: quantise the OLDEST one into cache row Tv (:386-399), bit-identical
+        // to the stand-alone pack kernel (shared quantiser).  Thread d owns channel d; group min / max and the word
+        // assembly go through lane shuffles (G <= 64: a group never leaves a wave), so no barrier is spent here.
+        const int d = threadIdx.x;
+        if constexpr (G <= 64) {
+            if (d < D) {   // wave-uniform: D is a multiple of 64
+                const uint32_t key = h_key(xflush);
+                uint32_t kmin = key, kmax = key;
+#pragma unroll
+                for (int m = 1; m < G; m <<= 1) {
+                    const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
+                    kmin = o1 < kmin ? o1 : kmin;
+                    kmax = o2 > kmax ? o2 : kmax;
+                }
+                const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+                uint32_t word = quant_one<BITS>(xflush, gq) << (BITS * (d % FPI));
+#pragma unroll
+                for (int m = 1; m < FPI; m <<= 1) word |= (uint32_t)__shfl_xor((int)word, m);
+                if ((d % FPI) == 0)
+                    const_cast<uint32_t*>(a.code)[b * a.code_sb + hk * a.code_sh + a.Tv * a.code_sr + d / FPI] = word;
+                if ((d % G) == 0) {
+                    const int64_t so = b * a.sm_sb + hk * a.sm_sh + a.Tv * a.sm_sr + d / G;
+                    const_cast<uint16_t*>(a.scale)[so] = gq.scale;
+                    const_cast<uint16_t*>(a.mn)[so] = gq.mn;
+                }
+            }
+        } else {
+            uint32_t* lds = reinterpret_cast<uint32_t*>(&red[0][0][0]);   // D keys, then D codes (red is still unused)
+            if (d < D) lds[d] = h_key(xflush);
+            __syncthreads();
+            GroupQ gq;
+            uint32_t c = 0;
+            if (d < D) {
+                uint32_t kmin = 0xFFFFu, kmax = 0u;
+                const int g0 = (d / G) * G;
+                for (int i = 0; i < G; i++) {
+                    const uint32_t k = lds[g0 + i];
+                    kmin = k < kmin ? k : kmin;
+                    kmax = k > kmax ? k : kmax;
+                }
+                gq = make_group(kmin, kmax, (1 << BITS) - 1);
+                c = quant_one<BITS>(xflush, gq);
+            }
+            __syncthreads();
+            if (d < D) lds[d] = c;
+            __syncthreads();
+            if (d < DW) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int i = 0; i < FPI; i++) word |= lds[d * FPI + i] << (BITS * i);
+                const_cast<uint32_t*>(a.code)[b * a.code_sb + hk * a.code_sh + a.Tv * a.code_sr + d] = word;
+            }
+            if (d < D && (d % G) == 0) {
+                const int64_t so = b * a.sm_sb + hk * a.sm_sh + a.Tv * a.sm_sr + d / G;
+                const_cast<uint16_t*>(a.scale)[so] = gq.scale;
+                const_cast<uint16_t*>(a.mn)[so] = gq.mn;
+            }
+            __syncthreads();
+        }
     }
 
     {
@@ -399,55 +506,6 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             compute_batch(wB, sB, mB, aB);
         }
         if (it < nbatch) compute_batch(wA, sA, mA, aA);
-    }
-
-    const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
-    if (a.fused && split == 0) {
-        // probs[..., -L:] @ V_window (llama_kivi.py:384): the <= R+1 fp16 window tokens (the last one is the new
-        // value, appended here, :377) are spread over the 4 waves, a lane owns channel pairs; all loads of a
-        // wave are independent, so this costs one L2 round trip instead of L serial ones.
-        constexpr int NP = (D / 2 + 63) / 64;            // channel pairs per lane
-        float racc[R][NP][2];
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int c = 0; c < NP; c++) racc[r][c][0] = racc[r][c][1] = 0.f;
-        const int L = a.res_len + 1;
-        const uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
-        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
-        for (int t = wave; t < L; t += 4) {
-            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
-            float at[R];
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                at[r] = h2f_bits(!a.softmax ? a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]
-                                 : (sm_loop ? pw[r][t] : pl[(size_t)r * a.n_pad + a.Tv + t]));
-#pragma unroll
-            for (int c = 0; c < NP; c++) {
-                const int p = lane + 64 * c;
-                if (p < D / 2) {
-                    const uint32_t vv = *(const uint32_t*)(vrow + 2 * p);
-                    const float v0 = h2f_bits((uint16_t)(vv & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv >> 16));
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        racc[r][c][0] = __builtin_fmaf(at[r], v0, racc[r][c][0]);
-                        racc[r][c][1] = __builtin_fmaf(at[r], v1, racc[r][c][1]);
-                    }
-                    if (t == a.res_len && owner)
-                        *(uint32_t*)(a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)(a.win_start + t) * a.vres_st + 2 * p) = vv;
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int c = 0; c < NP; c++) {
-                const int p = lane + 64 * c;
-                if (p < D / 2) {
-                    resl[wave][r][2 * p] = racc[r][c][0];
-                    resl[wave][r][2 * p + 1] = racc[r][c][1];
-                }
-            }
     }
 
     // undo the positional power-of-two factors, then combine the TPI lanes that share `lr`
@@ -537,9 +595,16 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             for (int i = threadIdx.x; i < R * D; i += 256) {
                 const int r = i / D, d = i - r * D;
                 float s = 0.f;
-                for (int sp = 0; sp < nsplit; sp++)
-                    s += __builtin_bit_cast(float, __hip_atomic_load(p0 + (size_t)sp * (R * D) + i, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_AGENT));
+                for (int sp0 = 0; sp0 < nsplit; sp0 += 8) {   // 8 independent loads in flight, added in split order
+                    uint32_t v8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        v8[k] = (sp0 + k < nsplit) ? __hip_atomic_load(p0 + (size_t)(sp0 + k) * (R * D) + i, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                                   : 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) s += __builtin_bit_cast(float, v8[k]);
+                }
                 uint16_t o = f2h_bits(s);
                 if (a.fused) {
                     const float res = __builtin_bit_cast(float, __hip_atomic_load(p0 + (size_t)nsplit * (R * D) + i,
@@ -550,79 +615,52 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             }
         }
     }
-    if (a.fused && a.flush && owner && split == 0) {
-        // the window now holds R+1 tokens: quantise the OLDEST one into cache row Tv (:386-399), bit-identical
-        // to the stand-alone pack kernel (shared quantiser)
-        __syncthreads();
-        uint32_t* lds = reinterpret_cast<uint32_t*>(&red[0][0][0]);   // D keys, then D codes
-        const int d = threadIdx.x;
-        uint16_t x = 0;
-        if (d < D) {
-            x = a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + d];
-            lds[d] = h_key(x);
-        }
-        __syncthreads();
-        GroupQ gq;
-        uint32_t c = 0;
-        if (d < D) {
-            uint32_t kmin = 0xFFFFu, kmax = 0u;
-            const int g0 = (d / G) * G;
-            for (int i = 0; i < G; i++) {
-                const uint32_t k = lds[g0 + i];
-                kmin = k < kmin ? k : kmin;
-                kmax = k > kmax ? k : kmax;
-            }
-            gq = make_group(kmin, kmax, (1 << BITS) - 1);
-            c = quant_one<BITS>(x, gq);
-        }
-        __syncthreads();
-        if (d < D) lds[d] = c;
-        __syncthreads();
-        if (d < DW) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int i = 0; i < FPI; i++) word |= lds[d * FPI + i] << (BITS * i);
-            const_cast<uint32_t*>(a.code)[b * a.code_sb + hk * a.code_sh + a.Tv * a.code_sr + d] = word;
-        }
-        if (d < D && (d % G) == 0) {
-            const int64_t so = b * a.sm_sb + hk * a.sm_sh + a.Tv * a.sm_sr + d / G;
-            const_cast<uint16_t*>(a.scale)[so] = gq.scale;
-            const_cast<uint16_t*>(a.mn)[so] = gq.mn;
-        }
-    }
 }
 
-// Row statistics for the split-T decode step: one block per (b, h) score row computes the residual scores
-// q . [fp16 K residual | new key] (+ the K append), then max and sum(exp) of the scaled / masked row with exactly the
-// element order and reduction tree of kivi_softmax_scaled.  The sV blocks of the row then normalise their own ranges.
-struct RowStatsArgs {
+// Stand-alone row softmax of the decode step, used when the block-prologue softmax of gemv_v_kernel does not pay
+// (grouped queries: R rows per block; rows longer than the register-resident form; rows split over blocks): one
+// block per (b, h) score row computes the residual scores q . [fp16 K residual | new key] (+ the K append) when a
+// query is given, then scale + mask + softmax with exactly the element order and reduction tree of
+// kivi_softmax_scaled, and overwrites the score row with the fp16 probabilities (llama_kivi.py:339, :364-375).
+struct RowSoftmaxArgs {
     uint16_t* scores;
     int64_t s_sb, s_sh;
     int n, Tq;
     float inv_scale;
     const uint16_t* mask;
     int64_t mask_sb;
-    const uint16_t* q;
+    const uint16_t* q;                 // null: the score rows are complete (no residual part to compute)
     int64_t q_sb, q_sh;
     uint16_t* kres;
     int64_t k_sb, k_sh, k_st;
     const uint16_t* knew;
     int64_t kn_sb, kn_sh;
     int rk_len, ratio, nh, D;
-    float* stats;
+    // long rows / few rows: P blocks per row, each owning `chunk` scores (the last one the rest, incl. the residual
+    // part); launch 1 leaves (max, sum exp) of every chunk in `partial`, launch 2 combines them and normalises.
+    int P, chunk;
+    float* partial;                    // [rows][P][2]
 };
 
-__global__ __launch_bounds__(256) void softmax_rowstats_kernel(const RowStatsArgs p) {
+// MODE 0: one block per row does everything.  MODE 1: chunk statistics.  MODE 2: combine + normalise the chunk.
+template <int MODE>
+__global__ __launch_bounds__(256) void row_softmax_kernel(const RowSoftmaxArgs p) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     __shared__ float sm_lds[4];
     __shared__ uint16_t rs_lds[136];
-    const int row = blockIdx.x;
+    const int row = (MODE == 0) ? (int)blockIdx.x : (int)blockIdx.x / p.P;
+    const int c = (MODE == 0) ? 0 : (int)blockIdx.x - row * p.P;
+    const int P = (MODE == 0) ? 1 : p.P;
     const int b = row / p.nh, h = row - b * p.nh;
     const int hk = h / p.ratio;
     uint16_t* srow = p.scores + b * p.s_sb + (int64_t)h * p.s_sh;
     const uint16_t* mrow = p.mask ? p.mask + b * p.mask_sb : nullptr;
-    const int L = p.rk_len + 1;
-    {
+    const int n = p.n;
+    const int lo = c * p.chunk;                               // multiple of 1024: the 8-byte loads stay aligned
+    const int hi = (c == P - 1) ? n : lo + p.chunk;
+    const bool res_here = (MODE != 2) && p.q != nullptr && c == P - 1;   // the last chunk contains [Tq, n)
+    if (res_here) {
+        const int L = p.rk_len + 1;
         const uint16_t* knew = p.knew + b * p.kn_sb + hk * p.kn_sh;
         uint16_t* kres = p.kres + b * p.k_sb + hk * p.k_sh;
         const int cpl = p.D / 8;
@@ -650,47 +688,71 @@ __global__ __launch_bounds__(256) void softmax_rowstats_kernel(const RowStatsArg
         }
         __syncthreads();
     }
-    const int n = p.n;
     auto sval = [&](int j) {
-        const uint16_t raw1 = (j >= p.Tq) ? rs_lds[j - p.Tq] : srow[j];
+        const uint16_t raw1 = (res_here && j >= p.Tq) ? rs_lds[j - p.Tq] : srow[j];
         return h2f_bits(kivi_scaled_score(raw1, p.inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
     };
-    const int nvec = p.Tq & ~3;
+    const int nvec = (res_here ? p.Tq : n) & ~3;   // scores below this index come straight from memory, 4 at a time
     float mx = -__builtin_inff();
-    for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
-        if (j0 + 4 <= nvec) {
-            const u16x4 v4 = *(const u16x4*)(srow + j0);
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                mx = __builtin_fmaxf(mx, h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)));
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (j0 + e < n) mx = __builtin_fmaxf(mx, sval(j0 + e));
-        }
-    }
-    mx = kivi_block_reduce(mx, true, sm_lds);
     float sum = 0.f;
-    for (int j0 = threadIdx.x * 4; j0 < n; j0 += 1024) {
-        if (j0 + 4 <= nvec) {
+    if constexpr (MODE != 2) {
+        for (int j0 = lo + threadIdx.x * 4; j0 < hi; j0 += 1024) {
+            if (j0 + 4 <= nvec && j0 + 4 <= hi) {
+                const u16x4 v4 = *(const u16x4*)(srow + j0);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    mx = __builtin_fmaxf(mx, h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (j0 + e < hi) mx = __builtin_fmaxf(mx, sval(j0 + e));
+            }
+        }
+        mx = kivi_block_reduce(mx, true, sm_lds);
+        for (int j0 = lo + threadIdx.x * 4; j0 < hi; j0 += 1024) {
+            if (j0 + 4 <= nvec && j0 + 4 <= hi) {
+                const u16x4 v4 = *(const u16x4*)(srow + j0);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    sum += __builtin_expf(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)) - mx);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (j0 + e < hi) sum += __builtin_expf(sval(j0 + e) - mx);
+            }
+        }
+        sum = kivi_block_reduce(sum, false, sm_lds);
+    }
+    if constexpr (MODE == 1) {
+        if (threadIdx.x == 0) {
+            p.partial[2 * ((int64_t)row * P + c)] = mx;
+            p.partial[2 * ((int64_t)row * P + c) + 1] = sum;
+        }
+        return;
+    }
+    if constexpr (MODE == 2) {   // every thread combines the P chunk statistics the same way (chunk order)
+        const float* pp = p.partial + 2 * (int64_t)row * P;
+        for (int i = 0; i < P; i++) mx = __builtin_fmaxf(mx, pp[2 * i]);
+        for (int i = 0; i < P; i++) sum += pp[2 * i + 1] * __builtin_expf(pp[2 * i] - mx);
+    }
+    // every thread rewrites exactly the elements it read (the reductions above are barriers), so in place is safe
+    for (int j0 = lo + threadIdx.x * 4; j0 < hi; j0 += 1024) {
+        if (j0 + 4 <= nvec && j0 + 4 <= hi) {
             const u16x4 v4 = *(const u16x4*)(srow + j0);
+            u16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                sum += __builtin_expf(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)) - mx);
+                o[e] = f2h_bits(__builtin_expf(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr,
+                                                                         mrow ? mrow[j0 + e] : 0)) - mx) / sum);
+            *(u16x4*)(srow + j0) = o;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (j0 + e < n) sum += __builtin_expf(sval(j0 + e) - mx);
+                if (j0 + e < hi) srow[j0 + e] = f2h_bits(__builtin_expf(sval(j0 + e) - mx) / sum);
         }
-    }
-    sum = kivi_block_reduce(sum, false, sm_lds);
-    if (threadIdx.x == 0) {
-        p.stats[2 * row] = mx;
-        p.stats[2 * row + 1] = sum;
     }
 }
 
-// Shape-agnostic fallback: one thread per output word (fpi channels), loops over tokens.
 template <int BITS>
 __global__ __launch_bounds__(64) void gemv_v_generic(const GemvVArgs a, int G, int Dw) {
     constexpr int FPI = 32 / BITS;
@@ -777,10 +839,10 @@ const VVariant v_variants[] = {
     VV(4, 64, 8, 4, 1, 4, 2, 1),
     VV(4, 32, 16, 4, 1, 4, 0, 0),
     // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
+    VV(2, 32, 8, 2, 4, 2, 4, 1),
     VV(2, 32, 8, 1, 4, 4, 4, 1),
     VV(2, 32, 8, 1, 8, 4, 4, 1),
     VV(2, 32, 8, 1, 4, 8, 4, 1),
-    VV(2, 32, 8, 2, 4, 2, 4, 1),
     VV(2, 32, 8, 2, 2, 4, 4, 1),
     VV(2, 64, 8, 2, 4, 2, 4, 1),
     VV(2, 128, 8, 2, 4, 2, 4, 1),
@@ -828,42 +890,59 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         const int64_t nchunk = (a.Tv + tpi - 1) / tpi;
         // split-T: with few (b, head unit) rows a block per row cannot fill 256 CUs; S blocks share a row and meet in
         // the caller's workspace.  Only when a workspace was supplied (kivi_decode_attend).
+        // split-T: with few (b, head unit) rows a block per row cannot fill 256 CUs; S blocks share a row and meet in
+        // the caller's workspace (kivi_decode_attend): ~3 blocks per CU in total, few enough that the per-block
+        // epilogue (butterfly, workspace hand-off) stays small next to the streamed range.
         int S = 1;
-        if (a.ws && units < 512 && nchunk >= 32) {
-            // ~3 blocks per CU in total: enough to fill the chip, few enough that the per-block prologue/epilogue
-            // (range normalisation, butterfly, workspace hand-off) stays small next to the streamed range
-            S = (int)((768 + units - 1) / units);
+        if (a.ws && nchunk >= 32 && units < 512 && units <= KIVI_WS_COUNTERS) {
+            // R >= 4 variants hold R x EPL accumulators: 2 blocks per CU are resident, so 512 blocks = one full round
+            const int64_t target = v.R >= 4 ? 512 : 768;
+            S = (int)((target + units - 1) / units);
+            static const char* forced_split = getenv("KIVI_V_SPLIT");   // tuning aid
+            if (forced_split) S = atoi(forced_split);
             if (S > nchunk / 32) S = (int)(nchunk / 32);
             if (S > 64) S = 64;
             const size_t need = (size_t)units * (S + 1) * v.R * a.D * sizeof(float);
             if (S < 2 || need > a.ws_bytes) S = 1;
         }
-        if (S > 1 && a.rq) {   // the row statistics (and the residual scores / K append) get their own launch
-            const size_t stats_bytes = ((size_t)B * a.nh * 2 * sizeof(float) + 255) / 256 * 256;
-            if (stats_bytes + (size_t)units * (S + 1) * v.R * a.D * sizeof(float) > a.ws_bytes) {
-                S = 1;
+        // Where the softmax runs.  In the prologue of the block that owns the row: one query head per block, a row
+        // of <= 8192 keys held in registers, nothing split (the MHA decode shape: no extra launch, the probabilities
+        // never leave the CU).  Otherwise (grouped queries = R rows per block, longer rows, split rows) that prologue
+        // would serialise R x n exps per block while the memory system idles (measured +150 us at B=64 / 8 kv heads /
+        // 8k keys): the well-parallel row-softmax launch turns the score rows into probabilities in place first.
+        if (a.softmax && (v.R > 1 || S > 1 || a.n_scores > 8192)) {
+            RowSoftmaxArgs rp;
+            rp.scores = const_cast<uint16_t*>(a.a); rp.s_sb = a.a_sb; rp.s_sh = a.a_sh;
+            rp.n = a.n_scores; rp.Tq = a.Tq; rp.inv_scale = a.inv_scale; rp.mask = a.mask; rp.mask_sb = a.mask_sb;
+            rp.q = a.rq; rp.q_sb = a.rq_sb; rp.q_sh = a.rq_sh;
+            rp.kres = a.rkres; rp.k_sb = a.rk_sb; rp.k_sh = a.rk_sh; rp.k_st = a.rk_st;
+            rp.knew = a.rknew; rp.kn_sb = a.rkn_sb; rp.kn_sh = a.rkn_sh;
+            rp.rk_len = a.rk_len; rp.ratio = a.ratio; rp.nh = a.nh; rp.D = a.D;
+            // few rows (long context, small batch): P blocks per row so that ~2048 blocks share the work
+            const int64_t rows = (int64_t)B * a.nh;
+            int P = (int)((2048 + rows - 1) / rows);
+            if (P > a.n_scores / 2048) P = a.n_scores / 2048;
+            if (P > 64) P = 64;
+            const size_t part_bytes = ((size_t)rows * (P > 0 ? P : 1) * 2 * sizeof(float) + 255) / 256 * 256;
+            if (P >= 2 && a.ws && part_bytes + (size_t)units * (S + 1) * v.R * a.D * sizeof(float) <= a.ws_bytes) {
+                rp.P = P;
+                rp.chunk = (a.n_scores / P) / 1024 * 1024;
+                rp.partial = a.ws;
+                a.ws = (float*)((char*)a.ws + part_bytes);
+                a.ws_bytes -= part_bytes;
+                hipLaunchKernelGGL(row_softmax_kernel<1>, dim3((unsigned)(rows * P)), dim3(256), 0, s, rp);
+                hipLaunchKernelGGL(row_softmax_kernel<2>, dim3((unsigned)(rows * P)), dim3(256), 0, s, rp);
             } else {
-                RowStatsArgs rp;
-                rp.scores = const_cast<uint16_t*>(a.a); rp.s_sb = a.a_sb; rp.s_sh = a.a_sh;
-                rp.n = a.n_scores; rp.Tq = a.Tq; rp.inv_scale = a.inv_scale; rp.mask = a.mask; rp.mask_sb = a.mask_sb;
-                rp.q = a.rq; rp.q_sb = a.rq_sb; rp.q_sh = a.rq_sh;
-                rp.kres = a.rkres; rp.k_sb = a.rk_sb; rp.k_sh = a.rk_sh; rp.k_st = a.rk_st;
-                rp.knew = a.rknew; rp.kn_sb = a.rkn_sb; rp.kn_sh = a.rkn_sh;
-                rp.rk_len = a.rk_len; rp.ratio = a.ratio; rp.nh = a.nh; rp.D = a.D;
-                rp.stats = a.ws;
-                hipLaunchKernelGGL(softmax_rowstats_kernel, dim3((unsigned)((int64_t)B * a.nh)), dim3(256), 0, s, rp);
-                a.stats = a.ws;
-                a.ws = (float*)((char*)a.ws + stats_bytes);
-                a.ws_bytes -= stats_bytes;
-                a.rq = nullptr;    // the sV blocks read the completed score rows
+                rp.P = 1; rp.chunk = a.n_scores; rp.partial = nullptr;
+                hipLaunchKernelGGL(row_softmax_kernel<0>, dim3((unsigned)rows), dim3(256), 0, s, rp);
             }
+            a.softmax = 0;     // the sV blocks read finished probabilities
+            a.rq = nullptr;
         }
         a.nsplit = S;
         a.cps = (int)((nchunk + S - 1) / S);
         if (a.softmax) {
-            const int64_t range = (S > 1) ? (int64_t)a.cps * tpi : (int64_t)a.n_scores;
-            a.n_pad = (int)((range + 7) / 8 * 8);
-            a.sm_loop = (S > 1 || a.n_scores > 8192) ? 1 : 0;
+            a.n_pad = (int)((a.n_scores + 7) / 8 * 8);
             KIVI_REQUIRE((size_t)v.R * a.n_pad * 2 <= 96 * 1024, KIVI_EUNSUPPORTED,
                          "kivi_decode_attend: %d probability rows of %d do not fit the LDS", v.R, a.n_pad);
         }
@@ -875,11 +954,9 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
     if (forced)
         for (int i = 0; i < v_nvariants; i++)
             if (!strcmp(forced, v_variants[i].name) && v_variant_fits(v_variants[i], a, bits, G)) return v_run(i, a, B, G, bits, s);
-    // GQA: unlike qK^T, sharing the unpack between the query heads of a kv head does not pay here (the R x EPL
-    // accumulators cut the occupancy, and the re-reads of a kv head by its other query heads hit the Infinity Cache):
-    // measured at B=64/nh_kv=8/T=8k and B=16/nh_kv=8/T=32k, one head per block wins with >= 1024 rows, two heads per
-    // block below that.  Table order decides among equals.
-    const int want_r = (a.ratio % 2 == 0 && (int64_t)B * a.nh < 1024) ? 2 : 1;
+    // GQA: R query heads of a kv head share every unpacked code.  Measured (B=64 / nh_kv=8 / T=8k, probabilities from
+    // memory, fp16 window of 128): R=4 108 us, R=2 143 us, R=1 (every head re-reads its kv head) 162 us.
+    const int want_r = (a.ratio % 4 == 0) ? 4 : (a.ratio % 2 == 0) ? 2 : 1;
     for (int pass = 0; pass < 2 && best < 0; pass++)
         for (int i = 0; i < v_nvariants; i++) {
             const VVariant& v = v_variants[i];
@@ -937,8 +1014,7 @@ static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, i
     a.sm_extent = (uint32_t)(a.extents_ok ? se : 0);
     a.a_extent = (uint32_t)(a.extents_ok ? ae : 0);
     a.softmax = 0; a.n_scores = 0; a.n_pad = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
-    a.stats = nullptr;
-    a.nsplit = 1; a.cps = 0; a.sm_loop = 0; a.ws = nullptr; a.counters = nullptr; a.ws_bytes = 0;
+    a.nsplit = 1; a.cps = 0; a.ws = nullptr; a.counters = nullptr; a.ws_bytes = 0;
     a.rq = nullptr; a.rkres = nullptr; a.rknew = nullptr; a.rk_len = 0; a.Tq = 0;
     a.rq_sb = a.rq_sh = a.rk_sb = a.rk_sh = a.rk_st = a.rkn_sb = a.rkn_sh = 0;
     a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
@@ -1055,10 +1131,10 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
             a.rknew = (const uint16_t*)rk.knew; a.rkn_sb = rk.knew_sb; a.rkn_sh = rk.knew_sh;
             a.rk_len = rk.res_len;
             a.Tq = (int)rk.Tq;
-            if (rk.workspace && rk.workspace_bytes > 4096) {   // first 4 KiB: arrival counters; rest: fp32 partials
+            if (rk.workspace && rk.workspace_bytes > KIVI_WS_COUNTERS * sizeof(int)) {   // arrival counters, then fp32 partials
                 a.counters = (int*)rk.workspace;
-                a.ws = (float*)((char*)rk.workspace + 4096);
-                a.ws_bytes = rk.workspace_bytes - 4096;
+                a.ws = (float*)((char*)rk.workspace + KIVI_WS_COUNTERS * sizeof(int));
+                a.ws_bytes = rk.workspace_bytes - KIVI_WS_COUNTERS * sizeof(int);
             }
         }
     }

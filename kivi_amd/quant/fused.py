@@ -94,9 +94,9 @@ _WS = {}
 
 
 def _workspace(device, row_floats: int) -> torch.Tensor:
-    """Zero-initialised scratch shared by every layer on a device (launches are stream-ordered): 4 KiB of arrival
-    counters + fp32 partials for up to 64 + 1 blocks per row (kivi_decode_attend, split-T)."""
-    need = 4096 + 4096 + 8 * row_floats // 64 + 4 * row_floats * 65
+    """Zero-initialised scratch shared by every layer on a device (launches are stream-ordered): 64 KiB of arrival
+    counters, then row statistics + fp32 partials for up to 64 + 1 blocks per row (kivi_decode_attend, split-T)."""
+    need = 65536 + 4096 + 8 * row_floats // 64 + 4 * row_floats * 65
     ws = _WS.get(device)
     if ws is None or ws.numel() < need:
         ws = torch.zeros(need, dtype=torch.uint8, device=device)
