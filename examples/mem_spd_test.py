@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""End-to-end decode throughput / peak memory of a Llama-shaped model with the KIVI attention hook.
+
+Counterpart of the reference's mem_spd_test.py (:8-12, :53-70: Llama-2-7b, k = v = 2 bit, g = 32, one prompt batch,
+N new tokens, ms per generate + torch.cuda.max_memory_allocated) for a box without network: the weights are RANDOM
+(Llama-2-7B architecture by default), so the generated tokens mean nothing -- time and memory do.  The decoder around
+the attention block (embedding, RMSNorm, rotary q/k/v/o projections, SwiGLU MLP, lm_head, greedy argmax) is plain
+torch (rocBLAS / hipBLASLt GEMMs); the attention block is kivi_amd.attention.LlamaAttention_KIVI, i.e. the drop-in
+for models/llama_kivi.py.  `--baseline` runs the same model with an fp16 KV cache and torch SDPA instead.
+
+    python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512          # BASELINE.json configs[2]
+    python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512 --baseline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class Fp16Attention(nn.Module):
+    """The un-quantised baseline: preallocated fp16 KV cache + torch SDPA."""
+
+    def __init__(self, cfg, layer_idx):
+        super().__init__()
+        from kivi_amd.attention import LlamaAttention_KIVI
+        inner = LlamaAttention_KIVI(cfg, layer_idx)   # reuse the projections / rotary code
+        self.inner = inner
+        self.cap = cfg.kivi_max_cache_len
+
+    def forward(self, hidden_states, past_key_value=None, use_cache=True, **kw):
+        m = self.inner
+        bsz, q_len, _ = hidden_states.size()
+        q = m.q_proj(hidden_states).view(bsz, q_len, m.num_heads, m.head_dim).transpose(1, 2)
+        k = m.k_proj(hidden_states).view(bsz, q_len, m.num_key_value_heads, m.head_dim).transpose(1, 2)
+        v = m.v_proj(hidden_states).view(bsz, q_len, m.num_key_value_heads, m.head_dim).transpose(1, 2)
+        past_len = 0 if past_key_value is None else past_key_value[2]
+        pos = torch.arange(past_len, past_len + q_len, device=q.device)[None].expand(bsz, -1)
+        q, k = m._rope(q, k, pos)
+        if past_key_value is None:
+            kc = torch.empty((bsz, m.num_key_value_heads, self.cap, m.head_dim), device=q.device, dtype=q.dtype)
+            vc = torch.empty_like(kc)
+        else:
+            kc, vc, _ = past_key_value
+        kc[:, :, past_len:past_len + q_len] = k
+        vc[:, :, past_len:past_len + q_len] = v
+        n = past_len + q_len
+        o = F.scaled_dot_product_attention(q, kc[:, :, :n], vc[:, :, :n], is_causal=(q_len > 1),
+                                           enable_gqa=(m.num_heads != m.num_key_value_heads))
+        o = o.transpose(1, 2).reshape(bsz, q_len, m.num_heads * m.head_dim)
+        return m.o_proj(o), None, (kc, vc, n)
+
+
+class Block(nn.Module):
+    def __init__(self, cfg, i, baseline):
+        super().__init__()
+        from kivi_amd.attention import LlamaAttention_KIVI
+        self.self_attn = Fp16Attention(cfg, i) if baseline else LlamaAttention_KIVI(cfg, i)
+        self.mlp = MLP(cfg)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+    def forward(self, x, past):
+        a, _, past = self.self_attn(self.input_layernorm(x), past_key_value=past, use_cache=True)
+        x = x + a
+        return x + self.mlp(self.post_attention_layernorm(x)), past
+
+
+class Model(nn.Module):
+    def __init__(self, cfg, baseline):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([Block(cfg, i, baseline) for i in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+
+    @torch.no_grad()
+    def forward(self, ids, pasts):
+        x = self.embed_tokens(ids)
+        new = []
+        for layer, past in zip(self.layers, pasts):
+            x, p = layer(x, past)
+            new.append(p)
+        return self.lm_head(self.norm(x[:, -1:])), new
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--prompt", type=int, default=2048)
+    ap.add_argument("--gen", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--hidden", type=int, default=4096)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=32)
+    ap.add_argument("--intermediate", type=int, default=11008)
+    ap.add_argument("--vocab", type=int, default=32000)
+    ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--group", type=int, default=32)
+    ap.add_argument("--residual", type=int, default=32)
+    ap.add_argument("--baseline", action="store_true", help="fp16 KV cache + torch SDPA instead of the KIVI hook")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = SimpleNamespace(hidden_size=args.hidden, num_attention_heads=args.heads, num_key_value_heads=args.kv_heads,
+                          num_hidden_layers=args.layers, intermediate_size=args.intermediate, vocab_size=args.vocab,
+                          max_position_embeddings=args.prompt + args.gen + 1, rope_theta=10000.0, rms_norm_eps=1e-5,
+                          k_bits=args.bits, v_bits=args.bits, group_size=args.group, residual_length=args.residual,
+                          kivi_max_cache_len=args.prompt + args.gen + 1, attention_bias=False)
+    torch.manual_seed(0)
+    with torch.device(dev):
+        torch.set_default_dtype(torch.float16)
+        model = Model(cfg, args.baseline)
+        torch.set_default_dtype(torch.float32)
+    for p in model.parameters():      # small weights keep the random activations finite through 32 layers
+        if p.dim() > 1:
+            p.data.normal_(0.0, 0.02)
+    weights = sum(p.numel() * p.element_size() for p in model.parameters())
+    ids = torch.randint(0, args.vocab, (args.batch, args.prompt), device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.time()
+    logits, pasts = model(ids, [None] * args.layers)
+    torch.cuda.synchronize()
+    t_prefill = time.time() - t0
+    tok = logits.argmax(-1)
+    t1 = time.time()
+    for _ in range(args.gen):
+        logits, pasts = model(tok, pasts)
+        tok = logits.argmax(-1)
+    torch.cuda.synchronize()
+    t_dec = time.time() - t1
+    if args.baseline:
+        kv = kv_alloc = sum(p[0].numel() * 2 * 2 for p in pasts)
+    else:
+        kv = sum(p.layer.nbytes() for p in pasts)                 # what the reference's 9-tuples would hold
+        kv_alloc = sum(p.layer.allocated_bytes() for p in pasts)  # incl. page / window slack of the in-place cache
+    print(json.dumps({
+        "mode": "fp16 KV + SDPA" if args.baseline else f"KIVI {args.bits}-bit g={args.group} R={args.residual}",
+        "model": f"llama-shaped random weights: L={args.layers} h={args.hidden} nh={args.heads}/{args.kv_heads} ffn={args.intermediate}",
+        "batch": args.batch, "prompt": args.prompt, "gen": args.gen,
+        "prefill_s": round(t_prefill, 3), "decode_ms_per_step": round(1e3 * t_dec / args.gen, 3),
+        "decode_tokens_per_s": round(args.batch * args.gen / t_dec, 1),
+        "weights_bytes": weights, "kv_cache_bytes": kv, "kv_cache_allocated_bytes": kv_alloc,
+        "max_memory_allocated": torch.cuda.max_memory_allocated()}))
+
+
+if __name__ == "__main__":
+    main()

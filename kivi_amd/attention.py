@@ -201,6 +201,9 @@ def _rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
+_ROPE_CACHE = {}   # (device, dtype, head_dim, theta, past_len, q_len) -> (cos, sin) of the current step
+
+
 class LlamaAttention_KIVI(nn.Module):
     """Self-contained Llama attention block with the KIVI cache hook (reference: LlamaFlashAttention_KIVI,
     models/llama_kivi.py:264-466; constructor fields :22-61).
@@ -249,9 +252,20 @@ class LlamaAttention_KIVI(nn.Module):
         k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         past_len = 0 if past_key_value is None else int(past_key_value[-1])
-        if position_ids is None:
-            position_ids = torch.arange(past_len, past_len + q_len, device=hidden_states.device)[None].expand(bsz, -1)
-        q, k = self._rope(q, k, position_ids)
+        if position_ids is None:   # consecutive positions: cos / sin are the same for every layer of this step
+            key = (hidden_states.device, q.dtype, self.head_dim, self.rope_theta, past_len, q_len)
+            cs = _ROPE_CACHE.get(key)
+            if cs is None:
+                pos = torch.arange(past_len, past_len + q_len, device=hidden_states.device)[None]
+                freqs = pos[:, :, None].float() * self.inv_freq[None, None, :].float()
+                emb = torch.cat((freqs, freqs), dim=-1)
+                cs = (emb.cos()[:, None].to(q.dtype), emb.sin()[:, None].to(q.dtype))
+                _ROPE_CACHE.clear()
+                _ROPE_CACHE[key] = cs
+            cos, sin = cs
+            q, k = q * cos + _rotate_half(q) * sin, k * cos + _rotate_half(k) * sin
+        else:
+            q, k = self._rope(q, k, position_ids)
 
         if past_key_value is not None:
             if isinstance(past_key_value, KiviCacheTuple):

@@ -67,6 +67,13 @@ __device__ __forceinline__ float kivi_block_reduce(float v, bool is_max, float* 
     return is_max ? __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)) : (a + b) + (c + d);
 }
 
+// exp() of the softmax kernels: one v_exp_f32 on x * log2(e).  The argument product rounds at 2^-24 relative, i.e. the
+// result carries a relative error <= ~|x| * 1e-7 (x <= 0 here, |x| < 100 where the result matters) -- three orders
+// below the fp16 rounding of the probabilities, and a tenth of the instructions of the libm expf.  Every softmax in
+// the library (stand-alone, row launches, sV prologue) uses this helper and multiplies by one correctly rounded
+// reciprocal of the row sum, so the same row gives the same probabilities on every path.
+__device__ __forceinline__ float kivi_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // One attention score -> the fp16 value the reference feeds its softmax (llama_kivi.py:339, :364-372):
 // fp16(s * inv_scale) [then fp16(+ mask) clamped at the fp16 minimum].
 __device__ __forceinline__ uint16_t kivi_scaled_score(uint16_t s, float inv_scale, bool has_mask, uint16_t m) {

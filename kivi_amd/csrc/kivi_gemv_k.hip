@@ -224,10 +224,11 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
 
     // channel d: w = packed codes, sraw/mraw = raw fp16 scale / zero-point bits; `odd` = d & 1 (folds to a
     // constant in the unrolled batches)
-    auto row = [&](int d, bool odd, const WV& w, SV sraw, SV mraw) {
+    // qp[r] = the fp16 pair (q[d & ~1], q[d | 1]) of head r, fetched one batch ahead together with the codes
+    auto row = [&](const uint32_t* qp, bool odd, const WV& w, SV sraw, SV mraw) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const uint32_t qb = qrow[r][d >> 1];                 // s_load_dword: fp16 pair (q[d & ~1], q[d | 1])
+            const uint32_t qb = qp[r];
             float qs[NGL];
             qs[0] = mul_hh_s(qb, odd, (uint32_t)sraw, false);
             zacc[r][0] = fma_hh_s(qb, odd, (uint32_t)mraw, false, zacc[r][0]);
@@ -247,17 +248,21 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
         }
     };
     // batch = U consecutive channels starting at `dr` (even: d0 and U are even)
-    auto load_batch = [&](int dr, WV* wb, SV* sb, SV* mb) {
+    auto load_batch = [&](int dr, WV* wb, SV* sb, SV* mb, uint32_t (*qb)[R]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             wb[u] = buf_load<WV, NT>(rc, coff, (uint32_t)(dr + u) * cstep);
             sb[u] = buf_load<SV, NT>(rs, soff, (uint32_t)(dr + u) * sstep);
             mb[u] = buf_load<SV, NT>(rm, soff, (uint32_t)(dr + u) * sstep);
         }
-    };
-    auto compute_batch = [&](int dr, const WV* wb, const SV* sb, const SV* mb) {
 #pragma unroll
-        for (int u = 0; u < U; u++) row(dr + u, (u & 1) != 0, wb[u], sb[u], mb[u]);
+        for (int u2 = 0; u2 < U / 2; u2++)
+#pragma unroll
+            for (int r = 0; r < R; r++) qb[u2][r] = qrow[r][(dr >> 1) + u2];   // s_load_dword, a batch ahead of its use
+    };
+    auto compute_batch = [&](const WV* wb, const SV* sb, const SV* mb, const uint32_t (*qb)[R]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) row(qb[u / 2], (u & 1) != 0, wb[u], sb[u], mb[u]);
     };
     static_assert(U % 2 == 0, "batches start on even channels");
 
@@ -265,22 +270,26 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(const GemvKArgs a) {
         // ping-pong register buffers: batch n+1 is in flight while batch n is consumed
         WV wA[U], wB[U];
         SV sA[U], sB[U], mA[U], mB[U];
+        uint32_t qA[U / 2][R], qB[U / 2][R];
         const int nfull = nrows / U;
-        if (nfull > 0) load_batch(d0, wA, sA, mA);
+        if (nfull > 0) load_batch(d0, wA, sA, mA, qA);
         int it = 0;
         for (; it + 2 <= nfull; it += 2) {
-            load_batch(d0 + (it + 1) * U, wB, sB, mB);
-            compute_batch(d0 + it * U, wA, sA, mA);
-            if (it + 2 < nfull) load_batch(d0 + (it + 2) * U, wA, sA, mA);
-            compute_batch(d0 + (it + 1) * U, wB, sB, mB);
+            load_batch(d0 + (it + 1) * U, wB, sB, mB, qB);
+            compute_batch(wA, sA, mA, qA);
+            if (it + 2 < nfull) load_batch(d0 + (it + 2) * U, wA, sA, mA, qA);
+            compute_batch(wB, sB, mB, qB);
         }
-        if (it < nfull) compute_batch(d0 + it * U, wA, sA, mA);
+        if (it < nfull) compute_batch(wA, sA, mA, qA);
         for (int d = d0 + nfull * U; d < d1; d++) {   // channel tail (rows per wave not a multiple of U)
             WV w = buf_load<WV, NT>(rc, coff, (uint32_t)d * cstep);
             SV sv = buf_load<SV, NT>(rs, soff, (uint32_t)d * sstep);
             SV mv = buf_load<SV, NT>(rm, soff, (uint32_t)d * sstep);
-            if (d & 1) row(d, true, w, sv, mv);
-            else row(d, false, w, sv, mv);
+            uint32_t qp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) qp[r] = qrow[r][d >> 1];
+            if (d & 1) row(qp, true, w, sv, mv);
+            else row(qp, false, w, sv, mv);
         }
     }
 

@@ -351,17 +351,18 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                 if (c < nch)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        x[c][e] = __builtin_expf(x[c][e] - mx);
+                        x[c][e] = kivi_exp(x[c][e] - mx);
                         sum += x[c][e];
                     }
             sum = kivi_block_reduce(sum, false, sm_lds);
+            const float inv = 1.0f / sum;
 #pragma unroll
             for (int c = 0; c < SMC; c++)
                 if (c < nch) {
                     const int j0 = c * 1024 + (int)threadIdx.x * 4;
                     u16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] / sum);
+                    for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] * inv);
                     if (j0 < a.n_pad) *(u16x4*)(prow + j0) = o;   // n_pad is a multiple of 8: whole vectors stay inside the row
                 }
         }
@@ -714,11 +715,11 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const RowSoftmaxArgs p
                 const u16x4 v4 = *(const u16x4*)(srow + j0);
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    sum += __builtin_expf(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)) - mx);
+                    sum += kivi_exp(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)) - mx);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    if (j0 + e < hi) sum += __builtin_expf(sval(j0 + e) - mx);
+                    if (j0 + e < hi) sum += kivi_exp(sval(j0 + e) - mx);
             }
         }
         sum = kivi_block_reduce(sum, false, sm_lds);
@@ -733,22 +734,23 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const RowSoftmaxArgs p
     if constexpr (MODE == 2) {   // every thread combines the P chunk statistics the same way (chunk order)
         const float* pp = p.partial + 2 * (int64_t)row * P;
         for (int i = 0; i < P; i++) mx = __builtin_fmaxf(mx, pp[2 * i]);
-        for (int i = 0; i < P; i++) sum += pp[2 * i + 1] * __builtin_expf(pp[2 * i] - mx);
+        for (int i = 0; i < P; i++) sum += pp[2 * i + 1] * kivi_exp(pp[2 * i] - mx);
     }
     // every thread rewrites exactly the elements it read (the reductions above are barriers), so in place is safe
+    const float inv = 1.0f / sum;
     for (int j0 = lo + threadIdx.x * 4; j0 < hi; j0 += 1024) {
         if (j0 + 4 <= nvec && j0 + 4 <= hi) {
             const u16x4 v4 = *(const u16x4*)(srow + j0);
             u16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                o[e] = f2h_bits(__builtin_expf(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr,
-                                                                         mrow ? mrow[j0 + e] : 0)) - mx) / sum);
+                o[e] = f2h_bits(kivi_exp(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr,
+                                                                         mrow ? mrow[j0 + e] : 0)) - mx) * inv);
             *(u16x4*)(srow + j0) = o;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (j0 + e < hi) srow[j0 + e] = f2h_bits(__builtin_expf(sval(j0 + e) - mx) / sum);
+                if (j0 + e < hi) srow[j0 + e] = f2h_bits(kivi_exp(sval(j0 + e) - mx) * inv);
         }
     }
 }
@@ -918,9 +920,9 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             rp.kres = a.rkres; rp.k_sb = a.rk_sb; rp.k_sh = a.rk_sh; rp.k_st = a.rk_st;
             rp.knew = a.rknew; rp.kn_sb = a.rkn_sb; rp.kn_sh = a.rkn_sh;
             rp.rk_len = a.rk_len; rp.ratio = a.ratio; rp.nh = a.nh; rp.D = a.D;
-            // few rows (long context, small batch): P blocks per row so that ~2048 blocks share the work
+            // long rows: P blocks per row so that ~4096 blocks of >= 2048 scores share the work
             const int64_t rows = (int64_t)B * a.nh;
-            int P = (int)((2048 + rows - 1) / rows);
+            int P = (int)((4096 + rows - 1) / rows);
             if (P > a.n_scores / 2048) P = a.n_scores / 2048;
             if (P > 64) P = 64;
             const size_t part_bytes = ((size_t)rows * (P > 0 ? P : 1) * 2 * sizeof(float) + 255) / 256 * 256;

@@ -51,16 +51,17 @@ __global__ __launch_bounds__(256) void softmax_scaled_kernel(const uint16_t* __r
     for (int c = 0; c < CHUNKS; c++)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            x[c][e] = __builtin_expf(x[c][e] - mx);   // exp(-inf) = 0 for the padding lanes
+            x[c][e] = kivi_exp(x[c][e] - mx);   // exp(-inf) = 0 for the padding lanes
             sum += x[c][e];
         }
     sum = kivi_block_reduce(sum, false, lds);
+    const float inv = 1.0f / sum;
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++) {
         const int64_t j0 = (int64_t)c * 1024 + threadIdx.x * 4;
         u16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] / sum);
+        for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] * inv);
         if (j0 + 4 <= n) *(u16x4*)(prow + j0) = o;
         else
 #pragma unroll
@@ -85,9 +86,10 @@ __global__ __launch_bounds__(256) void softmax_scaled_generic(const uint16_t* __
     for (int64_t j = threadIdx.x; j < n; j += 256) mx = __builtin_fmaxf(mx, val(j));
     mx = kivi_block_reduce(mx, true, lds);
     float sum = 0.f;
-    for (int64_t j = threadIdx.x; j < n; j += 256) sum += __builtin_expf(val(j) - mx);
+    for (int64_t j = threadIdx.x; j < n; j += 256) sum += kivi_exp(val(j) - mx);
     sum = kivi_block_reduce(sum, false, lds);
-    for (int64_t j = threadIdx.x; j < n; j += 256) prow[j] = f2h_bits(__builtin_expf(val(j) - mx) / sum);
+    const float inv = 1.0f / sum;
+    for (int64_t j = threadIdx.x; j < n; j += 256) prow[j] = f2h_bits(kivi_exp(val(j) - mx) * inv);
 }
 
 }  // namespace

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("nh,nh_kv,T0,R", [(4, 4, 2100, 32), (8, 2, 4200, 128), (2, 1, 9000, 32)])
 def test_long_context_small_batch_split_rows(oracle, nh, nh_kv, T0, R):
     """Few (b, kv head) rows and a long context: the sV launch splits every row over several blocks that meet in a
-    workspace (and rows > 8192 use the multi-pass softmax).  Must match the reference logic like any other shape."""
+    workspace, and the row softmax runs as its own launches (several blocks per row, chunk statistics combined in a
+    second launch).  Must match the reference logic like any other shape."""
     from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
     from oracle import hook_ref as H
     B, D, g = 1, 128, 32
@@ -135,6 +136,33 @@ def test_fused_and_composed_paths_agree_with_mask():
         oa = kivi_attention_decode(q, kn, vn, la, attention_mask=mask, fused_kernels=True)
         ob = kivi_attention_decode(q, kn, vn, lb, attention_mask=mask, fused_kernels=False)
         assert not getattr(la, "_fused_unsupported", False)
+        ok, ratio = gemv_close(oa, ob.cpu(), rtol=2e-3)
+        assert ok, (s, ratio)
+        for x, y in zip(la.as_tuple()[:8], lb.as_tuple()[:8]):
+            assert (x is None) == (y is None) and (x is None or same_bits(x, y))
+
+
+@pytest.mark.parametrize("B,nh,nh_kv,T0,R", [(2, 8, 1, 4500, 128), (1, 16, 4, 2300, 32), (3, 4, 2, 6200, 64)])
+def test_grouped_queries_long_rows_masked(B, nh, nh_kv, T0, R):
+    """Grouped queries (ratio 8 / 4 / 2) with rows long enough for the multi-block row softmax, plus the additive
+    mask: the fused step (qK^T launch, row-softmax launches, shared-unpack sV launch) against the reference-style
+    composition -- outputs within fp16 rounding, cache contents bit-identical."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    D = 128
+    cfg = KiviConfig(2, 2, 32, R)
+    k0, v0 = make_kv(11, B, nh_kv, T0, D), make_kv(12, B, nh_kv, T0, D)
+    la = KiviLayerCache(cfg, B, nh_kv, D, T0 + 8, "cuda")
+    lb = KiviLayerCache(cfg, B, nh_kv, D, T0 + 8, "cuda")
+    for lc in (la, lb):
+        lc.prefill(k0.cuda(), v0.cuda())
+    for s in range(4):
+        q = make_kv(100 + s, B, nh, 1, D).cuda()
+        kn, vn = make_kv(200 + s, B, nh_kv, 1, D).cuda(), make_kv(300 + s, B, nh_kv, 1, D).cuda()
+        mask = torch.zeros((B, 1, 1, T0 + s + 1), dtype=torch.float16, device="cuda")
+        mask[0, :, :, : 1000 + 7 * s] = torch.finfo(torch.float16).min      # left padding of sequence 0
+        oa = kivi_attention_decode(q, kn, vn, la, attention_mask=mask, fused_kernels=True)
+        ob = kivi_attention_decode(q, kn, vn, lb, attention_mask=mask, fused_kernels=False)
+        assert not getattr(la, "_fused_unsupported", False) and not getattr(la, "_attend_unfusable", False)
         ok, ratio = gemv_close(oa, ob.cpu(), rtol=2e-3)
         assert ok, (s, ratio)
         for x, y in zip(la.as_tuple()[:8], lb.as_tuple()[:8]):
