@@ -183,10 +183,11 @@ int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh, void* code
                        int64_t vnew_sb, int64_t vnew_sh, int flush, void* out, int64_t out_sb, int64_t out_sh, int B,
                        int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits, kivi_stream_t stream);
 
-/* kivi_softmax_scaled + kivi_decode_output in ONE launch: `scores` are the pre-softmax rows written by
- * kivi_decode_scores (row length Tv + res_len + 1); every block turns its rows into fp16 probabilities in LDS
- * (bit-identical to kivi_softmax_scaled) and goes on with the sV product.  KIVI_EUNSUPPORTED if the rows do not
- * fit the LDS (very long contexts with a wide GQA unit): call the two entry points separately then. */
+/* kivi_softmax_scaled + kivi_decode_output in ONE call: `scores` are the pre-softmax rows written by
+ * kivi_decode_scores (row length Tv + res_len + 1).  MHA rows of <= 8192 keys: one launch, every block turns its
+ * row into fp16 probabilities in LDS (bit-identical to kivi_softmax_scaled) and goes on with the sV product.
+ * Grouped queries (nh > nh_kv) or longer rows: a row-softmax launch first OVERWRITES `scores` with the probabilities
+ * (same arithmetic), then the sV launch reads them; `scores` is scratch in that case despite the const. */
 int kivi_decode_softmax_output(const void* scores, int64_t a_sb, int64_t a_sh, float inv_scale, const void* mask,
                                int64_t mask_sb, void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
                                void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr, void* vres,
