@@ -218,6 +218,28 @@ def main():
                     "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min(us), 2),
                     "algorithmic_bytes_per_launch": tot_bytes // len(us),
                     "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
+        # BASELINE configs[1] beside it: the same qK^T kernel launched back to back over the L layer caches (each launch
+        # reads a different ~200 MiB cache, L x 200 MiB >> the 256 MiB Infinity Cache), every dispatch timed -- the
+        # isolated single-layer K-GEMV number, without the decode loop's kernel alternation
+        single = None
+        if roof is not None and layers[0].k_quant_len:
+            scratch = torch.empty((B, nh, 1, layers[0].k_quant_len), device=dev, dtype=torch.float16)
+            ev1 = []
+            for rep in range(6):
+                for lc in layers:
+                    pair = (klib.kivi_event_create(), klib.kivi_event_create())
+                    klib.kivi_set_launch_events(*pair)
+                    matmul.gemv_k_paged(g, qs[0], lc.k_code, lc.k_scale, lc.k_mn, lc.k_quant_len, bits, out=scratch)
+                    if rep:          # first pass = warm-up
+                        ev1.append(pair)
+            torch.cuda.synchronize()
+            us1 = sorted(klib.kivi_event_elapsed_us(a, b) for a, b in ev1)
+            nbytes = kgemv_bytes(B, nh, nh_kv, D, layers[0].k_quant_len, g, bits)
+            med = us1[len(us1) // 2]
+            single = {"workload": "BASELINE configs[1]: single-layer packed-K qK^T GEMV, back-to-back over the layer caches",
+                      "launches": len(us1), "median_launch_us": round(med, 2), "min_launch_us": round(us1[0], 2),
+                      "achieved": round(nbytes / (med * 1e-6) / 1e9, 1), "unit": "GB/s",
+                      "frac": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         kv_bytes = sum(lc.nbytes() for lc in layers)
         fp16_bytes = 2 * L * B * nh_kv * layers[0].kv_seq_len * D * 2
         out = {
@@ -236,6 +258,7 @@ def main():
             "allocator_peak_bytes": torch.cuda.max_memory_allocated(dev),
             "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / args.steps, 4),
             "roofline": roof,
+            "roofline_single_layer_kgemv": single,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, nh, T0, D, g, bits, L)

@@ -1056,7 +1056,6 @@ struct ResidualK {
     void* workspace;
     size_t workspace_bytes;
 };
-static thread_local const ResidualK* g_residual_k = nullptr;   // set only for the duration of kivi_decode_attend (same thread)
 
 static int decode_output_impl(int softmax, float inv_scale, const void* mask, int64_t mask_sb, const void* probs,
                               int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb, int64_t code_sh, int64_t code_sr,
@@ -1064,7 +1063,7 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
                               int64_t vres_sb, int64_t vres_sh, int64_t vres_st, int win_start, int res_len,
                               const void* vnew, int64_t vnew_sb, int64_t vnew_sh, int flush, void* out, int64_t out_sb,
                               int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits,
-                              kivi_stream_t stream);
+                              kivi_stream_t stream, const ResidualK* rkp = nullptr);
 
 extern "C" int kivi_decode_output(const void* probs, int64_t a_sb, int64_t a_sh, void* code, int64_t code_sb,
                                   int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh,
@@ -1096,7 +1095,7 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
                               int64_t vres_sb, int64_t vres_sh, int64_t vres_st, int win_start, int res_len,
                               const void* vnew, int64_t vnew_sb, int64_t vnew_sh, int flush, void* out, int64_t out_sb,
                               int64_t out_sh, int B, int nh, int nh_kv, int64_t Tv, int D, int group_size, int bits,
-                              kivi_stream_t stream) {
+                              kivi_stream_t stream, const ResidualK* rkp) {
     GemvVArgs a;
     int rc = v_fill(a, "kivi_decode_output", probs, a_sb, a_sh, code, code_sb, code_sh, code_sr, scale, mn, sm_sb, sm_sh,
                     sm_sr, out, out_sb, out_sh, B, nh, nh_kv, Tv, D, group_size, bits);
@@ -1120,8 +1119,8 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
         a.inv_scale = inv_scale;
         a.mask = (const uint16_t*)mask;
         a.mask_sb = mask_sb;
-        if (g_residual_k) {
-            const ResidualK& rk = *g_residual_k;
+        if (rkp) {
+            const ResidualK& rk = *rkp;
             KIVI_REQUIRE(rk.res_len + 1 <= 136 && rk.Tq + rk.res_len + 1 == n, KIVI_EUNSUPPORTED,
                          "kivi_decode_attend: residual of %d keys does not fit / lengths disagree", rk.res_len);
             KIVI_REQUIRE(D % 64 == 0 && rk.q_sb % 8 == 0 && rk.q_sh % 8 == 0 && rk.kres_sb % 8 == 0 && rk.kres_sh % 8 == 0 &&
@@ -1147,12 +1146,10 @@ extern "C" int kivi_decode_attend(const kivi_decode_attend_args* p, kivi_stream_
     KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_decode_attend: null arguments");
     ResidualK rk = {p->q, p->q_sb, p->q_sh, p->kres, p->kres_sb, p->kres_sh, p->kres_st, p->knew, p->knew_sb, p->knew_sh,
                     p->k_res_len, p->Tq, p->workspace, (size_t)p->workspace_bytes};
-    g_residual_k = &rk;
     const int rc = decode_output_impl(1, p->inv_scale, p->mask, p->mask_sb, p->scores, p->s_sb, p->s_sh, p->v_code, p->vc_sb,
                                       p->vc_sh, p->vc_sr, p->v_scale, p->v_mn, p->vs_sb, p->vs_sh, p->vs_sr, p->vres,
                                       p->vres_sb, p->vres_sh, p->vres_st, p->v_win_start, p->v_res_len, p->vnew, p->vnew_sb,
                                       p->vnew_sh, p->v_flush, p->out, p->out_sb, p->out_sh, p->B, p->nh, p->nh_kv, p->Tv, p->D,
-                                      p->group_size, p->v_bits, stream);
-    g_residual_k = nullptr;
+                                      p->group_size, p->v_bits, stream, &rk);
     return rc;
 }

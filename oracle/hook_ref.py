@@ -2,8 +2,14 @@
 
 TEST INFRASTRUCTURE ONLY.  Tuple-based and torch.cat-grown exactly like the reference; the quantise/pack and
 the fused GEMV go through the C oracle (oracle/kivi_oracle.c), the fp16 residual matmuls / softmax through
-torch on CPU.  models/llama_kivi.py itself cannot be imported here (transformers 4.43 API, flash-attn, CUDA
-extension), so this part of the oracle is a restatement only: "parity unpinned" for the hook.
+torch on CPU.
+
+PINNED: models/llama_kivi.py cannot be imported as a module here (transformers 4.43 API, flash-attn, CUDA extension),
+but oracle/pin_hook.py executes the source of its two attention classes (LlamaAttention_KIVI :19-262,
+LlamaFlashAttention_KIVI :264-466) on CPU with only the environment shimmed, and checks this restatement against them:
+the 9-tuple bit for bit after the prompt pass and after EVERY decode step (MHA / GQA, 2 / 4 bit, with and without the
+additive mask, prompts shorter and longer than the residual length), step outputs within the GEMV bar.  The reference's
+outputs are committed as tests/golden/hook_*.npz (tests/test_hook_golden_cpu.py, tests/test_hook_gpu.py).
 """
 from __future__ import annotations
 

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Pin the hook restatement (oracle/hook_ref.py) against the reference's OWN attention classes, executed here on CPU.
+
+TEST INFRASTRUCTURE ONLY; needs /root/reference (build container), never runs on the GPU box.
+
+models/llama_kivi.py cannot be imported as a module in this container (its star-imports expect the transformers 4.43
+API; flash-attn and the CUDA extension are absent).  The two attention classes themselves are plain torch, so this
+script takes their SOURCE TEXT from the reference file (ast, unmodified: LlamaAttention_KIVI :19-262 and
+LlamaFlashAttention_KIVI :264-466) and executes it in a namespace where only the environment is shimmed:
+  * triton_quantize_and_pack_along_last_dim -> the reference's own pure-PyTorch quant_and_pack_vcache
+    (quant/new_pack.py:30-48; same arithmetic op for op) imported from /root/reference;
+  * cuda_bmm_fA_qB_outer -> the C oracle's restatement of the CUDA kernel (oracle/kivi_oracle.c);
+  * rotary embedding -> identity (the hook logic under test starts after RoPE), o_proj -> identity,
+    flash-attn prefill -> zeros (the prompt pass output is not part of the cache state).
+Then, for every case: prefill + N decode steps through the REFERENCE class; the same post-projection q/k/v through
+hook_ref.prefill_cache / decode_step; the 9-tuples must agree BIT FOR BIT after every step (cache policy, cat order,
+flush conditions, quantised contents) and the step outputs within 2e-3 of max(|ref|, rms(row)) (CPU half matmul vs the
+restatement's fp32 matmul differ in accumulation / intermediate rounding only).  The reference's outputs and final tuples are
+written to tests/golden/hook_*.npz for the CPU and GPU test suites.
+"""
+import ast
+import importlib.util
+import math
+import os
+import sys
+import warnings
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from oracle import hook_ref as H          # noqa: E402
+from oracle import kivi_oracle as O       # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+
+def load_reference_classes():
+    spec = importlib.util.spec_from_file_location("ref_new_pack", os.path.join(REF, "quant", "new_pack.py"))
+    ref_pack = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_pack)
+
+    def pack_stub(data, group_size, bit):          # stands in for the Triton launcher, new_pack.py:217-252
+        code, scale, mn = ref_pack.quant_and_pack_vcache(data.contiguous(), group_size, bit)
+        return code, scale.squeeze(-1), mn.squeeze(-1)
+
+    def repeat_kv(hidden_states, n_rep):           # transformers.models.llama.modeling_llama.repeat_kv
+        b, h, t, d = hidden_states.shape
+        if n_rep == 1:
+            return hidden_states
+        return hidden_states[:, :, None, :, :].expand(b, h, n_rep, t, d).reshape(b, h * n_rep, t, d)
+
+    class LlamaRotaryEmbedding(nn.Module):        # identity rotary: cos / sin are never used by the shim below
+        def __init__(self, config=None):
+            super().__init__()
+
+        def forward(self, x, position_ids):
+            return None, None
+
+    src = open(os.path.join(REF, "models", "llama_kivi.py")).read()
+    tree = ast.parse(src)
+    ns = dict(math=math, warnings=warnings, torch=torch, F=F, nn=nn, List=List, Optional=Optional, Tuple=Tuple,
+              LlamaConfig=SimpleNamespace, LlamaRotaryEmbedding=LlamaRotaryEmbedding,
+              apply_rotary_pos_emb=lambda q, k, cos, sin, position_ids=None: (q, k), repeat_kv=repeat_kv,
+              triton_quantize_and_pack_along_last_dim=pack_stub,
+              cuda_bmm_fA_qB_outer=lambda g, fA, qB, s, z, bits: O.bmm_fA_qB_outer(g, fA, qB, s, z, bits),
+              logger=SimpleNamespace(warning_once=lambda *a, **k: None))
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name in ("LlamaAttention_KIVI", "LlamaFlashAttention_KIVI"):
+            exec(compile(ast.get_source_segment(src, node), f"<reference models/llama_kivi.py:{node.lineno}>", "exec"), ns)
+    return ns["LlamaAttention_KIVI"], ns["LlamaFlashAttention_KIVI"]
+
+
+def same_bits(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return a.shape == b.shape and a.dtype == b.dtype and bool((a.contiguous().view(torch.uint8) == b.contiguous().view(torch.uint8)).all())
+
+
+def close(out, ref, rtol=2e-3):
+    """|out - ref| <= rtol * max(|ref|, rms(ref row)): the GEMV bar of tests/helpers.py (an element that is small by
+    cancellation is judged against the size of its row, not against itself)."""
+    o, r = out.float(), ref.float()
+    rms = r.pow(2).mean(-1, keepdim=True).sqrt()
+    tol = rtol * torch.maximum(r.abs(), rms) + 1e-6
+    d = (o - r).abs()
+    return bool((d <= tol).all()), float((d / tol).max())
+
+
+CASES = [
+    # name, class, B, nh, nh_kv, D, bits, g, R, T0, steps, masked
+    ("eager_mha_b2_r32", "eager", 2, 4, 4, 128, 2, 32, 32, 70, 40, False),
+    ("flash_gqa_b2_r32_mask", "flash", 2, 8, 2, 128, 2, 32, 32, 33, 36, True),
+    ("flash_mha_b4_g64_r64_short", "flash", 1, 2, 2, 128, 4, 64, 64, 5, 70, False),
+    ("flash_gqa_b2_r128", "flash", 1, 8, 2, 128, 2, 32, 128, 300, 8, True),
+]
+
+
+def run_case(classes, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps, masked):
+    torch.manual_seed(abs(hash(name)) % 10000)
+    hidden = nh * D
+    cfg = SimpleNamespace(attention_dropout=0.0, hidden_size=hidden, num_attention_heads=nh, num_key_value_heads=nh_kv,
+                          max_position_embeddings=4096, rope_theta=10000.0, k_bits=bits, v_bits=bits, group_size=g,
+                          residual_length=R, use_flash=True, attention_bias=False, pretraining_tp=1)
+    mod = (classes[0] if kind == "eager" else classes[1])(cfg).half()
+    with torch.no_grad():
+        mod.o_proj.weight.copy_(torch.eye(hidden))
+        for lin in (mod.q_proj, mod.k_proj, mod.v_proj):
+            lin.weight.copy_(torch.randn_like(lin.weight.float()) * hidden ** -0.5)
+    if kind == "flash":   # the prompt pass goes through flash-attn in the reference; its output is not cache state
+        mod._flash_attention_forward = lambda q, k, v, m, ql, dropout=0.0, softmax_scale=None: torch.zeros_like(q)
+
+    def qkv(h):
+        b, t, _ = h.shape
+        q = mod.q_proj(h).view(b, t, nh, D).transpose(1, 2)
+        k = mod.k_proj(h).view(b, t, nh_kv, D).transpose(1, 2)
+        v = mod.v_proj(h).view(b, t, nh_kv, D).transpose(1, 2)
+        return q, k, v
+
+    rec = {}
+    with torch.no_grad():
+        h0 = torch.randn(B, T0, hidden).half()
+        causal = None
+        if kind == "eager":
+            causal = torch.full((T0, T0), torch.finfo(torch.float16).min).triu(1)[None, None].expand(B, 1, T0, T0).half()
+        _, _, past_ref = mod(h0, attention_mask=causal, past_key_value=None, use_cache=True)
+        q0, k0, v0 = qkv(h0)
+        past = H.prefill_cache(k0, v0, bits, bits, g, R)
+        for i, (a, b) in enumerate(zip(past_ref[:8], past[:8])):
+            assert same_bits(a, b), (name, "prefill", i)
+        assert past_ref[8] == past[8]
+        rec["k0"], rec["v0"] = k0.numpy(), v0.numpy()
+        qs, ks, vs, masks, outs = [], [], [], [], []
+        worst = 0.0
+        for s in range(steps):
+            h = torch.randn(B, 1, hidden).half()
+            kv_len = T0 + s + 1
+            mask = None
+            if masked:
+                mask = torch.zeros(B, 1, 1, kv_len, dtype=torch.float16)
+                mask[0, :, :, : min(3 + 2 * s, kv_len - 1)] = torch.finfo(torch.float16).min
+            out_ref, _, past_ref = mod(h, attention_mask=mask, past_key_value=past_ref, use_cache=True)
+            out_ref = out_ref.view(B, 1, nh, D).transpose(1, 2)           # o_proj is the identity
+            q, k, v = qkv(h)
+            out, past = H.decode_step(q, k, v, past, bits, bits, g, R, attention_mask=mask)
+            for i, (a, b) in enumerate(zip(past_ref[:8], past[:8])):
+                assert same_bits(a, b), (name, "step", s, "tuple member", i)
+            assert past_ref[8] == past[8] == kv_len
+            ok, ratio = close(out, out_ref)
+            assert ok, (name, "step", s, ratio)
+            worst = max(worst, ratio)
+            qs.append(q.numpy()); ks.append(k.numpy()); vs.append(v.numpy()); outs.append(out_ref.numpy())
+            masks.append(mask.numpy() if mask is not None else None)
+    rec.update(q=np.stack(qs), k=np.stack(ks), v=np.stack(vs), out=np.stack(outs),
+               cfg=np.array([B, nh, nh_kv, D, bits, g, R, T0, steps, int(masked)], dtype=np.int64))
+    if masked:
+        rec["mask_prefix"] = np.array([min(3 + 2 * s, T0 + s) for s in range(steps)], dtype=np.int64)
+    names = ["K_code_T", "K_full", "K_scale_T", "K_mn_T", "V_code", "V_full", "V_scale", "V_mn"]
+    for n, t in zip(names, past_ref[:8]):
+        if t is not None:
+            rec["final_" + n] = t.contiguous().numpy()
+    rec["final_len"] = np.array([past_ref[8]], dtype=np.int64)
+    path = os.path.join(ROOT, "tests", "golden", f"hook_{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name:32s} OK  {steps} steps, tuples bit-identical after every step, outputs within {worst:.2f} x the 2e-3 bar; "
+          f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    classes = load_reference_classes()
+    for case in CASES:
+        run_case(classes, *case)
+
+
+if __name__ == "__main__":
+    main()

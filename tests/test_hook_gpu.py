@@ -52,6 +52,35 @@ def test_fused_step_partial_support():
         _cmp_cache(layer.as_tuple(), past)
 
 
+def _golden_hook_cases():
+    import glob, os
+    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hook_*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden_hook_cases(), ids=lambda p: p.split("hook_")[-1][:-4])
+def test_hook_matches_reference_class_fixtures(path):
+    """The HIP hook replays the inputs of fixtures recorded from the REFERENCE's own attention classes
+    (oracle/pin_hook.py): step outputs within the hook bar, final 9-tuple bit-identical to the reference's."""
+    from test_hook_golden_cpu import NAMES, load_case
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    c = load_case(path)
+    cfg = KiviConfig(c["bits"], c["bits"], c["g"], c["R"])
+    layer = KiviLayerCache(cfg, c["B"], c["nh_kv"], c["D"], c["T0"] + c["steps"] + 4, "cuda")
+    layer.prefill(c["k0"].cuda(), c["v0"].cuda())
+    for s in range(c["steps"]):
+        m = c["masks"][s].cuda() if c["masks"][s] is not None else None
+        out = kivi_attention_decode(c["q"][s].cuda(), c["k"][s].cuda(), c["v"][s].cuda(), layer, attention_mask=m)
+        ok, ratio = gemv_close(out, c["out"][s], rtol=3e-3)
+        assert ok, (s, ratio)
+    t = layer.as_tuple()
+    for n, a, b in zip(NAMES, t[:8], c["final"]):
+        if b is None:
+            assert a is None or a.numel() == 0, n
+        else:
+            assert a is not None and tuple(a.shape) == tuple(b.shape) and same_bits(a, b), n
+    assert t[8] == c["final_len"]
+
+
 def _cmp_cache(t_gpu, t_ref):
     names = ["K_code_T", "K_full", "K_scale_T", "K_mn_T", "V_code", "V_full", "V_scale", "V_mn"]
     for n, a, b in zip(names, t_gpu[:8], t_ref[:8]):
