@@ -3,10 +3,9 @@
 
 Counterpart of the reference's mem_spd_test.py (:8-12, :53-70: Llama-2-7b, k = v = 2 bit, g = 32, one prompt batch,
 N new tokens, ms per generate + torch.cuda.max_memory_allocated) for a box without network: the weights are RANDOM
-(Llama-2-7B architecture by default), so the generated tokens mean nothing -- time and memory do.  The decoder around
-the attention block (embedding, RMSNorm, rotary q/k/v/o projections, SwiGLU MLP, lm_head, greedy argmax) is plain
-torch (rocBLAS / hipBLASLt GEMMs); the attention block is kivi_amd.attention.LlamaAttention_KIVI, i.e. the drop-in
-for models/llama_kivi.py.  `--baseline` runs the same model with an fp16 KV cache and torch SDPA instead.
+(Llama-2-7B architecture by default), so the generated tokens mean nothing -- time and memory do.  The decoder is
+kivi_amd.llama.LlamaForCausalLM_KIVI (plain-torch embedding / RMSNorm / projections / SwiGLU MLP / lm_head around
+kivi_amd.attention.LlamaAttention_KIVI, the drop-in for models/llama_kivi.py).  `--baseline` runs the same model with an fp16 KV cache and torch SDPA instead.
 
     python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512          # BASELINE.json configs[2]
     python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512 --baseline
@@ -23,27 +22,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-
-
-class RMSNorm(nn.Module):
-    def __init__(self, dim, eps=1e-5):
-        super().__init__()
-        self.weight = nn.Parameter(torch.ones(dim))
-        self.eps = eps
-
-    def forward(self, x):
-        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
-
-
-class MLP(nn.Module):
-    def __init__(self, cfg):
-        super().__init__()
-        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
-        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
-        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
-
-    def forward(self, x):
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
 class Fp16Attention(nn.Module):
@@ -79,39 +57,6 @@ class Fp16Attention(nn.Module):
         return m.o_proj(o), None, (kc, vc, n)
 
 
-class Block(nn.Module):
-    def __init__(self, cfg, i, baseline):
-        super().__init__()
-        from kivi_amd.attention import LlamaAttention_KIVI
-        self.self_attn = Fp16Attention(cfg, i) if baseline else LlamaAttention_KIVI(cfg, i)
-        self.mlp = MLP(cfg)
-        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
-        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
-
-    def forward(self, x, past):
-        a, _, past = self.self_attn(self.input_layernorm(x), past_key_value=past, use_cache=True)
-        x = x + a
-        return x + self.mlp(self.post_attention_layernorm(x)), past
-
-
-class Model(nn.Module):
-    def __init__(self, cfg, baseline):
-        super().__init__()
-        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
-        self.layers = nn.ModuleList([Block(cfg, i, baseline) for i in range(cfg.num_hidden_layers)])
-        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
-        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
-
-    @torch.no_grad()
-    def forward(self, ids, pasts):
-        x = self.embed_tokens(ids)
-        new = []
-        for layer, past in zip(self.layers, pasts):
-            x, p = layer(x, past)
-            new.append(p)
-        return self.lm_head(self.norm(x[:, -1:])), new
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
@@ -131,13 +76,15 @@ def main():
     dev = torch.device("cuda:0")
     cfg = SimpleNamespace(hidden_size=args.hidden, num_attention_heads=args.heads, num_key_value_heads=args.kv_heads,
                           num_hidden_layers=args.layers, intermediate_size=args.intermediate, vocab_size=args.vocab,
-                          max_position_embeddings=args.prompt + args.gen + 1, rope_theta=10000.0, rms_norm_eps=1e-5,
+                          max_position_embeddings=args.prompt + args.gen + 1, rope_theta=10000.0, rms_norm_eps=1e-5, tie_word_embeddings=False,
                           k_bits=args.bits, v_bits=args.bits, group_size=args.group, residual_length=args.residual,
                           kivi_max_cache_len=args.prompt + args.gen + 1, attention_bias=False)
     torch.manual_seed(0)
+    from kivi_amd.llama import LlamaForCausalLM_KIVI
+    from kivi_amd.attention import LlamaAttention_KIVI
     with torch.device(dev):
         torch.set_default_dtype(torch.float16)
-        model = Model(cfg, args.baseline)
+        model = LlamaForCausalLM_KIVI(cfg, Fp16Attention if args.baseline else LlamaAttention_KIVI)
         torch.set_default_dtype(torch.float32)
     for p in model.parameters():      # small weights keep the random activations finite through 32 layers
         if p.dim() > 1:
@@ -147,7 +94,7 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     t0 = time.time()
-    logits, pasts = model(ids, [None] * args.layers)
+    logits, pasts = model(ids)
     torch.cuda.synchronize()
     t_prefill = time.time() - t0
     tok = logits.argmax(-1)

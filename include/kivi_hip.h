@@ -215,7 +215,7 @@ typedef struct kivi_decode_attend_args {
     void* out; int64_t out_sb, out_sh;                           /* (B, nh, D) attention output */
     int B, nh, nh_kv, D, group_size, v_bits; int64_t Tq, Tv;
     void* workspace; int64_t workspace_bytes;                    /* optional (may be NULL): zero-initialised device
-        scratch, >= 65536 + 4096 + B*nh*8 + 4 * B*nh*D*65 bytes.  With it, rows are split over several blocks when
+        scratch, >= 65536 + 4096 + B*nh*512 + 4 * B*nh*D*65 bytes.  With it, rows are split over several blocks when
         B*nh_kv is too small to fill the GPU (long context, small batch) or the probabilities of a block's rows would
         not fit a small LDS budget (grouped queries, long rows); counters in it are left at zero after every call. */
 } kivi_decode_attend_args;

@@ -1,0 +1,149 @@
+"""A Llama / Mistral-shaped decoder around the KIVI attention hook -- the callers' side of the hot path.
+
+Counterpart of the reference's LlamaForCausalLM_KIVI / MistralForCausalLM_KIVI wrappers (models/llama_kivi.py:564-1000,
+models/mistral_kivi.py:673-1100) reduced to what decoding needs: token embedding, pre-norm decoder blocks
+(RMSNorm, LlamaAttention_KIVI, SwiGLU MLP), final norm, lm_head, greedy generate.  Parameter names follow the Hugging
+Face checkpoints (model.embed_tokens, model.layers.N.self_attn.q_proj, ..., lm_head), so `load_state_dict` /
+`from_pretrained` take an unmodified Llama-2 / Llama-3 / Mistral checkpoint directory; everything outside the attention
+block is plain torch (rocBLAS / hipBLASLt GEMMs).  The reference patches k_bits / v_bits / group_size /
+residual_length onto the HF config (README.md:72-75); the same four fields are read here.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .attention import LlamaAttention_KIVI
+
+
+def make_config(d: dict, k_bits: int = 2, v_bits: int = 2, group_size: int = 32, residual_length: int = 32,
+                max_cache_len: Optional[int] = None) -> SimpleNamespace:
+    """HF config.json fields (+ the four KIVI fields) -> the namespace the modules read."""
+    hidden, heads = d["hidden_size"], d["num_attention_heads"]
+    return SimpleNamespace(
+        hidden_size=hidden, num_attention_heads=heads, num_key_value_heads=d.get("num_key_value_heads", heads),
+        num_hidden_layers=d["num_hidden_layers"], intermediate_size=d["intermediate_size"], vocab_size=d["vocab_size"],
+        max_position_embeddings=d.get("max_position_embeddings", 4096), rope_theta=d.get("rope_theta", 10000.0),
+        rms_norm_eps=d.get("rms_norm_eps", 1e-5), attention_bias=d.get("attention_bias", False),
+        tie_word_embeddings=d.get("tie_word_embeddings", False),
+        k_bits=d.get("k_bits", k_bits), v_bits=d.get("v_bits", v_bits), group_size=d.get("group_size", group_size),
+        residual_length=d.get("residual_length", residual_length),
+        kivi_max_cache_len=max_cache_len or d.get("max_position_embeddings", 4096))
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class DecoderLayer_KIVI(nn.Module):
+    def __init__(self, cfg, layer_idx: int, attention_cls=LlamaAttention_KIVI):
+        super().__init__()
+        self.self_attn = attention_cls(cfg, layer_idx)
+        self.mlp = MLP(cfg)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+    def forward(self, x, past, attention_mask=None):
+        a, _, past = self.self_attn(self.input_layernorm(x), attention_mask=attention_mask, past_key_value=past,
+                                    use_cache=True)
+        x = x + a
+        return x + self.mlp(self.post_attention_layernorm(x)), past
+
+
+class _Body(nn.Module):
+    def __init__(self, cfg, attention_cls):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([DecoderLayer_KIVI(cfg, i, attention_cls) for i in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+
+class LlamaForCausalLM_KIVI(nn.Module):
+    """`past_key_values` is a list with one entry per layer: None before the prompt pass, afterwards the 9-tuple of
+    models/llama_kivi.py:454-455 (here the lazy KiviCacheTuple over the in-place cache)."""
+
+    def __init__(self, config, attention_cls=LlamaAttention_KIVI):
+        super().__init__()
+        self.config = config
+        self.model = _Body(config, attention_cls)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        if getattr(config, "tie_word_embeddings", False):
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    @torch.no_grad()
+    def forward(self, input_ids: torch.LongTensor, past_key_values: Optional[List] = None, attention_mask=None,
+                last_token_only: bool = True):
+        """logits (B, 1 or T, vocab), new past_key_values.  `attention_mask`: the reference's additive (B, 1, 1, kv_len)
+        fp16 mask for decode steps (llama_kivi.py:364-372); the prompt pass is causal over equal-length prompts."""
+        pasts = past_key_values or [None] * len(self.model.layers)
+        x = self.model.embed_tokens(input_ids)
+        new = []
+        for layer, past in zip(self.model.layers, pasts):
+            x, p = layer(x, past, attention_mask if past is not None else None)
+            new.append(p)
+        if last_token_only:
+            x = x[:, -1:]
+        return self.lm_head(self.model.norm(x)), new
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.LongTensor, max_new_tokens: int) -> torch.LongTensor:
+        """Greedy decoding of equal-length prompts (the recipe of the reference's mem_spd_test.py / example.py)."""
+        logits, pasts = self.forward(input_ids)
+        out = [input_ids]
+        tok = logits.argmax(-1)
+        for _ in range(max_new_tokens):
+            out.append(tok)
+            logits, pasts = self.forward(tok, pasts)
+            tok = logits.argmax(-1)
+        return torch.cat(out, dim=1)
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda", dtype=torch.float16, **kivi):
+        """`path`: a local HF checkpoint directory (config.json + *.safetensors).  `kivi`: k_bits, v_bits, group_size,
+        residual_length, max_cache_len."""
+        from safetensors.torch import load_file
+        cfg = make_config(json.load(open(os.path.join(path, "config.json"))), **kivi)
+        with torch.device(device):
+            prev = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            try:
+                model = cls(cfg)
+            finally:
+                torch.set_default_dtype(prev)
+        state = {}
+        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+            state.update(load_file(f, device=str(device)))
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        missing = [m for m in missing if "inv_freq" not in m and not (cfg.tie_word_embeddings and m == "lm_head.weight")]
+        if missing:
+            raise KeyError(f"checkpoint lacks {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        return model
+
+
+# Mistral-7B differs in GQA ratio, rope_theta and a sliding-window field the reference never applies to the quantised
+# cache (models/mistral_kivi.py keeps the whole history): the same modules serve it.
+MistralForCausalLM_KIVI = LlamaForCausalLM_KIVI

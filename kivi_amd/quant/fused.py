@@ -93,10 +93,11 @@ def decode_output(layer, probs: torch.Tensor, value_states: torch.Tensor, out: t
 _WS = {}
 
 
-def _workspace(device, row_floats: int) -> torch.Tensor:
-    """Zero-initialised scratch shared by every layer on a device (launches are stream-ordered): 64 KiB of arrival
-    counters, then row statistics + fp32 partials for up to 64 + 1 blocks per row (kivi_decode_attend, split-T)."""
-    need = 65536 + 4096 + 8 * row_floats // 64 + 4 * row_floats * 65
+def _workspace(device, rows: int, head_dim: int) -> torch.Tensor:
+    """Zero-initialised scratch shared by every layer on a device (launches are stream-ordered), as
+    kivi_decode_attend documents it: 64 KiB of arrival counters, chunk statistics of the row softmax (up to 64 chunks
+    per row), fp32 partial outputs for up to 64 + 1 blocks per row (split-T)."""
+    need = 65536 + 4096 + rows * 64 * 8 + 4 * rows * head_dim * 65
     ws = _WS.get(device)
     if ws is None or ws.numel() < need:
         ws = torch.zeros(need, dtype=torch.uint8, device=device)
@@ -118,7 +119,7 @@ def decode_attend(layer, query_states: torch.Tensor, key_states: torch.Tensor, v
     flush = layer.v_res_len + 1 > cfg.residual_length
     if mask is not None:
         assert mask.dtype == torch.float16 and mask.stride(3) == 1
-    ws = _workspace(q.device, B * nh * D)
+    ws = _workspace(q.device, B * nh, D)
     a = _lib.DecodeAttendArgs(
         q=q.data_ptr(), q_sb=q.stride(0), q_sh=q.stride(1),
         kres=kr.data_ptr(), kres_sb=kr.stride(0), kres_sh=kr.stride(1), kres_st=kr.stride(2),

@@ -11,3 +11,5 @@ from kivi_amd.attention import (KiviConfig, KiviLayerCache, LlamaAttention_KIVI,
 
 MistralAttention_KIVI = LlamaAttention_KIVI
 MistralFlashAttention_KIVI = LlamaAttention_KIVI
+
+from kivi_amd.llama import MistralForCausalLM_KIVI  # noqa: E402,F401  (decoder wrapper, models/mistral_kivi.py:921)

@@ -94,3 +94,22 @@ def test_product_does_not_import_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b|kivi_oracle", txt, flags=re.M):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_decoder_wrapper_uses_hf_parameter_names():
+    """kivi_amd.llama keeps the Hugging Face checkpoint names, so a Llama / Mistral state dict loads unmodified."""
+    import torch
+    from kivi_amd.llama import LlamaForCausalLM_KIVI, make_config
+    cfg = make_config(dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, num_hidden_layers=2,
+                           intermediate_size=512, vocab_size=100))
+    m = LlamaForCausalLM_KIVI(cfg)
+    keys = set(m.state_dict().keys())
+    want = {"model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"}
+    for i in range(2):
+        for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
+                  "mlp.up_proj", "mlp.down_proj", "input_layernorm", "post_attention_layernorm"):
+            want.add(f"model.layers.{i}.{n}.weight")
+    assert want <= keys, sorted(want - keys)
+    assert m.model.layers[0].self_attn.k_proj.weight.shape == (128, 256)
+    with __import__("pytest").raises(Exception):   # no CPU fallback: the forward pass needs the HIP path
+        m(torch.zeros((1, 4), dtype=torch.long))

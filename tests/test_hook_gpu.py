@@ -218,3 +218,35 @@ def test_softmax_scaled_kernel(n, pitch):
         err = (got.float() - ref.float()).abs()
         assert bool((err <= 1.5e-3 * ref.float() + 1e-7).all()), err.max().item()
         assert abs(got.float().sum(-1) - 1).max().item() < 2e-3
+
+
+def test_decoder_wrapper_generate_fused_vs_composed():
+    """A tiny random Llama-shaped model through kivi_amd.llama: greedy generation runs, and the fused decode step
+    gives the same logits as the reference-style composition to fp16 rounding."""
+    import kivi_amd.attention as A
+    from kivi_amd.llama import LlamaForCausalLM_KIVI, make_config
+    torch.manual_seed(0)
+    cfg = make_config(dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
+                           intermediate_size=1024, vocab_size=320), residual_length=32, max_cache_len=128)
+    model = LlamaForCausalLM_KIVI(cfg).half().cuda()
+    for p in model.parameters():
+        if p.dim() > 1:
+            p.data.normal_(0.0, 0.05)
+    ids = torch.randint(0, 320, (2, 40), device="cuda")
+    out = model.generate(ids, 12)
+    assert out.shape == (2, 52) and bool((out[:, :40] == ids).all())
+    logits_f, pasts_f = model(ids)
+    logits_c, pasts_c = model(ids)
+    tok = logits_f.argmax(-1)
+    orig = A.kivi_attention_decode
+    for step in range(40):   # crosses the K flush (every 32 tokens) and flushes V every step
+        lf, pasts_f = model(tok, pasts_f)
+        A.kivi_attention_decode = lambda *a, **k: orig(*a, **{**k, "fused_kernels": False})
+        try:
+            lc, pasts_c = model(tok, pasts_c)
+        finally:
+            A.kivi_attention_decode = orig
+        assert torch.isfinite(lf).all()
+        assert (lf.float() - lc.float()).abs().max().item() <= 2e-2 * lc.float().abs().max().item() + 1e-3, step
+        tok = lf.argmax(-1)
+    assert pasts_f[0][-1] == 80
