@@ -221,6 +221,34 @@ typedef struct kivi_decode_attend_args {
 } kivi_decode_attend_args;
 int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream);
 
+/* ------------------------------------------------------ layer step --- */
+
+/*
+ * One decode step of one layer in ONE host call: kivi_gemv_k_paged + kivi_decode_attend + the cache bookkeeping of
+ * the hook (models/llama_kivi.py:314-399): lengths, the K flush when the residual reaches R tokens (:343-356, packed
+ * in place at the end of the prefix), the V flush of the token leaving the window (:386-399), window compaction.
+ * Stateless: the descriptor names the caller's buffers (all device memory, layouts as in kivi_gemv_k_paged /
+ * kivi_decode_attend; `scores` = (B, nh, s_pitch) fp16 scratch rows), `state` = {k_quant_len, k_res_len, v_quant_len,
+ * v_win_start, v_res_len, kv_seq_len} is read and, on success, advanced.  KIVI_EUNSUPPORTED = no tuned kernel for the
+ * shape, state untouched (except a completed window compaction): compose the step from the entry points above.
+ */
+typedef struct {
+    int B, nh_kv, D, k_bits, v_bits, group_size, residual_length;
+    float inv_scale;                                   /* 1 / sqrt(D) */
+    int64_t cap, page_tokens, v_window_rows, s_pitch;
+    void* k_code; int64_t kc_sb, kc_sh, kc_sp, kc_sr;  /* (B, nh_kv, P, D, page_tokens/fpi) int32 */
+    void* k_scale; void* k_mn; int64_t ks_sb, ks_sh, ks_sp, ks_sr;
+    void* k_res; int64_t kr_sb, kr_sh, kr_st;          /* (B, nh_kv, R, D) fp16 */
+    void* v_code; int64_t vc_sb, vc_sh, vc_sr;         /* (B, nh_kv, cap, D/fpi) int32 */
+    void* v_scale; void* v_mn; int64_t vs_sb, vs_sh, vs_sr;
+    void* v_res; int64_t vr_sb, vr_sh, vr_st;          /* (B, nh_kv, v_window_rows, D) fp16, contiguous */
+    void* scores; int64_t s_sb, s_sh;
+    void* workspace; int64_t workspace_bytes;          /* as in kivi_decode_attend_args */
+} kivi_layer_desc;
+int kivi_decode_layer(const kivi_layer_desc* layer, int64_t* state, const void* q, int64_t q_sb, int64_t q_sh, int nh,
+                      const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb, int64_t vn_sh,
+                      const void* mask, int64_t mask_sb, void* out, int64_t out_sb, int64_t out_sh, kivi_stream_t stream);
+
 /* ------------------------------------------------- tuning / bench hooks --- */
 
 /* Kernel variants of kivi_gemv_k (same arguments + variant id; -1 = the default heuristic).

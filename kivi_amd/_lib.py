@@ -42,6 +42,23 @@ class DecodeAttendArgs(ctypes.Structure):
     ]
 
 
+class LayerDesc(ctypes.Structure):
+    """kivi_layer_desc (include/kivi_hip.h), field for field."""
+    _fields_ = [
+        ("B", _i32), ("nh_kv", _i32), ("D", _i32), ("k_bits", _i32), ("v_bits", _i32), ("group_size", _i32),
+        ("residual_length", _i32), ("inv_scale", ctypes.c_float),
+        ("cap", _i64), ("page_tokens", _i64), ("v_window_rows", _i64), ("s_pitch", _i64),
+        ("k_code", _vp), ("kc_sb", _i64), ("kc_sh", _i64), ("kc_sp", _i64), ("kc_sr", _i64),
+        ("k_scale", _vp), ("k_mn", _vp), ("ks_sb", _i64), ("ks_sh", _i64), ("ks_sp", _i64), ("ks_sr", _i64),
+        ("k_res", _vp), ("kr_sb", _i64), ("kr_sh", _i64), ("kr_st", _i64),
+        ("v_code", _vp), ("vc_sb", _i64), ("vc_sh", _i64), ("vc_sr", _i64),
+        ("v_scale", _vp), ("v_mn", _vp), ("vs_sb", _i64), ("vs_sh", _i64), ("vs_sr", _i64),
+        ("v_res", _vp), ("vr_sb", _i64), ("vr_sh", _i64), ("vr_st", _i64),
+        ("scores", _vp), ("s_sb", _i64), ("s_sh", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/kivi_hip.h declares
 SIGNATURES = {
     "kivi_abi_version": (_i32, []),
@@ -67,6 +84,8 @@ SIGNATURES = {
                                           _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64,
                                           _i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "kivi_decode_attend": (_i32, [ctypes.POINTER(DecodeAttendArgs), _vp]),
+    "kivi_decode_layer": (_i32, [ctypes.POINTER(LayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
+                                 _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),

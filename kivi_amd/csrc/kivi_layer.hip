@@ -1,0 +1,87 @@
+// One decode step of one layer in ONE host call: cache bookkeeping of the attention hook
+// (models/llama_kivi.py:314-399 -- residual / window lengths, the K flush every R tokens, the V flush of the token
+// leaving the window) around the two fused launches.  kivi_amd/attention.py does the same in Python with ~40 us of
+// interpreter + ctypes work per layer; at small batch the GPU finishes a step faster than that, so the host side of
+// the step lives here.  Stateless: the caller owns the buffers (descriptor) and the six lengths (state array).
+#include "kivi_common.h"
+
+extern "C" int kivi_decode_layer(const kivi_layer_desc* L, int64_t* st, const void* q, int64_t q_sb, int64_t q_sh, int nh,
+                                 const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb,
+                                 int64_t vn_sh, const void* mask, int64_t mask_sb, void* out, int64_t out_sb,
+                                 int64_t out_sh, kivi_stream_t stream) {
+    KIVI_REQUIRE(L && st && q && knew && vnew && out, KIVI_EINVAL, "kivi_decode_layer: null argument");
+    int64_t Tq = st[0], kres = st[1], Tv = st[2], wstart = st[3], vres = st[4], kv = st[5];
+    const int R = L->residual_length;
+    KIVI_REQUIRE(Tq >= 0 && kres >= 0 && kres < R && Tv >= 0 && wstart >= 0 && vres >= 0 && vres <= R &&
+                     kv == Tq + kres && kv == Tv + vres,
+                 KIVI_EINVAL, "kivi_decode_layer: inconsistent lengths (Tq=%lld kres=%lld Tv=%lld vres=%lld kv=%lld)",
+                 (long long)Tq, (long long)kres, (long long)Tv, (long long)vres, (long long)kv);
+    KIVI_REQUIRE(kv + 1 <= L->cap && Tv + 1 <= L->cap, KIVI_EINVAL, "kivi_decode_layer: cache capacity %lld exceeded",
+                 (long long)L->cap);
+    KIVI_REQUIRE(R % L->group_size == 0 && L->page_tokens % R == 0, KIVI_EINVAL,
+                 "kivi_decode_layer: residual_length must be a multiple of group_size and divide the page");
+    KIVI_REQUIRE(kv + 1 <= L->s_pitch, KIVI_EINVAL, "kivi_decode_layer: score rows too short");
+    hipStream_t s = (hipStream_t)stream;
+
+    if (wstart + vres + 1 > L->v_window_rows) {
+        // live rows to the front of the window buffer (every ~R steps): [wstart, wstart+vres) and [0, vres) never
+        // overlap because wstart + vres == window rows >= 2R + 1 and vres <= R
+        KIVI_REQUIRE(L->vr_sb == (int64_t)L->nh_kv * L->vr_sh && wstart >= vres, KIVI_EUNSUPPORTED,
+                     "kivi_decode_layer: window buffer layout not compactable in place");
+        const size_t pitch = (size_t)L->vr_sh * 2, width = (size_t)vres * L->vr_st * 2;
+        if (vres) {
+            const hipError_t e = hipMemcpy2DAsync(L->v_res, pitch, (const char*)L->v_res + (size_t)wstart * L->vr_st * 2,
+                                                  pitch, width, (size_t)L->B * L->nh_kv, hipMemcpyDeviceToDevice, s);
+            KIVI_REQUIRE(e == hipSuccess, (int)e, "kivi_decode_layer: window compaction: %s", hipGetErrorString(e));
+        }
+        wstart = 0;
+        st[3] = 0;   // a compaction is complete on its own: commit it even if a later launch is refused
+    }
+    int rc;
+    if (Tq) {
+        rc = kivi_gemv_k_paged(-1, L->page_tokens, L->kc_sp, L->ks_sp, q, q_sb, q_sh, L->k_code, L->kc_sb, L->kc_sh, L->kc_sr,
+                               L->k_scale, L->k_mn, L->ks_sb, L->ks_sh, L->ks_sr, L->scores, L->s_sb, L->s_sh, L->B, nh,
+                               L->nh_kv, L->D, Tq, L->group_size, L->k_bits, stream);
+        if (rc) return rc;
+    }
+    const int flush = vres + 1 > R;
+    kivi_decode_attend_args a;
+    a.q = q; a.q_sb = q_sb; a.q_sh = q_sh;
+    a.kres = L->k_res; a.kres_sb = L->kr_sb; a.kres_sh = L->kr_sh; a.kres_st = L->kr_st;
+    a.knew = knew; a.knew_sb = kn_sb; a.knew_sh = kn_sh; a.k_res_len = (int)kres;
+    a.scores = L->scores; a.s_sb = L->s_sb; a.s_sh = L->s_sh;
+    a.inv_scale = L->inv_scale; a.mask = mask; a.mask_sb = mask_sb;
+    a.v_code = L->v_code; a.vc_sb = L->vc_sb; a.vc_sh = L->vc_sh; a.vc_sr = L->vc_sr;
+    a.v_scale = L->v_scale; a.v_mn = L->v_mn; a.vs_sb = L->vs_sb; a.vs_sh = L->vs_sh; a.vs_sr = L->vs_sr;
+    a.vres = L->v_res; a.vres_sb = L->vr_sb; a.vres_sh = L->vr_sh; a.vres_st = L->vr_st;
+    a.v_win_start = (int)wstart; a.v_res_len = (int)vres;
+    a.vnew = vnew; a.vnew_sb = vn_sb; a.vnew_sh = vn_sh; a.v_flush = flush;
+    a.out = out; a.out_sb = out_sb; a.out_sh = out_sh;
+    a.B = L->B; a.nh = nh; a.nh_kv = L->nh_kv; a.D = L->D; a.group_size = L->group_size; a.v_bits = L->v_bits;
+    a.Tq = Tq; a.Tv = Tv;
+    a.workspace = L->workspace; a.workspace_bytes = L->workspace_bytes;
+    rc = kivi_decode_attend(&a, stream);
+    if (rc) return rc;            // nothing of the step has been committed: the caller may compose it instead
+
+    kres += 1;                    // the attend launch appended the new key (llama_kivi.py:333-336)
+    if (kres == R) {              // :343-356: quantise the R residual tokens in place, at token offset Tq of the prefix
+        const int64_t page = Tq / L->page_tokens, off = Tq - page * L->page_tokens;
+        const int kfpi = 32 / L->k_bits;
+        rc = kivi_quant_pack_k_tmajor(L->k_res, L->kr_sb, L->kr_sh, L->kr_st, (char*)L->k_code + (size_t)page * L->kc_sp * 4,
+                                      L->kc_sb, L->kc_sh, L->kc_sr, off / kfpi,
+                                      (char*)L->k_scale + (size_t)page * L->ks_sp * 2, (char*)L->k_mn + (size_t)page * L->ks_sp * 2,
+                                      L->ks_sb, L->ks_sh, L->ks_sr, off / L->group_size, L->B, L->nh_kv, R, L->D,
+                                      L->group_size, L->k_bits, stream);
+        if (rc) return rc;
+        Tq += R;
+        kres = 0;
+    }
+    vres += 1;                    // :377
+    if (flush) {                  // :386-399, done inside the attend launch
+        Tv += 1;
+        wstart += 1;
+        vres -= 1;
+    }
+    st[0] = Tq; st[1] = kres; st[2] = Tv; st[3] = wstart; st[4] = vres; st[5] = kv + 1;
+    return 0;
+}
