@@ -92,12 +92,17 @@ def _cmp_cache(t_gpu, t_ref):
     assert t_gpu[8] == t_ref[8]
 
 
-@pytest.mark.parametrize("fused_kernels", [True, False])
+@pytest.mark.parametrize("fused_kernels", ["native", "python", False])
 @pytest.mark.parametrize("nh,nh_kv,T0,R,g,bits", [(4, 4, 70, 32, 32, 2), (8, 2, 33, 32, 32, 2), (4, 2, 5, 32, 32, 2),
                                                    (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2), (6, 2, 40, 32, 32, 2)])
-def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits, fused_kernels):
+def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits, fused_kernels, monkeypatch):
+    """"native": the one-call layer step (kivi_decode_layer); "python": the same launches with the bookkeeping in
+    kivi_amd.attention; False: one launch per reference op."""
+    import kivi_amd.attention as A
     from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
     from oracle import hook_ref as H
+    monkeypatch.setattr(A, "_NATIVE_STEP", fused_kernels == "native")
+    fused_kernels = bool(fused_kernels)
     B, D = 2, 128
     steps = R + 9
     cfg = KiviConfig(bits, bits, g, R)
