@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--group", type=int, default=32)
     ap.add_argument("--residual", type=int, default=32)
     ap.add_argument("--baseline", action="store_true", help="fp16 KV cache + torch SDPA instead of the KIVI hook")
+    ap.add_argument("--graphs", action="store_true", help="replay the dense part of every decode step from hipGraphs")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = SimpleNamespace(hidden_size=args.hidden, num_attention_heads=args.heads, num_key_value_heads=args.kv_heads,
@@ -98,10 +99,17 @@ def main():
     torch.cuda.synchronize()
     t_prefill = time.time() - t0
     tok = logits.argmax(-1)
+    if args.graphs:
+        assert not args.baseline, "--graphs drives the KIVI hook (the fp16 baseline cache grows in shape every step)"
+        model.prepare_graphs(args.batch, dev)
+        torch.cuda.synchronize()
     t1 = time.time()
-    for _ in range(args.gen):
-        logits, pasts = model(tok, pasts)
-        tok = logits.argmax(-1)
+    if args.graphs:
+        model.decode_graphed(tok, pasts, args.prompt, args.gen)
+    else:
+        for _ in range(args.gen):
+            logits, pasts = model(tok, pasts)
+            tok = logits.argmax(-1)
     torch.cuda.synchronize()
     t_dec = time.time() - t1
     if args.baseline:
@@ -110,7 +118,7 @@ def main():
         kv = sum(p.layer.nbytes() for p in pasts)                 # what the reference's 9-tuples would hold
         kv_alloc = sum(p.layer.allocated_bytes() for p in pasts)  # incl. page / window slack of the in-place cache
     print(json.dumps({
-        "mode": "fp16 KV + SDPA" if args.baseline else f"KIVI {args.bits}-bit g={args.group} R={args.residual}",
+        "mode": "fp16 KV + SDPA" if args.baseline else f"KIVI {args.bits}-bit g={args.group} R={args.residual}" + (" + hipGraph dense" if args.graphs else ""),
         "model": f"llama-shaped random weights: L={args.layers} h={args.hidden} nh={args.heads}/{args.kv_heads} ffn={args.intermediate}",
         "batch": args.batch, "prompt": args.prompt, "gen": args.gen,
         "prefill_s": round(t_prefill, 3), "decode_ms_per_step": round(1e3 * t_dec / args.gen, 3),

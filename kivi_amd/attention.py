@@ -111,7 +111,7 @@ def _native_desc(layer: KiviLayerCache, nh: int):
     return layer._native
 
 
-def _decode_native(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask) -> torch.Tensor:
+def _decode_native(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask, out=None) -> torch.Tensor:
     """The whole step (both launches + cache bookkeeping + K flush) through ONE library call (kivi_decode_layer):
     the host side of a layer step drops from ~40 us of Python to one ctypes call.  Same launches, same results as
     _decode_fused; raises KiviUnsupported (state untouched) when no tuned kernel covers the shape."""
@@ -130,7 +130,10 @@ def _decode_native(query_states, key_states, value_states, layer: KiviLayerCache
         mask_ptr, mask_sb = attention_mask.data_ptr(), attention_mask.stride(0)
     state[0], state[1], state[2] = layer.k_quant_len, layer.k_res_len, layer.v_quant_len
     state[3], state[4], state[5] = layer.v_res_start, layer.v_res_len, layer.kv_seq_len
-    out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=q.device)
+    if out is None:
+        out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=q.device)
+    else:
+        assert out.shape == (B, nh, 1, D) and out.dtype == torch.float16 and out.stride(3) == 1
     hook = _matmul_mod().launch_hook
     if hook is not None and layer.k_quant_len:   # bench.py: bracket the qK^T dispatch (the first launch of the call)
         hook("pre", "k", dict(B=B, nh=nh, nh_kv=layer.nh_kv, K=D, N=layer.k_quant_len, bits=layer.cfg.k_bits,
@@ -206,10 +209,19 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
 
 def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
                           layer: KiviLayerCache, attention_mask: Optional[torch.Tensor] = None,
-                          fused_kernels: bool = True) -> torch.Tensor:
+                          fused_kernels: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One decode step for one layer.  query (B, nh, 1, D), key/value (B, nh_kv, 1, D), RoPE already applied.
     Mutates `layer` in place and returns attn_output (B, nh, 1, D) fp16 (before the o_proj transpose).
-    `fused_kernels=False` forces the reference-style composition (one launch per reference op)."""
+    `fused_kernels=False` forces the reference-style composition (one launch per reference op).
+    `out`: optional preallocated (B, nh, 1, D) fp16 result buffer (static buffers of graph-captured callers)."""
+    res = _attention_decode(query_states, key_states, value_states, layer, attention_mask, fused_kernels, out)
+    if out is not None and res is not out:
+        out.copy_(res)
+        return out
+    return res
+
+
+def _attention_decode(query_states, key_states, value_states, layer: KiviLayerCache, attention_mask, fused_kernels, out):
     cfg = layer.cfg
     B, nh, q_len, D = query_states.shape
     assert q_len == 1, "decode branch: one new token (the reference kernel is q_len == 1 only)"
@@ -217,7 +229,7 @@ def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, 
         if (_NATIVE_STEP and _fusion_level(layer, nh, layer.kv_seq_len + 1) == 2
                 and not getattr(layer, "_attend_unfusable", False)):
             try:
-                return _decode_native(query_states, key_states, value_states, layer, attention_mask)
+                return _decode_native(query_states, key_states, value_states, layer, attention_mask, out)
             except KiviUnsupported:
                 layer._attend_unfusable = True   # the Python path below picks the next fusion level
         try:

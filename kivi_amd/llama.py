@@ -121,6 +121,107 @@ class LlamaForCausalLM_KIVI(nn.Module):
             tok = logits.argmax(-1)
         return torch.cat(out, dim=1)
 
+    # ------------------------------------------------------------------ hipGraph decode
+    # The dense part of a decode step is ~30 small launches per layer; in eager mode the host needs longer to enqueue
+    # them than the GPU to run them.  Everything with static shapes is captured once per batch size into hipGraphs
+    # (torch.cuda.CUDAGraph): per layer one graph from the block input to the rotated q / k / v, one from the attention
+    # output to the block output, plus embedding and head; the KIVI step between them stays one eager
+    # kivi_decode_layer call per layer (its lengths change every step).  Same kernels, same results as forward().
+    def _build_graphs(self, B: int, device):
+        cfg = self.config
+        nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        D, H = cfg.hidden_size // nh, cfg.hidden_size
+        dt = self.lm_head.weight.dtype
+        g = SimpleNamespace(B=B, tok=torch.zeros((B, 1), dtype=torch.long, device=device),
+                            cos=torch.zeros((1, 1, 1, D), dtype=dt, device=device),
+                            sin=torch.zeros((1, 1, 1, D), dtype=dt, device=device),
+                            x=[torch.zeros((B, 1, H), dtype=dt, device=device) for _ in range(len(self.model.layers) + 1)],
+                            attn=torch.zeros((B, nh, 1, D), dtype=dt, device=device), qkv=[], pre=[], post=[])
+
+        def rot(t):
+            return torch.cat((-t[..., D // 2:], t[..., : D // 2]), dim=-1)
+
+        def pre(i):
+            layer = self.model.layers[i]
+            a = layer.self_attn
+            if i == 0:
+                g.x[0].copy_(self.model.embed_tokens(g.tok))
+            h = layer.input_layernorm(g.x[i])
+            q = a.q_proj(h).view(B, 1, nh, D).transpose(1, 2)
+            k = a.k_proj(h).view(B, 1, nkv, D).transpose(1, 2)
+            v = a.v_proj(h).view(B, 1, nkv, D).transpose(1, 2)
+            g.qkv[i][0].copy_(q * g.cos + rot(q) * g.sin)
+            g.qkv[i][1].copy_(k * g.cos + rot(k) * g.sin)
+            g.qkv[i][2].copy_(v)
+
+        def post(i):
+            layer = self.model.layers[i]
+            x = g.x[i] + layer.self_attn.o_proj(g.attn.transpose(1, 2).reshape(B, 1, H))
+            g.x[i + 1].copy_(x + layer.mlp(layer.post_attention_layernorm(x)))
+            if i == len(self.model.layers) - 1:
+                g.tok.copy_(self.lm_head(self.model.norm(g.x[i + 1])).argmax(-1))
+
+        for _ in self.model.layers:
+            g.qkv.append((torch.zeros((B, nh, 1, D), dtype=dt, device=device),
+                          torch.zeros((B, nkv, 1, D), dtype=dt, device=device),
+                          torch.zeros((B, nkv, 1, D), dtype=dt, device=device)))
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):          # warm-up outside capture (library workspaces, autotuning)
+            for i in range(len(self.model.layers)):
+                pre(i)
+                post(i)
+        torch.cuda.current_stream(device).wait_stream(side)
+        pool = None
+        for i in range(len(self.model.layers)):
+            for fn, dst in ((pre, g.pre), (post, g.post)):
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg, pool=pool):
+                    fn(i)
+                pool = pool or cg.pool()
+                dst.append(cg)
+        g.tok.zero_()
+        return g
+
+    def prepare_graphs(self, batch: int, device) -> None:
+        """Capture the decode graphs for this batch size now (otherwise on the first graphed step)."""
+        g = getattr(self, "_graphs", None)
+        if g is None or g.B != batch:
+            self._graphs = self._build_graphs(batch, device)
+
+    @torch.no_grad()
+    def decode_graphed(self, tok: torch.LongTensor, past_key_values: List, position: int, steps: int) -> torch.LongTensor:
+        """`steps` greedy decode steps from token `tok` (B, 1) at position `position` with the dense part replayed from
+        hipGraphs; the caches in `past_key_values` are advanced in place.  Returns the (B, steps) tokens fed to the model
+        (tok first); the token following them is left in the graph's token buffer (`self._graphs.tok`)."""
+        from .attention import kivi_attention_decode
+        self.prepare_graphs(tok.shape[0], tok.device)
+        g = self._graphs
+        attn0 = self.model.layers[0].self_attn
+        caches = [p.layer for p in past_key_values]
+        g.tok.copy_(tok)
+        out = []
+        for _ in range(steps):
+            out.append(g.tok.clone())
+            freqs = position * attn0.inv_freq.float()
+            emb = torch.cat((freqs, freqs), dim=-1)
+            g.cos.copy_(emb.cos().view(1, 1, 1, -1))
+            g.sin.copy_(emb.sin().view(1, 1, 1, -1))
+            for i in range(len(self.model.layers)):
+                g.pre[i].replay()
+                q, k, v = g.qkv[i]
+                kivi_attention_decode(q, k, v, caches[i], out=g.attn)
+                g.post[i].replay()
+            position += 1
+        return torch.cat(out, dim=1)
+
+    @torch.no_grad()
+    def generate_graphed(self, input_ids: torch.LongTensor, max_new_tokens: int) -> torch.LongTensor:
+        """generate() with the dense part of every decode step replayed from hipGraphs (see _build_graphs)."""
+        logits, pasts = self.forward(input_ids)
+        new = self.decode_graphed(logits.argmax(-1), pasts, input_ids.shape[1], max_new_tokens)
+        return torch.cat([input_ids, new], dim=1)
+
     @classmethod
     def from_pretrained(cls, path: str, device="cuda", dtype=torch.float16, **kivi):
         """`path`: a local HF checkpoint directory (config.json + *.safetensors).  `kivi`: k_bits, v_bits, group_size,

@@ -255,3 +255,20 @@ def test_decoder_wrapper_generate_fused_vs_composed():
         assert (lf.float() - lc.float()).abs().max().item() <= 2e-2 * lc.float().abs().max().item() + 1e-3, step
         tok = lf.argmax(-1)
     assert pasts_f[0][-1] == 80
+
+
+def test_decoder_wrapper_graphed_decode_equals_eager():
+    """The hipGraph-replayed decode (dense part captured, KIVI step eager) generates the same tokens as the eager loop."""
+    from kivi_amd.llama import LlamaForCausalLM_KIVI, make_config
+    torch.manual_seed(1)
+    cfg = make_config(dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=3,
+                           intermediate_size=1024, vocab_size=500), residual_length=32, max_cache_len=160)
+    model = LlamaForCausalLM_KIVI(cfg).half().cuda()
+    for p in model.parameters():
+        if p.dim() > 1:
+            p.data.normal_(0.0, 0.05)
+    ids = torch.randint(0, 500, (2, 37), device="cuda")
+    a = model.generate(ids, 45)
+    b = model.generate_graphed(ids, 45)
+    assert a.shape == b.shape == (2, 82)
+    assert bool((a == b).all()), (a != b).nonzero()[:4]
