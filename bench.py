@@ -177,8 +177,14 @@ def main():
             return
         e0, e1 = klib.kivi_event_create(), klib.kivi_event_create()
         klib.kivi_set_launch_events(e0, e1)
-        kev.append((e0, e1, kgemv_bytes(info["B"], info["nh"], info["nh_kv"], info["K"], info["N"], info["group_size"],
-                                        info["bits"])))
+        kb = kgemv_bytes(info["B"], info["nh"], info["nh_kv"], info["K"], info["N"], info["group_size"], info["bits"])
+        rb = None
+        if "Tv" in info:   # what the fused decode-row launch moves: packed K + packed V + fp16 residual / window + q + out
+            Bq, nhq, nkv, Dq = info["B"], info["nh"], info["nh_kv"], info["K"]
+            rb = (kb - Bq * nhq * info["N"] * 2
+                  + vgemv_bytes(Bq, nhq, nkv, Dq, info["Tv"], info["group_size"], info["v_bits"]) - Bq * nhq * info["Tv"] * 2
+                  + Bq * nkv * (info["k_res"] + info["v_res"]) * Dq * 2)
+        kev.append((e0, e1, kb, rb))
 
     if not args.no_kernel_events:
         matmul.launch_hook = hook
@@ -200,20 +206,25 @@ def main():
     if rank == 0:
         roof = None
         if kev:
-            us = [klib.kivi_event_elapsed_us(a, b) for a, b, _ in kev]
-            tot_bytes = sum(n for _, _, n in kev)
+            us = [klib.kivi_event_elapsed_us(a, b) for a, b, _, _ in kev]
+            timed = (klib.kivi_last_timed_kernel() or b"").decode()
+            row_fused = "decode_row_kernel" in timed and all(r is not None for _, _, _, r in kev)
+            tot_bytes = sum((r if row_fused else n) for _, _, n, r in kev)
             avg_us = sum(us) / len(us)
             achieved = tot_bytes / (sum(us) * 1e-6) / 1e9
             traffic = None
             prof = os.path.join(ROOT, "profiles", "kgemv_pmc.json")
             if os.path.exists(prof):
                 try:
-                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                    pj = json.load(open(prof))
+                    traffic = pj.get("decode_row_hbm_bytes_per_launch") if row_fused else pj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "gemv_k_kernel (fused int2 qK^T over packed K)", "launches": len(us),
+                    "kernel": ("decode_row_kernel (one launch per layer: packed qK^T of the row -> LDS scores -> residual "
+                               "scores + softmax + window + packed sV + cache update)" if row_fused
+                               else "gemv_k_kernel (fused int2 qK^T over packed K)"), "launches": len(us),
                     "sampled": f"every {args.event_every}th qK^T dispatch of the timed region (an event pair costs ~10 us of stream time)",
                     "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min(us), 2),
                     "algorithmic_bytes_per_launch": tot_bytes // len(us),
@@ -249,7 +260,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
-                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (2: scores; softmax+output; +1 K flush every R steps)",
+                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (1 decode-row launch for MHA rows <= 8192 keys, else qK^T + [row softmax] + sV; +1 K flush every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
                        "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)"},

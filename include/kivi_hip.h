@@ -218,6 +218,14 @@ typedef struct kivi_decode_attend_args {
         scratch, >= 65536 + 4096 + B*nh*512 + 4 * B*nh*D*65 bytes.  With it, rows are split over several blocks when
         B*nh_kv is too small to fill the GPU (long context, small batch) or the probabilities of a block's rows would
         not fit a small LDS budget (grouped queries, long rows); counters in it are left at zero after every call. */
+    /* optional (k_code may be NULL): the packed-K side of the same step, as kivi_gemv_k_paged takes it.  With it the
+       call covers the WHOLE step -- the library runs the packed qK^T itself (do not call kivi_gemv_k_paged first) and,
+       for the MHA decode shape (rows <= 8192 keys, nothing split), fuses it into the same launch: the block that
+       owns a (b, head) row computes the row's packed scores into LDS and goes straight on (no score round trip
+       through HBM, one launch per layer). */
+    const void* k_code; int64_t kc_sb, kc_sh, kc_sp, kc_sr;
+    const void* k_scale; const void* k_mn; int64_t ks_sb, ks_sh, ks_sp, ks_sr;
+    int64_t k_page_tokens; int k_bits;
 } kivi_decode_attend_args;
 int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream);
 
@@ -274,6 +282,8 @@ void* kivi_event_create(void);
 void kivi_event_destroy(void* event);
 void kivi_set_launch_events(void* start, void* stop);
 float kivi_event_elapsed_us(void* start, void* stop);
+/* source text of the kernel instantiation the last consumed event pair bracketed ("" if none yet) */
+const char* kivi_last_timed_kernel(void);
 
 #ifdef __cplusplus
 }

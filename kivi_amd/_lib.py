@@ -39,6 +39,9 @@ class DecodeAttendArgs(ctypes.Structure):
         ("B", _i32), ("nh", _i32), ("nh_kv", _i32), ("D", _i32), ("group_size", _i32), ("v_bits", _i32),
         ("Tq", _i64), ("Tv", _i64),
         ("workspace", _vp), ("workspace_bytes", _i64),
+        ("k_code", _vp), ("kc_sb", _i64), ("kc_sh", _i64), ("kc_sp", _i64), ("kc_sr", _i64),
+        ("k_scale", _vp), ("k_mn", _vp), ("ks_sb", _i64), ("ks_sh", _i64), ("ks_sp", _i64), ("ks_sr", _i64),
+        ("k_page_tokens", _i64), ("k_bits", _i32),
     ]
 
 
@@ -97,6 +100,7 @@ SIGNATURES = {
     "kivi_event_destroy": (None, [_vp]),
     "kivi_set_launch_events": (None, [_vp, _vp]),
     "kivi_event_elapsed_us": (ctypes.c_float, [_vp, _vp]),
+    "kivi_last_timed_kernel": (ctypes.c_char_p, []),
 }
 
 _lib = None

@@ -137,7 +137,8 @@ def _decode_native(query_states, key_states, value_states, layer: KiviLayerCache
     hook = _matmul_mod().launch_hook
     if hook is not None and layer.k_quant_len:   # bench.py: bracket the qK^T dispatch (the first launch of the call)
         hook("pre", "k", dict(B=B, nh=nh, nh_kv=layer.nh_kv, K=D, N=layer.k_quant_len, bits=layer.cfg.k_bits,
-                              group_size=layer.cfg.group_size))
+                              group_size=layer.cfg.group_size, v_bits=layer.cfg.v_bits, Tv=layer.v_quant_len,
+                              k_res=layer.k_res_len + 1, v_res=layer.v_res_len + 1))
     rc = fn(ctypes.byref(d), state, q.data_ptr(), q.stride(0), q.stride(1), nh, k.data_ptr(), k.stride(0), k.stride(1),
             v.data_ptr(), v.stride(0), v.stride(1), mask_ptr, mask_sb, out.data_ptr(), out.stride(0), out.stride(1),
             torch.cuda.current_stream(q.device).cuda_stream)

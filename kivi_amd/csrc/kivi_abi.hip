@@ -26,6 +26,10 @@ KiviLaunchEvents kivi_take_launch_events() {
     return e;
 }
 
+static thread_local char g_timed[160] = "";
+void kivi_note_timed_kernel(const char* name) { snprintf(g_timed, sizeof g_timed, "%s", name); }
+extern "C" const char* kivi_last_timed_kernel(void) { return g_timed; }
+
 extern "C" void* kivi_event_create(void) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;

@@ -40,13 +40,15 @@ struct KiviLaunchEvents {
     hipEvent_t start, stop;
 };
 KiviLaunchEvents kivi_take_launch_events();
+void kivi_note_timed_kernel(const char* name);   // remembers which kernel the last event pair bracketed
 
 #define KIVI_LAUNCH_LDS(kernel, grid, block, lds, stream, ...)                                              \
     do {                                                                                                   \
         KiviLaunchEvents ev__ = kivi_take_launch_events();                                                 \
-        if (ev__.start || ev__.stop)                                                                       \
+        if (ev__.start || ev__.stop) {                                                                     \
+            kivi_note_timed_kernel(#kernel);                                                               \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev__.start, ev__.stop, 0, __VA_ARGS__); \
-        else                                                                                               \
+        } else                                                                                               \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                             \
     } while (0)
 #define KIVI_LAUNCH(kernel, grid, block, stream, ...) KIVI_LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "kivi_common.h"
+#include "kivi_gemv_k_dev.h"
 #include "kivi_quant.h"
 
 namespace {
@@ -69,10 +70,22 @@ struct GemvVArgs {
     float* ws;                         // [units][nsplit + 1][R * D] fp32 partials (+1: the window part)
     int* counters;                     // [units] arrival counters, zero between launches
     size_t ws_bytes;                   // bytes available at ws
+    // fused decode row (decode_row_kernel): the packed qK^T of the row ran in this block just before, its fp16 scores
+    // are already in `pl` (the dynamic LDS row) and are not written to memory
+    int scores_lds;
+    // host only: the packed-K side of the step when the caller handed it over (kivi_decode_attend with K fields)
+    const struct KSide* kside;
+};
+
+struct KSide {     // host only
+    GemvKArgs args;                    // filled for the paged layout, R = 1 mapping
+    bool fusable;                      // static conditions of decode_row_kernel hold for the K side
+    int64_t page_tokens;
+    int B, nh_kv, group_size, bits;
 };
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT>
-__global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
+__device__ __forceinline__ void v_row_body(const GemvVArgs& a) {
     constexpr int FPI = 32 / BITS;
     constexpr int LPR = DW / WPL;               // lanes per token row
     static_assert(LPR >= 1 && LPR <= 16 && (LPR & (LPR - 1)) == 0, "D/fpi must be 4, 8, 16 or 32 words");
@@ -228,12 +241,13 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
             const int j0 = c * 1024 + (int)threadIdx.x * 4;
             raw[c] = u16x4{0, 0, 0, 0};
             if (c < nch_sc) {
+                const uint16_t* src = a.scores_lds ? pl : srow;   // fused row: the packed scores are in LDS already
                 if (j0 + 4 <= lim) {
-                    raw[c] = *(const u16x4*)(srow + j0);
+                    raw[c] = *(const u16x4*)(src + j0);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        if (j0 + e < lim) raw[c][e] = srow[j0 + e];
+                        if (j0 + e < lim) raw[c][e] = src[j0 + e];
                 }
             }
         }
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
                 if (sub == 0) {
                     const uint16_t hs = f2h_bits(sc);
                     rs_lds[r][t] = hs;
-                    const_cast<uint16_t*>(a.a)[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tq + t] = hs;
+                    if (!a.scores_lds) const_cast<uint16_t*>(a.a)[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tq + t] = hs;
                 }
             }
         }
@@ -618,6 +632,26 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
     }
 }
 
+template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT>
+__global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
+    v_row_body<BITS, G, DW, WPL, R, U, MODE, NT, SPLIT>(a);
+}
+
+// The whole decode step of one (b, head) row in ONE block (MHA, rows <= 8192 keys): the packed qK^T of the row tile
+// by tile (k_tile_body, the scores go to the LDS row instead of memory), then everything v_row_body does with them
+// (residual scores, softmax, window, packed sV).  Against the two-launch form this drops the 2 x 8 MB score round
+// trip through HBM, one launch ramp/drain and the cold start of the second kernel.
+template <int BITS, int G, int DW, int KWPL, int KU, int VWPL, int VU>
+__global__ __launch_bounds__(256) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
+    extern __shared__ uint16_t pl_row[];
+    const int unit = (int)blockIdx.x;
+    for (int tb = 0; tb < ak.tile_blocks; tb++) {
+        k_tile_body<BITS, G, KWPL, 4, 1, KU, KIVI_UNPACK_MIX, true>(ak, unit * ak.tile_blocks + tb, pl_row);
+        __syncthreads();   // the exchange buffer is reused by the next tile; the scores must be visible below
+    }
+    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false>(av);
+}
+
 // Stand-alone row softmax of the decode step, used when the block-prologue softmax of gemv_v_kernel does not pay
 // (grouped queries: R rows per block; rows longer than the register-resident form; rows split over blocks): one
 // block per (b, h) score row computes the residual scores q . [fp16 K residual | new key] (+ the K append) when a
@@ -913,6 +947,23 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         // never leave the CU).  Otherwise (grouped queries = R rows per block, longer rows, split rows) that prologue
         // would serialise R x n exps per block while the memory system idles (measured +150 us at B=64 / 8 kv heads /
         // 8k keys): the well-parallel row-softmax launch turns the score rows into probabilities in place first.
+        // The caller may have handed over the packed-K side of the step too (kivi_decode_attend with K fields): one
+        // launch for the whole row when the shape is the tuned MHA one (in-block softmax, nothing split), otherwise the
+        // stand-alone qK^T launch goes first.
+        bool fuse_row = false;
+        if (a.kside) {
+            const KSide& ks = *a.kside;
+            static const char* nofuse = getenv("KIVI_NO_ROW_FUSION");   // tuning aid
+            fuse_row = !nofuse && ks.fusable && a.softmax && S == 1 && v.R == 1 && a.n_scores <= 8192 && a.rq != nullptr &&
+                       bits == 2 && G == 32 && a.D == 128 && v.wpl == 4 && v.U == 1 && v.mode == KIVI_UNPACK_MIX && v.nt == 1;
+            if (!fuse_row && ks.args.T > 0) {
+                const GemvKArgs& k = ks.args;
+                const int rc = kivi_gemv_k_paged(-1, ks.page_tokens, k.code_sp, k.sm_sp, k.q, k.q_sb, k.q_sh, k.code, k.code_sb,
+                                                 k.code_sh, k.code_sr, k.scale, k.mn, k.sm_sb, k.sm_sh, k.sm_sr, k.out, k.out_sb,
+                                                 k.out_sh, ks.B, k.nh, ks.nh_kv, k.D, k.T, ks.group_size, ks.bits, (kivi_stream_t)s);
+                if (rc) return rc;
+            }
+        }
         if (a.softmax && (v.R > 1 || S > 1 || a.n_scores > 8192)) {
             RowSoftmaxArgs rp;
             rp.scores = const_cast<uint16_t*>(a.a); rp.s_sb = a.a_sb; rp.s_sh = a.a_sh;
@@ -948,6 +999,16 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             a.n_pad = (int)((a.n_scores + 7) / 8 * 8);
             KIVI_REQUIRE((size_t)v.R * a.n_pad * 2 <= 96 * 1024, KIVI_EUNSUPPORTED,
                          "kivi_decode_attend: %d probability rows of %d do not fit the LDS", v.R, a.n_pad);
+        }
+        if (fuse_row) {
+            GemvKArgs ak = a.kside->args;
+            ak.units_per_b = a.nh;
+            ak.tile_blocks = (int)((ak.Tw + 127) / 128);
+            ak.res_blocks = 0;
+            a.scores_lds = 1;
+            const size_t lds = (size_t)a.n_pad * sizeof(uint16_t);
+            KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 1>), dim3((unsigned)units), dim3(256), lds, s, ak, a);
+            return kivi_launch_status("decode_row");
         }
         v.fn(a, dim3((unsigned)(units * S)), s);
         return kivi_launch_status(v.name);
@@ -1021,6 +1082,7 @@ static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, i
     a.rq = nullptr; a.rkres = nullptr; a.rknew = nullptr; a.rk_len = 0; a.Tq = 0;
     a.rq_sb = a.rq_sh = a.rk_sb = a.rk_sh = a.rk_st = a.rkn_sb = a.rkn_sh = 0;
     a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
+    a.scores_lds = 0; a.kside = nullptr;
     a.vres_sb = a.vres_sh = a.vres_st = a.vnew_sb = a.vnew_sh = 0;
     return 0;
 }
@@ -1056,6 +1118,7 @@ struct ResidualK {
     int64_t Tq;
     void* workspace;
     size_t workspace_bytes;
+    const KSide* kside;                // packed-K side of the step, or null
 };
 
 static int decode_output_impl(int softmax, float inv_scale, const void* mask, int64_t mask_sb, const void* probs,
@@ -1133,6 +1196,7 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
             a.rknew = (const uint16_t*)rk.knew; a.rkn_sb = rk.knew_sb; a.rkn_sh = rk.knew_sh;
             a.rk_len = rk.res_len;
             a.Tq = (int)rk.Tq;
+            a.kside = rk.kside;
             if (rk.workspace && rk.workspace_bytes > KIVI_WS_COUNTERS * sizeof(int)) {   // arrival counters, then fp32 partials
                 a.counters = (int*)rk.workspace;
                 a.ws = (float*)((char*)rk.workspace + KIVI_WS_COUNTERS * sizeof(int));
@@ -1146,7 +1210,32 @@ static int decode_output_impl(int softmax, float inv_scale, const void* mask, in
 extern "C" int kivi_decode_attend(const kivi_decode_attend_args* p, kivi_stream_t stream) {
     KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_decode_attend: null arguments");
     ResidualK rk = {p->q, p->q_sb, p->q_sh, p->kres, p->kres_sb, p->kres_sh, p->kres_st, p->knew, p->knew_sb, p->knew_sh,
-                    p->k_res_len, p->Tq, p->workspace, (size_t)p->workspace_bytes};
+                    p->k_res_len, p->Tq, p->workspace, (size_t)p->workspace_bytes, nullptr};
+    KSide ks;
+    if (p->k_code) {
+        int rc = k_check_and_fill(ks.args, p->q, p->q_sb, p->q_sh, p->k_code, p->kc_sb, p->kc_sh, p->kc_sr, p->k_scale, p->k_mn,
+                                  p->ks_sb, p->ks_sh, p->ks_sr, p->scores, p->s_sb, p->s_sh, p->B, p->nh, p->nh_kv, p->D, p->Tq,
+                                  p->group_size, p->k_bits);
+        if (rc) return rc;
+        const int fpi = 32 / p->k_bits;
+        KIVI_REQUIRE(p->k_page_tokens > 0 && p->k_page_tokens % p->group_size == 0 && p->k_page_tokens % fpi == 0, KIVI_EINVAL,
+                     "kivi_decode_attend: k_page_tokens=%lld must be a positive multiple of group_size=%d",
+                     (long long)p->k_page_tokens, p->group_size);
+        GemvKArgs& k = ks.args;
+        k.page_words = p->k_page_tokens / fpi;
+        k.page_groups = p->k_page_tokens / p->group_size;
+        k.code_sp = p->kc_sp;
+        k.sm_sp = p->ks_sp;
+        ks.page_tokens = p->k_page_tokens; ks.B = p->B; ks.nh_kv = p->nh_kv; ks.group_size = p->group_size; ks.bits = p->k_bits;
+        // decode_row_kernel runs the qK^T mapping {2-bit, g=32, 2 words per lane, 4 waves split D, 4-row batches}
+        ks.fusable = p->k_bits == 2 && p->v_bits == 2 && p->group_size == 32 && p->nh == p->nh_kv && p->D == 128 &&
+                     k.page_words % 128 == 0 && k.code_sp % 2 == 0 && k.q_sh % 2 == 0 && k.q_sb % 2 == 0 &&
+                     (uintptr_t)k.q % 4 == 0 && k.Tw % 2 == 0 && k.code_sr % 2 == 0 && k.code_sh % 2 == 0 &&
+                     k.code_sb % 2 == 0 && (uintptr_t)k.code % 8 == 0 && (uintptr_t)k.scale % 2 == 0 &&
+                     (uintptr_t)k.mn % 2 == 0 && (int64_t)k.D * k.code_sr * 4 < ((int64_t)1 << 31) &&
+                     (int64_t)k.D * k.sm_sr * 2 < ((int64_t)1 << 31);
+        rk.kside = &ks;
+    }
     const int rc = decode_output_impl(1, p->inv_scale, p->mask, p->mask_sb, p->scores, p->s_sb, p->s_sh, p->v_code, p->vc_sb,
                                       p->vc_sh, p->vc_sr, p->v_scale, p->v_mn, p->vs_sb, p->vs_sh, p->vs_sr, p->vres,
                                       p->vres_sb, p->vres_sh, p->vres_st, p->v_win_start, p->v_res_len, p->vnew, p->vnew_sb,

@@ -38,12 +38,6 @@ extern "C" int kivi_decode_layer(const kivi_layer_desc* L, int64_t* st, const vo
         st[3] = 0;   // a compaction is complete on its own: commit it even if a later launch is refused
     }
     int rc;
-    if (Tq) {
-        rc = kivi_gemv_k_paged(-1, L->page_tokens, L->kc_sp, L->ks_sp, q, q_sb, q_sh, L->k_code, L->kc_sb, L->kc_sh, L->kc_sr,
-                               L->k_scale, L->k_mn, L->ks_sb, L->ks_sh, L->ks_sr, L->scores, L->s_sb, L->s_sh, L->B, nh,
-                               L->nh_kv, L->D, Tq, L->group_size, L->k_bits, stream);
-        if (rc) return rc;
-    }
     const int flush = vres + 1 > R;
     kivi_decode_attend_args a;
     a.q = q; a.q_sb = q_sb; a.q_sh = q_sh;
@@ -60,6 +54,11 @@ extern "C" int kivi_decode_layer(const kivi_layer_desc* L, int64_t* st, const vo
     a.B = L->B; a.nh = nh; a.nh_kv = L->nh_kv; a.D = L->D; a.group_size = L->group_size; a.v_bits = L->v_bits;
     a.Tq = Tq; a.Tv = Tv;
     a.workspace = L->workspace; a.workspace_bytes = L->workspace_bytes;
+    // the packed-K side goes in the same call: the library fuses the qK^T of a row into the launch when it can and
+    // runs it as its own launch first otherwise
+    a.k_code = Tq ? L->k_code : nullptr; a.kc_sb = L->kc_sb; a.kc_sh = L->kc_sh; a.kc_sp = L->kc_sp; a.kc_sr = L->kc_sr;
+    a.k_scale = L->k_scale; a.k_mn = L->k_mn; a.ks_sb = L->ks_sb; a.ks_sh = L->ks_sh; a.ks_sp = L->ks_sp; a.ks_sr = L->ks_sr;
+    a.k_page_tokens = L->page_tokens; a.k_bits = L->k_bits;
     rc = kivi_decode_attend(&a, stream);
     if (rc) return rc;            // nothing of the step has been committed: the caller may compose it instead
 

@@ -10,6 +10,9 @@ rm -rf $O/prof/bench_trace $O/prof/pmc_fetch $O/prof/pmc_write $O/prof/pmc_calib
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/bench_trace -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $O/prof/bench_trace.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof/pmc_fetch -o k -- python $R/tools/gpu_sweep.py --nbuf 12 --iters 12 --skip_pack --only $KV > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof/pmc_write -o k -- python $R/tools/gpu_sweep.py --nbuf 12 --iters 12 --skip_pack --only $KV > /dev/null 2>&1
+rm -rf $O/prof/pmc_fetch_row $O/prof/pmc_write_row
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof/pmc_fetch_row -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof/pmc_write_row -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof/pmc_calib -o c -- $R/tools/hbm_read_bw.bin 2 > $O/hbm_bw.log 2>&1
 python $R/tools/gpu_sweep.py 2>&1 | grep -v "^/opt" > $O/sweep_final.log
 cd $R

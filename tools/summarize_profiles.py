@@ -38,8 +38,9 @@ def main():
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                         r["MaxNs"], r["StdDev"]])
-    kg = next(r for r in rows if "gemv_k_kernel" in r["Name"])
-    vg = next(r for r in rows if "gemv_v_kernel" in r["Name"])
+    kg = next((r for r in rows if "gemv_k_kernel" in r["Name"]), None)
+    vg = next((r for r in rows if "gemv_v_kernel" in r["Name"]), None)
+    rg = next((r for r in rows if "decode_row_kernel" in r["Name"]), None)   # the fused MHA decode step (one launch)
 
     # ---- PMC
     def pmc(path, counter, match):
@@ -68,16 +69,25 @@ def main():
         "correction": "FETCH_SIZE[KB] x 1024 x 2 (gfx950 tallies 128-B fabric reads at 64 B: calibration below gives "
                       "~2048 bytes per unit for both 16-B and 8-B per-lane loads); WRITE_SIZE[KB] x 1024",
         "calibration": calib,
-        "gemv_k": {"kernel": short(kg["Name"]), "FETCH_SIZE_KB": fetch_k, "WRITE_SIZE_KB": write_k, "launches": [n1, n2],
+        "gemv_k": {"kernel": "gemv_k_kernel<2, 32, 2, 4, 1, 4, 2, true>(GemvKArgs)", "FETCH_SIZE_KB": fetch_k, "WRITE_SIZE_KB": write_k, "launches": [n1, n2],
                    "hbm_read_bytes": fetch_k * unit, "hbm_write_bytes": write_k * 1024,
                    "hbm_bytes_per_launch": fetch_k * unit + write_k * 1024,
                    "algorithmic_bytes_per_launch": 209977344},
-        "gemv_v": {"kernel": short(vg["Name"]), "FETCH_SIZE_KB": fetch_v, "WRITE_SIZE_KB": write_v, "launches": [n3, n4],
+        "gemv_v": {"kernel": "gemv_v_kernel<2, 32, 8, 4, 1, 1, 2, true, false>(GemvVArgs)", "FETCH_SIZE_KB": fetch_v, "WRITE_SIZE_KB": write_v, "launches": [n3, n4],
                    "hbm_bytes_per_launch": fetch_v * unit + write_v * 1024, "algorithmic_bytes_per_launch": 209977344},
         "hbm_bytes_per_launch": fetch_k * unit + write_k * 1024,
-        "bench_kernel_trace": {"gemv_k_avg_us": float(kg["AverageNs"]) / 1e3, "gemv_k_calls": int(kg["Calls"]),
-                               "gemv_v_avg_us": float(vg["AverageNs"]) / 1e3, "gemv_v_calls": int(vg["Calls"])},
+        "bench_kernel_trace": {(k + "_avg_us"): float(r["AverageNs"]) / 1e3 for k, r in
+                               (("gemv_k", kg), ("gemv_v", vg), ("decode_row", rg)) if r is not None},
     }
+    # the fused decode-row launch, measured on the bench command itself (separate --pmc passes)
+    rf, rw = os.path.join(SRC, "pmc_fetch_row", "b_counter_collection.csv"), os.path.join(SRC, "pmc_write_row", "b_counter_collection.csv")
+    if os.path.exists(rf) and os.path.exists(rw):
+        fr, m1 = pmc(rf, "FETCH_SIZE", "decode_row_kernel")
+        wr, m2 = pmc(rw, "WRITE_SIZE", "decode_row_kernel")
+        out["decode_row"] = {"kernel": "decode_row_kernel<2, 32, 8, 2, 4, 4, 1>", "FETCH_SIZE_KB": fr, "WRITE_SIZE_KB": wr,
+                             "launches": [m1, m2], "hbm_read_bytes": fr * unit, "hbm_write_bytes": wr * 1024,
+                             "hbm_bytes_per_launch": fr * unit + wr * 1024}
+        out["decode_row_hbm_bytes_per_launch"] = fr * unit + wr * 1024
     with open(os.path.join(DST, f"{tag}_kgemv_pmc.json"), "w") as f:
         json.dump(out, f, indent=1)
     with open(os.path.join(DST, "kgemv_pmc.json"), "w") as f:   # what bench.py reads for roofline.traffic
