@@ -23,4 +23,4 @@ cd $R
   tools/gqa_ab.sh "--batch 1 --prompt 32768" -
 } > $O/shapes.log 2>&1; cat $O/shapes.log
 tools/prof_shapes.sh c4 c5 b1 > $O/prof_shapes.log 2>&1
-{ python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512; python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512 --baseline; } 2>/dev/null > $O/e2e.log; cat $O/e2e.log | cut -c1-400
+{ python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512; python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512 --graphs; python examples/mem_spd_test.py --batch 32 --prompt 2048 --gen 512 --baseline; } 2>/dev/null > $O/e2e.log; cat $O/e2e.log | cut -c1-400

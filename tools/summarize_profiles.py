@@ -23,7 +23,7 @@ DST = os.path.join(ROOT, "profiles")
 
 def short(name: str) -> str:
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
-    name = re.sub(r"<.*", lambda m: m.group(0) if ("gemv_" in name or "quant_" in name or "unpack_" in name) else "<...>", name)
+    name = re.sub(r"<.*", lambda m: m.group(0) if ("gemv_" in name or "quant_" in name or "unpack_" in name or "decode_row" in name or "row_softmax" in name) else "<...>", name)
     return name[:140]
 
 
@@ -84,7 +84,7 @@ def main():
     if os.path.exists(rf) and os.path.exists(rw):
         fr, m1 = pmc(rf, "FETCH_SIZE", "decode_row_kernel")
         wr, m2 = pmc(rw, "WRITE_SIZE", "decode_row_kernel")
-        out["decode_row"] = {"kernel": "decode_row_kernel<2, 32, 8, 2, 4, 4, 1>", "FETCH_SIZE_KB": fr, "WRITE_SIZE_KB": wr,
+        out["decode_row"] = {"kernel": short(rg["Name"]) if rg is not None else "decode_row_kernel", "FETCH_SIZE_KB": fr, "WRITE_SIZE_KB": wr,
                              "launches": [m1, m2], "hbm_read_bytes": fr * unit, "hbm_write_bytes": wr * 1024,
                              "hbm_bytes_per_launch": fr * unit + wr * 1024}
         out["decode_row_hbm_bytes_per_launch"] = fr * unit + wr * 1024
