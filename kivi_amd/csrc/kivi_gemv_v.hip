@@ -84,8 +84,64 @@ struct KSide {     // host only
     int B, nh_kv, group_size, bits;
 };
 
-template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT>
-__device__ __forceinline__ void v_row_body(const GemvVArgs& a) {
+// Small operands of a row's step, requested ahead of time by the fused decode-row kernel (before its qK^T phase) so that
+// their memory round trips are over when v_row_body needs them: the first window rows of every wave, the window token
+// about to be quantised, and this thread's share of the residual keys / query.
+template <int D>
+struct RowPre {
+    static constexpr int NP = (D / 2 + 63) / 64;
+    static constexpr int PWT = 9;
+    static constexpr int NK = D / 64;                // 16-byte pieces of a thread's D/8 channels
+    uint32_t vpre[PWT][NP];
+    uint16_t xflush;
+    u16x8 rk[NK], rq[NK];
+};
+
+template <int D>
+__device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D>& pre) {   // R = 1, not split
+    constexpr int NP = RowPre<D>::NP, PWT = RowPre<D>::PWT, NK = RowPre<D>::NK, CPL = D / 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = (int)blockIdx.x;
+    const int b = unit / a.units_per_b;
+    const int h0 = unit - b * a.units_per_b;
+    const int hk = h0 / a.ratio;
+    const bool owner = (h0 % a.ratio) == 0;
+    const int Lw = a.res_len + 1;
+    const uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+    const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+#pragma unroll
+    for (int k = 0; k < PWT; k++) {
+        const int t = wave + 4 * k;
+        const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+#pragma unroll
+        for (int c = 0; c < NP; c++) {
+            const int p = lane + 64 * c;
+            pre.vpre[k][c] = (a.fused && t < Lw && p < D / 2) ? *(const uint32_t*)(vrow + 2 * p) : 0u;
+        }
+    }
+    pre.xflush = 0;
+    if (a.fused && a.flush && owner && (int)threadIdx.x < D) pre.xflush = vwin[threadIdx.x];
+    const int L = a.rk_len + 1;
+    const int idx = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NK; i++) pre.rk[i] = pre.rq[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.rq && idx < L * 8) {
+        const int sub = idx & 7, t = idx >> 3;
+        const uint16_t* kres = a.rkres + b * a.rk_sb + hk * a.rk_sh;
+        const uint16_t* knew = a.rknew + b * a.rkn_sb + hk * a.rkn_sh;
+        const uint16_t* krow = ((t < a.rk_len) ? kres + (int64_t)t * a.rk_st : knew) + sub * CPL;
+        const uint16_t* qrow = a.rq + b * a.rq_sb + (int64_t)h0 * a.rq_sh + sub * CPL;
+#pragma unroll
+        for (int i = 0; i < NK; i++) {
+            pre.rk[i] = *(const u16x8*)(krow + 8 * i);
+            pre.rq[i] = *(const u16x8*)(qrow + 8 * i);
+        }
+    }
+}
+
+template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT, bool PRE = false>
+__device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW * (32 / BITS)>* pre = nullptr) {
     constexpr int FPI = 32 / BITS;
     constexpr int LPR = DW / WPL;               // lanes per token row
     static_assert(LPR >= 1 && LPR <= 16 && (LPR & (LPR - 1)) == 0, "D/fpi must be 4, 8, 16 or 32 words");
@@ -259,7 +315,12 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a) {
     constexpr int PWT = 9;
     const int Lw = a.res_len + 1;
     uint32_t vpre[PWT][NP];
-    if (do_win) {
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < PWT; k++)
+#pragma unroll
+            for (int c = 0; c < NP; c++) vpre[k][c] = pre->vpre[k][c];
+    } else if (do_win) {
         const uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
         const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
 #pragma unroll
@@ -275,7 +336,8 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a) {
     }
     // (c) the oldest window token, quantised below
     uint16_t xflush = 0;
-    if (do_flush && (int)threadIdx.x < D)
+    if constexpr (PRE) xflush = pre->xflush;
+    else if (do_flush && (int)threadIdx.x < D)
         xflush = a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + threadIdx.x];
 
     if (a.softmax) {
@@ -304,8 +366,14 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a) {
                 float sc = 0.f;
 #pragma unroll
                 for (int d = 0; d < CPL; d += 8) {
-                    const u16x8 kv = *(const u16x8*)(krow + d);
-                    const u16x8 qv = *(const u16x8*)(qrow + d);
+                    u16x8 kv, qv;
+                    if (PRE && idx == (int)threadIdx.x) {   // this thread's first item was requested before the qK^T phase
+                        kv = pre->rk[d / 8];
+                        qv = pre->rq[d / 8];
+                    } else {
+                        kv = *(const u16x8*)(krow + d);
+                        qv = *(const u16x8*)(qrow + d);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qv[e]), h2f_bits(kv[e]), sc);
                     if (append) *(u16x8*)(kres + (int64_t)t * a.rk_st + sub * CPL + d) = kv;
@@ -645,11 +713,13 @@ template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU>
 __global__ __launch_bounds__(256) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
     extern __shared__ uint16_t pl_row[];
     const int unit = (int)blockIdx.x;
+    RowPre<DW * (32 / BITS)> pre;
+    row_prefetch(av, pre);   // in flight during the whole qK^T phase
     for (int tb = 0; tb < ak.tile_blocks; tb++) {
         k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true>(ak, unit * ak.tile_blocks + tb, pl_row);
         __syncthreads();   // the exchange buffer is reused by the next tile; the scores must be visible below
     }
-    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false>(av);
+    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, true>(av, &pre);
 }
 
 // Stand-alone row softmax of the decode step, used when the block-prologue softmax of gemv_v_kernel does not pay
