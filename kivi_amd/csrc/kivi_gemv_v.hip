@@ -709,17 +709,17 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 // by tile (k_tile_body, the scores go to the LDS row instead of memory), then everything v_row_body does with them
 // (residual scores, softmax, window, packed sV).  Against the two-launch form this drops the 2 x 8 MB score round
 // trip through HBM, one launch ramp/drain and the cold start of the second kernel.
-template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU>
+template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU, bool PRE = true>
 __global__ __launch_bounds__(256) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
     extern __shared__ uint16_t pl_row[];
     const int unit = (int)blockIdx.x;
     RowPre<DW * (32 / BITS)> pre;
-    row_prefetch(av, pre);   // in flight during the whole qK^T phase
+    if constexpr (PRE) row_prefetch(av, pre);   // in flight during the whole qK^T phase (26 VGPRs, where they fit)
     for (int tb = 0; tb < ak.tile_blocks; tb++) {
         k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true>(ak, unit * ak.tile_blocks + tb, pl_row);
         __syncthreads();   // the exchange buffer is reused by the next tile; the scores must be visible below
     }
-    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, true>(av, &pre);
+    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, PRE>(av, &pre);
 }
 
 // Stand-alone row softmax of the decode step, used when the block-prologue softmax of gemv_v_kernel does not pay
@@ -1025,7 +1025,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const KSide& ks = *a.kside;
             static const char* nofuse = getenv("KIVI_NO_ROW_FUSION");   // tuning aid
             fuse_row = !nofuse && ks.fusable && a.softmax && S == 1 && v.R == 1 && a.n_scores <= 8192 && a.rq != nullptr &&
-                       bits == 2 && G == 32 && a.D == 128 && v.mode == KIVI_UNPACK_MIX;
+                       (bits == 2 || bits == 4) && G == 32 && a.D == 128 && v.mode == KIVI_UNPACK_MIX;
             if (!fuse_row && ks.args.T > 0) {
                 const GemvKArgs& k = ks.args;
                 const int rc = kivi_gemv_k_paged(-1, ks.page_tokens, k.code_sp, k.sm_sp, k.q, k.q_sb, k.q_sh, k.code, k.code_sb,
@@ -1073,6 +1073,14 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         if (fuse_row) {
             GemvKArgs ak = a.kside->args;
             ak.units_per_b = a.nh;
+            if (bits == 4) {   // 4-bit: 8 codes per word, 4 words per lane = the same 2048-token tile; sV over 16 words per row
+                ak.tile_blocks = (int)(((ak.Tw + 255) / 256 + 1) / 2);
+                ak.res_blocks = 0;
+                a.scores_lds = 1;
+                KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false>), dim3((unsigned)units), dim3(256),
+                                (size_t)a.n_pad * sizeof(uint16_t), s, ak, a);
+                return kivi_launch_status("decode_row");
+            }
             const int tiles = (int)((ak.Tw + 127) / 128);
             ak.res_blocks = 0;
             a.scores_lds = 1;
@@ -1308,10 +1316,12 @@ extern "C" int kivi_decode_attend(const kivi_decode_attend_args* p, kivi_stream_
         k.sm_sp = p->ks_sp;
         ks.page_tokens = p->k_page_tokens; ks.B = p->B; ks.nh_kv = p->nh_kv; ks.group_size = p->group_size; ks.bits = p->k_bits;
         // decode_row_kernel runs the qK^T mapping {2-bit, g=32, 2 words per lane, 4 waves split D, 4-row batches}
-        ks.fusable = p->k_bits == 2 && p->v_bits == 2 && p->group_size == 32 && p->nh == p->nh_kv && p->D == 128 &&
-                     k.page_words % 128 == 0 && k.code_sp % 2 == 0 && k.q_sh % 2 == 0 && k.q_sb % 2 == 0 &&
-                     (uintptr_t)k.q % 4 == 0 && k.Tw % 2 == 0 && k.code_sr % 2 == 0 && k.code_sh % 2 == 0 &&
-                     k.code_sb % 2 == 0 && (uintptr_t)k.code % 8 == 0 && (uintptr_t)k.scale % 2 == 0 &&
+        const int kw = p->k_bits == 2 ? 2 : 4;   // words per lane of the qK^T mapping
+        ks.fusable = (p->k_bits == 2 || p->k_bits == 4) && p->v_bits == p->k_bits && p->group_size == 32 &&
+                     p->nh == p->nh_kv && p->D == 128 &&
+                     k.page_words % (64 * kw) == 0 && k.code_sp % kw == 0 && k.q_sh % 2 == 0 && k.q_sb % 2 == 0 &&
+                     (uintptr_t)k.q % 4 == 0 && k.Tw % kw == 0 && k.code_sr % kw == 0 && k.code_sh % kw == 0 &&
+                     k.code_sb % kw == 0 && (uintptr_t)k.code % (4 * kw) == 0 && (uintptr_t)k.scale % 2 == 0 &&
                      (uintptr_t)k.mn % 2 == 0 && (int64_t)k.D * k.code_sr * 4 < ((int64_t)1 << 31) &&
                      (int64_t)k.D * k.sm_sr * 2 < ((int64_t)1 << 31);
         rk.kside = &ks;
