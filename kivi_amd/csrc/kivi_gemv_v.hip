@@ -1084,7 +1084,8 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const int tiles = (int)((ak.Tw + 127) / 128);
             ak.res_blocks = 0;
             a.scores_lds = 1;
-            const size_t lds = (size_t)a.n_pad * sizeof(uint16_t);
+            static const char* xl = getenv("KIVI_ROW_EXTRA_LDS");   // diagnostic: fewer co-resident blocks per CU
+            const size_t lds = (size_t)a.n_pad * sizeof(uint16_t) + (xl ? (size_t)atoi(xl) : 0);
             static const char* rv = getenv("KIVI_ROW_VARIANT");   // tuning aid: K-phase shape "ds<DSPLIT>u<U>"
             static const char* rvv = getenv("KIVI_ROW_V");        // tuning aid: sV-phase shape "w<WPL>u<U>"
             const int sel = !rv ? 1 : !strcmp(rv, "ds4u4") ? 0 : !strcmp(rv, "ds2u4") ? 1 : !strcmp(rv, "ds2u8") ? 2 : !strcmp(rv, "ds4u8") ? 3 : 1;
