@@ -1025,7 +1025,8 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const KSide& ks = *a.kside;
             static const char* nofuse = getenv("KIVI_NO_ROW_FUSION");   // tuning aid
             fuse_row = !nofuse && ks.fusable && a.softmax && S == 1 && v.R == 1 && a.n_scores <= 8192 && a.rq != nullptr &&
-                       (bits == 2 || bits == 4) && G == 32 && a.D == 128 && v.mode == KIVI_UNPACK_MIX;
+                       ((bits == 2 && (G == 32 || G == 64 || G == 128)) || (bits == 4 && G == 32)) && a.D == 128 &&
+                       v.mode == KIVI_UNPACK_MIX;
             if (!fuse_row && ks.args.T > 0) {
                 const GemvKArgs& k = ks.args;
                 const int rc = kivi_gemv_k_paged(-1, ks.page_tokens, k.code_sp, k.sm_sp, k.q, k.q_sb, k.q_sh, k.code, k.code_sb,
@@ -1090,9 +1091,11 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             static const char* rvv = getenv("KIVI_ROW_V");        // tuning aid: sV-phase shape "w<WPL>u<U>"
             const int sel = !rv ? 1 : !strcmp(rv, "ds4u4") ? 0 : !strcmp(rv, "ds2u4") ? 1 : !strcmp(rv, "ds2u8") ? 2 : !strcmp(rv, "ds4u8") ? 3 : 1;
             const int selv = (rvv && !strcmp(rvv, "w2u4")) ? 1 : 0;
-            ak.tile_blocks = (selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
+            ak.tile_blocks = (G != 32 || selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
             const dim3 grid((unsigned)units);
-            if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
+            if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (G == 128) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 0) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 2) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
@@ -1318,7 +1321,8 @@ extern "C" int kivi_decode_attend(const kivi_decode_attend_args* p, kivi_stream_
         ks.page_tokens = p->k_page_tokens; ks.B = p->B; ks.nh_kv = p->nh_kv; ks.group_size = p->group_size; ks.bits = p->k_bits;
         // decode_row_kernel runs the qK^T mapping {2-bit, g=32, 2 words per lane, 4 waves split D, 4-row batches}
         const int kw = p->k_bits == 2 ? 2 : 4;   // words per lane of the qK^T mapping
-        ks.fusable = (p->k_bits == 2 || p->k_bits == 4) && p->v_bits == p->k_bits && p->group_size == 32 &&
+        ks.fusable = (p->k_bits == 2 || p->k_bits == 4) && p->v_bits == p->k_bits &&
+                     (p->group_size == 32 || (p->k_bits == 2 && (p->group_size == 64 || p->group_size == 128))) &&
                      p->nh == p->nh_kv && p->D == 128 &&
                      k.page_words % (64 * kw) == 0 && k.code_sp % kw == 0 && k.q_sh % 2 == 0 && k.q_sb % 2 == 0 &&
                      (uintptr_t)k.q % 4 == 0 && k.Tw % kw == 0 && k.code_sr % kw == 0 && k.code_sh % kw == 0 &&

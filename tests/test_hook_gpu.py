@@ -96,7 +96,8 @@ def _cmp_cache(t_gpu, t_ref):
 
 @pytest.mark.parametrize("fused_kernels", ["native", "python", False])
 @pytest.mark.parametrize("nh,nh_kv,T0,R,g,bits", [(4, 4, 70, 32, 32, 2), (8, 2, 33, 32, 32, 2), (4, 2, 5, 32, 32, 2),
-                                                   (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2), (6, 2, 40, 32, 32, 2)])
+                                                   (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2), (6, 2, 40, 32, 32, 2),
+                                                   (4, 4, 130, 64, 64, 2), (2, 2, 260, 128, 128, 2)])
 def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits, fused_kernels, monkeypatch):
     """"native": the one-call layer step (kivi_decode_layer); "python": the same launches with the bookkeeping in
     kivi_amd.attention; False: one launch per reference op."""
