@@ -154,11 +154,13 @@ def test_module_hook_prefill_then_decode():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_fused_and_composed_paths_agree_with_mask():
-    """Same inputs through the 3-launch fused step and the reference-style composition: identical cache contents,
-    outputs within fp16 rounding of each other -- including the additive attention mask branch (llama_kivi.py:364-372)."""
+@pytest.mark.parametrize("nh_kv", [4, 8])
+def test_fused_and_composed_paths_agree_with_mask(nh_kv):
+    """Same inputs through the fused step (nh_kv = 8: MHA, the one-launch decode-row kernel; nh_kv = 4: grouped queries,
+    qK^T + row softmax + shared-unpack sV) and the reference-style composition: identical cache contents, outputs
+    within fp16 rounding of each other -- including the additive attention mask branch (llama_kivi.py:364-372)."""
     from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
-    B, nh, nh_kv, D, T0, R = 2, 8, 4, 128, 100, 32
+    B, nh, D, T0, R = 2, 8, 128, 100, 32
     cfg = KiviConfig(2, 2, 32, R)
     k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
     la = KiviLayerCache(cfg, B, nh_kv, D, 256, "cuda")
