@@ -801,32 +801,44 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const RowSoftmaxArgs p
     float mx = -__builtin_inff();
     float sum = 0.f;
     if constexpr (MODE != 2) {
+        // ONE pass over the chunk: every thread keeps a running (max, sum of exp(x - max)) of its scores and rescales
+        // the sum when the max grows; the 256 pairs are then merged the same way (wave shuffles, 4 values of LDS).
         for (int j0 = lo + threadIdx.x * 4; j0 < hi; j0 += 1024) {
+            float x[4];
             if (j0 + 4 <= nvec && j0 + 4 <= hi) {
                 const u16x4 v4 = *(const u16x4*)(srow + j0);
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    mx = __builtin_fmaxf(mx, h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)));
+                    x[e] = h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (j0 + e < hi) mx = __builtin_fmaxf(mx, sval(j0 + e));
+                for (int e = 0; e < 4; e++) x[e] = (j0 + e < hi) ? sval(j0 + e) : -__builtin_inff();
             }
+            const float m4 = __builtin_fmaxf(__builtin_fmaxf(x[0], x[1]), __builtin_fmaxf(x[2], x[3]));
+            const float mn = __builtin_fmaxf(mx, m4);   // finite: every score is a finite fp16 (masked ones sit at -65504)
+            sum = sum * kivi_exp(mx - mn) + ((kivi_exp(x[0] - mn) + kivi_exp(x[1] - mn)) + (kivi_exp(x[2] - mn) + kivi_exp(x[3] - mn)));
+            mx = mn;
         }
-        mx = kivi_block_reduce(mx, true, sm_lds);
-        for (int j0 = lo + threadIdx.x * 4; j0 < hi; j0 += 1024) {
-            if (j0 + 4 <= nvec && j0 + 4 <= hi) {
-                const u16x4 v4 = *(const u16x4*)(srow + j0);
+        auto merge = [](float& m, float& l, float m2, float l2) {
+            const float mn = __builtin_fmaxf(m, m2);
+            const float a = (m == mn) ? 1.0f : kivi_exp(m - mn);      // also covers -inf - -inf (an empty side)
+            const float b = (m2 == mn) ? 1.0f : kivi_exp(m2 - mn);
+            l = l * a + l2 * b;
+            m = mn;
+        };
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    sum += kivi_exp(h2f_bits(kivi_scaled_score(v4[e], p.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0)) - mx);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (j0 + e < hi) sum += kivi_exp(sval(j0 + e) - mx);
-            }
+        for (int k = 1; k < 64; k <<= 1) merge(mx, sum, __shfl_xor(mx, k), __shfl_xor(sum, k));
+        __shared__ float ml_lds[8];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            ml_lds[threadIdx.x >> 6] = mx;
+            ml_lds[4 + (threadIdx.x >> 6)] = sum;
         }
-        sum = kivi_block_reduce(sum, false, sm_lds);
+        __syncthreads();
+        mx = ml_lds[0];
+        sum = ml_lds[4];
+#pragma unroll
+        for (int w = 1; w < 4; w++) merge(mx, sum, ml_lds[w], ml_lds[4 + w]);
     }
     if constexpr (MODE == 1) {
         if (threadIdx.x == 0) {
