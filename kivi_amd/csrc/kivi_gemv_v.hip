@@ -143,6 +143,9 @@ __device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D>& pre)
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT, bool PRE = false>
 __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW * (32 / BITS)>* pre = nullptr) {
     constexpr int FPI = 32 / BITS;
+    // R > 1 (grouped queries) and SPLIT kernels always get finished probabilities from the row-softmax launch (v_run):
+    // the in-block softmax is compiled out of them
+    constexpr bool CAN_SOFTMAX = (R == 1) && !SPLIT;
     constexpr int LPR = DW / WPL;               // lanes per token row
     static_assert(LPR >= 1 && LPR <= 16 && (LPR & (LPR - 1)) == 0, "D/fpi must be 4, 8, 16 or 32 words");
     typedef typename std::conditional<WPL == 4, u32x4, typename std::conditional<WPL == 2, u32x2, uint32_t>::type>::type WV;
@@ -258,7 +261,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * 4 + wave);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                if (!SPLIT && a.softmax) {   // probabilities produced by this block, in LDS
+                if (CAN_SOFTMAX && a.softmax) {   // probabilities produced by this block, in LDS
                     const int64_t t = (int64_t)c * TPI + lt;
                     ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
                 } else {
@@ -285,7 +288,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
     const bool do_win = a.fused && split == 0;
     const bool do_flush = do_win && a.flush && owner;
-    const bool reg_softmax = a.softmax;
+    const bool reg_softmax = CAN_SOFTMAX && a.softmax;
     const int n_sc = a.n_scores;
     const int nch_sc = (n_sc + 1023) / 1024;
     // (a) row 0 of the register-resident softmax: the part of the score row that is already in memory
@@ -340,7 +343,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     else if (do_flush && (int)threadIdx.x < D)
         xflush = a.vres[b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st + threadIdx.x];
 
-    if (a.softmax) {
+    if (reg_softmax) {
         // scale + mask + softmax of this block's R score rows, the arithmetic of kivi_softmax_scaled (same element ->
         // thread assignment and reduction tree, so the probabilities are bit-identical to the stand-alone kernel).
         // The whole row (<= 8192 scores) is fetched with up to 8 independent 8-byte loads per thread: one L2 round trip.
@@ -469,7 +472,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             float at[R];
 #pragma unroll
             for (int r = 0; r < R; r++)
-                at[r] = h2f_bits(!a.softmax ? a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]
+                at[r] = h2f_bits(!reg_softmax ? a.a[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tv + t]
                                  : pl[(size_t)r * a.n_pad + a.Tv + t]);
 #pragma unroll
             for (int c = 0; c < NP; c++) {
@@ -958,6 +961,9 @@ const VVariant v_variants[] = {
     VV(4, 32, 16, 4, 1, 4, 0, 0),
     // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
     VV(2, 32, 8, 2, 4, 2, 4, 1),
+    VV(2, 32, 8, 1, 4, 2, 4, 1),
+    VV(2, 32, 8, 1, 4, 1, 4, 1),
+    VV(2, 32, 8, 2, 4, 1, 4, 1),
     VV(2, 32, 8, 1, 4, 4, 4, 1),
     VV(2, 32, 8, 1, 8, 4, 4, 1),
     VV(2, 32, 8, 1, 4, 8, 4, 1),
