@@ -495,15 +495,25 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             const int t = wave + 4 * k;
             if (t < Lw) win_tok(t, vpre[k]);
         }
-        for (int t = wave + 4 * PWT; t < Lw; t += 4) {
-            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
-            uint32_t vv_c[NP];
+        // longer windows (residual_length 64 / 128): PWT rows per round, all their loads in flight together
+        constexpr int PW2 = (R >= 4) ? 4 : PWT;   // the R x EPL accumulators of the grouped-query kernels leave fewer registers
+        for (int k0 = PWT; wave + 4 * k0 < Lw; k0 += PW2) {
+            uint32_t vb[PW2][NP];
 #pragma unroll
-            for (int c = 0; c < NP; c++) {
-                const int p = lane + 64 * c;
-                vv_c[c] = (p < D / 2) ? *(const uint32_t*)(vrow + 2 * p) : 0u;
+            for (int k = 0; k < PW2; k++) {
+                const int t = wave + 4 * (k0 + k);
+                const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+#pragma unroll
+                for (int c = 0; c < NP; c++) {
+                    const int p = lane + 64 * c;
+                    vb[k][c] = (t < Lw && p < D / 2) ? *(const uint32_t*)(vrow + 2 * p) : 0u;
+                }
             }
-            win_tok(t, vv_c);
+#pragma unroll
+            for (int k = 0; k < PW2; k++) {
+                const int t = wave + 4 * (k0 + k);
+                if (t < Lw) win_tok(t, vb[k]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; r++)
