@@ -277,3 +277,34 @@ def test_decoder_wrapper_graphed_decode_equals_eager():
     b = model.generate_graphed(ids, 45)
     assert a.shape == b.shape == (2, 82)
     assert bool((a == b).all()), (a != b).nonzero()[:4]
+
+
+def test_full_size_row_kernel_vs_two_launch_path(monkeypatch):
+    """BASELINE config C2 at full size (B=32, 32 heads, 4096-token cache, 2-bit, g=32, R=32): the one-launch decode-row
+    kernel against the same step done with the stand-alone qK^T and attend launches (different summation order in the
+    qK^T phase only): outputs within fp16 rounding, cache contents bit-identical, probabilities sum to one."""
+    import kivi_amd.attention as A
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    B, nh, D, T0, R = 32, 32, 128, 4096, 32
+    cfg = KiviConfig(2, 2, 32, R)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    k0 = torch.randn((B, nh, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+    v0 = torch.randn((B, nh, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+    la = KiviLayerCache(cfg, B, nh, D, T0 + 40, "cuda")
+    lb = KiviLayerCache(cfg, B, nh, D, T0 + 40, "cuda")
+    for lc in (la, lb):
+        lc.prefill(k0, v0)
+    del k0, v0
+    for s in range(34):     # crosses a K flush (every 32 tokens) and a window compaction
+        q = torch.randn((B, nh, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        kn = torch.randn((B, nh, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        vn = torch.randn((B, nh, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        monkeypatch.setattr(A, "_NATIVE_STEP", True)
+        oa = kivi_attention_decode(q, kn, vn, la)
+        monkeypatch.setattr(A, "_NATIVE_STEP", False)     # Python bookkeeping: gemv_k_paged + kivi_decode_attend
+        ob = kivi_attention_decode(q, kn, vn, lb)
+        ok, ratio = gemv_close(oa, ob.cpu(), rtol=3e-3)   # hook bar; worst of 131k outputs per step (1-ulp score flips)
+        assert ok, (s, ratio)
+    for x, y in zip(la.as_tuple()[:8], lb.as_tuple()[:8]):
+        assert (x is None) == (y is None) and (x is None or same_bits(x, y))
+    assert la.as_tuple()[8] == lb.as_tuple()[8] == T0 + 34
