@@ -1071,11 +1071,14 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             rp.kres = a.rkres; rp.k_sb = a.rk_sb; rp.k_sh = a.rk_sh; rp.k_st = a.rk_st;
             rp.knew = a.rknew; rp.kn_sb = a.rkn_sb; rp.kn_sh = a.rkn_sh;
             rp.rk_len = a.rk_len; rp.ratio = a.ratio; rp.nh = a.nh; rp.D = a.D;
-            // long rows: P blocks per row so that ~4096 blocks of >= 2048 scores share the work
+            // few rows: P blocks per row so that ~2048 blocks of >= 2048 scores share the work (measured: 2048 rows of
+            // 8k scores run best as one launch of whole rows, 512 rows of 32k as 4 chunks, 32 rows as 16)
             const int64_t rows = (int64_t)B * a.nh;
-            int P = (int)((4096 + rows - 1) / rows);
+            int P = (int)((2048 + rows - 1) / rows);
             if (P > a.n_scores / 2048) P = a.n_scores / 2048;
             if (P > 64) P = 64;
+            static const char* fp = getenv("KIVI_SOFTMAX_P");   // tuning aid: blocks per row of the row softmax
+            if (fp) P = atoi(fp);
             const size_t part_bytes = ((size_t)rows * (P > 0 ? P : 1) * 2 * sizeof(float) + 255) / 256 * 256;
             if (P >= 2 && a.ws && part_bytes + (size_t)units * (S + 1) * v.R * a.D * sizeof(float) <= a.ws_bytes) {
                 rp.P = P;
