@@ -215,6 +215,7 @@ def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, 
     Mutates `layer` in place and returns attn_output (B, nh, 1, D) fp16 (before the o_proj transpose).
     `fused_kernels=False` forces the reference-style composition (one launch per reference op).
     `out`: optional preallocated (B, nh, 1, D) fp16 result buffer (static buffers of graph-captured callers)."""
+    layer.ensure_room(1)     # the reference's tuple grows without bound; the in-place cache doubles when it is full
     res = _attention_decode(query_states, key_states, value_states, layer, attention_mask, fused_kernels, out)
     if out is not None and res is not out:
         out.copy_(res)

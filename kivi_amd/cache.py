@@ -102,6 +102,38 @@ class KiviLayerCache:
         self.v_res_len = 0     # tokens in the fp16 V window (<= R between steps)
         self.kv_seq_len = 0
 
+    # ------------------------------------------------------------------ capacity
+    def reserve(self, max_len: int) -> None:
+        """Grow the capacity to at least `max_len` tokens (the reference's torch.cat-grown tuple has no limit,
+        llama_kivi.py:350-352, :393-395): new page / row buffers, the live contents copied once.  Scratch buffers and the
+        cached native descriptor of the attention hook are dropped and rebuilt on the next step."""
+        R = self.cfg.residual_length
+        cap = ((max_len + R - 1) // R) * R
+        if cap <= self.cap:
+            return
+        n_pages = (cap + self.page_tokens - 1) // self.page_tokens
+
+        def grown(x, dim, n):
+            shape = list(x.shape)
+            shape[dim] = n
+            y = torch.empty(shape, dtype=x.dtype, device=x.device)
+            y.narrow(dim, 0, x.shape[dim]).copy_(x)
+            return y
+        if n_pages > self.n_pages:
+            self.k_code, self.k_scale, self.k_mn = (grown(x, 2, n_pages) for x in (self.k_code, self.k_scale, self.k_mn))
+            self.n_pages = n_pages
+        self.v_code, self.v_scale, self.v_mn = (grown(x, 2, cap) for x in (self.v_code, self.v_scale, self.v_mn))
+        self.cap = cap
+        for name in ("_native", "_scores", "_probs"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def ensure_room(self, tokens: int = 1) -> None:
+        """Make room for `tokens` more tokens, doubling the capacity when it runs out (amortised O(1) copies)."""
+        need = self.kv_seq_len + tokens
+        if need > self.cap:
+            self.reserve(max(need, 2 * self.cap))
+
     # ------------------------------------------------------------------ the 9-tuple
     def k_quant_reference_layout(self):
         """(K_code_T, K_scale_T, K_mn_T) in the reference layout (B, nh_kv, D, Tq/...): gathers the pages (a copy)."""
@@ -170,7 +202,7 @@ class KiviLayerCache:
         cfg = self.cfg
         R, g = cfg.residual_length, cfg.group_size
         T = key_states.shape[2]
-        assert T <= self.cap, f"prompt of {T} tokens exceeds the cache capacity {self.cap}"
+        self.reserve(T)
         nq = (T // R) * R                      # quantised K prefix, fp16 remainder T % R
         if nq:
             self._quantise_k(key_states[:, :, :nq], 0)

@@ -308,3 +308,26 @@ def test_full_size_row_kernel_vs_two_launch_path(monkeypatch):
     for x, y in zip(la.as_tuple()[:8], lb.as_tuple()[:8]):
         assert (x is None) == (y is None) and (x is None or same_bits(x, y))
     assert la.as_tuple()[8] == lb.as_tuple()[8] == T0 + 34
+
+
+def test_cache_grows_past_its_initial_capacity():
+    """The reference's tuple grows without bound; the in-place cache doubles its capacity when it runs out.  A cache that
+    starts too small must give bit-identical outputs and contents to one that was big from the start."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    B, nh, nh_kv, D, T0, R = 2, 4, 4, 128, 60, 32
+    cfg = KiviConfig(2, 2, 32, R)
+    k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
+    small = KiviLayerCache(cfg, B, nh_kv, D, T0 + 2, "cuda")       # capacity 64 tokens
+    big = KiviLayerCache(cfg, B, nh_kv, D, 4096, "cuda")
+    for lc in (small, big):
+        lc.prefill(k0.cuda(), v0.cuda())
+    cap0 = small.cap
+    for s in range(150):
+        q = make_kv(100 + s, B, nh, 1, D).cuda()
+        kn, vn = make_kv(200 + s, B, nh_kv, 1, D).cuda(), make_kv(300 + s, B, nh_kv, 1, D).cuda()
+        oa = kivi_attention_decode(q, kn, vn, small)
+        ob = kivi_attention_decode(q, kn, vn, big)
+        assert same_bits(oa, ob), s
+    assert small.cap > cap0 and small.kv_seq_len == big.kv_seq_len == T0 + 150
+    for x, y in zip(small.as_tuple()[:8], big.as_tuple()[:8]):
+        assert (x is None) == (y is None) and (x is None or same_bits(x, y))
