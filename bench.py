@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference-style composition (one launch per reference op)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the K-GEMV launches with HIP events")
-    ap.add_argument("--event-every", type=int, default=9, help="bracket every n-th qK^T dispatch of the timed region")
+    ap.add_argument("--event-every", type=int, default=9, help="bracket the dominant kernel of every n-th layer step of the timed region")
     args = ap.parse_args()
 
     rank, world, local, dist = dist_setup(args.gpus)
@@ -225,7 +225,7 @@ def main():
                     "kernel": ("decode_row_kernel (one launch per layer: packed qK^T of the row -> LDS scores -> residual "
                                "scores + softmax + window + packed sV + cache update)" if row_fused
                                else "gemv_k_kernel (fused int2 qK^T over packed K)"), "launches": len(us),
-                    "sampled": f"every {args.event_every}th qK^T dispatch of the timed region (an event pair costs ~10 us of stream time)",
+                    "sampled": f"every {args.event_every}th layer step of the timed region (an event pair costs ~10 us of stream time)",
                     "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min(us), 2),
                     "algorithmic_bytes_per_launch": tot_bytes // len(us),
                     "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
