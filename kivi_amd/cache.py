@@ -23,6 +23,8 @@ Cache policy (llama_kivi.py:343-356, 386-399, 425-452):
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -85,10 +87,12 @@ class KiviLayerCache:
         self.n_pages = (self.cap + page_tokens - 1) // page_tokens
         kf, vf = 32 // cfg.k_bits, 32 // cfg.v_bits
         dev = device
-        self.k_code = torch.empty((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // kf), dtype=torch.int32,
-                                  device=dev)
-        self.k_scale = torch.empty((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // g), dtype=dtype, device=dev)
-        self.k_mn = torch.empty_like(self.k_scale)
+        # logical shape (B, nh_kv, P, D, page/fpi); in MEMORY the page index is outside the head index, so the pages in
+        # use form one dense region and the spare capacity sits behind it (with the head index outside, every head's
+        # unused pages would punch 64 KiB holes into the streamed range)
+        self.k_code = self._paged((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // kf), torch.int32, dev)
+        self.k_scale = self._paged((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // g), dtype, dev)
+        self.k_mn = self._paged((batch, num_kv_heads, self.n_pages, head_dim, page_tokens // g), dtype, dev)
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=dev)
         self.v_code = torch.empty((batch, num_kv_heads, self.cap, head_dim // vf), dtype=torch.int32, device=dev)
         self.v_scale = torch.empty((batch, num_kv_heads, self.cap, head_dim // g), dtype=dtype, device=dev)
@@ -101,6 +105,13 @@ class KiviLayerCache:
         self.v_res_start = 0
         self.v_res_len = 0     # tokens in the fp16 V window (<= R between steps)
         self.kv_seq_len = 0
+
+    @staticmethod
+    def _paged(shape, dtype, device) -> torch.Tensor:
+        B, h, P, D, W = shape
+        if os.environ.get("KIVI_K_HEAD_MAJOR"):   # tuning aid: the plain (B, nh_kv, P, ...) memory order
+            return torch.empty(shape, dtype=dtype, device=device)
+        return torch.empty((B, P, h, D, W), dtype=dtype, device=device).permute(0, 2, 1, 3, 4)
 
     # ------------------------------------------------------------------ capacity
     def reserve(self, max_len: int) -> None:
@@ -120,7 +131,11 @@ class KiviLayerCache:
             y.narrow(dim, 0, x.shape[dim]).copy_(x)
             return y
         if n_pages > self.n_pages:
-            self.k_code, self.k_scale, self.k_mn = (grown(x, 2, n_pages) for x in (self.k_code, self.k_scale, self.k_mn))
+            def grown_pages(x):
+                y = self._paged((x.shape[0], x.shape[1], n_pages, x.shape[3], x.shape[4]), x.dtype, x.device)
+                y[:, :, : x.shape[2]].copy_(x)
+                return y
+            self.k_code, self.k_scale, self.k_mn = (grown_pages(x) for x in (self.k_code, self.k_scale, self.k_mn))
             self.n_pages = n_pages
         self.v_code, self.v_scale, self.v_mn = (grown(x, 2, cap) for x in (self.v_code, self.v_scale, self.v_mn))
         self.cap = cap
