@@ -113,3 +113,29 @@ def test_decoder_wrapper_uses_hf_parameter_names():
     assert m.model.layers[0].self_attn.k_proj.weight.shape == (128, 256)
     with __import__("pytest").raises(Exception):   # no CPU fallback: the forward pass needs the HIP path
         m(torch.zeros((1, 4), dtype=torch.long))
+
+
+def test_cache_reserve_keeps_contents_and_page_layout():
+    """KiviLayerCache.reserve (host logic, no kernels): bigger buffers, live contents bit-identical, K pages keep the
+    page-outside-head memory order."""
+    import torch
+    from kivi_amd.cache import KiviConfig, KiviLayerCache
+    cfg = KiviConfig(2, 2, 32, 32)
+    lc = KiviLayerCache(cfg, 2, 3, 128, 100, "cpu", page_tokens=64)
+    assert lc.cap == 128 and lc.n_pages == 2
+    g = torch.Generator().manual_seed(0)
+    for name in ("k_code", "v_code"):
+        getattr(lc, name).copy_(torch.randint(-2**31, 2**31 - 1, getattr(lc, name).shape, generator=g, dtype=torch.int64).int())
+    for name in ("k_scale", "k_mn", "v_scale", "v_mn", "k_res", "v_res"):
+        getattr(lc, name).copy_(torch.randn(getattr(lc, name).shape, generator=g).half())
+    before = {n: getattr(lc, n).clone() for n in ("k_code", "k_scale", "k_mn", "v_code", "v_scale", "v_mn", "k_res", "v_res")}
+    lc.kv_seq_len = 128
+    lc.ensure_room(1)
+    assert lc.cap == 256 and lc.n_pages == 4
+    assert torch.equal(lc.k_code[:, :, :2], before["k_code"]) and torch.equal(lc.k_scale[:, :, :2], before["k_scale"])
+    assert torch.equal(lc.k_mn[:, :, :2], before["k_mn"]) and torch.equal(lc.v_code[:, :, :128], before["v_code"])
+    assert torch.equal(lc.v_scale[:, :, :128], before["v_scale"]) and torch.equal(lc.v_mn[:, :, :128], before["v_mn"])
+    assert torch.equal(lc.k_res, before["k_res"]) and torch.equal(lc.v_res, before["v_res"])
+    assert lc.k_code.stride(2) == 3 * lc.k_code.stride(1)      # page stride = nh_kv head slabs: pages outside heads
+    lc.reserve(10)                                             # never shrinks
+    assert lc.cap == 256
