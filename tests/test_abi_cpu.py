@@ -139,3 +139,18 @@ def test_cache_reserve_keeps_contents_and_page_layout():
     assert lc.k_code.stride(2) == 3 * lc.k_code.stride(1)      # page stride = nh_kv head slabs: pages outside heads
     lc.reserve(10)                                             # never shrinks
     assert lc.cap == 256
+
+
+def test_decoder_wrapper_accepts_a_patched_hf_config():
+    """The reference's usage (README.md:72-75): an HF LlamaConfig with k_bits / v_bits / group_size / residual_length
+    patched on goes straight into the model class."""
+    pytest = __import__("pytest")
+    transformers = pytest.importorskip("transformers")
+    from kivi_amd.llama import LlamaForCausalLM_KIVI
+    cfg = transformers.LlamaConfig(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, num_hidden_layers=1,
+                                   intermediate_size=512, vocab_size=64)
+    cfg.k_bits, cfg.v_bits, cfg.group_size, cfg.residual_length = 2, 2, 32, 32
+    m = LlamaForCausalLM_KIVI(cfg)
+    att = m.model.layers[0].self_attn
+    assert (att.k_bits, att.v_bits, att.group_size, att.residual_length) == (2, 2, 32, 32)
+    assert att.num_key_value_heads == 1 and att.head_dim == 128
