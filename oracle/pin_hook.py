@@ -6,7 +6,8 @@ TEST INFRASTRUCTURE ONLY; needs /root/reference (build container), never runs on
 models/llama_kivi.py cannot be imported as a module in this container (its star-imports expect the transformers 4.43
 API; flash-attn and the CUDA extension are absent).  The two attention classes themselves are plain torch, so this
 script takes their SOURCE TEXT from the reference file (ast, unmodified: LlamaAttention_KIVI :19-262 and
-LlamaFlashAttention_KIVI :264-466) and executes it in a namespace where only the environment is shimmed:
+LlamaFlashAttention_KIVI :264-466; and from models/mistral_kivi.py: repeat_kv_quant :58-67, MistralAttention_KIVI :69-309,
+MistralFlashAttention_KIVI :312-534) and executes it in a namespace where only the environment is shimmed:
   * triton_quantize_and_pack_along_last_dim -> the reference's own pure-PyTorch quant_and_pack_vcache
     (quant/new_pack.py:30-48; same arithmetic op for op, SURVEY section 8 a4) imported from /root/reference;
   * cuda_bmm_fA_qB_outer -> the C oracle's restatement of the CUDA kernel (oracle/kivi_oracle.c);
@@ -17,13 +18,25 @@ hook_ref.prefill_cache / decode_step; the 9-tuples must agree BIT FOR BIT after 
 flush conditions, quantised contents) and the step outputs within 2e-3 of max(|ref|, rms(row)) (CPU half matmul vs the
 restatement's fp32 matmul differ in accumulation / intermediate rounding only).  The reference's outputs and final tuples are
 written to tests/golden/hook_*.npz for the CPU and GPU test suites.
+
+    python oracle/pin_hook.py            # regenerate the fixtures (byte-stable: same seeds -> same files)
+    python oracle/pin_hook.py --check    # verify only: re-run the reference classes and compare every array with the
+                                         # committed fixtures, writing nothing
+
+Seeds are zlib.crc32(case name) (the built-in hash() is randomised per process); the .npz members are written
+uncompressed-deterministic (fixed zip timestamps, sorted keys), so regenerating on the same torch build reproduces the
+committed bytes.
 """
+import argparse
 import ast
 import importlib.util
+import io
 import math
 import os
 import sys
 import warnings
+import zipfile
+import zlib
 from types import SimpleNamespace
 from typing import List, Optional, Tuple
 
@@ -63,18 +76,35 @@ def load_reference_classes():
         def forward(self, x, position_ids):
             return None, None
 
-    src = open(os.path.join(REF, "models", "llama_kivi.py")).read()
-    tree = ast.parse(src)
-    ns = dict(math=math, warnings=warnings, torch=torch, F=F, nn=nn, List=List, Optional=Optional, Tuple=Tuple,
-              LlamaConfig=SimpleNamespace, LlamaRotaryEmbedding=LlamaRotaryEmbedding,
-              apply_rotary_pos_emb=lambda q, k, cos, sin, position_ids=None: (q, k), repeat_kv=repeat_kv,
-              triton_quantize_and_pack_along_last_dim=pack_stub,
-              cuda_bmm_fA_qB_outer=lambda g, fA, qB, s, z, bits: O.bmm_fA_qB_outer(g, fA, qB, s, z, bits),
-              logger=SimpleNamespace(warning_once=lambda *a, **k: None))
-    for node in tree.body:
-        if isinstance(node, ast.ClassDef) and node.name in ("LlamaAttention_KIVI", "LlamaFlashAttention_KIVI"):
-            exec(compile(ast.get_source_segment(src, node), f"<reference models/llama_kivi.py:{node.lineno}>", "exec"), ns)
-    return ns["LlamaAttention_KIVI"], ns["LlamaFlashAttention_KIVI"]
+    def repeat_kv_any(hidden_states, n_rep):
+        return repeat_kv(hidden_states, n_rep)
+
+    class MistralRotaryEmbedding(nn.Module):      # identity rotary (MistralRotaryEmbedding(dim, max_position_embeddings=, base=))
+        def __init__(self, dim=None, max_position_embeddings=2048, base=10000, device=None):
+            super().__init__()
+
+        def forward(self, x, seq_len=None):
+            return None, None
+
+    out = {}
+    for fname, wanted in (("llama_kivi.py", ("LlamaAttention_KIVI", "LlamaFlashAttention_KIVI")),
+                          ("mistral_kivi.py", ("repeat_kv_quant", "MistralAttention_KIVI", "MistralFlashAttention_KIVI"))):
+        src = open(os.path.join(REF, "models", fname)).read()
+        tree = ast.parse(src)
+        ns = dict(math=math, warnings=warnings, torch=torch, F=F, nn=nn, List=List, Optional=Optional, Tuple=Tuple,
+                  LlamaConfig=SimpleNamespace, MistralConfig=SimpleNamespace, LlamaRotaryEmbedding=LlamaRotaryEmbedding,
+                  MistralRotaryEmbedding=MistralRotaryEmbedding,
+                  apply_rotary_pos_emb=lambda q, k, cos, sin, position_ids=None: (q, k), repeat_kv=repeat_kv,
+                  triton_quantize_and_pack_along_last_dim=pack_stub,
+                  cuda_bmm_fA_qB_outer=lambda g, fA, qB, s, z, bits: O.bmm_fA_qB_outer(g, fA, qB, s, z, bits),
+                  logger=SimpleNamespace(warning_once=lambda *a, **k: None))
+        for node in tree.body:
+            if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in wanted:
+                exec(compile(ast.get_source_segment(src, node), f"<reference models/{fname}:{node.lineno}>", "exec"), ns)
+        for n in wanted:
+            out[n] = ns[n]
+    return {"eager": out["LlamaAttention_KIVI"], "flash": out["LlamaFlashAttention_KIVI"],
+            "mistral_eager": out["MistralAttention_KIVI"], "mistral_flash": out["MistralFlashAttention_KIVI"]}
 
 
 def same_bits(a, b):
@@ -99,21 +129,51 @@ CASES = [
     ("flash_gqa_b2_r32_mask", "flash", 2, 8, 2, 128, 2, 32, 32, 33, 36, True),
     ("flash_mha_b4_g64_r64_short", "flash", 1, 2, 2, 128, 4, 64, 64, 5, 70, False),
     ("flash_gqa_b2_r128", "flash", 1, 8, 2, 128, 2, 32, 128, 300, 8, True),
+    # the reference's Mistral hook (models/mistral_kivi.py:69-534: repeat_kv_quant copies of codes / scale / mn into the
+    # fused GEMV instead of the kernel's own head mapping; config carries sliding_window, which the hook never applies):
+    # Mistral-7B head ratio (4 query heads per kv head), R = 128, across a K flush
+    ("mistral_flash_gqa4_r128", "mistral_flash", 1, 8, 2, 128, 2, 32, 128, 300, 90, False),
+    ("mistral_eager_gqa4_r32_mask", "mistral_eager", 2, 4, 1, 128, 2, 32, 32, 40, 36, True),
 ]
 
 
-def run_case(classes, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps, masked):
-    torch.manual_seed(abs(hash(name)) % 10000)
+def save_npz_stable(path, rec):
+    """np.savez_compressed with fixed member order and zip timestamps: identical arrays -> identical bytes."""
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as zf:
+        for key in sorted(rec):
+            buf = io.BytesIO()
+            np.lib.format.write_array(buf, np.ascontiguousarray(rec[key]), allow_pickle=False)
+            info = zipfile.ZipInfo(key + ".npy", date_time=(1980, 1, 1, 0, 0, 0))
+            info.compress_type = zipfile.ZIP_DEFLATED
+            info.external_attr = 0o644 << 16
+            zf.writestr(info, buf.getvalue(), compresslevel=6)
+
+
+def check_npz(path, rec):
+    """Every array of `rec` must equal the committed fixture bit for bit (and the fixture must hold nothing else)."""
+    if not os.path.exists(path):
+        raise SystemExit(f"--check: {path} is missing")
+    z = np.load(path)
+    if sorted(z.files) != sorted(rec):
+        raise SystemExit(f"--check: {path}: members differ: {sorted(set(z.files) ^ set(rec))}")
+    for key in rec:
+        a, b = np.ascontiguousarray(rec[key]), z[key]
+        if a.shape != b.shape or a.dtype != b.dtype or a.tobytes() != b.tobytes():
+            raise SystemExit(f"--check: {path}: array {key!r} differs from what the reference classes produce now")
+
+
+def run_case(classes, check, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps, masked):
+    torch.manual_seed(zlib.crc32(name.encode()) % 100003)
     hidden = nh * D
     cfg = SimpleNamespace(attention_dropout=0.0, hidden_size=hidden, num_attention_heads=nh, num_key_value_heads=nh_kv,
                           max_position_embeddings=4096, rope_theta=10000.0, k_bits=bits, v_bits=bits, group_size=g,
-                          residual_length=R, use_flash=True, attention_bias=False, pretraining_tp=1)
-    mod = (classes[0] if kind == "eager" else classes[1])(cfg).half()
+                          residual_length=R, use_flash=True, attention_bias=False, pretraining_tp=1, sliding_window=4096)
+    mod = classes[kind](cfg).half()
     with torch.no_grad():
         mod.o_proj.weight.copy_(torch.eye(hidden))
         for lin in (mod.q_proj, mod.k_proj, mod.v_proj):
             lin.weight.copy_(torch.randn_like(lin.weight.float()) * hidden ** -0.5)
-    if kind == "flash":   # the prompt pass goes through flash-attn in the reference; its output is not cache state
+    if kind.endswith("flash"):   # the prompt pass goes through flash-attn in the reference; its output is not cache state
         mod._flash_attention_forward = lambda q, k, v, m, ql, dropout=0.0, softmax_scale=None: torch.zeros_like(q)
 
     def qkv(h):
@@ -127,9 +187,10 @@ def run_case(classes, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps, masked
     with torch.no_grad():
         h0 = torch.randn(B, T0, hidden).half()
         causal = None
-        if kind == "eager":
+        if kind.endswith("eager"):
             causal = torch.full((T0, T0), torch.finfo(torch.float16).min).triu(1)[None, None].expand(B, 1, T0, T0).half()
-        _, _, past_ref = mod(h0, attention_mask=causal, past_key_value=None, use_cache=True)
+        pos0 = torch.arange(T0)[None].expand(B, T0)       # the Mistral flash class reads position_ids[:, -1]
+        _, _, past_ref = mod(h0, attention_mask=causal, position_ids=pos0, past_key_value=None, use_cache=True)
         q0, k0, v0 = qkv(h0)
         past = H.prefill_cache(k0, v0, bits, bits, g, R)
         for i, (a, b) in enumerate(zip(past_ref[:8], past[:8])):
@@ -145,7 +206,8 @@ def run_case(classes, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps, masked
             if masked:
                 mask = torch.zeros(B, 1, 1, kv_len, dtype=torch.float16)
                 mask[0, :, :, : min(3 + 2 * s, kv_len - 1)] = torch.finfo(torch.float16).min
-            out_ref, _, past_ref = mod(h, attention_mask=mask, past_key_value=past_ref, use_cache=True)
+            out_ref, _, past_ref = mod(h, attention_mask=mask, position_ids=torch.full((B, 1), kv_len - 1),
+                                       past_key_value=past_ref, use_cache=True)
             out_ref = out_ref.view(B, 1, nh, D).transpose(1, 2)           # o_proj is the identity
             q, k, v = qkv(h)
             out, past = H.decode_step(q, k, v, past, bits, bits, g, R, attention_mask=mask)
@@ -167,15 +229,22 @@ def run_case(classes, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps, masked
             rec["final_" + n] = t.contiguous().numpy()
     rec["final_len"] = np.array([past_ref[8]], dtype=np.int64)
     path = os.path.join(ROOT, "tests", "golden", f"hook_{name}.npz")
-    np.savez_compressed(path, **rec)
+    if check:
+        check_npz(path, rec)
+    else:
+        save_npz_stable(path, rec)
     print(f"{name:32s} OK  {steps} steps, tuples bit-identical after every step, outputs within {worst:.2f} x the 2e-3 bar; "
-          f"{os.path.getsize(path) / 1024:.0f} KiB")
+          f"{'fixture verified' if check else 'fixture written'} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true", help="verify the committed fixtures, write nothing")
+    args = ap.parse_args()
+    torch.set_num_threads(1)          # fp16 CPU matmul reduction order must not depend on the host's core count
     classes = load_reference_classes()
     for case in CASES:
-        run_case(classes, *case)
+        run_case(classes, args.check, *case)
 
 
 if __name__ == "__main__":
