@@ -237,8 +237,12 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  * in place at the end of the prefix), the V flush of the token leaving the window (:386-399), window compaction.
  * Stateless: the descriptor names the caller's buffers (all device memory, layouts as in kivi_gemv_k_paged /
  * kivi_decode_attend; `scores` = (B, nh, s_pitch) fp16 scratch rows), `state` = {k_quant_len, k_res_len, v_quant_len,
- * v_win_start, v_res_len, kv_seq_len} is read and, on success, advanced.  KIVI_EUNSUPPORTED = no tuned kernel for the
- * shape, state untouched (except a completed window compaction): compose the step from the entry points above.
+ * v_win_start, v_res_len, kv_seq_len} is read and advanced.  KIVI_EUNSUPPORTED = no tuned kernel for the shape, state
+ * untouched (except a completed window compaction): compose the step from the entry points above.
+ * Failure atomicity: every argument the K flush could reject is validated before the first launch, so an argument
+ * error never leaves a half-done step; `state` is written after each phase that has been enqueued (window compaction,
+ * attend launch, K flush).  If the K flush LAUNCH itself fails after the attend launch was enqueued, the state reads
+ * k_res_len == residual_length ("flush pending") and the next call performs that flush first.
  */
 typedef struct {
     int B, nh_kv, D, k_bits, v_bits, group_size, residual_length;

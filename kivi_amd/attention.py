@@ -26,6 +26,7 @@ from .quant import fused
 from .quant.matmul import cuda_bmm_fA_qB_outer, gemv_k_paged
 
 __all__ = ["kivi_attention_decode", "kivi_attention_prefill", "LlamaAttention_KIVI", "LlamaFlashAttention_KIVI",
+           "MistralAttention_KIVI", "MistralFlashAttention_KIVI",
            "KiviConfig", "KiviLayerCache"]
 
 
@@ -142,11 +143,12 @@ def _decode_native(query_states, key_states, value_states, layer: KiviLayerCache
     rc = fn(ctypes.byref(d), state, q.data_ptr(), q.stride(0), q.stride(1), nh, k.data_ptr(), k.stride(0), k.stride(1),
             v.data_ptr(), v.stride(0), v.stride(1), mask_ptr, mask_sb, out.data_ptr(), out.stride(0), out.stride(1),
             torch.cuda.current_stream(q.device).cuda_stream)
-    layer.v_res_start = state[3]          # a window compaction is committed even when the step is refused
+    # the library writes `state` after every phase it has enqueued (a refused step leaves it untouched apart from a
+    # completed window compaction), so the lengths are read back whether or not the call succeeded
+    layer.k_quant_len, layer.k_res_len, layer.v_quant_len = state[0], state[1], state[2]
+    layer.v_res_start, layer.v_res_len, layer.kv_seq_len = state[3], state[4], state[5]
     if rc:
         _lib.check(rc, "kivi_decode_layer")
-    layer.k_quant_len, layer.k_res_len, layer.v_quant_len = state[0], state[1], state[2]
-    layer.v_res_len, layer.kv_seq_len = state[4], state[5]
     return out
 
 
@@ -173,18 +175,21 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
         layer._softmax_unfusable = True
     if not getattr(layer, "_attend_unfusable", False):
         # two launches: packed qK^T GEMV (:324), then residual scores + K append + softmax + output + V append/flush
+        # only the launches that may be refused sit inside the try (they write scratch rows until the attend launch
+        # runs); the bookkeeping follows once they have been enqueued
         try:
             if layer.k_quant_len:
                 gemv_k_paged(cfg.group_size, query_states, layer.k_code, layer.k_scale, layer.k_mn, layer.k_quant_len,
                              cfg.k_bits, out=scores[..., : layer.k_quant_len])
             flushed = fused.decode_attend(layer, query_states, key_states, value_states, scores, out, inv, attention_mask)
-            layer.k_res_len += 1
-            layer.maybe_flush_k()                                          # :343-356
         except KiviUnsupported:
             layer._attend_unfusable = True       # e.g. rows too long for the LDS: use the three-launch form below
+        else:
+            layer.k_res_len += 1
+            layer.maybe_flush_k()                                          # :343-356
     if flushed is None:
         fused.decode_scores(layer, query_states, key_states, scores)      # :323-337 (+ the K append of :333-336)
-        layer.k_res_len += 1
+        layer.k_res_len += 1                     # committed: the launch above appended the key
         layer.maybe_flush_k()                                              # :343-356
         if not getattr(layer, "_softmax_unfusable", False):
             try:   # scale + mask + softmax (:339, :364-375) inside the sV launch (:377-399)
@@ -245,10 +250,10 @@ def _attention_decode(query_states, key_states, value_states, layer: KiviLayerCa
 
     # ---- scores over [quantised K prefix | fp16 K residual]  (:323-341)
     Tq = layer.k_quant_len
-    layer.append_k(key_states)                                           # :333-336
     scores = _scores_buffer(layer, nh, kv_seq_len)
-    if Tq:   # :324, reading the K pages in place and writing straight into the scores buffer
+    if Tq:   # :324, reading the K pages in place and writing straight into the scores buffer (scratch: may still raise)
         gemv_k_paged(g, query_states, layer.k_code, layer.k_scale, layer.k_mn, Tq, cfg.k_bits, out=scores[..., :Tq])
+    layer.append_k(key_states)                                           # :333-336
     k_full = layer.k_res_view()                                          # (B, nh_kv, L, D)
     att_qkfull = torch.matmul(query_states.reshape(B, nh_kv, rep, D), k_full.transpose(2, 3))  # :337 (repeat_kv folded)
     scores[..., Tq:].copy_(att_qkfull.view(B, nh, 1, -1))
@@ -292,6 +297,31 @@ def _rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
+def _rope_inv_freq(config, head_dim: int, theta: float) -> torch.Tensor:
+    """Rotary frequencies incl. config.json's rope_scaling (the reference delegates RoPE to HF's rotary_emb,
+    llama_kivi.py:52, which honours it): default, "linear" and Llama-3.1's "llama3" are implemented; anything else
+    raises instead of decoding with silently wrong positions."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    rs = getattr(config, "rope_scaling", None)
+    if not rs:
+        return inv_freq
+    rs = dict(rs) if not isinstance(rs, dict) else rs
+    kind = rs.get("rope_type", rs.get("type", "default"))
+    if kind == "default":
+        return inv_freq
+    if kind == "linear":
+        return inv_freq / float(rs["factor"])
+    if kind == "llama3":
+        factor, lo, hi = float(rs["factor"]), float(rs["low_freq_factor"]), float(rs["high_freq_factor"])
+        old = float(rs["original_max_position_embeddings"])
+        wavelen = 2 * math.pi / inv_freq
+        scaled = torch.where(wavelen > old / lo, inv_freq / factor, inv_freq)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        medium = (wavelen >= old / hi) & (wavelen <= old / lo)
+        return torch.where(medium, (1 - smooth) * scaled / factor + smooth * scaled, scaled)
+    raise NotImplementedError(f"rope_scaling type {kind!r} is not implemented (default / linear / llama3 are)")
+
+
 _ROPE_CACHE = {}   # (device, dtype, head_dim, theta, past_len, q_len) -> (cos, sin) of the current step
 
 
@@ -311,7 +341,7 @@ class LlamaAttention_KIVI(nn.Module):
         self.layer_idx = layer_idx
         self.hidden_size = config.hidden_size
         self.num_heads = config.num_attention_heads
-        self.head_dim = self.hidden_size // self.num_heads
+        self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.num_heads
         self.num_key_value_heads = getattr(config, "num_key_value_heads", self.num_heads)
         self.num_key_value_groups = self.num_heads // self.num_key_value_heads
         self.max_position_embeddings = getattr(config, "max_position_embeddings", 4096)
@@ -319,15 +349,14 @@ class LlamaAttention_KIVI(nn.Module):
         self.kivi = KiviConfig(config.k_bits, config.v_bits, config.group_size, config.residual_length)
         self.k_bits, self.v_bits = config.k_bits, config.v_bits
         self.group_size, self.residual_length = config.group_size, config.residual_length
-        if self.head_dim * self.num_heads != self.hidden_size:
+        if self.head_dim * self.num_heads != self.hidden_size and getattr(config, "head_dim", None) is None:
             raise ValueError("hidden_size must be divisible by num_heads")
         bias = getattr(config, "attention_bias", False)
         self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
         self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
         self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
         self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=bias)
-        inv_freq = 1.0 / (self.rope_theta ** (torch.arange(0, self.head_dim, 2, dtype=torch.float32) / self.head_dim))
-        self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self.register_buffer("inv_freq", _rope_inv_freq(config, self.head_dim, self.rope_theta), persistent=False)
 
     def _rope(self, q, k, position_ids):
         freqs = position_ids[:, :, None].float() * self.inv_freq[None, None, :].float()   # (B, T, D/2)
@@ -361,6 +390,13 @@ class LlamaAttention_KIVI(nn.Module):
         if past_key_value is not None:
             if isinstance(past_key_value, KiviCacheTuple):
                 layer = past_key_value.layer
+                if past_len != layer.kv_seq_len:
+                    # the reference's tuple is an immutable snapshot; this one is a single-use handle on a cache that is
+                    # appended in place -- replaying an older one would append twice and rotate at the wrong position
+                    raise RuntimeError(
+                        f"stale KIVI past_key_value: the tuple was issued at kv length {past_len}, its cache has since "
+                        f"advanced to {layer.kv_seq_len}. In-place cache tuples are single-use; clone the cache "
+                        f"(KiviLayerCache.clone()) to continue one prefix twice.")
             else:  # a plain reference-style tuple: adopt it once
                 layer = KiviLayerCache.from_tuple(self.kivi, past_key_value, self._capacity(past_len + 1))
             attn_output = kivi_attention_decode(q, k, v, layer, attention_mask)
@@ -373,8 +409,34 @@ class LlamaAttention_KIVI(nn.Module):
         return self.o_proj(attn_output), None, past
 
     def _capacity(self, needed: int) -> int:
-        return max(needed, getattr(self.config, "kivi_max_cache_len", self.max_position_embeddings))
+        """Initial cache capacity: the prompt plus a few residual windows (the cache doubles when it runs out, like the
+        reference's torch.cat-grown tuple, so memory follows the sequence).  `config.kivi_max_cache_len` is an opt-in
+        reservation for callers that know their final length; max_position_embeddings is never used (a 128k-context
+        config would otherwise pre-allocate GBs per sequence for a 1k-token run)."""
+        reserve = getattr(self.config, "kivi_max_cache_len", None) or 0
+        return max(needed + 4 * self.residual_length, reserve)
 
 
 # The reference has an eager and a flash class with identical cache logic; both names resolve here.
 LlamaFlashAttention_KIVI = LlamaAttention_KIVI
+
+
+class MistralAttention_KIVI(LlamaAttention_KIVI):
+    """Reference: MistralAttention_KIVI / MistralFlashAttention_KIVI (models/mistral_kivi.py:69-534).  Against the Llama
+    hook the reference differs in three places, all reproduced or made unnecessary here:
+      * projections never carry a bias (:96-99) -- `attention_bias` of the config is ignored;
+      * grouped queries reach the fused GEMV through `repeat_kv_quant` copies of codes / scale / mn (:58-67, :381-385,
+        :441-445, a 4x cache-sized copy per call at Mistral-7B's ratio); the kernels here map the nh / nh_kv query heads
+        of a kv head themselves (gemv_cuda.cu:361-365 semantics), same results, no copy;
+      * `config.sliding_window` exists but is never applied to the quantised history (:356-367 is commented out):
+        the whole prefix stays attended.  The field is kept on the module for callers that inspect it."""
+
+    def __init__(self, config, layer_idx: Optional[int] = None):
+        if getattr(config, "attention_bias", False):
+            from types import SimpleNamespace
+            config = SimpleNamespace(**{**vars(config), "attention_bias": False})
+        super().__init__(config, layer_idx)
+        self.sliding_window = getattr(config, "sliding_window", None)
+
+
+MistralFlashAttention_KIVI = MistralAttention_KIVI

@@ -47,7 +47,11 @@ class KiviCacheTuple(tuple):
 
     def _materialise(self):
         if self._items is None:
-            self._items = self.layer._tuple_members() + (tuple.__getitem__(self, 8),)
+            n = tuple.__getitem__(self, 8)
+            if self.layer.kv_seq_len != n:
+                raise RuntimeError(f"stale KIVI cache tuple: issued at kv length {n}, the in-place cache is now at "
+                                   f"{self.layer.kv_seq_len}; index the members before the next decode step (or clone the cache)")
+            self._items = self.layer._tuple_members() + (n,)
         return self._items
 
     def __getitem__(self, i):
@@ -148,6 +152,20 @@ class KiviLayerCache:
         need = self.kv_seq_len + tokens
         if need > self.cap:
             self.reserve(max(need, 2 * self.cap))
+
+    def clone(self) -> "KiviLayerCache":
+        """Independent copy of the cache (what holding on to an old reference tuple gives for free): use it to continue one
+        prefix twice (beam / contrastive / assisted decoding)."""
+        import copy
+        other = copy.copy(self)
+        for name in ("k_code", "k_scale", "k_mn", "k_res", "v_code", "v_scale", "v_mn", "v_res"):
+            src = getattr(self, name)
+            dst = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device)
+            dst.copy_(src)
+            setattr(other, name, dst)
+        for name in ("_native", "_scores", "_probs"):
+            other.__dict__.pop(name, None)
+        return other
 
     # ------------------------------------------------------------------ the 9-tuple
     def k_quant_reference_layout(self):

@@ -12,16 +12,48 @@ extern "C" int kivi_decode_layer(const kivi_layer_desc* L, int64_t* st, const vo
     KIVI_REQUIRE(L && st && q && knew && vnew && out, KIVI_EINVAL, "kivi_decode_layer: null argument");
     int64_t Tq = st[0], kres = st[1], Tv = st[2], wstart = st[3], vres = st[4], kv = st[5];
     const int R = L->residual_length;
-    KIVI_REQUIRE(Tq >= 0 && kres >= 0 && kres < R && Tv >= 0 && wstart >= 0 && vres >= 0 && vres <= R &&
+    KIVI_REQUIRE(R > 0 && Tq >= 0 && kres >= 0 && kres <= R && Tv >= 0 && wstart >= 0 && vres >= 0 && vres <= R &&
                      kv == Tq + kres && kv == Tv + vres,
                  KIVI_EINVAL, "kivi_decode_layer: inconsistent lengths (Tq=%lld kres=%lld Tv=%lld vres=%lld kv=%lld)",
                  (long long)Tq, (long long)kres, (long long)Tv, (long long)vres, (long long)kv);
+    // Everything the K flush (kivi_quant_pack_k_tmajor, below) can reject is checked HERE, before anything is launched:
+    // a step is either refused with `state` untouched or committed phase by phase (state is written after every phase
+    // that has been enqueued, so the caller's lengths always describe the buffers).
+    KIVI_REQUIRE((L->k_bits == 2 || L->k_bits == 4) && (L->v_bits == 2 || L->v_bits == 4), KIVI_EINVAL,
+                 "kivi_decode_layer: k_bits / v_bits must be 2 or 4 (matmul.py:215), got %d / %d", L->k_bits, L->v_bits);
+    KIVI_REQUIRE(L->group_size > 0 && L->group_size % (32 / L->k_bits) == 0 && L->group_size % (32 / L->v_bits) == 0,
+                 KIVI_EINVAL, "kivi_decode_layer: group_size %d must be a positive multiple of the codes per word", L->group_size);
+    KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && L->D > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL,
+                 "kivi_decode_layer: bad shape (B=%d nh=%d nh_kv=%d D=%d)", L->B, nh, L->nh_kv, L->D);
+    KIVI_REQUIRE((int64_t)(R / L->group_size) * L->B * L->nh_kv < ((int64_t)1 << 31), KIVI_EINVAL,
+                 "kivi_decode_layer: K flush grid too large");
+    KIVI_REQUIRE(L->k_code && L->k_scale && L->k_mn && L->k_res && L->v_code && L->v_scale && L->v_mn && L->v_res && L->scores,
+                 KIVI_EINVAL, "kivi_decode_layer: null cache buffer in the descriptor");
     KIVI_REQUIRE(kv + 1 <= L->cap && Tv + 1 <= L->cap, KIVI_EINVAL, "kivi_decode_layer: cache capacity %lld exceeded",
                  (long long)L->cap);
     KIVI_REQUIRE(R % L->group_size == 0 && L->page_tokens % R == 0, KIVI_EINVAL,
                  "kivi_decode_layer: residual_length must be a multiple of group_size and divide the page");
     KIVI_REQUIRE(kv + 1 <= L->s_pitch, KIVI_EINVAL, "kivi_decode_layer: score rows too short");
     hipStream_t s = (hipStream_t)stream;
+
+    // K flush (llama_kivi.py:343-356): quantise the R residual tokens in place, at token offset Tq of the packed prefix
+    auto flush_k = [&]() -> int {
+        const int64_t page = Tq / L->page_tokens, off = Tq - page * L->page_tokens;
+        const int kfpi = 32 / L->k_bits;
+        const int rc = kivi_quant_pack_k_tmajor(
+            L->k_res, L->kr_sb, L->kr_sh, L->kr_st, (char*)L->k_code + (size_t)page * L->kc_sp * 4, L->kc_sb, L->kc_sh,
+            L->kc_sr, off / kfpi, (char*)L->k_scale + (size_t)page * L->ks_sp * 2, (char*)L->k_mn + (size_t)page * L->ks_sp * 2,
+            L->ks_sb, L->ks_sh, L->ks_sr, off / L->group_size, L->B, L->nh_kv, R, L->D, L->group_size, L->k_bits, stream);
+        if (rc) return rc;
+        Tq += R;
+        kres = 0;
+        st[0] = Tq; st[1] = 0;
+        return 0;
+    };
+    if (kres == R) {   // a previous call committed its attend phase but its K flush launch failed: finish that first
+        const int rc = flush_k();
+        if (rc) return rc;
+    }
 
     if (wstart + vres + 1 > L->v_window_rows) {
         // live rows to the front of the window buffer (every ~R steps): [wstart, wstart+vres) and [0, vres) never
@@ -62,25 +94,19 @@ extern "C" int kivi_decode_layer(const kivi_layer_desc* L, int64_t* st, const vo
     rc = kivi_decode_attend(&a, stream);
     if (rc) return rc;            // nothing of the step has been committed: the caller may compose it instead
 
-    kres += 1;                    // the attend launch appended the new key (llama_kivi.py:333-336)
-    if (kres == R) {              // :343-356: quantise the R residual tokens in place, at token offset Tq of the prefix
-        const int64_t page = Tq / L->page_tokens, off = Tq - page * L->page_tokens;
-        const int kfpi = 32 / L->k_bits;
-        rc = kivi_quant_pack_k_tmajor(L->k_res, L->kr_sb, L->kr_sh, L->kr_st, (char*)L->k_code + (size_t)page * L->kc_sp * 4,
-                                      L->kc_sb, L->kc_sh, L->kc_sr, off / kfpi,
-                                      (char*)L->k_scale + (size_t)page * L->ks_sp * 2, (char*)L->k_mn + (size_t)page * L->ks_sp * 2,
-                                      L->ks_sb, L->ks_sh, L->ks_sr, off / L->group_size, L->B, L->nh_kv, R, L->D,
-                                      L->group_size, L->k_bits, stream);
-        if (rc) return rc;
-        Tq += R;
-        kres = 0;
-    }
-    vres += 1;                    // :377
-    if (flush) {                  // :386-399, done inside the attend launch
+    // phase committed: the attend launch appended the new key (llama_kivi.py:333-336) and value (:377) and, when the
+    // window was full, quantised the token leaving it (:386-399)
+    kres += 1;
+    vres += 1;
+    if (flush) {
         Tv += 1;
         wstart += 1;
         vres -= 1;
     }
-    st[0] = Tq; st[1] = kres; st[2] = Tv; st[3] = wstart; st[4] = vres; st[5] = kv + 1;
+    st[1] = kres; st[2] = Tv; st[3] = wstart; st[4] = vres; st[5] = kv + 1;
+    if (kres == R) {              // :343-356; on a launch failure the state says "R residual tokens, flush pending"
+        rc = flush_k();
+        if (rc) return rc;
+    }
     return 0;
 }

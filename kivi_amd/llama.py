@@ -32,10 +32,11 @@ def make_config(d: dict, k_bits: int = 2, v_bits: int = 2, group_size: int = 32,
         num_hidden_layers=d["num_hidden_layers"], intermediate_size=d["intermediate_size"], vocab_size=d["vocab_size"],
         max_position_embeddings=d.get("max_position_embeddings", 4096), rope_theta=d.get("rope_theta", 10000.0),
         rms_norm_eps=d.get("rms_norm_eps", 1e-5), attention_bias=d.get("attention_bias", False),
+        rope_scaling=d.get("rope_scaling"), head_dim=d.get("head_dim"), sliding_window=d.get("sliding_window"),
         tie_word_embeddings=d.get("tie_word_embeddings", False),
         k_bits=d.get("k_bits", k_bits), v_bits=d.get("v_bits", v_bits), group_size=d.get("group_size", group_size),
         residual_length=d.get("residual_length", residual_length),
-        kivi_max_cache_len=max_cache_len or d.get("max_position_embeddings", 4096))
+        kivi_max_cache_len=max_cache_len)   # opt-in reservation; by default the cache starts prompt-sized and doubles
 
 
 class RMSNorm(nn.Module):
@@ -130,7 +131,7 @@ class LlamaForCausalLM_KIVI(nn.Module):
     def _build_graphs(self, B: int, device):
         cfg = self.config
         nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
-        D, H = cfg.hidden_size // nh, cfg.hidden_size
+        D, H = self.model.layers[0].self_attn.head_dim, cfg.hidden_size
         dt = self.lm_head.weight.dtype
         g = SimpleNamespace(B=B, tok=torch.zeros((B, 1), dtype=torch.long, device=device),
                             cos=torch.zeros((1, 1, 1, D), dtype=dt, device=device),
@@ -156,7 +157,7 @@ class LlamaForCausalLM_KIVI(nn.Module):
 
         def post(i):
             layer = self.model.layers[i]
-            x = g.x[i] + layer.self_attn.o_proj(g.attn.transpose(1, 2).reshape(B, 1, H))
+            x = g.x[i] + layer.self_attn.o_proj(g.attn.transpose(1, 2).reshape(B, 1, nh * D))
             g.x[i + 1].copy_(x + layer.mlp(layer.post_attention_layernorm(x)))
             if i == len(self.model.layers) - 1:
                 g.tok.copy_(self.lm_head(self.model.norm(g.x[i + 1])).argmax(-1))
@@ -245,6 +246,11 @@ class LlamaForCausalLM_KIVI(nn.Module):
         return model
 
 
-# Mistral-7B differs in GQA ratio, rope_theta and a sliding-window field the reference never applies to the quantised
-# cache (models/mistral_kivi.py keeps the whole history): the same modules serve it.
-MistralForCausalLM_KIVI = LlamaForCausalLM_KIVI
+class MistralForCausalLM_KIVI(LlamaForCausalLM_KIVI):
+    """Counterpart of models/mistral_kivi.py:921 (MistralForCausalLM_KIVI): the same decoder around MistralAttention_KIVI
+    (bias-free projections, grouped queries mapped inside the kernels, `sliding_window` carried but -- like the reference,
+    mistral_kivi.py:356-367 -- never applied to the quantised history)."""
+
+    def __init__(self, config, attention_cls=None):
+        from .attention import MistralAttention_KIVI
+        super().__init__(config, attention_cls or MistralAttention_KIVI)
