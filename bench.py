@@ -11,15 +11,24 @@ packed per-token V cache + fp16 residual, and the in-place cache append / quanti
 .kivi_attention_decode, the reference's llama_kivi.py:314-399).  The dense projections / MLP are outside the
 hot path and are not run.  Inputs are synthetic (seeded randn), resident in HBM before the timed region.
 
-N > 1: one process per GPU (launched by torch.distributed.run), batch-sharded replicas -- the path has no
-exchange step, so there is no data-path collective; ranks only barrier and max-reduce the elapsed time.
-Rank 0 prints ONE JSON line.
+The default prompt is 4080 tokens ("seq = 4k"): the fp16 K residual then starts at 16 tokens, so the K flush of R = 32
+tokens (llama_kivi.py:343-356) happens INSIDE the timed region (warm-up 5 + timed step 11) instead of never.
+
+N > 1: one process per GPU, batch-sharded replicas -- the path has no exchange step, so there is no data-path
+collective; ranks only barrier and reduce the elapsed time (MAX = the job's time, all-gather = per-rank times).
+`python bench.py --gpus N` starts its N ranks itself (re-executes this file once per GPU with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, backend nccl = RCCL); under `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N` it uses the ranks it was given.  Rank 0 prints ONE JSON line.
+`--dry-run` replaces the GPU work by a sleep (CPU / gloo: exercises launcher, barriers, reductions and the JSON line).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,23 +53,73 @@ def vgemv_bytes(B, nh, nh_kv, D, Tv, g, bits):
     return B * nh_kv * per_kv_head + B * nh * (Tv * 2 + D * 2)
 
 
+def launch_ranks(n_gpus: int, argv, timeout_s: float = 3600.0) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, the same
+    environment contract as torch.distributed.run) and wait for them.  Rank 0 inherits stdout (the JSON line)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL over xGMI needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.time() + timeout_s
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+            if rc or time.time() > deadline:           # one rank died (or a hang): stop the others, by PID
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    return rc
+
+
 def dist_setup(n_gpus: int):
-    """Returns (rank, world, local_rank, dist-or-None).  backend nccl (= RCCL) on GPUs."""
+    """Returns (rank, world, local_rank, dist-or-None).  backend nccl (= RCCL) on GPUs, gloo without."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if n_gpus > 1 and world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} needs `python -m torch.distributed.run --nproc-per-node {n_gpus} bench.py ...` "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {n_gpus}` (it starts its own "
+                         f"ranks) or `python -m torch.distributed.run --nproc-per-node {n_gpus} bench.py --gpus {n_gpus}`")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         return rank, world, local, dist
     return 0, 1, local, None
+
+
+def gather_over_ranks(seconds: float, dist, device):
+    """Every rank's own elapsed seconds (list of length world), on every rank."""
+    if dist is None:
+        return [seconds]
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
 
 
 def max_over_ranks(seconds: float, dist, device) -> float:
@@ -98,10 +157,37 @@ def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=15.0):
     per_layer_row = dec_s / reps
     return {
         "value": 1.0 / (per_layer_row * layers), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"1 batch row x {nh} heads x T={T} x 1 layer, {reps} reps: unpack+dequant K,V + 2 matmuls "
-                  f"{per_layer_row * 1e3:.0f} ms/layer-row (pack of a full {T}-token prompt {pack_s / reps * 1e3:.0f} ms, "
-                  f"not in value); extrapolated x{layers} layers",
+        "sample": f"ONE batch row (of the {B} the GPU step processes) x {nh} heads x T={T} x 1 layer, {reps} reps: "
+                  f"unpack+dequant K,V + 2 matmuls {per_layer_row * 1e3:.0f} ms per row and layer (pack of a full {T}-token "
+                  f"prompt {pack_s / reps * 1e3:.0f} ms, not in value); value = 1 / (that x {layers} layers) = tokens/s of one "
+                  f"sequence, extrapolated linearly over the batch (a batch of {B} takes {B}x as long per step and yields "
+                  f"{B} tokens: same tokens/s)",
+        "port_of": "quant/new_pack.py:51-83 unpack_and_dequant_{k,v}cache + torch.matmul (procedure of quant/test.py:187-195), "
+                   "vectorised (oracle/torch_fakequant.py, checked bit for bit against the C oracle)",
     }
+
+
+def dry_run(args, rank, world, dist):
+    """The multi-process skeleton of the benchmark without the GPU work: same barriers, same reductions, same JSON keys."""
+    dev = torch.device("cpu")
+    barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))            # rank r is (r + 1) x slower: the slowest rank sets the job's time
+    barrier(dist)
+    own = time.perf_counter() - t0
+    elapsed = max_over_ranks(own, dist, dev)
+    per_rank = gather_over_ranks(own, dist, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": round(world * args.batch * args.steps / elapsed, 2),
+                          "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+                          "per_rank_ms_per_step": [round(x * 1e3 / args.steps, 4) for x in per_rank],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "dry_run": True, "config": {"workload": "sleep", "batch_per_gpu": args.batch,
+                                                      "parallelism": f"batch-sharded replicas x{world}"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -114,7 +200,8 @@ def main():
     ap.add_argument("--heads", type=int, default=32)
     ap.add_argument("--kv-heads", type=int, default=32)
     ap.add_argument("--head-dim", type=int, default=128)
-    ap.add_argument("--prompt", type=int, default=4096)
+    ap.add_argument("--prompt", type=int, default=4080,
+                    help="prompt tokens in the cache (4080 = seq 4k with the K flush of R tokens inside the timed region)")
     ap.add_argument("--bits", type=int, default=2)
     ap.add_argument("--group", type=int, default=32)
     ap.add_argument("--residual", type=int, default=32)
@@ -122,9 +209,14 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="reference-style composition (one launch per reference op)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the K-GEMV launches with HIP events")
     ap.add_argument("--event-every", type=int, default=9, help="bracket the dominant kernel of every n-th layer step of the timed region")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: a sleep per step (launcher / reduction / JSON plumbing on CPU, gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # plain `python bench.py --gpus N`: start the ranks ourselves
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank, world, local, dist = dist_setup(args.gpus)
+    if args.dry_run:
+        return dry_run(args, rank, world, dist)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -197,8 +289,14 @@ def main():
     host_enqueue_s = time.perf_counter() - t0      # how long the host needed to enqueue the timed steps
     torch.cuda.synchronize()
     barrier(dist)
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    own = time.perf_counter() - t0
+    elapsed = max_over_ranks(own, dist, dev)
+    per_rank = gather_over_ranks(own, dist, dev)
     matmul.launch_hook = None
+    # K flushes (llama_kivi.py:343-356: R residual tokens quantised per channel, in place) that fell into the timed region
+    R_ = cfg.residual_length
+    k_res0 = T0 % R_
+    flushes_timed = (k_res0 + total_steps) // R_ - (k_res0 + args.warmup) // R_
 
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = world * B * args.steps / elapsed
@@ -213,20 +311,23 @@ def main():
             avg_us = sum(us) / len(us)
             achieved = tot_bytes / (sum(us) * 1e-6) / 1e9
             traffic = None
-            prof = os.path.join(ROOT, "profiles", "kgemv_pmc.json")
-            if os.path.exists(prof):
+            traffic_src = None
+            profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kgemv_pmc.json")))
+            if profs:           # HBM bytes per launch from the newest rocprofv3 --pmc passes of the same command (profiles/)
                 try:
-                    pj = json.load(open(prof))
+                    pj = json.load(open(profs[-1]))
                     traffic = pj.get("decode_row_hbm_bytes_per_launch") if row_fused else pj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/" + os.path.basename(profs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 correction)"
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": ("decode_row_kernel (one launch per layer: packed qK^T of the row -> LDS scores -> residual "
                                "scores + softmax + window + packed sV + cache update)" if row_fused
                                else "gemv_k_kernel (fused int2 qK^T over packed K)"), "launches": len(us),
                     "sampled": f"every {args.event_every}th layer step of the timed region (an event pair costs ~10 us of stream time)",
-                    "avg_launch_us": round(avg_us, 2), "min_launch_us": round(min(us), 2),
+                    "avg_launch_us": round(avg_us, 2), "median_launch_us": round(sorted(us)[len(us) // 2], 2),
+                    "min_launch_us": round(min(us), 2),
                     "algorithmic_bytes_per_launch": tot_bytes // len(us),
                     "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
         # BASELINE configs[1] beside it: the same qK^T kernel launched back to back over the L layer caches (each launch
@@ -251,19 +352,38 @@ def main():
                       "launches": len(us1), "median_launch_us": round(med, 2), "min_launch_us": round(us1[0], 2),
                       "achieved": round(nbytes / (med * 1e-6) / 1e9, 1), "unit": "GB/s",
                       "frac": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        # cost of one K flush per layer (the launch of kivi_quant_pack_k_tmajor over the R residual tokens), timed apart
+        flush_us = None
+        try:
+            from kivi_amd.quant import new_pack
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
+            scratch_page = [torch.empty_like(x[:, :, 0]) for x in (layers[0].k_code, layers[0].k_scale, layers[0].k_mn)]
+            for rep in range(2):
+                for i, lc in enumerate(layers):
+                    ev[i][0].record()
+                    new_pack.quantize_and_pack_k_tmajor(lc.k_res, g, bits, out=tuple(scratch_page), token_offset=0)
+                    ev[i][1].record()
+            torch.cuda.synchronize()
+            fl = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+            flush_us = round(fl[len(fl) // 2], 2)
+        except Exception as e:    # instrumentation only
+            flush_us = f"n/a ({type(e).__name__})"
         kv_bytes = sum(lc.nbytes() for lc in layers)
         fp16_bytes = 2 * L * B * nh_kv * layers[0].kv_seq_len * D * 2
         out = {
             "metric": "decode-step tokens/sec (KIVI attention hot path, Llama-2-7B shape, B=32/GPU, seq=4k, 2b/2b g=32)",
             "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "per_rank_ms_per_step": [round(x * 1e3 / args.steps, 4) for x in per_rank],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
                        "launches_per_layer": "composed (~20)" if args.unfused else "fused (1 decode-row launch for MHA rows <= 8192 keys, else qK^T + [row softmax] + sV; +1 K flush every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
-                       "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)"},
+                       "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)",
+                       "k_flushes_in_timed_region": flushes_timed, "k_flush_launch_us_per_layer": flush_us},
             "peak_kv_bytes": kv_bytes, "peak_kv_bytes_fp16_equivalent": fp16_bytes,
             "kv_compression": round(fp16_bytes / kv_bytes, 3),
             "allocator_peak_bytes": torch.cuda.max_memory_allocated(dev),
@@ -272,7 +392,7 @@ def main():
             "roofline_single_layer_kgemv": single,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(B, nh, T0, D, g, bits, L)
+            out["cpu_baseline"] = cpu_baseline(B, nh, (T0 // R) * R, D, g, bits, L)   # the packed K prefix holds floor(T0 / R) * R tokens
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,203 @@
+"""GPU parity at the sizes bench.py and BASELINE.json's configs actually run, against the CPU oracle.
+
+Heads are independent, so the full-size step runs on the GPU while the CPU restatement of the
+hook (oracle/hook_ref.py, pinned against the reference's own attention classes by oracle/pin_hook.py) follows a few
+sampled (batch row, kv head) slices of the SAME inputs: outputs within the hook bar at every step, the sampled
+slices of the final 9-tuple bit-identical.  Reference call sites: models/llama_kivi.py:314-399 (decode branch),
+models/mistral_kivi.py:381-445 (grouped queries), quant/csrc/gemv_cuda.cu:348-427 (the fused GEMV itself).
+"""
+import ctypes
+
+import pytest
+import torch
+
+from helpers import gemv_close, same_bits
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["K_code_T", "K_full", "K_scale_T", "K_mn_T", "V_code", "V_full", "V_scale", "V_mn"]
+
+
+class LaunchProbe:
+    """Names the kernel of the first fused launch of the next step (the library stamps the event pair it is handed on
+    that dispatch and remembers the kernel's source name: include/kivi_hip.h, kivi_set_launch_events)."""
+
+    def __init__(self):
+        from kivi_amd import _lib
+        self.lib = _lib.load()
+        self.e0, self.e1 = self.lib.kivi_event_create(), self.lib.kivi_event_create()
+
+    def arm(self):
+        self.lib.kivi_set_launch_events(self.e0, self.e1)
+
+    def kernel(self):
+        torch.cuda.synchronize()
+        assert self.lib.kivi_event_elapsed_us(self.e0, self.e1) > 0
+        return (self.lib.kivi_last_timed_kernel() or b"").decode()
+
+
+def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False, expect_kernel=None, D=128):
+    """Full-size decode steps on the GPU; hook_ref on the sampled (b, kv head) slices.  Returns the kernels seen."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    from oracle import hook_ref as H
+    ratio = nh // nh_kv
+    cfg = KiviConfig(bits, bits, g, R)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    k0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+    v0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+    k0[:, :, :, ::19] *= 6.0          # a few large-magnitude channels, like real K caches (KIVI paper fig. 2)
+    layer = KiviLayerCache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda")
+    layer.prefill(k0, v0)
+    pasts = {}
+    for (b, hk) in samples:
+        pasts[(b, hk)] = H.prefill_cache(k0[b:b + 1, hk:hk + 1].cpu(), v0[b:b + 1, hk:hk + 1].cpu(), bits, bits, g, R)
+    del k0, v0
+    probe = LaunchProbe()
+    seen = set()
+    worst = 0.0
+    for s in range(steps):
+        q = torch.randn((B, nh, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        kn = torch.randn((B, nh_kv, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        vn = torch.randn((B, nh_kv, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        mask = None
+        if masked:
+            mask = torch.zeros((B, 1, 1, T0 + s + 1), dtype=torch.float16, device="cuda")
+            for b in range(0, B, 2):                       # left padding on every other sequence, growing with the step
+                mask[b, :, :, : 100 + 7 * b + s] = torch.finfo(torch.float16).min
+        probe.arm()
+        out = kivi_attention_decode(q, kn, vn, layer, attention_mask=mask)
+        assert not getattr(layer, "_fused_unsupported", False) and not getattr(layer, "_attend_unfusable", False)
+        seen.add(probe.kernel().split("<")[0].strip("( "))
+        for (b, hk) in samples:
+            hs = slice(hk * ratio, (hk + 1) * ratio)
+            ref, pasts[(b, hk)] = H.decode_step(q[b:b + 1, hs].cpu(), kn[b:b + 1, hk:hk + 1].cpu(), vn[b:b + 1, hk:hk + 1].cpu(),
+                                                pasts[(b, hk)], bits, bits, g, R,
+                                                attention_mask=None if mask is None else mask[b:b + 1].cpu())
+            ok, ratio_err = gemv_close(out[b:b + 1, hs], ref, rtol=3e-3)      # the hook bar (tests/test_hook_gpu.py)
+            worst = max(worst, ratio_err)
+            assert ok, (s, b, hk, ratio_err)
+    t = layer.as_tuple()
+    for (b, hk) in samples:
+        for n, a, r in zip(NAMES, t[:8], pasts[(b, hk)][:8]):
+            if r is None:
+                assert a is None or a.numel() == 0, n
+                continue
+            assert a is not None and same_bits(a[b:b + 1, hk:hk + 1], r), (n, b, hk)
+        assert t[8] == pasts[(b, hk)][8] == T0 + steps
+    if expect_kernel is not None:
+        assert seen == {expect_kernel}, seen
+    return seen, worst
+
+
+@pytest.mark.parametrize("bits,masked", [(2, False), (4, True)])
+def test_bench_shape_decode_row_kernel_vs_oracle(oracle, bits, masked):
+    """BENCH / BASELINE config C2: B=32, 32 heads (1024 row units -> nothing splits), 4096-token prompt = two 2048-token
+    K pages, g=32, R=32, 40 steps: crosses the K flush at 4096+32 (a third, partial page) and a V-window compaction, the
+    V flush runs every step.  The launch probe proves it is the one-launch decode_row_kernel that was checked."""
+    seen, worst = run_sampled(B=32, nh=32, nh_kv=32, T0=4096, R=32, bits=bits, g=32, steps=40,
+                              samples=[(0, 0), (13, 7), (31, 31)], seed=11, masked=masked,
+                              expect_kernel="decode_row_kernel")
+    print("worst ratio vs the 3e-3 hook bar:", worst)
+
+
+def test_bench_shape_prompt_4080_k_flush_mid_page(oracle):
+    """bench.py's default prompt (4080 tokens: K residual starts at 16, the flush lands inside the timed region)."""
+    run_sampled(B=32, nh=32, nh_kv=32, T0=4080, R=32, bits=2, g=32, steps=20, samples=[(5, 3), (30, 17)], seed=12,
+                expect_kernel="decode_row_kernel")
+
+
+@pytest.mark.parametrize("B,steps", [(64, 8), (2, 8)])
+def test_config4_shape_gqa_8k_vs_oracle(oracle, B, steps):
+    """BASELINE config 4 (Llama-3-8B attention shape): 32 query / 8 kv heads, 8k context, R=128.  B=64: 512 row units,
+    rows are not split; B=2: 16 units, the sV rows are split over blocks and the row softmax runs multi-block.  T0 puts
+    the K residual at 124 so the flush of 128 tokens (models/llama_kivi.py:343-356) happens at step 4."""
+    samples = [(0, 0), (B - 1, 7), (B // 2, 3)]
+    run_sampled(B=B, nh=32, nh_kv=8, T0=8192 + 124, R=128, bits=2, g=32, steps=steps, samples=samples, seed=13,
+                masked=(B == 2))
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_config5_slice_gqa_32k_vs_oracle(oracle, B):
+    """BASELINE config 5, per-GPU slice shape (Mistral-7B attention: 32 / 8 heads, 32k context, R=128) at B = 1-2:
+    16-chunk row softmax, split-T sV with the maximal split.  Mistral call sites: models/mistral_kivi.py:381-385, 441-445."""
+    run_sampled(B=B, nh=32, nh_kv=8, T0=32768 + 125, R=128, bits=2, g=32, steps=6, samples=[(0, 0), (B - 1, 5)], seed=14)
+
+
+def test_full_size_sv_vs_oracle(oracle):
+    """BASELINE C2 sV product alone (B=32, 32 heads, Tv=4064 packed tokens, the reference's non-contiguous probability
+    slice, llama_kivi.py:382) on sampled heads vs the oracle, + linearity over the whole output."""
+    from kivi_amd.quant import matmul, new_pack
+    B, nh, Tv, D, g, bits, L = 32, 32, 4064, 128, 32, 2, 33
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    v = torch.randn((B, nh, Tv, D), device="cuda", dtype=torch.float16, generator=gen)
+    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(v, g, bits)
+    del v
+    w = torch.softmax(torch.randn((B, nh, 1, Tv + L), device="cuda", generator=gen) * 3, -1).half()
+    a = w[..., :-L]                                         # the reference's slice: row pitch Tv + L
+    out = matmul.cuda_bmm_fA_qB_outer(g, a, code, scale, mn, bits)
+    assert out.shape == (B, nh, 1, D) and torch.isfinite(out).all()
+    for (b, h) in [(0, 0), (17, 5), (31, 31), (8, 30)]:
+        ref = oracle.bmm_fA_qB_outer(g, a[b:b + 1, h:h + 1].cpu().contiguous(), code[b:b + 1, h:h + 1].cpu(),
+                                     scale[b:b + 1, h:h + 1].cpu(), mn[b:b + 1, h:h + 1].cpu(), bits)
+        ok, ratio = gemv_close(out[b:b + 1, h:h + 1], ref)
+        assert ok, (b, h, ratio)
+    a2 = torch.softmax(torch.randn((B, nh, 1, Tv), device="cuda", generator=gen), -1).half()
+    o2 = matmul.cuda_bmm_fA_qB_outer(g, a2, code, scale, mn, bits)
+    o12 = matmul.cuda_bmm_fA_qB_outer(g, (a.float() + a2.float()).half(), code, scale, mn, bits)
+    lin = (out.float() + o2.float() - o12.float()).abs()
+    assert (lin / o12.float().pow(2).mean(-1, keepdim=True).sqrt()).max().item() < 6e-3
+
+
+def test_mistral_7b_attention_module_vs_oracle(oracle):
+    """The Mistral hook as a module (models/mistral_kivi.py:69-534): Mistral-7B attention config (4096 hidden, 32 / 8
+    heads, sliding_window 4096, R=128), prompt 300, 100 decode steps across the K flush at 384; the module's own
+    post-RoPE q / k / v drive hook_ref.  Final 9-tuple bit-identical, step outputs within the hook bar."""
+    from types import SimpleNamespace
+
+    import models.mistral_kivi as M
+    from kivi_amd.cache import KiviCacheTuple
+    from oracle import hook_ref as H
+    cfg = SimpleNamespace(hidden_size=4096, num_attention_heads=32, num_key_value_heads=8, max_position_embeddings=32768,
+                          rope_theta=1000000.0, sliding_window=4096, k_bits=2, v_bits=2, group_size=32, residual_length=128)
+    torch.manual_seed(0)
+    attn = M.MistralFlashAttention_KIVI(cfg).half().cuda()
+    assert attn.sliding_window == 4096 and attn.num_key_value_groups == 4
+    with torch.no_grad():
+        attn.o_proj.weight.copy_(torch.eye(4096))
+    B, T0, steps = 2, 300, 100
+    captured = {}
+    import kivi_amd.attention as A
+    orig_dec, orig_pre = A.kivi_attention_decode, A.kivi_attention_prefill
+
+    def spy_dec(q, k, v, layer, attention_mask=None, **kw):
+        captured["qkv"] = (q.cpu(), k.cpu(), v.cpu())
+        return orig_dec(q, k, v, layer, attention_mask, **kw)
+
+    def spy_pre(q, k, v, layer):
+        captured["qkv"] = (q.cpu(), k.cpu(), v.cpu())
+        return orig_pre(q, k, v, layer)
+
+    A.kivi_attention_decode, A.kivi_attention_prefill = spy_dec, spy_pre
+    try:
+        with torch.no_grad():
+            x = torch.randn(B, T0, 4096, device="cuda", dtype=torch.float16) * 0.3
+            _, w, past = attn(x, use_cache=True)
+            assert w is None and isinstance(past, KiviCacheTuple) and past[-1] == T0
+            _, k0, v0 = captured["qkv"]
+            ref_past = H.prefill_cache(k0, v0, 2, 2, 32, 128)
+            for s in range(steps):
+                xs = torch.randn(B, 1, 4096, device="cuda", dtype=torch.float16) * 0.3
+                out, _, past = attn(xs, past_key_value=past, use_cache=True)
+                q, k, v = captured["qkv"]
+                ref, ref_past = H.decode_step(q, k, v, ref_past, 2, 2, 32, 128)
+                got = out.view(B, 1, 32, 128).transpose(1, 2)              # o_proj is the identity
+                ok, ratio = gemv_close(got, ref, rtol=3e-3)
+                assert ok, (s, ratio)
+    finally:
+        A.kivi_attention_decode, A.kivi_attention_prefill = orig_dec, orig_pre
+    assert past[-1] == T0 + steps == ref_past[8]
+    for n, a, r in zip(NAMES, past[:8], ref_past[:8]):
+        if r is None:
+            assert a is None or a.numel() == 0, n
+        else:
+            assert same_bits(a, r), n
