@@ -229,6 +229,39 @@ typedef struct kivi_decode_attend_args {
 } kivi_decode_attend_args;
 int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream);
 
+/* ------------------------------------ grouped queries on the matrix pipe --- */
+
+/*
+ * MFMA-friendly cache layout for grouped-query models (nh / nh_kv in {4, 8}; 2-bit, group_size 32, head_dim 128).
+ * Same codes, scales and zero points as the hook-state tensors above -- kivi_kt_relayout / kivi_vt_relayout convert
+ * both ways bit for bit -- stored so that one masked code word IS a B-operand register of v_mfma_f32_16x16x32_f16
+ * (kivi_amd/csrc/kivi_mfma_layout.h): per (batch row, kv head) a sequence of super-blocks of 512 tokens,
+ *   [ codes 16 x 256 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 6144 int32 words each,
+ * addressed as base + b*sb_b + hk*sb_h + (t / 512)*sb_s (strides in words).  Never-written slots must be ZERO.
+ * The reference has no counterpart: it expands codes / scale / mn nh / nh_kv times (models/mistral_kivi.py:58-67,
+ * :381-385, :441-445) or lets the CUDA kernel map heads (quant/csrc/gemv_cuda.cu:361-365).
+ *
+ * kivi_kt_pack: per-channel K quantise + pack of whole 32-token blocks (T % 32 == 0) from un-transposed keys
+ *   k[b, h, t, :] = k + b*k_sb + h*k_sh + t*k_st straight into the layout at token_offset (prompt pass
+ *   models/llama_kivi.py:436, residual flush :343-356); bit-identical to kivi_quant_pack_k_tmajor + relayout.
+ * kivi_kt_relayout / kivi_vt_relayout: to_ref != 0 writes tokens [0, T) of the hook-state tensors
+ *   (K_code_T (B,nh_kv,D,T/16) / V_code (B,nh_kv,T,D/16) + scale, mn) from the layout, to_ref == 0 the reverse.
+ * kivi_gqa_scores: out[b, h, :T] = packed qK^T (the arithmetic of kivi_gemv_k: fp32 accumulate, one fp16 rounding; the
+ *   q * scale products enter the matrix pipe as exact hi + lo fp16 pairs).
+ */
+int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* kt, int64_t kt_sb, int64_t kt_sh,
+                 int64_t kt_ss, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
+                 kivi_stream_t stream);
+int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* code, int64_t code_sb,
+                     int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
+                     int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
+int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss, void* code, int64_t code_sb,
+                     int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
+                     int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
+int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss,
+                    void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
+                    int bits, kivi_stream_t stream);
+
 /* ------------------------------------------------------ layer step --- */
 
 /*

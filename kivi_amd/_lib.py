@@ -89,6 +89,13 @@ SIGNATURES = {
     "kivi_decode_attend": (_i32, [ctypes.POINTER(DecodeAttendArgs), _vp]),
     "kivi_decode_layer": (_i32, [ctypes.POINTER(LayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
                                  _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "kivi_kt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_kt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                _i64, _i32, _i32, _i32, _vp]),
+    "kivi_vt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                _i64, _i32, _i32, _i32, _vp]),
+    "kivi_gqa_scores": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
+                               _i32, _vp]),
     "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),

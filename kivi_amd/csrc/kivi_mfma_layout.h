@@ -1,0 +1,49 @@
+// MFMA-friendly internal cache layouts for grouped-query decode ("KT" for K, "VT" for V), gfx950.
+//
+// Why: the reference packs 16 codes of ONE channel (K: 16 tokens, quant/new_pack.py:146-154 along the token axis) or of
+// one token (V: 16 channels) into a word, i.e. along the OUTPUT axis of the fused GEMV (quant/csrc/gemv_cuda.cu:348-427,
+// "outer dim").  v_mfma_f32_16x16x32_f16 wants every lane to hold 8 consecutive elements of the REDUCTION axis of one
+// output column.  With nh / nh_kv = R query heads per kv head the VALU form costs one mask + R FMAs per code and is
+// VALU bound at R >= 4; on the matrix pipe the R heads are free.  So for grouped queries the
+// cache keeps the SAME codes / scales / zero points (bit for bit: the 9-tuple of models/llama_kivi.py:454-455 is
+// reproduced exactly by the *_to_ref kernels) in a layout whose words ARE B-operand registers after one mask:
+//
+//   block  = 32 consecutive tokens (= one K quantisation group at group_size 32) of one (batch row, kv head),
+//            1024 B of codes = one 16-byte load per lane of a wave, lane = n + 16 * kb
+//   super-block (SB) = 16 blocks = 512 tokens, stored contiguously:
+//            [ codes 16 x 256 words | scale 16 x 128 halves | mn 16 x 128 halves ]  = 6144 words = 24 KiB
+//
+//   K block, token tt (0..31), channel d (0..127):      c = d >> 5, kb = (d >> 3) & 3, e = d & 7
+//        word (n + 16 kb) * 4 + c   with n = tt & 15, tile = tt >> 4
+//        bits 2 * ((e >> 1) + 4 * tile) + 16 * (e & 1)          (lo half: even channel, hi half: odd channel)
+//        scale / mn of (channel d, this group): half kb * 32 + c * 8 + e
+//   V block, token tt, channel d:                        c = d >> 5 (= channel group), tile = (d >> 4) & 1, n = d & 15
+//        word (n + 16 kb) * 4 + c   with kb = tt >> 3, e = tt & 7
+//        bits 2 * ((e >> 1) + 4 * tile) + 16 * (e & 1)          (lo half: even token, hi half: odd token)
+//        scale / mn of (token tt, channel group c): half kb * 32 + c * 8 + e
+//
+// In both, `w & (0x00030003 << 2 i)` (i = 0..3) is the pair (k = 2 i, 2 i + 1) of the 8 reduction-axis elements a lane
+// feeds to one MFMA, as fp16 SUBNORMALS code * 4^i * 2^-24 (the matrix pipe keeps fp16 subnormals: tools/
+// mfma_f16_probe.hip), for the output column n of tile 0; `(w >> 8) & ...` is the same for tile 1.  The A operand carries
+// q * scale (K) or p * scale (V) times 2^(6 - 2 i), split into an fp16 hi and lo row so the product is exact.
+#pragma once
+#include <stdint.h>
+
+#define KIVI_MF_BLOCK_TOKENS 32
+#define KIVI_MF_SB_BLOCKS 16
+#define KIVI_MF_SB_TOKENS 512
+#define KIVI_MF_BLOCK_WORDS 256        // code words of one block
+#define KIVI_MF_SB_CODE_WORDS 4096
+#define KIVI_MF_SB_SCALE_WORD0 4096    // scale halves start here (as words)
+#define KIVI_MF_SB_MN_WORD0 5120
+#define KIVI_MF_SB_WORDS 6144
+#define KIVI_MF_SHIFT 6                // A operands carry 2^(6 - 2 i)
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int kt_word(int tt, int d) { return ((tt & 15) + 16 * ((d >> 3) & 3)) * 4 + (d >> 5); }
+__device__ __forceinline__ int kt_bit(int tt, int d) { return 2 * (((d & 7) >> 1) + 4 * (tt >> 4)) + 16 * (d & 1); }
+__device__ __forceinline__ int kt_half(int d) { return ((d >> 3) & 3) * 32 + (d >> 5) * 8 + (d & 7); }
+__device__ __forceinline__ int vt_word(int tt, int d) { return ((d & 15) + 16 * (tt >> 3)) * 4 + (d >> 5); }
+__device__ __forceinline__ int vt_bit(int tt, int d) { return 2 * (((tt & 7) >> 1) + 4 * ((d >> 4) & 1)) + 16 * (tt & 1); }
+__device__ __forceinline__ int vt_half(int tt, int c) { return (tt >> 3) * 32 + c * 8 + (tt & 7); }
+#endif

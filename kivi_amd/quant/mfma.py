@@ -1,0 +1,91 @@
+"""The MFMA-friendly cache layout for grouped-query decode (include/kivi_hip.h, "grouped queries on the matrix pipe").
+
+Not part of the reference's Python surface: the reference keeps the hook-state tensors (models/llama_kivi.py:454-455)
+and, for grouped queries, expands them nh / nh_kv times per call (models/mistral_kivi.py:58-67) or lets the CUDA kernel
+map heads (quant/csrc/gemv_cuda.cu:361-365).  Here the same codes / scales / zero points live in super-blocks whose
+words are matrix-core operands; `*_to_ref` reproduces the hook-state tensors bit for bit.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+SB_TOKENS = 512
+SB_WORDS = 6144
+BLOCK_TOKENS = 32
+
+
+def supported(k_bits: int, v_bits: int, group_size: int, head_dim: int, residual_length: int, ratio: int) -> bool:
+    return (k_bits == 2 and v_bits == 2 and group_size == 32 and head_dim == 128 and residual_length % 32 == 0
+            and ratio in (4, 8))
+
+
+def alloc_store(B: int, nh_kv: int, n_sb: int, device) -> torch.Tensor:
+    """Zero-initialised storage of n_sb super-blocks per (batch row, kv head): logical shape (B, nh_kv, n_sb, 6144) int32,
+    in memory the super-block index sits outside the head index (the super-blocks in use form one dense region)."""
+    return torch.zeros((B, n_sb, nh_kv, SB_WORDS), dtype=torch.int32, device=device).permute(0, 2, 1, 3)
+
+
+def _st(store: torch.Tensor):
+    assert store.dtype == torch.int32 and store.dim() == 4 and store.shape[3] == SB_WORDS and store.stride(3) == 1
+    return _lib.ptr(store), store.stride(0), store.stride(1), store.stride(2)
+
+
+def kt_pack(k: torch.Tensor, store: torch.Tensor, token_offset: int = 0, group_size: int = 32, bits: int = 2) -> None:
+    """k (B, nh_kv, T, 128) fp16, T % 32 == 0 -> quantised per channel into `store` at token_offset."""
+    _lib.require_gpu(k, "k")
+    B, nh_kv, T, D = k.shape
+    assert k.dtype == torch.float16 and k.stride(3) == 1 and (token_offset + T) <= store.shape[2] * SB_TOKENS
+    lib = _lib.load()
+    _lib.check(lib.kivi_kt_pack(_lib.ptr(k), k.stride(0), k.stride(1), k.stride(2), *_st(store), token_offset, B, nh_kv, T, D,
+                                group_size, bits, _lib.stream_ptr(k)), "kivi_kt_pack")
+
+
+def _relayout(fn, name, to_ref, store, code, scale, mn, T, D, group_size, bits):
+    B, nh_kv = store.shape[0], store.shape[1]
+    assert code.dtype == torch.int32 and scale.dtype == mn.dtype == torch.float16
+    assert code.stride(3) == 1 and scale.stride(3) == 1 and scale.stride() == mn.stride()
+    _lib.check(fn(int(to_ref), *_st(store), _lib.ptr(code), code.stride(0), code.stride(1), code.stride(2), _lib.ptr(scale),
+                  _lib.ptr(mn), scale.stride(0), scale.stride(1), scale.stride(2), B, nh_kv, T, D, group_size, bits,
+                  _lib.stream_ptr(code)), name)
+
+
+def kt_to_ref(store: torch.Tensor, T: int, D: int = 128, group_size: int = 32, bits: int = 2):
+    """-> K_code_T (B, nh_kv, D, T/16) int32, K_scale_T, K_mn_T (B, nh_kv, D, T/32) fp16 of tokens [0, T)."""
+    B, nh_kv = store.shape[0], store.shape[1]
+    code = torch.empty((B, nh_kv, D, T // 16), dtype=torch.int32, device=store.device)
+    scale = torch.empty((B, nh_kv, D, T // group_size), dtype=torch.float16, device=store.device)
+    mn = torch.empty_like(scale)
+    _relayout(_lib.load().kivi_kt_relayout, "kivi_kt_relayout", True, store, code, scale, mn, T, D, group_size, bits)
+    return code, scale, mn
+
+
+def kt_from_ref(store: torch.Tensor, code: torch.Tensor, scale: torch.Tensor, mn: torch.Tensor, group_size: int = 32, bits: int = 2):
+    T = code.shape[3] * 16
+    _relayout(_lib.load().kivi_kt_relayout, "kivi_kt_relayout", False, store, code, scale, mn, T, code.shape[2], group_size, bits)
+
+
+def vt_to_ref(store: torch.Tensor, T: int, D: int = 128, group_size: int = 32, bits: int = 2):
+    """-> V_code (B, nh_kv, T, D/16) int32, V_scale, V_mn (B, nh_kv, T, D/32) fp16 of tokens [0, T)."""
+    B, nh_kv = store.shape[0], store.shape[1]
+    code = torch.empty((B, nh_kv, T, D // 16), dtype=torch.int32, device=store.device)
+    scale = torch.empty((B, nh_kv, T, D // group_size), dtype=torch.float16, device=store.device)
+    mn = torch.empty_like(scale)
+    _relayout(_lib.load().kivi_vt_relayout, "kivi_vt_relayout", True, store, code, scale, mn, T, D, group_size, bits)
+    return code, scale, mn
+
+
+def vt_from_ref(store: torch.Tensor, code: torch.Tensor, scale: torch.Tensor, mn: torch.Tensor, group_size: int = 32, bits: int = 2):
+    T = code.shape[2]
+    _relayout(_lib.load().kivi_vt_relayout, "kivi_vt_relayout", False, store, code, scale, mn, T, code.shape[3] * 16, group_size, bits)
+
+
+def gqa_scores(q: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tensor, group_size: int = 32, bits: int = 2) -> None:
+    """out[..., :T] <- packed qK^T.  q (B, nh, 1, 128) fp16, out (B, nh, 1, >= T) fp16 rows (16-byte aligned)."""
+    B, nh, _, D = q.shape
+    nh_kv = store.shape[1]
+    assert q.dtype == out.dtype == torch.float16 and q.stride(3) == 1 and out.stride(3) == 1
+    _lib.check(_lib.load().kivi_gqa_scores(_lib.ptr(q), q.stride(0), q.stride(1), *_st(store), _lib.ptr(out), out.stride(0),
+                                           out.stride(1), B, nh, nh_kv, D, T, group_size, bits, _lib.stream_ptr(q)),
+               "kivi_gqa_scores")
