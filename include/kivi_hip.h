@@ -321,6 +321,9 @@ void kivi_set_launch_events(void* start, void* stop);
 float kivi_event_elapsed_us(void* start, void* stop);
 /* source text of the kernel instantiation the last consumed event pair bracketed ("" if none yet) */
 const char* kivi_last_timed_kernel(void);
+/* Diagnostic: device buffer of (blocks x 4 waves x 16) uint64 that decode_row_kernel fills with per-wave phase time
+ * stamps (shader clock; slot 1 = 100 MHz realtime at entry); null switches it off (default). */
+void kivi_debug_set_stamps(void* device_buffer);
 
 #ifdef __cplusplus
 }

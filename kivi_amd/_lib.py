@@ -108,6 +108,7 @@ SIGNATURES = {
     "kivi_set_launch_events": (None, [_vp, _vp]),
     "kivi_event_elapsed_us": (ctypes.c_float, [_vp, _vp]),
     "kivi_last_timed_kernel": (ctypes.c_char_p, []),
+    "kivi_debug_set_stamps": (None, [_vp]),
 }
 
 _lib = None

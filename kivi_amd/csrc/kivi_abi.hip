@@ -48,3 +48,9 @@ extern "C" float kivi_event_elapsed_us(void* start, void* stop) {
     if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
     return ms * 1000.0f;
 }
+
+// ---- phase time stamps of the fused decode-row kernel (tools/row_phases.py): a caller-owned device buffer of
+// grid x 4 waves x 16 uint64; null (the default) compiles to one uniform branch per stamp
+static unsigned long long* g_stamps = nullptr;
+unsigned long long* kivi_debug_stamps() { return g_stamps; }
+extern "C" void kivi_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }

@@ -40,7 +40,8 @@ struct KiviLaunchEvents {
     hipEvent_t start, stop;
 };
 KiviLaunchEvents kivi_take_launch_events();
-void kivi_note_timed_kernel(const char* name);   // remembers which kernel the last event pair bracketed
+void kivi_note_timed_kernel(const char* name);
+unsigned long long* kivi_debug_stamps();         // kivi_debug_set_stamps buffer or null   // remembers which kernel the last event pair bracketed
 
 #define KIVI_LAUNCH_LDS(kernel, grid, block, lds, stream, ...)                                              \
     do {                                                                                                   \

@@ -36,7 +36,18 @@ struct GemvKArgs {
     const uint16_t* knew;              // (B, nh_kv, D) the new key
     int64_t knew_sb, knew_sh;
     int res_len;                       // tokens already in the residual; the new one becomes index res_len
+    unsigned long long* dbg;           // phase time stamps (kivi_debug_set_stamps; tools/row_phases.py), normally null
 };
+
+// phase time stamp of this wave: slot i of its 16-entry record (s_memtime = shader clock); compiled only into the
+// diagnostic instantiation of decode_row_kernel (DBG)
+template <bool DBG>
+__device__ __forceinline__ void kivi_stamp(unsigned long long* dbg, int i) {
+    if constexpr (DBG) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i] = t;
+    }
+}
 
 template <int N> struct WordVec;
 template <> struct WordVec<1> { typedef uint32_t type; };
@@ -131,7 +142,7 @@ __device__ __forceinline__ void k_residual_role(const GemvKArgs& a, int unit) {
 // One block's share of the product: TILES_PER_BLOCK tiles of 64*WPL words of one (b, head unit), `bid` = index among
 // the streaming blocks.  `lds_out` == nullptr: results go to a.out (the stand-alone kernel).  Otherwise (fused decode
 // row, R == 1): the fp16 scores of the tile's tokens are written to lds_out[token] and nothing goes to memory.
-template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
+template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT, bool DBG = false>
 __device__ __forceinline__ void k_tile_body(const GemvKArgs& a, const int bid, uint16_t* lds_out) {
     constexpr int FPI = 32 / BITS;
     constexpr int TPL = WPL * FPI;                   // tokens per lane
@@ -265,6 +276,7 @@ __device__ __forceinline__ void k_tile_body(const GemvKArgs& a, const int bid, u
             compute_batch(wB, sB, mB, qB);
         }
         if (it < nfull) compute_batch(wA, sA, mA, qA);
+        kivi_stamp<DBG>(a.dbg, 3);
         for (int d = d0 + nfull * U; d < d1; d++) {   // channel tail (rows per wave not a multiple of U)
             WV w = buf_load<WV, NT>(rc, coff, (uint32_t)d * cstep);
             SV sv = buf_load<SV, NT>(rs, soff, (uint32_t)d * sstep);
@@ -385,7 +397,7 @@ int k_check_and_fill(GemvKArgs& a, const void* q, int64_t q_sb, int64_t q_sh, co
     a.nh = nh; a.ratio = nh / nh_kv; a.D = D; a.T = T; a.Tw = T / fpi;
     a.units_per_b = nh; a.tile_blocks = 1;
     a.page_words = 0; a.page_groups = 0; a.code_sp = 0; a.sm_sp = 0;
-    a.main_blocks = -1; a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
+    a.main_blocks = -1; a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0; a.dbg = nullptr;
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     return 0;
 }

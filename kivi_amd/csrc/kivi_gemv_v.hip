@@ -34,17 +34,38 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 // by tile (k_tile_body, the scores go to the LDS row instead of memory), then everything v_row_body does with them
 // (residual scores, softmax, window, packed sV).  Against the two-launch form this drops the 2 x 8 MB score round
 // trip through HBM, one launch ramp/drain and the cold start of the second kernel.
-template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU, bool PRE = true>
-__global__ __launch_bounds__(256) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
+template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU, bool PRE = true, bool DBG = false, int EARLY = 0,
+          int PRIO = 0>
+__global__ __launch_bounds__(256, (DBG || EARLY || PRIO) ? 4 : 1) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
     extern __shared__ uint16_t pl_row[];
     const int unit = (int)blockIdx.x;
+    if constexpr (PRIO != 0) {   // experiment: issue priority by hardware wave slot (the SIMD arbiter is oldest-first otherwise)
+        const int slot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;
+        const int pr = PRIO == 1 ? 3 - slot : slot;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    kivi_stamp<DBG>(av.dbg, 0);
+    if (DBG && (threadIdx.x & 63) == 0)
+        av.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 1] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
     RowPre<DW * (32 / BITS)> pre;
     if constexpr (PRE) row_prefetch(av, pre);   // in flight during the whole qK^T phase (26 VGPRs, where they fit)
+    kivi_stamp<DBG>(av.dbg, 2);
     for (int tb = 0; tb < ak.tile_blocks; tb++) {
-        k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true>(ak, unit * ak.tile_blocks + tb, pl_row);
+        k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true, DBG>(ak, unit * ak.tile_blocks + tb, pl_row);
+        if (tb == 0) kivi_stamp<DBG>(av.dbg, 4);
         __syncthreads();   // the exchange buffer is reused by the next tile; the scores must be visible below
     }
-    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, PRE>(av, &pre);
+    kivi_stamp<DBG>(av.dbg, 5);
+    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, PRE, DBG, true, EARLY>(av, &pre);
+    kivi_stamp<DBG>(av.dbg, 11);
+    if (DBG && (threadIdx.x & 63) == 0) {
+        unsigned long long* rec = av.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+        rec[12] = __builtin_amdgcn_s_memrealtime();
+        rec[13] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID: wave slot, SIMD, CU, SE
+        rec[14] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // XCC_ID
+    }
 }
 
 template <int BITS>
@@ -268,6 +289,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         if (fuse_row) {
             GemvKArgs ak = a.kside->args;
             ak.units_per_b = a.nh;
+            ak.dbg = a.dbg;
             if (bits == 4) {   // 4-bit: 8 codes per word, 4 words per lane = the same 2048-token tile; sV over 16 words per row
                 ak.tile_blocks = (int)(((ak.Tw + 255) / 256 + 1) / 2);
                 ak.res_blocks = 0;
@@ -283,14 +305,27 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const size_t lds = (size_t)a.n_pad * sizeof(uint16_t) + (xl ? (size_t)atoi(xl) : 0);
             static const char* rv = getenv("KIVI_ROW_VARIANT");   // tuning aid: K-phase shape "ds<DSPLIT>u<U>"
             static const char* rvv = getenv("KIVI_ROW_V");        // tuning aid: sV-phase shape "w<WPL>u<U>"
+            static const char* rx = getenv("KIVI_ROW_X");         // tuning aid: experimental instantiations
             const int sel = !rv ? 1 : !strcmp(rv, "ds4u4") ? 0 : !strcmp(rv, "ds2u4") ? 1 : !strcmp(rv, "ds2u8") ? 2 : !strcmp(rv, "ds4u8") ? 3 : 1;
             const int selv = (rvv && !strcmp(rvv, "w2u4")) ? 1 : 0;
             ak.tile_blocks = (G != 32 || selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
             const dim3 grid((unsigned)units);
             if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else if (G == 128) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (selv == 1 && a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4, true, true>), grid, dim3(256), lds, s, ak, a);
             else if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 0) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 1 && a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "e1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 2>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "u2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 2, true, false, 0>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "u2e1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 2, true, false, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "u2e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 2, true, false, 2>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "w2u4e1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4, true, false, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "p1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "p2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 2>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "p1e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 2, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (rx && !strcmp(rx, "p2e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 2, 2>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 2) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
@@ -369,6 +404,7 @@ static int v_fill(GemvVArgs& a, const char* who, const void* av, int64_t a_sb, i
     a.rq_sb = a.rq_sh = a.rk_sb = a.rk_sh = a.rk_st = a.rkn_sb = a.rkn_sh = 0;
     a.fused = 0; a.vres = nullptr; a.vnew = nullptr; a.flush = 0; a.win_start = 0; a.res_len = 0;
     a.scores_lds = 0; a.kside = nullptr;
+    a.dbg = kivi_debug_stamps();
     a.vres_sb = a.vres_sh = a.vres_st = a.vnew_sb = a.vnew_sh = 0;
     return 0;
 }

@@ -59,6 +59,7 @@ struct GemvVArgs {
     // fused decode row (decode_row_kernel): the packed qK^T of the row ran in this block just before, its fp16 scores
     // are already in `pl` (the dynamic LDS row) and are not written to memory
     int scores_lds;
+    unsigned long long* dbg;           // phase time stamps, normally null (see kivi_stamp)
     // host only: the packed-K side of the step when the caller handed it over (kivi_decode_attend with K fields)
     const struct KSide* kside;
 };
@@ -126,7 +127,8 @@ __device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D>& pre)
     }
 }
 
-template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT, bool PRE = false>
+template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT, bool PRE = false, bool DBG = false,
+          bool FROW = false, int EARLY = 0>
 __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW * (32 / BITS)>* pre = nullptr) {
     constexpr int FPI = 32 / BITS;
     // R > 1 (grouped queries) and SPLIT kernels always get finished probabilities from the row-softmax launch (v_run):
@@ -286,7 +288,9 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             const int j0 = c * 1024 + (int)threadIdx.x * 4;
             raw[c] = u16x4{0, 0, 0, 0};
             if (c < nch_sc) {
-                const uint16_t* src = a.scores_lds ? pl : srow;   // fused row: the packed scores are in LDS already
+                // fused row: the packed scores are in LDS already (FROW: known at compile time, so no global load -- and no
+                // s_waitcnt vmcnt(0) that would drain the V batches requested ahead -- is left in the softmax)
+                const uint16_t* src = (FROW || a.scores_lds) ? pl : srow;
                 if (j0 + 4 <= lim) {
                     raw[c] = *(const u16x4*)(src + j0);
                 } else {
@@ -297,6 +301,10 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             }
         }
     };
+    // EARLY: the first (two) batch(es) of packed V are requested before anything else of this half: they fly during the
+    // residual scores, the softmax and the window part
+    if constexpr (EARLY >= 1) { if (nbatch > 0) load_wsm(0, wA, sA, mA); }
+    if constexpr (EARLY >= 2) { if (nbatch > 1) load_wsm(1, wB, sB, mB); }
     u16x4 raw0[SMC];
     if (reg_softmax) load_raw(0, raw0);
     // (b) the first PWT window tokens of this wave (covers a window of 4*PWT-1 = 35 tokens; longer ones loop below)
@@ -373,12 +381,13 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
                 if (sub == 0) {
                     const uint16_t hs = f2h_bits(sc);
                     rs_lds[r][t] = hs;
-                    if (!a.scores_lds) const_cast<uint16_t*>(a.a)[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tq + t] = hs;
+                    if (!FROW && !a.scores_lds) const_cast<uint16_t*>(a.a)[b * a.a_sb + (int64_t)(h0 + r) * a.a_sh + a.Tq + t] = hs;
                 }
             }
         }
         // the first batch of packed V is requested before the softmax arithmetic so the stream is already moving
-        if (nbatch > 0) load_wsm(0, wA, sA, mA);
+        if constexpr (EARLY == 0) { if (nbatch > 0) load_wsm(0, wA, sA, mA); }
+        kivi_stamp<DBG>(a.dbg, 6);
         if (a.rq) __syncthreads();
         {
 #pragma unroll 1
@@ -439,8 +448,9 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         }
         }
         __syncthreads();
+        kivi_stamp<DBG>(a.dbg, 7);
     } else {
-        if (nbatch > 0) load_wsm(0, wA, sA, mA);
+        if constexpr (EARLY == 0) { if (nbatch > 0) load_wsm(0, wA, sA, mA); }
     }
 
     if (do_win) {
@@ -574,11 +584,12 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         }
     }
 
+    kivi_stamp<DBG>(a.dbg, 8);
     {
         if (nbatch > 0) load_a(0, aA);
         int it = 0;
         for (; it + 2 <= nbatch; it += 2) {
-            load_wsm(it + 1, wB, sB, mB);
+            if (EARLY < 2 || it > 0) load_wsm(it + 1, wB, sB, mB);
             load_a(it + 1, aB);
             compute_batch(wA, sA, mA, aA);
             if (it + 2 < nbatch) {
@@ -589,6 +600,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         }
         if (it < nbatch) compute_batch(wA, sA, mA, aA);
     }
+    kivi_stamp<DBG>(a.dbg, 9);
 
     // undo the positional power-of-two factors, then combine the TPI lanes that share `lr`
 #pragma unroll
@@ -634,6 +646,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             red[wave][r][lr * EPL + e] = acc[r][i] + z;
         }
     __syncthreads();
+    kivi_stamp<DBG>(a.dbg, 10);
     if constexpr (!SPLIT) {
         for (int i = threadIdx.x; i < R * D; i += 256) {
             const int r = i / D, d = i - r * D;
