@@ -221,7 +221,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
     from kivi_amd.quant import matmul
 
     B, L, nh, nh_kv, D = args.batch, args.layers, args.heads, args.kv_heads, args.head_dim
@@ -233,7 +233,8 @@ def main():
     # ---- build the per-layer caches (prefill with synthetic K/V), inputs resident in HBM
     layers = []
     for _ in range(L):
-        lc = KiviLayerCache(cfg, B, nh_kv, D, T0 + total_steps + 1, dev)
+        # hook-state layout for MHA, the matrix-pipe layout for the grouped-query shapes it covers (nh / nh_kv in {4, 8})
+        lc = make_layer_cache(cfg, B, nh_kv, D, T0 + total_steps + 1, dev, num_heads=nh)
         k = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
         v = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
         lc.prefill(k, v)
@@ -320,10 +321,15 @@ def main():
                     traffic_src = "profiles/" + os.path.basename(profs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 correction)"
                 except Exception:
                     traffic = None
+            mf = getattr(layers[0], "layout", "hook") == "mfma"
+            if mf:
+                traffic, traffic_src = None, None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": ("decode_row_kernel (one launch per layer: packed qK^T of the row -> LDS scores -> residual "
                                "scores + softmax + window + packed sV + cache update)" if row_fused
+                               else "gqa_k_kernel (grouped-query packed qK^T on the matrix pipe + residual scores + softmax "
+                                    "statistics; first of the two launches of a layer step)" if mf
                                else "gemv_k_kernel (fused int2 qK^T over packed K)"), "launches": len(us),
                     "sampled": f"every {args.event_every}th layer step of the timed region (an event pair costs ~10 us of stream time)",
                     "avg_launch_us": round(avg_us, 2), "median_launch_us": round(sorted(us)[len(us) // 2], 2),
@@ -334,7 +340,7 @@ def main():
         # reads a different ~200 MiB cache, L x 200 MiB >> the 256 MiB Infinity Cache), every dispatch timed -- the
         # isolated single-layer K-GEMV number, without the decode loop's kernel alternation
         single = None
-        if roof is not None and layers[0].k_quant_len:
+        if roof is not None and layers[0].k_quant_len and hasattr(layers[0], "k_code"):
             scratch = torch.empty((B, nh, 1, layers[0].k_quant_len), device=dev, dtype=torch.float16)
             ev1 = []
             for rep in range(6):
@@ -356,6 +362,8 @@ def main():
         flush_us = None
         try:
             from kivi_amd.quant import new_pack
+            if not hasattr(layers[0], "k_code"):
+                raise AttributeError("matrix-pipe layout")
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
             scratch_page = [torch.empty_like(x[:, :, 0]) for x in (layers[0].k_code, layers[0].k_scale, layers[0].k_mn)]
             for rep in range(2):
@@ -379,7 +387,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
-                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (1 decode-row launch for MHA rows <= 8192 keys, else qK^T + [row softmax] + sV; +1 K flush every R steps)",
+                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (MHA rows <= 8192 keys: 1 decode-row launch; nh / nh_kv in {4, 8}: 2 launches on the matrix-pipe layout; else qK^T + [row softmax] + sV; +1 K flush every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
                        "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)",

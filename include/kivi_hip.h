@@ -262,6 +262,35 @@ int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, i
                     void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
                     int bits, kivi_stream_t stream);
 
+/*
+ * kivi_gqa_decode: the whole decode step of one layer for grouped queries over the KT / VT layouts, two launches:
+ *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies
+ *      1/sqrt(D) and the mask (:339, :364-372), writes the scaled scores to `scores` and (max, sum exp) of every
+ *      512-token segment to `stats`;
+ *   2. packed sV on the matrix pipe with the softmax applied on the fly (p = fp16(exp(x - max) / sum), :375) + fp16
+ *      window (:377-384) + V append + quantisation of the token leaving the window into the VT layout (:386-399);
+ *      rows are cut into slices, partial sums meet in `workspace`.
+ * Lengths: Tq packed keys (multiple of 32) + k_res_len residual keys == Tv packed values + v_res_len window values.
+ * `stats`: >= B * nh * (ceil(Tq / 512) + 4) * 2 floats.  `workspace`: 64 KiB of arrival counters (zeroed once by the
+ * caller) followed by B * nh_kv * (slices + 1) * (nh / nh_kv) * 128 floats (slices <= ceil(Tv / 512)).
+ */
+typedef struct {
+    int B, nh, nh_kv, D, group_size, bits;
+    float inv_scale;
+    const void* q; int64_t q_sb, q_sh;
+    const void* mask; int64_t mask_sb;
+    void* kt; int64_t kt_sb, kt_sh, kt_ss; int64_t Tq;
+    void* kres; int64_t kres_sb, kres_sh, kres_st; const void* knew; int64_t knew_sb, knew_sh; int k_res_len;
+    void* vt; int64_t vt_sb, vt_sh, vt_ss; int64_t Tv;
+    void* vres; int64_t vres_sb, vres_sh, vres_st; int v_win_start, v_res_len;
+    const void* vnew; int64_t vnew_sb, vnew_sh; int v_flush;
+    void* scores; int64_t s_sb, s_sh;
+    void* stats; int64_t stats_bytes;
+    void* workspace; int64_t workspace_bytes;
+    void* out; int64_t out_sb, out_sh;
+} kivi_gqa_decode_args;
+int kivi_gqa_decode(const kivi_gqa_decode_args* args, kivi_stream_t stream);
+
 /* ------------------------------------------------------ layer step --- */
 
 /*

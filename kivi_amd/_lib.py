@@ -62,6 +62,26 @@ class LayerDesc(ctypes.Structure):
     ]
 
 
+class GqaDecodeArgs(ctypes.Structure):
+    """kivi_gqa_decode_args of include/kivi_hip.h (field order must match)."""
+    _fields_ = [
+        ("B", _i32), ("nh", _i32), ("nh_kv", _i32), ("D", _i32), ("group_size", _i32), ("bits", _i32),
+        ("inv_scale", ctypes.c_float),
+        ("q", _vp), ("q_sb", _i64), ("q_sh", _i64),
+        ("mask", _vp), ("mask_sb", _i64),
+        ("kt", _vp), ("kt_sb", _i64), ("kt_sh", _i64), ("kt_ss", _i64), ("Tq", _i64),
+        ("kres", _vp), ("kres_sb", _i64), ("kres_sh", _i64), ("kres_st", _i64),
+        ("knew", _vp), ("knew_sb", _i64), ("knew_sh", _i64), ("k_res_len", _i32),
+        ("vt", _vp), ("vt_sb", _i64), ("vt_sh", _i64), ("vt_ss", _i64), ("Tv", _i64),
+        ("vres", _vp), ("vres_sb", _i64), ("vres_sh", _i64), ("vres_st", _i64), ("v_win_start", _i32), ("v_res_len", _i32),
+        ("vnew", _vp), ("vnew_sb", _i64), ("vnew_sh", _i64), ("v_flush", _i32),
+        ("scores", _vp), ("s_sb", _i64), ("s_sh", _i64),
+        ("stats", _vp), ("stats_bytes", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64),
+        ("out", _vp), ("out_sb", _i64), ("out_sh", _i64),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/kivi_hip.h declares
 SIGNATURES = {
     "kivi_abi_version": (_i32, []),
@@ -96,6 +116,7 @@ SIGNATURES = {
                                 _i64, _i32, _i32, _i32, _vp]),
     "kivi_gqa_scores": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
                                _i32, _vp]),
+    "kivi_gqa_decode": (_i32, [ctypes.POINTER(GqaDecodeArgs), _vp]),
     "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),

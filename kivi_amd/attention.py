@@ -22,12 +22,13 @@ import torch.nn.functional as F
 
 from ._lib import KiviUnsupported
 from .cache import KiviCacheTuple, KiviConfig, KiviLayerCache
+from .cache_mf import KiviLayerCacheMF, make_layer_cache, supported as _mf_supported
 from .quant import fused
 from .quant.matmul import cuda_bmm_fA_qB_outer, gemv_k_paged
 
 __all__ = ["kivi_attention_decode", "kivi_attention_prefill", "LlamaAttention_KIVI", "LlamaFlashAttention_KIVI",
            "MistralAttention_KIVI", "MistralFlashAttention_KIVI",
-           "KiviConfig", "KiviLayerCache"]
+           "KiviConfig", "KiviLayerCache", "KiviLayerCacheMF", "make_layer_cache"]
 
 
 def _row_buffer(layer: KiviLayerCache, name: str, nh: int) -> torch.Tensor:
@@ -221,6 +222,8 @@ def kivi_attention_decode(query_states: torch.Tensor, key_states: torch.Tensor, 
     `fused_kernels=False` forces the reference-style composition (one launch per reference op).
     `out`: optional preallocated (B, nh, 1, D) fp16 result buffer (static buffers of graph-captured callers)."""
     layer.ensure_room(1)     # the reference's tuple grows without bound; the in-place cache doubles when it is full
+    if isinstance(layer, KiviLayerCacheMF):   # grouped queries on the matrix pipe: two launches for the whole step
+        return layer.decode_step(query_states, key_states, value_states, attention_mask, out)
     res = _attention_decode(query_states, key_states, value_states, layer, attention_mask, fused_kernels, out)
     if out is not None and res is not out:
         out.copy_(res)
@@ -397,12 +400,14 @@ class LlamaAttention_KIVI(nn.Module):
                         f"stale KIVI past_key_value: the tuple was issued at kv length {past_len}, its cache has since "
                         f"advanced to {layer.kv_seq_len}. In-place cache tuples are single-use; clone the cache "
                         f"(KiviLayerCache.clone()) to continue one prefix twice.")
+            elif _mf_supported(self.kivi, self.head_dim, self.num_heads, self.num_key_value_heads):
+                layer = KiviLayerCacheMF.from_tuple(self.kivi, past_key_value, self._capacity(past_len + 1), self.num_heads)
             else:  # a plain reference-style tuple: adopt it once
                 layer = KiviLayerCache.from_tuple(self.kivi, past_key_value, self._capacity(past_len + 1))
             attn_output = kivi_attention_decode(q, k, v, layer, attention_mask)
         else:
-            layer = KiviLayerCache(self.kivi, bsz, self.num_key_value_heads, self.head_dim, self._capacity(q_len),
-                                   hidden_states.device, q.dtype)
+            layer = make_layer_cache(self.kivi, bsz, self.num_key_value_heads, self.head_dim, self._capacity(q_len),
+                                     hidden_states.device, q.dtype, num_heads=self.num_heads)
             attn_output = kivi_attention_prefill(q, k, v, layer)
         past = layer.as_tuple() if use_cache else None                                     # :454-455
         attn_output = attn_output.transpose(1, 2).reshape(bsz, q_len, self.num_heads * self.head_dim)

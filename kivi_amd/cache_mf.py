@@ -1,0 +1,270 @@
+"""Per-layer KIVI cache for grouped-query models in the matrix-pipe layout (kivi_amd/csrc/kivi_mfma_layout.h).
+
+Same state machine and the same bits as KiviLayerCache (cache.py; reference contract models/llama_kivi.py:454-455, read
+back at :315-322; Mistral: models/mistral_kivi.py:381-385, :441-445): the 9-tuple members are reproduced bit for bit by
+the relayout kernels.  What differs is where the packed codes live: super-blocks of 512 tokens whose words are B operands
+of v_mfma_f32_16x16x32_f16, so that the nh / nh_kv query heads of a kv head share every code on the matrix pipe instead of
+costing one FMA each (the shared-unpack VALU kernels run at ~0.35 of the HBM roofline for nh / nh_kv = 4).
+
+A decode step is two launches (kivi_gqa_decode): packed qK^T + residual scores + K append + softmax statistics, then
+softmax-on-the-fly + packed sV + fp16 window + V append / quantise; + one kivi_kt_pack every R steps (the K flush).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+
+import torch
+
+from . import _lib
+from .cache import KiviCacheTuple, KiviConfig
+from .quant import mfma, new_pack
+
+SB = mfma.SB_TOKENS
+_SCRATCH = {}   # device -> dict(scores, stats, ws): shared by every layer on the device (launches are stream-ordered)
+_WS_COUNTER_BYTES = 65536
+
+
+def supported(cfg: KiviConfig, head_dim: int, num_heads: int, num_kv_heads: int) -> bool:
+    if os.environ.get("KIVI_NO_MFMA_LAYOUT"):     # tuning aid: keep grouped-query models on the hook-state layout
+        return False
+    return num_heads % num_kv_heads == 0 and mfma.supported(cfg.k_bits, cfg.v_bits, cfg.group_size, head_dim,
+                                                            cfg.residual_length, num_heads // num_kv_heads) \
+        and cfg.residual_length <= 128
+
+
+def _scratch(device, B: int, nh: int, nh_kv: int, pitch: int, nseg: int, slices: int):
+    d = _SCRATCH.setdefault(device, {})
+    sc = d.get("scores")
+    if sc is None or sc.shape[0] < B or sc.shape[1] < nh or sc.shape[3] < pitch:
+        sc = torch.empty((B, nh, 1, pitch), dtype=torch.float16, device=device)
+        d["scores"] = sc
+    st = d.get("stats")
+    need = B * nh * nseg * 2
+    if st is None or st.numel() < need:
+        st = torch.empty(need, dtype=torch.float32, device=device)
+        d["stats"] = st
+    ws = d.get("ws")
+    need = _WS_COUNTER_BYTES + B * nh_kv * (slices + 1) * (nh // nh_kv) * 128 * 4
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)   # arrival counters start at zero; the kernel resets them
+        d["ws"] = ws
+    return sc, st, ws
+
+
+class KiviLayerCacheMF:
+    """One layer's quantised KV cache (capacity `max_len` tokens, appended in place) for nh / nh_kv in {4, 8}."""
+
+    layout = "mfma"
+
+    def __init__(self, cfg: KiviConfig, batch: int, num_kv_heads: int, head_dim: int, max_len: int, device,
+                 dtype=torch.float16, num_heads: int = None):
+        assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
+        assert num_heads is not None and supported(cfg, head_dim, num_heads, num_kv_heads), \
+            "matrix-pipe layout: 2-bit, group 32, head_dim 128, nh / nh_kv in {4, 8}, residual_length <= 128"
+        self.cfg = cfg
+        R = cfg.residual_length
+        self.B, self.nh_kv, self.D, self.nh = batch, num_kv_heads, head_dim, num_heads
+        self.cap = ((max_len + R - 1) // R) * R
+        self.n_sb = (self.cap + SB - 1) // SB
+        self.kt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
+        self.vt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
+        self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=device)
+        self.v_res = torch.empty((batch, num_kv_heads, 2 * R + 1, head_dim), dtype=dtype, device=device)
+        self.k_quant_len = 0
+        self.k_res_len = 0
+        self.v_quant_len = 0
+        self.v_res_start = 0
+        self.v_res_len = 0
+        self.kv_seq_len = 0
+
+    # ------------------------------------------------------------------ capacity
+    def reserve(self, max_len: int) -> None:
+        R = self.cfg.residual_length
+        cap = ((max_len + R - 1) // R) * R
+        if cap <= self.cap:
+            return
+        n_sb = (cap + SB - 1) // SB
+        if n_sb > self.n_sb:
+            for name in ("kt", "vt"):
+                old = getattr(self, name)
+                new = mfma.alloc_store(self.B, self.nh_kv, n_sb, old.device)
+                new[:, :, : self.n_sb].copy_(old)
+                setattr(self, name, new)
+            self.n_sb = n_sb
+        self.cap = cap
+
+    def ensure_room(self, tokens: int = 1) -> None:
+        need = self.kv_seq_len + tokens
+        if need > self.cap:
+            self.reserve(max(need, 2 * self.cap))
+
+    def clone(self) -> "KiviLayerCacheMF":
+        import copy
+        other = copy.copy(self)
+        for name in ("kt", "vt", "k_res", "v_res"):
+            src = getattr(self, name)
+            dst = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device)
+            dst.copy_(src)
+            setattr(other, name, dst)
+        return other
+
+    # ------------------------------------------------------------------ the 9-tuple
+    def k_quant_reference_layout(self):
+        if self.k_quant_len == 0:
+            return None, None, None
+        return mfma.kt_to_ref(self.kt, self.k_quant_len, self.D, self.cfg.group_size, self.cfg.k_bits)
+
+    def v_quant_views(self):
+        if self.v_quant_len == 0:
+            return None, None, None
+        return mfma.vt_to_ref(self.vt, self.v_quant_len, self.D, self.cfg.group_size, self.cfg.v_bits)
+
+    def k_res_view(self):
+        return self.k_res[:, :, : self.k_res_len] if self.k_res_len else None
+
+    def v_res_view(self):
+        return self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len]
+
+    def _tuple_members(self):
+        kc, ks, km = self.k_quant_reference_layout()
+        vc, vs, vm = self.v_quant_views()
+        return (kc, self.k_res_view(), ks, km, vc, self.v_res_view(), vs, vm)
+
+    def as_tuple(self) -> KiviCacheTuple:
+        return KiviCacheTuple(self)
+
+    def nbytes(self) -> int:
+        c = self.cfg
+        per_k = self.D * self.k_quant_len * c.k_bits // 8 + 2 * self.D * (self.k_quant_len // c.group_size) * 2
+        per_v = self.v_quant_len * self.D * c.v_bits // 8 + 2 * self.v_quant_len * (self.D // c.group_size) * 2
+        res = (self.k_res_len + self.v_res_len) * self.D * 2
+        return self.B * self.nh_kv * (per_k + per_v + res)
+
+    def allocated_bytes(self) -> int:
+        return sum(x.numel() * x.element_size() for x in (self.kt, self.vt, self.k_res, self.v_res))
+
+    # ------------------------------------------------------------------ prefill (llama_kivi.py:425-452)
+    def prefill(self, key_states: torch.Tensor, value_states: torch.Tensor) -> None:
+        cfg = self.cfg
+        R, g = cfg.residual_length, cfg.group_size
+        T = key_states.shape[2]
+        self.reserve(T)
+        nq = (T // R) * R
+        if nq:
+            mfma.kt_pack(key_states[:, :, :nq], self.kt, 0, g, cfg.k_bits)
+        self.k_quant_len = nq
+        self.k_res_len = T - nq
+        if self.k_res_len:
+            self.k_res[:, :, : self.k_res_len].copy_(key_states[:, :, nq:])
+        nv = max(T - R, 0)
+        if nv:
+            code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(value_states[:, :, :nv].contiguous(), g, cfg.v_bits)
+            mfma.vt_from_ref(self.vt, code, scale, mn, g, cfg.v_bits)
+        self.v_quant_len = nv
+        self.v_res_start = 0
+        self.v_res_len = T - nv
+        self.v_res[:, :, : self.v_res_len].copy_(value_states[:, :, nv:])
+        self.kv_seq_len = T
+
+    def compact_v_window(self) -> None:
+        live = self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len].clone()
+        self.v_res[:, :, : self.v_res_len].copy_(live)
+        self.v_res_start = 0
+
+    @classmethod
+    def from_tuple(cls, cfg: KiviConfig, past, max_len: int, num_heads: int) -> "KiviLayerCacheMF":
+        kc, kfull, ks, km, vc, vfull, vs, vm, kv_len = past
+        ref = vfull if vfull is not None else kfull
+        B, nh_kv, _, D = ref.shape
+        self = cls(cfg, B, nh_kv, D, max_len, ref.device, ref.dtype, num_heads=num_heads)
+        if kc is not None:
+            self.k_quant_len = kc.shape[-1] * (32 // cfg.k_bits)
+            mfma.kt_from_ref(self.kt, kc.contiguous(), ks.contiguous(), km.contiguous(), cfg.group_size, cfg.k_bits)
+        if kfull is not None:
+            self.k_res_len = kfull.shape[2]
+            self.k_res[:, :, : self.k_res_len].copy_(kfull)
+        if vc is not None:
+            self.v_quant_len = vc.shape[2]
+            mfma.vt_from_ref(self.vt, vc.contiguous(), vs.contiguous(), vm.contiguous(), cfg.group_size, cfg.v_bits)
+        self.v_res_len = vfull.shape[2]
+        self.v_res[:, :, : self.v_res_len].copy_(vfull)
+        self.kv_seq_len = int(kv_len)
+        return self
+
+    # ------------------------------------------------------------------ decode step (llama_kivi.py:314-399)
+    def decode_step(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
+                    attention_mask: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
+        cfg = self.cfg
+        R = cfg.residual_length
+        B, nh, _, D = query_states.shape
+        assert nh == self.nh and B == self.B and D == self.D
+        q = query_states if query_states.stride(3) == 1 else query_states.contiguous()
+        k = key_states if key_states.stride(3) == 1 else key_states.contiguous()
+        v = value_states if value_states.stride(3) == 1 else value_states.contiguous()
+        kv_seq_len = self.kv_seq_len + 1
+        mask_ptr, mask_sb = None, 0
+        if attention_mask is not None:
+            if attention_mask.size() != (B, 1, 1, kv_seq_len):
+                raise ValueError(f"Attention mask should be of size {(B, 1, 1, kv_seq_len)}, but is {attention_mask.size()}")
+            assert attention_mask.dtype == torch.float16 and attention_mask.stride(3) == 1
+            mask_ptr, mask_sb = attention_mask.data_ptr(), attention_mask.stride(0)
+        if self.v_res_start + self.v_res_len + 1 > self.v_res.shape[2]:
+            self.compact_v_window()
+        if out is None:
+            out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=q.device)
+        pitch = ((self.cap + 1 + 7) // 8) * 8
+        nseg = (self.k_quant_len + SB - 1) // SB + 4
+        scores, stats, ws = _scratch(q.device, B, nh, self.nh_kv, pitch, max(nseg, self.n_sb + 4), self.n_sb)
+        flush = self.v_res_len + 1 > R
+        kt, vt, kr, vr = self.kt, self.vt, self.k_res, self.v_res
+        a = _lib.GqaDecodeArgs(
+            B=B, nh=nh, nh_kv=self.nh_kv, D=D, group_size=cfg.group_size, bits=cfg.k_bits, inv_scale=1.0 / math.sqrt(D),
+            q=q.data_ptr(), q_sb=q.stride(0), q_sh=q.stride(1), mask=mask_ptr, mask_sb=mask_sb,
+            kt=kt.data_ptr(), kt_sb=kt.stride(0), kt_sh=kt.stride(1), kt_ss=kt.stride(2), Tq=self.k_quant_len,
+            kres=kr.data_ptr(), kres_sb=kr.stride(0), kres_sh=kr.stride(1), kres_st=kr.stride(2),
+            knew=k.data_ptr(), knew_sb=k.stride(0), knew_sh=k.stride(1), k_res_len=self.k_res_len,
+            vt=vt.data_ptr(), vt_sb=vt.stride(0), vt_sh=vt.stride(1), vt_ss=vt.stride(2), Tv=self.v_quant_len,
+            vres=vr.data_ptr(), vres_sb=vr.stride(0), vres_sh=vr.stride(1), vres_st=vr.stride(2),
+            v_win_start=self.v_res_start, v_res_len=self.v_res_len,
+            vnew=v.data_ptr(), vnew_sb=v.stride(0), vnew_sh=v.stride(1), v_flush=int(flush),
+            scores=scores.data_ptr(), s_sb=scores.stride(0), s_sh=scores.stride(1),
+            stats=stats.data_ptr(), stats_bytes=stats.numel() * 4,
+            workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+            out=out.data_ptr(), out_sb=out.stride(0), out_sh=out.stride(1))
+        hook = _launch_hook()
+        if hook is not None and self.k_quant_len:
+            hook("pre", "k", dict(B=B, nh=nh, nh_kv=self.nh_kv, K=D, N=self.k_quant_len, bits=cfg.k_bits,
+                                  group_size=cfg.group_size, v_bits=cfg.v_bits, Tv=self.v_quant_len,
+                                  k_res=self.k_res_len + 1, v_res=self.v_res_len + 1))
+        _lib.check(_lib.load().kivi_gqa_decode(ctypes.byref(a), _lib.stream_ptr(q)), "kivi_gqa_decode")
+        # committed: the launches appended the new key (:333-336) and value (:377) and, when the window was full,
+        # quantised the token leaving it (:386-399)
+        self.k_res_len += 1
+        self.v_res_len += 1
+        if flush:
+            self.v_quant_len += 1
+            self.v_res_start += 1
+            self.v_res_len -= 1
+        self.kv_seq_len = kv_seq_len
+        if self.k_res_len == R:              # :343-356
+            mfma.kt_pack(self.k_res, self.kt, self.k_quant_len, cfg.group_size, cfg.k_bits)
+            self.k_quant_len += R
+            self.k_res_len = 0
+        return out
+
+
+def _launch_hook():
+    from .quant import matmul
+    return matmul.launch_hook
+
+
+def make_layer_cache(cfg: KiviConfig, batch: int, num_kv_heads: int, head_dim: int, max_len: int, device,
+                     dtype=torch.float16, num_heads: int = None):
+    """The cache class for a model shape: the matrix-pipe layout for grouped queries it covers, the hook-state layout
+    (KiviLayerCache) otherwise."""
+    from .cache import KiviLayerCache
+    if num_heads is not None and supported(cfg, head_dim, num_heads, num_kv_heads):
+        return KiviLayerCacheMF(cfg, batch, num_kv_heads, head_dim, max_len, device, dtype, num_heads=num_heads)
+    return KiviLayerCache(cfg, batch, num_kv_heads, head_dim, max_len, device, dtype)

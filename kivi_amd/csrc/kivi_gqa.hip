@@ -16,24 +16,12 @@
 #include <string.h>
 
 #include "kivi_common.h"
-#include "kivi_mfma_layout.h"
+#include "kivi_gqa_dev.h"
 #include "kivi_quant.h"
-#include "kivi_row_softmax.h"
 
 namespace {
 
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-struct MfStore {              // one cache side (K or V) in the super-block layout
-    uint32_t* base;
-    int64_t sb_b, sb_h, sb_s; // word strides: batch row, kv head, super-block
-};
-
-__device__ __forceinline__ uint32_t* mf_sb(const MfStore& s, int b, int hk, int64_t sb) {
-    return s.base + b * s.sb_b + hk * s.sb_h + sb * s.sb_s;
-}
+constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per unit)
 
 // ------------------------------------------------------------------------------------------------ pack / relayout
 
@@ -64,7 +52,8 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
     for (int n = 0; n < 16; n++) {
         const uint32_t ce = quant_one<2>((uint16_t)(x[n] & 0xFFFFu), g0), co = quant_one<2>((uint16_t)(x[n] >> 16), g1);
         const uint32_t ce2 = quant_one<2>((uint16_t)(x[n + 16] & 0xFFFFu), g0), co2 = quant_one<2>((uint16_t)(x[n + 16] >> 16), g1);
-        uint32_t w = (ce << (2 * i)) | (co << (2 * i + 16)) | (ce2 << (2 * i + 8)) | (co2 << (2 * i + 24));
+        const int p0 = mf_pos(0, i), p1 = mf_pos(1, i);
+        uint32_t w = (ce << p0) | (co << (p0 + 16)) | (ce2 << p1) | (co2 << (p1 + 16));
         w |= (uint32_t)__shfl_xor((int)w, 1);      // the 4 lanes of a quad hold the 4 channel pairs of one word
         w |= (uint32_t)__shfl_xor((int)w, 2);
         pw[n] = w;
@@ -182,79 +171,107 @@ __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ shared MFMA pieces
-
-__device__ __forceinline__ h8 as_h8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    return __builtin_bit_cast(h8, (u32x4){a, b, c, d});
-}
-__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) * __builtin_bit_cast(h2, b));
-}
-// a * b - c, one rounding (v_pk_fma_f16): with c = fp16(a * b) the exact remainder of the product
-__device__ __forceinline__ uint32_t pk_fms(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b),
-                                                                  -__builtin_bit_cast(h2, c)));
-}
-// 2^(2 i - 6) in both halves: brings a zero-point operand to the scale of the A rows (which carry 2^(6 - 2 i))
-__device__ __forceinline__ constexpr uint32_t zfac(int i) { return i == 0 ? 0x24002400u : i == 1 ? 0x2C002C00u : i == 2 ? 0x34003400u : 0x3C003C00u; }
-// 2^(6 - 2 i) in both halves
-__device__ __forceinline__ constexpr uint32_t afac(int i) { return i == 0 ? 0x54005400u : i == 1 ? 0x4C004C00u : i == 2 ? 0x44004400u : 0x3C003C00u; }
-
-// hi / lo rows of the A operand without a branch: `xf` is x in the lanes of a "lo" row and 0 in the lanes of a "hi" row,
-// so  fma(x, s, -fp16(xf * s))  is the rounded product in hi rows and its exact remainder in lo rows (two packed ops).
-// Without the split (HILO = false) `xf` is x in hi rows and 0 in lo rows and the element is one packed multiply.
-template <bool HILO>
-__device__ __forceinline__ uint32_t a_elem(uint32_t x, uint32_t xf, uint32_t s) {
-    if constexpr (HILO) return pk_fms(x, s, pk_mul(xf, s));
-    else return pk_mul(xf, s);
-}
-
-// one 32-channel (K) / 32-token (V) chunk: two MFMAs, the masked code words are the B operands
-__device__ __forceinline__ void mfma_pair(const uint32_t* A, uint32_t w, f4& acc0, f4& acc1) {
-    const uint32_t ws = w >> 8;
-    const h8 a = as_h8(A[0], A[1], A[2], A[3]);
-    const h8 b0 = as_h8(w & 0x00030003u, w & 0x000C000Cu, w & 0x00300030u, w & 0x00C000C0u);
-    const h8 b1 = as_h8(ws & 0x00030003u, ws & 0x000C000Cu, ws & 0x00300030u, ws & 0x00C000C0u);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc1, 0, 0, 0);
-}
-
-// rows hi + lo of two accumulator registers (tile 0 in x, tile 1 in y) in one swap + add:
-//   R = 4: lanes 0-15 <- tile 0 rows j + (4 + j), lanes 16-31 <- tile 1 (v_permlane16_swap: odd rows of x <-> even rows of y)
-//   R = 8: lanes 0-31 <- tile 0 rows (0..7) + (8..15), lanes 32-63 <- tile 1 (v_permlane32_swap)
-// (inline asm: on ROCm 7.2 the __builtin_amdgcn_permlane16_swap / 32_swap builtins return the FIRST result in both slots
-// -- hipcc emits v_add v, v, v after the swap; checked with hipcc -S)
-template <int R>
-__device__ __forceinline__ float fold_rows(float x, float y) {
-    if constexpr (R == 4) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-
 // ------------------------------------------------------------------------------------------------ qK^T
 
 struct GqaKArgs {
     const uint16_t* q;
     int64_t q_sb, q_sh;
     MfStore kt;
-    uint16_t* out;
+    uint16_t* out;              // score rows: raw fp16 scores (stats == null) or scaled + masked scores (decode step)
     int64_t out_sb, out_sh;
-    int nh_kv, ratio;
+    int nh_kv, ratio, nh;
     int64_t Tq;                 // packed tokens (multiple of 32)
     int nsb, sb_blocks;         // super-blocks of a row, thread blocks per (b, kv head)
+    // decode step (kivi_gqa_decode): the epilogue applies 1/sqrt(D) + mask exactly as the reference feeds its softmax
+    // (llama_kivi.py:339, :364-372) and leaves (max, sum exp(x - max)) of every segment of the row in `stats`
+    float* stats;               // [B][nh][nseg][2] or null
+    int nseg;                   // nsb + KIVI_GQA_RES_SEGS
+    float inv_scale;
+    const uint16_t* mask;       // (B, 1, 1, n) additive fp16 mask or null
+    int64_t mask_sb;
+    // residual role (the FIRST res_blocks blocks of the grid): q . [fp16 K residual | new key] (:333-337) + the K append
+    int res_blocks;             // units * KIVI_GQA_RES_SEGS or 0
+    uint16_t* kres;
+    int64_t kres_sb, kres_sh, kres_st;
+    const uint16_t* knew;
+    int64_t knew_sb, knew_sh;
+    int res_len;                // keys already in the residual; the new one becomes index res_len
 };
 
+// Residual role of the decode step: block (unit, j) scores keys [j c, (j + 1) c) of the residual (c = ceil(L / 4), L =
+// res_len + 1 incl. the new key) for the R query heads of the unit, 8 lanes per (head, key) with 16-byte loads, fp32
+// accumulate, one rounding (the reference's fp16 torch.matmul, llama_kivi.py:337), writes the scaled scores and the
+// statistics of its segment, and appends the new key (:333-336).  Short, latency-bound blocks: first in the grid.
+template <int R>
+__device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
+    constexpr int CH = 36;                                         // keys per segment: L <= 129 -> c <= 33
+    __shared__ float xs[R][CH];
+    const int unit = bid / KIVI_GQA_RES_SEGS, j = bid - unit * KIVI_GQA_RES_SEGS;
+    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
+    const int h0 = hk * a.ratio;
+    const int L = a.res_len + 1;
+    const int c = (L + KIVI_GQA_RES_SEGS - 1) / KIVI_GQA_RES_SEGS;
+    const int t0 = j * c;
+    const int nt = (t0 + c <= L ? c : L - t0) > 0 ? (t0 + c <= L ? c : L - t0) : 0;
+    const uint16_t* knew = a.knew + b * a.knew_sb + hk * a.knew_sh;
+    uint16_t* kres = a.kres + b * a.kres_sb + hk * a.kres_sh;
+    const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb : nullptr;
+    const int nthr = (int)blockDim.x;
+    for (int idx = threadIdx.x; idx < R * nt * 8; idx += nthr) {
+        const int sub = idx & 7, rt = idx >> 3;
+        const int r = rt / nt, t = t0 + (rt - r * nt);
+        const uint16_t* krow = ((t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew) + sub * 16;
+        const uint16_t* qrow = a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + sub * 16;
+        const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
+        const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
+        float sc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
+        if (t == a.res_len && r == 0) {                             // append the new key
+            *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16) = k0;
+            *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16 + 8) = k1;
+        }
+        sc += __shfl_xor(sc, 1);
+        sc += __shfl_xor(sc, 2);
+        sc += __shfl_xor(sc, 4);
+        if (sub == 0) {
+            const uint16_t x = kivi_scaled_score(f2h_bits(sc), a.inv_scale, mrow != nullptr, mrow ? mrow[a.Tq + t] : 0);
+            a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.Tq + t] = x;
+            xs[r][t - t0] = h2f_bits(x);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthr >> 6;
+    for (int r = wave; r < R; r += nw) {
+        const float v = lane < nt ? xs[r][lane] : -__builtin_inff();
+        const float m = wave_max(v);
+        const float l = wave_sum(lane < nt ? kivi_exp(v - m) : 0.f);
+        if (lane == 0) {
+            float* st = a.stats + (((int64_t)b * a.nh + h0 + r) * a.nseg + a.nsb + j) * 2;
+            st[0] = m;
+            st[1] = l;
+        }
+    }
+}
+
 // W waves per thread block, one super-block each; nothing is shared between the waves of a block.
-template <int R, int W, bool HILO>
+// RING = code blocks requested ahead of the one being multiplied (1 KiB per wave each).
+template <int R, int W, bool HILO, int RING>
 __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
-    constexpr int S = KIVI_MF_SHIFT;
     extern __shared__ uint32_t lds_all[];
+    if ((int)blockIdx.x < a.res_blocks) {
+        gqa_k_residual<R>(a, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.res_blocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_s = lds_all + wave * (1024 + R * 256);          // scale of the super-block: 16 groups x 64 words
     uint16_t* lds_o = (uint16_t*)(lds_s + 1024);                  // R x 512 fp16 scores
-    const int unit = (int)blockIdx.x / a.sb_blocks;
-    const int sb = ((int)blockIdx.x - unit * a.sb_blocks) * W + wave;
+    const int unit = bid / a.sb_blocks;
+    const int sb = (bid - unit * a.sb_blocks) * W + wave;
     if (sb >= a.nsb) return;
     const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
     const int h0 = hk * a.ratio;
@@ -268,14 +285,15 @@ __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
     const rsrc_t rk = make_rsrc(sbp, KIVI_MF_SB_WORDS * 4);
 
     // requests first: scale of the whole super-block (-> LDS), zero points (B operand of the zero-point MFMAs: lane
-    // (n, kb) takes group n), the first two code blocks
+    // (n, kb) takes group n), the first RING code blocks
     u32x4 sreg[4], zreg[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
 #pragma unroll
     for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + n * 256 + kb * 64 + c * 16), 0);
-    u32x4 w0 = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), 0);
-    u32x4 w1 = buf_load<u32x4, true>(rk, (uint32_t)(1024 + lane * 16), 0);
+    u32x4 wr[RING];
+#pragma unroll
+    for (int i = 0; i < RING; i++) wr[i] = buf_load<u32x4, true>(rk, (uint32_t)(i * 1024 + lane * 16), 0);
 
     // q of this lane's row: channels 32 c + 8 kb + e, normalised to max |q| in [1, 2) (Sq) and pre-multiplied by
     // 2^(6 - 2 i) per channel pair i, so that A = q'' * scale stays a normal fp16 for any realistic scale
@@ -300,18 +318,18 @@ __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
     for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sq + S - 2 * i);
-            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sq + S - 2 * i);
+            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sq + aexp(i));
+            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sq + aexp(i));
             qq[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
             qf[c][i] = (lo_row == HILO) ? qq[c][i] : 0u;           // see a_elem
         }
-    // per output register j of a lane: which head, its 2^(24 - S - Sq) and 2^-Sq
+    // per output register j of a lane: which head, its 2^(12 - Sq) and 2^-Sq
     float cmul[4], zmul[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int rj = (R == 4) ? j : 4 * ((lane >> 4) & 1) + j;  // head of output register j after fold_rows
         const int sqj = __shfl(sq, rj);                           // lane rj (kb = 0, n = rj) holds head rj's exponent
-        cmul[j] = __builtin_ldexpf(1.0f, 24 - S - sqj);
+        cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
     }
 
@@ -363,32 +381,430 @@ __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
         }
     };
 
-    // ring of code blocks: two groups in flight ahead of the one being multiplied
+    // ring of code blocks: RING groups in flight ahead of the one being multiplied (loads past the last group of a
+    // partial super-block read the zero-filled rest of it: harmless)
+    // (rolled over rounds of RING groups, unrolled inside a round: the ring slots are static registers)
+    for (int g0 = 0; g0 < ng; g0 += RING) {
 #pragma unroll
-    for (int g = 0; g < 16; g += 2) {
-        if (g >= ng) break;
-        const u32x4 w2 = buf_load<u32x4, true>(rk, (uint32_t)((g + 2) * 1024 + lane * 16), 0);
-        group(g, w0);
-        const u32x4 w3 = buf_load<u32x4, true>(rk, (uint32_t)((g + 3) * 1024 + lane * 16), 0);
-        if (g + 1 < ng) group(g + 1, w1);
-        w0 = w2;
-        w1 = w3;
+        for (int j = 0; j < RING; j++) {
+            const int g = g0 + j;
+            if (g < ng) {
+                const u32x4 w = wr[j];
+                wr[j] = buf_load<u32x4, true>(rk, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the super-block: zeros
+                group(g, w);
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // 512 tokens x R heads of fp16 scores: one 16-byte store per lane and head
+    const bool valid = lane * 8 < ng * 32;
+    const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8 : nullptr;
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
-        if (lane * 8 < ng * 32) {
-            const u16x8 v = *(const u16x8*)(lds_o + rr * 512 + lane * 8);
-            *(u16x8*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
+        u16x8 v = valid ? *(const u16x8*)(lds_o + rr * 512 + lane * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.stats) {
+            float x[8], m = -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[e] = kivi_scaled_score(v[e], a.inv_scale, mrow != nullptr, (mrow && valid) ? mrow[e] : 0);
+                x[e] = h2f_bits(v[e]);
+                m = __builtin_fmaxf(m, x[e]);
+            }
+            m = wave_max(valid ? m : -__builtin_inff());
+            float l = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) l += kivi_exp(x[e] - m);
+            l = wave_sum(valid ? l : 0.f);
+            if (lane == 0) {
+                float* st = a.stats + (((int64_t)b * a.nh + h0 + rr) * a.nseg + sb) * 2;
+                st[0] = m;
+                st[1] = l;
+            }
         }
+        if (valid)
+            *(u16x8*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
     }
 }
 
-template <int R, int W, bool HILO>
+template <int R, int W, bool HILO, int RING>
 void launch_gqa_k(const GqaKArgs& a, int units, hipStream_t s) {
     const size_t lds = (size_t)W * (1024 + R * 256) * 4;
-    KIVI_LAUNCH_LDS((gqa_k_kernel<R, W, HILO>), dim3((unsigned)(units * a.sb_blocks)), dim3(64 * W), lds, s, a);
+    KIVI_LAUNCH_LDS((gqa_k_kernel<R, W, HILO, RING>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a);
+}
+
+// shared by kivi_gqa_scores and kivi_gqa_decode
+int run_gqa_k(GqaKArgs& a, int units, hipStream_t s) {
+    static const char* nohilo = getenv("KIVI_GQA_NO_HILO");      // tuning aid: fp16-rounded q * scale (no remainder rows)
+    static const char* fw = getenv("KIVI_GQA_K_WAVES");          // tuning aid: waves per block (1 or 4)
+    static const char* fr = getenv("KIVI_GQA_K_RING");           // tuning aid: code blocks in flight (2, 4 or 8)
+    int W = ((int64_t)units * a.nsb >= 2048) ? 4 : 1;            // few super-blocks: one wave per block spreads them over the CUs
+    if (fw) W = atoi(fw) == 1 ? 1 : 4;
+    const int ring = fr ? atoi(fr) : 4;
+    a.sb_blocks = (a.nsb + W - 1) / W;
+    if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
+#define KIVI_GK(RR, WW, HL)                                       \
+    do {                                                          \
+        if (ring == 2) launch_gqa_k<RR, WW, HL, 2>(a, units, s);  \
+        else if (ring == 8) launch_gqa_k<RR, WW, HL, 8>(a, units, s); \
+        else launch_gqa_k<RR, WW, HL, 4>(a, units, s);            \
+    } while (0)
+    if (a.ratio == 4) {
+        if (nohilo) { if (W == 4) KIVI_GK(4, 4, false); else KIVI_GK(4, 1, false); }
+        else { if (W == 4) KIVI_GK(4, 4, true); else KIVI_GK(4, 1, true); }
+    } else {
+        if (nohilo) { if (W == 4) KIVI_GK(8, 4, false); else KIVI_GK(8, 1, false); }
+        else { if (W == 4) KIVI_GK(8, 4, true); else KIVI_GK(8, 1, true); }
+    }
+#undef KIVI_GK
+    return kivi_launch_status("gqa_k");
+}
+
+// ------------------------------------------------------------------------------------------------ sV (+ softmax, window)
+
+struct GqaVArgs {
+    const uint16_t* x;          // scaled + masked scores of the row (written by the qK^T launch)
+    int64_t x_sb, x_sh;
+    const float* stats;         // [B][nh][nseg][2]
+    int nseg;
+    MfStore vt;
+    int nh_kv, ratio, nh;
+    int64_t Tv;                 // packed tokens
+    int nsb;                    // super-blocks holding them
+    int S, spb;                 // stream blocks per (b, kv head), super-blocks per stream block
+    int win_blocks;             // = units: the FIRST blocks of the grid do the fp16 window, the V append and the flush
+    uint16_t* vres;             // (B, nh_kv, W, D) fp16 window buffer
+    int64_t vres_sb, vres_sh, vres_st;
+    int win_start, res_len;     // live rows [win_start, win_start + res_len); the new token goes right after
+    const uint16_t* vnew;
+    int64_t vnew_sb, vnew_sh;
+    int flush;                  // quantise the oldest window row into the layout at token Tv (llama_kivi.py:386-399)
+    uint16_t* out;
+    int64_t out_sb, out_sh;
+    float* ws;                  // [units][S + 1][R * 128] fp32 partial sums (slot S: the window part)
+    int* counters;              // [units] arrival counters, zero between launches
+};
+
+// softmax constants of the R rows of a unit from the segment statistics: M = max, 1 / sum exp(x - M).  Every lane of the
+// calling wave ends up with the same values.
+template <int R>
+__device__ __forceinline__ void gqa_row_consts(const GqaVArgs& a, int b, int h0, float* M, float* invS) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float* st = a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2;
+        float m = -__builtin_inff();
+        for (int i = lane; i < a.nseg; i += 64) m = __builtin_fmaxf(m, st[2 * i]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int i = lane; i < a.nseg; i += 64) l += st[2 * i + 1] * kivi_exp(st[2 * i] - m);
+        l = wave_sum(l);
+        M[r] = m;
+        invS[r] = 1.0f / l;
+    }
+}
+
+// Combine of a unit's partial sums by the block that arrives last (hand-off as in gemv_v_kernel<SPLIT>: write-through
+// payload, drained, one relaxed arrival counter; cdna_hip_programming.md G16).
+template <int R>
+__device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0) {
+    __shared__ int last_flag;
+    constexpr int RD = R * 128;
+    const int nslot = a.S + 1;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * nslot + slot) * RD);
+    for (int i = threadIdx.x; i < RD; i += 256)
+        __hip_atomic_store(dst + i, __builtin_bit_cast(uint32_t, part_lds[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == nslot - 1);
+        if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * nslot * RD);
+    for (int i = threadIdx.x; i < RD; i += 256) {
+        const int r = i >> 7, d = i & 127;
+        float q = 0.f;
+        for (int s0 = 0; s0 < a.S; s0 += 8) {   // 8 independent loads in flight, added in slice order
+            uint32_t v8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                v8[k] = (s0 + k < a.S) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) q += __builtin_bit_cast(float, v8[k]);
+        }
+        const float w = __builtin_bit_cast(float, __hip_atomic_load(p0 + (size_t)a.S * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (llama_kivi.py:382-384);
+        // only the window part exists before anything is quantised (:380)
+        const uint16_t o = (a.Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(q)) + h2f_bits(f2h_bits(w))) : f2h_bits(w);
+        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
+    }
+}
+
+// Window role: probs[..., -L:] @ V_window (llama_kivi.py:384) for the R heads of a unit, the V append (:377) and the
+// quantisation of the token that leaves the window (:386-399) into the VT layout.
+template <int R>
+__device__ __forceinline__ void gqa_v_window(const GqaVArgs& a, int unit, float* lds_f) {
+    constexpr int PW = 136;
+    __shared__ uint16_t pw[R][PW];
+    __shared__ float cst[2][R];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
+    const int h0 = hk * a.ratio;
+    const int L = a.res_len + 1;
+    uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+    const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+    // the token about to be quantised is requested first
+    uint16_t xflush = 0;
+    if (a.flush && threadIdx.x < 128) xflush = vwin[threadIdx.x];
+    float M[R], invS[R];
+    gqa_row_consts<R>(a, b, h0, M, invS);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) { cst[0][r] = M[r]; cst[1][r] = invS[r]; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < R * L; idx += 256) {
+        const int r = idx / L, t = idx - r * L;
+        const float x = h2f_bits(a.x[b * a.x_sb + (int64_t)(h0 + r) * a.x_sh + a.Tv + t]);
+        pw[r][t] = f2h_bits(kivi_exp(x - cst[0][r]) * cst[1][r]);
+    }
+    __syncthreads();
+    float o[R][2];
+#pragma unroll
+    for (int r = 0; r < R; r++) o[r][0] = o[r][1] = 0.f;
+    for (int t0 = wave; t0 < L; t0 += 16) {      // 4 tokens of this wave per round, their loads in flight together
+        uint32_t vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 4 * u;
+            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+            vv[u] = (t < L) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 4 * u;
+            if (t < L) {
+                const float v0 = h2f_bits((uint16_t)(vv[u] & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv[u] >> 16));
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float p = h2f_bits(pw[r][t]);
+                    o[r][0] = __builtin_fmaf(p, v0, o[r][0]);
+                    o[r][1] = __builtin_fmaf(p, v1, o[r][1]);
+                }
+                if (t == a.res_len) *(uint32_t*)(vwin + (int64_t)t * a.vres_st + 2 * lane) = vv[u];   // V append
+            }
+        }
+    }
+    // per-wave partials -> lds_f[wave][r][d]
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        lds_f[(wave * R + r) * 128 + 2 * lane] = o[r][0];
+        lds_f[(wave * R + r) * 128 + 2 * lane + 1] = o[r][1];
+    }
+    if (a.flush && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
+        const int d = threadIdx.x;
+        const uint32_t key = h_key(xflush);
+        uint32_t kmin = key, kmax = key;
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
+            kmin = o1 < kmin ? o1 : kmin;
+            kmax = o2 > kmax ? o2 : kmax;
+        }
+        const GroupQ gq = make_group(kmin, kmax, 3);
+        const uint32_t code = quant_one<2>(xflush, gq);
+        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+        const int e = tt & 7, kbq = tt >> 3;
+        const int c = d >> 5, tile = (d >> 4) & 1, n = d & 15;
+        uint32_t val = code << (mf_pos(tile, e >> 1) + 16 * (e & 1));
+        val |= (uint32_t)__shfl_xor((int)val, 16);
+        uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+        if (tile == 0) {
+            uint32_t* wp = sbp + blk * KIVI_MF_BLOCK_WORDS + (n + 16 * kbq) * 4 + c;
+            *wp = *wp | val;                 // the slot of a token is written once, on zero-initialised storage
+        }
+        if ((d & 31) == 0) {
+            const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
+            ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
+            ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * 128; i += 256)
+        lds_f[4 * R * 128 + i] = (lds_f[i] + lds_f[R * 128 + i]) + (lds_f[2 * R * 128 + i] + lds_f[3 * R * 128 + i]);
+    __syncthreads();
+    gqa_arrive_and_combine<R>(a, unit, a.S, lds_f + 4 * R * 128, b, h0);
+}
+
+// Stream role: block (unit, slice) takes `spb` consecutive super-blocks of the unit's packed V, one per wave at a time.
+template <int R, bool HILO, int RING>
+__global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
+    extern __shared__ uint32_t lds_all[];                          // 4 waves x 2048 words (scale | mn of the super-block)
+    if ((int)blockIdx.x < a.win_blocks) {
+        gqa_v_window<R>(a, (int)blockIdx.x, reinterpret_cast<float*>(lds_all));
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.win_blocks;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* lds_s = lds_all + wave * 2048;
+    uint32_t* lds_m = lds_s + 1024;
+    const int unit = bid / a.S, slice = bid - unit * a.S;
+    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
+    const int h0 = hk * a.ratio;
+    const int n = lane & 15, kb = lane >> 4;
+    const int r = n % R;
+    const bool lo_row = ((n / R) & 1) != 0;
+    const uint32_t lomask = (lo_row == HILO) ? 0xFFFFFFFFu : 0u;   // see a_elem
+
+    float M[R], invS[R];
+    gqa_row_consts<R>(a, b, h0, M, invS);
+    // per head: Sp = floor(log2(sum)) (<= 14): the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp before they enter
+    // the A operand, so that p * scale * 2^(6 - 2 i) stays a normal fp16 whatever the row length
+    int sp[R];
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) {
+        const float sum = 1.0f / invS[rr];
+        int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
+        sp[rr] = e < 0 ? 0 : (e > 14 ? 14 : e);
+    }
+    float myM = M[0], myInv = invS[0];
+    int mySp = sp[0];
+#pragma unroll
+    for (int rr = 1; rr < R; rr++)
+        if (r == rr) { myM = M[rr]; myInv = invS[rr]; mySp = sp[rr]; }
+    const uint32_t c1h = (uint32_t)(mySp + 15) << 10;              // fp16 2^Sp
+    const uint32_t c1 = c1h | (c1h << 16);
+
+    f4 acc[4][2], zacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c][0] = acc[c][1] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // score rows of the unit's R heads as one buffer: lane (n, kb) reads 8 scores of its head r per 32-token block
+    // (extent rounded up to whole 16-byte loads: the rows are padded to a multiple of 8 scores)
+    const rsrc_t rx = make_rsrc(a.x + b * a.x_sb + (int64_t)h0 * a.x_sh, (uint32_t)((R - 1) * a.x_sh * 2 + ((a.Tv + 7) & ~(int64_t)7) * 2));
+    const uint32_t xoff = (uint32_t)((r * a.x_sh + 8 * kb) * 2);
+
+    const int sb_begin = slice * a.spb;
+    const int sb_end = (sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb;
+    for (int sb = sb_begin + wave; sb < sb_end; sb += 4) {
+        const int64_t tok0 = (int64_t)sb * KIVI_MF_SB_TOKENS;
+        int ng = (int)((a.Tv - tok0 + 31) / 32);
+        ng = ng > 16 ? 16 : ng;
+        const rsrc_t rv = make_rsrc(mf_sb(a.vt, b, hk, sb), KIVI_MF_SB_WORDS * 4);
+        u32x4 sreg[4], mreg[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rv, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) mreg[j] = buf_load<u32x4, true>(rv, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + (j * 64 + lane) * 16), 0);
+        u32x4 wr[RING], xr[RING];
+#pragma unroll
+        for (int i = 0; i < RING; i++) {
+            wr[i] = buf_load<u32x4, true>(rv, (uint32_t)(i * 1024 + lane * 16), 0);
+            xr[i] = buf_load<u32x4, false>(rx, xoff + (uint32_t)((tok0 + i * 32) * 2), 0);
+        }
+        __builtin_amdgcn_wave_barrier();                           // the previous super-block's LDS reads are over
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            *(u32x4*)(lds_s + (j * 64 + lane) * 4) = sreg[j];
+            *(u32x4*)(lds_m + (j * 64 + lane) * 4) = mreg[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int g0 = 0; g0 < ng; g0 += RING) {
+#pragma unroll
+            for (int j = 0; j < RING; j++) {
+                const int g = g0 + j;
+                if (g >= ng) continue;
+                const u32x4 w = wr[j], xv = xr[j];
+                wr[j] = buf_load<u32x4, true>(rv, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the super-block: bounds-checked zeros
+                xr[j] = buf_load<u32x4, false>(rx, xoff + (uint32_t)((tok0 + (g + RING) * 32) * 2), 0);
+                // probabilities of this lane's 8 tokens: fp16(exp(x - M) / sum) as the reference casts them (llama_kivi.py:375),
+                // then the exact power-of-two scalings
+                const int64_t tl = tok0 + g * 32 + 8 * kb;
+                uint32_t pz[4], pp[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float p0 = kivi_exp(h2f_bits((uint16_t)(xv[i] & 0xFFFFu)) - myM) * myInv;
+                    float p1 = kivi_exp(h2f_bits((uint16_t)(xv[i] >> 16)) - myM) * myInv;
+                    if (tl + 2 * i >= a.Tv) p0 = 0.f;              // slots past the packed prefix (last block only)
+                    if (tl + 2 * i + 1 >= a.Tv) p1 = 0.f;
+                    const uint32_t pk = (uint32_t)f2h_bits(p0) | ((uint32_t)f2h_bits(p1) << 16);
+                    pz[i] = pk_mul(pk, c1);
+                    pp[i] = pk_mul(pz[i], afac(i));
+                }
+                // Every MFMA starts from a ZERO accumulator and its result is added to the fp32 running sums on the VALU:
+                // the matrix pipe aligns the 32 products and C to the largest exponent and truncates what falls below
+                // ~2^-23 of it (tools/mfma_prec_probe.hip), so a long chain of same-sign products (codes >= 0, zero
+                // points < 0) through C loses ~2^-19 |C| per step -- 2e-3 of the output after the two sums cancel.
+                const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const u32x4 s = *(const u32x4*)(lds_s + g * 64 + kb * 16 + c * 4);
+                    uint32_t A[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) A[i] = a_elem<HILO>(pp[i], pp[i] & lomask, s[i]);
+                    f4 d0 = zero4, d1 = zero4;
+                    mfma_pair(A, w[c], d0, d1);
+                    acc[c][0] += d0;
+                    acc[c][1] += d1;
+                }
+                // zero-point term: Z[row, c] += sum_t p' * mn[t, c]  (columns n -> channel group n & 3)
+                const u32x4 bz = *(const u32x4*)(lds_m + g * 64 + kb * 16 + (n & 3) * 4);
+                zacc += __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(pz[0], pz[1], pz[2], pz[3]), as_h8(bz[0], bz[1], bz[2], bz[3]), zero4, 0, 0, 0);
+            }
+        }
+    }
+
+    // fold: O[r, d] = 2^-Sp * (2^12 * (hi + lo rows) + Z[r, d >> 5]); lane takes d = lane and lane + 64
+    float zsel[R][2];
+#pragma unroll
+    for (int rr = 0; rr < R; rr++)
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+            zsel[rr][half] = __shfl(zacc[rr % 4], (rr / 4) * 16 + (lane >> 5) + 2 * half);
+    float* Lf = reinterpret_cast<float*>(lds_s);                   // [16 rows][128 columns], the wave's own 8 KiB
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) Lf[(4 * kb + j) * 128 + 32 * c + 16 * tile + n] = acc[c][tile][j];
+    __builtin_amdgcn_wave_barrier();
+    float o[R][2];
+#pragma unroll
+    for (int rr = 0; rr < R; rr++)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int d = lane + 64 * half;
+            const float v = Lf[rr * 128 + d] + Lf[(rr + R) * 128 + d];
+            o[rr][half] = __builtin_ldexpf(__builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), zsel[rr][half]), -sp[rr]);
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) {
+        Lf[rr * 128 + lane] = o[rr][0];
+        Lf[rr * 128 + lane + 64] = o[rr][1];
+    }
+    __syncthreads();
+    float* lf = reinterpret_cast<float*>(lds_all);
+    float tot[(R * 128 + 255) / 256];
+#pragma unroll
+    for (int k = 0; k < (R * 128 + 255) / 256; k++) {
+        const int i = threadIdx.x + 256 * k;
+        tot[k] = (i < R * 128) ? (lf[i] + lf[2048 + i]) + (lf[4096 + i] + lf[6144 + i]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (R * 128 + 255) / 256; k++) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < R * 128) lf[i] = tot[k];
+    }
+    __syncthreads();
+    gqa_arrive_and_combine<R>(a, unit, slice, lf, b, h0);
 }
 
 bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
@@ -482,21 +898,103 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.out = (uint16_t*)out; a.out_sb = out_sb; a.out_sh = out_sh;
     a.nh_kv = nh_kv; a.ratio = nh / nh_kv; a.Tq = T;
     a.nsb = (int)((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
+    a.nh = nh;
+    a.stats = nullptr; a.nseg = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
+    a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
+    a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
+    return run_gqa_k(a, B * nh_kv, (hipStream_t)stream);
+}
+
+template <int R, bool HILO, int RING>
+static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
+    KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(a.win_blocks + units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+}
+
+extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stream) {
+    KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_gqa_decode: null arguments");
+    const int B = p->B, nh = p->nh, nh_kv = p->nh_kv, D = p->D, group_size = p->group_size, bits = p->bits;
+    const int64_t T = p->Tq > p->Tv ? p->Tq : p->Tv;
+    KIVI_MF_SHAPE_CHECK("kivi_gqa_decode");
+    KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
+                 "kivi_gqa_decode: nh / nh_kv must be 4 or 8 (got %d / %d)", nh, nh_kv);
+    const int R = nh / nh_kv;
     const int units = B * nh_kv;
-    static const char* nohilo = getenv("KIVI_GQA_NO_HILO");      // tuning aid: fp16-rounded q * scale (no remainder rows)
-    static const char* fw = getenv("KIVI_GQA_K_WAVES");          // tuning aid: waves per block (1 or 4)
-    int W = ((int64_t)units * a.nsb >= 2048) ? 4 : 1;            // few super-blocks: one wave per block spreads them over the CUs
-    if (fw) W = atoi(fw) == 1 ? 1 : 4;
-    a.sb_blocks = (a.nsb + W - 1) / W;
-    hipStream_t s = (hipStream_t)stream;
-#define KIVI_GK(RR, WW, HL) launch_gqa_k<RR, WW, HL>(a, units, s)
-    if (a.ratio == 4) {
-        if (nohilo) { if (W == 4) KIVI_GK(4, 4, false); else KIVI_GK(4, 1, false); }
-        else { if (W == 4) KIVI_GK(4, 4, true); else KIVI_GK(4, 1, true); }
-    } else {
-        if (nohilo) { if (W == 4) KIVI_GK(8, 4, false); else KIVI_GK(8, 1, false); }
-        else { if (W == 4) KIVI_GK(8, 4, true); else KIVI_GK(8, 1, true); }
+    KIVI_REQUIRE(p->Tq >= 0 && p->Tq % 32 == 0 && p->Tv >= 0 && p->k_res_len >= 0 && p->k_res_len <= 128 && p->v_res_len >= 0 &&
+                     p->v_res_len <= 128 && p->Tq + p->k_res_len == p->Tv + p->v_res_len,
+                 KIVI_EINVAL, "kivi_gqa_decode: inconsistent lengths (Tq=%lld k_res=%d Tv=%lld v_res=%d)", (long long)p->Tq,
+                 p->k_res_len, (long long)p->Tv, p->v_res_len);
+    const int64_t n = p->Tq + p->k_res_len + 1;
+    KIVI_REQUIRE(mf_store_ok(p->kt, p->kt_sb, p->kt_sh, p->kt_ss) && mf_store_ok(p->vt, p->vt_sb, p->vt_sh, p->vt_ss), KIVI_EALIGN,
+                 "kivi_gqa_decode: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(p->q && (uintptr_t)p->q % 16 == 0 && p->q_sb % 8 == 0 && p->q_sh % 8 == 0, KIVI_EALIGN,
+                 "kivi_gqa_decode: q rows must be 16-byte aligned");
+    KIVI_REQUIRE(p->kres && p->knew && (uintptr_t)p->kres % 16 == 0 && (uintptr_t)p->knew % 16 == 0 && p->kres_sb % 8 == 0 &&
+                     p->kres_sh % 8 == 0 && p->kres_st % 8 == 0 && p->knew_sb % 8 == 0 && p->knew_sh % 8 == 0,
+                 KIVI_EALIGN, "kivi_gqa_decode: key rows must be 16-byte aligned");
+    KIVI_REQUIRE(p->vres && p->vnew && (uintptr_t)p->vres % 4 == 0 && (uintptr_t)p->vnew % 4 == 0 && p->vres_sb % 2 == 0 &&
+                     p->vres_sh % 2 == 0 && p->vres_st % 2 == 0 && p->vnew_sb % 2 == 0 && p->vnew_sh % 2 == 0,
+                 KIVI_EALIGN, "kivi_gqa_decode: value rows must be 4-byte aligned");
+    KIVI_REQUIRE(p->scores && (uintptr_t)p->scores % 16 == 0 && p->s_sb % 8 == 0 && p->s_sh % 8 == 0 && p->s_sh >= ((n + 7) & ~(int64_t)7),
+                 KIVI_EALIGN, "kivi_gqa_decode: score rows must be 16-byte aligned and hold %lld scores", (long long)n);
+    KIVI_REQUIRE((int64_t)(R - 1) * p->s_sh * 2 + n * 2 + 16 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_decode: score rows too long");
+    KIVI_REQUIRE(p->out != nullptr, KIVI_EINVAL, "kivi_gqa_decode: null output");
+    const int nsbk = (int)((p->Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
+    const int nseg = nsbk + KIVI_GQA_RES_SEGS;
+    KIVI_REQUIRE(p->stats && (uintptr_t)p->stats % 8 == 0 && p->stats_bytes >= (int64_t)B * nh * nseg * 2 * (int64_t)sizeof(float), KIVI_EINVAL,
+                 "kivi_gqa_decode: statistics buffer too small (%lld bytes for %d segments)", (long long)p->stats_bytes, nseg);
+    const int nsbv = (int)((p->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
+    int S = 0, spb = 0;
+    if (nsbv > 0) {
+        // ~1024 stream blocks (4 per CU) of 4 waves: a wave then streams 1-2 super-blocks (24 KiB each)
+        static const char* fs = getenv("KIVI_GQA_V_BLOCKS");     // tuning aid: target number of stream blocks
+        const int target = fs ? atoi(fs) : 1024;
+        S = (target + units - 1) / units;
+        S = S < 1 ? 1 : (S > nsbv ? nsbv : S);
+        spb = (nsbv + S - 1) / S;
+        S = (nsbv + spb - 1) / spb;
     }
-#undef KIVI_GK
-    return kivi_launch_status("gqa_k");
+    KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
+    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * (S + 1) * R * 128 * 4;
+    KIVI_REQUIRE(p->workspace && (uintptr_t)p->workspace % 16 == 0 && p->workspace_bytes >= need, KIVI_EINVAL,
+                 "kivi_gqa_decode: workspace too small (%lld bytes needed)", (long long)need);
+    hipStream_t s = (hipStream_t)stream;
+
+    GqaKArgs k;
+    k.q = (const uint16_t*)p->q; k.q_sb = p->q_sb; k.q_sh = p->q_sh;
+    k.kt = {(uint32_t*)p->kt, p->kt_sb, p->kt_sh, p->kt_ss};
+    k.out = (uint16_t*)p->scores; k.out_sb = p->s_sb; k.out_sh = p->s_sh;
+    k.nh_kv = nh_kv; k.ratio = R; k.nh = nh; k.Tq = p->Tq; k.nsb = nsbk; k.sb_blocks = 0;
+    k.stats = (float*)p->stats; k.nseg = nseg; k.inv_scale = p->inv_scale;
+    k.mask = (const uint16_t*)p->mask; k.mask_sb = p->mask_sb;
+    k.res_blocks = units * KIVI_GQA_RES_SEGS;
+    k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
+    k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
+    static const char* skipk = getenv("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
+    int rc = skipk ? 0 : run_gqa_k(k, units, s);
+    if (rc) return rc;
+
+    GqaVArgs v;
+    v.x = (const uint16_t*)p->scores; v.x_sb = p->s_sb; v.x_sh = p->s_sh;
+    v.stats = (const float*)p->stats; v.nseg = nseg;
+    v.vt = {(uint32_t*)p->vt, p->vt_sb, p->vt_sh, p->vt_ss};
+    v.nh_kv = nh_kv; v.ratio = R; v.nh = nh; v.Tv = p->Tv; v.nsb = nsbv; v.S = S; v.spb = spb; v.win_blocks = units;
+    v.vres = (uint16_t*)p->vres; v.vres_sb = p->vres_sb; v.vres_sh = p->vres_sh; v.vres_st = p->vres_st;
+    v.win_start = p->v_win_start; v.res_len = p->v_res_len;
+    v.vnew = (const uint16_t*)p->vnew; v.vnew_sb = p->vnew_sb; v.vnew_sh = p->vnew_sh; v.flush = p->v_flush ? 1 : 0;
+    v.out = (uint16_t*)p->out; v.out_sb = p->out_sb; v.out_sh = p->out_sh;
+    v.counters = (int*)p->workspace;
+    v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
+    static const char* nohilo = getenv("KIVI_GQA_NO_HILO");
+    static const char* fr = getenv("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 3 or 4)
+    const int ring = fr ? atoi(fr) : 3;
+#define KIVI_GV(RR, HL)                                          \
+    do {                                                         \
+        if (ring == 2) launch_gqa_v<RR, HL, 2>(v, units, s);     \
+        else if (ring == 4) launch_gqa_v<RR, HL, 4>(v, units, s); \
+        else launch_gqa_v<RR, HL, 3>(v, units, s);               \
+    } while (0)
+    if (R == 4) { if (nohilo) KIVI_GV(4, false); else KIVI_GV(4, true); }
+    else { if (nohilo) KIVI_GV(8, false); else KIVI_GV(8, true); }
+#undef KIVI_GV
+    return kivi_launch_status("gqa_v");
 }
