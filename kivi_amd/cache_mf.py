@@ -200,9 +200,10 @@ class KiviLayerCacheMF:
         R = cfg.residual_length
         B, nh, _, D = query_states.shape
         assert nh == self.nh and B == self.B and D == self.D
-        q = query_states if query_states.stride(3) == 1 else query_states.contiguous()
-        k = key_states if key_states.stride(3) == 1 else key_states.contiguous()
-        v = value_states if value_states.stride(3) == 1 else value_states.contiguous()
+        def rows16(x):   # 16-byte loads of whole rows: unit inner stride, 16-byte aligned rows
+            ok = x.stride(3) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0
+            return x if ok else x.contiguous()
+        q, k, v = rows16(query_states), rows16(key_states), rows16(value_states)
         kv_seq_len = self.kv_seq_len + 1
         mask_ptr, mask_sb = None, 0
         if attention_mask is not None:

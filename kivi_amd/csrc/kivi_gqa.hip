@@ -19,6 +19,8 @@
 #include "kivi_gqa_dev.h"
 #include "kivi_quant.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per unit)
@@ -383,16 +385,18 @@ __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
 
     // ring of code blocks: RING groups in flight ahead of the one being multiplied (loads past the last group of a
     // partial super-block read the zero-filled rest of it: harmless)
-    // (rolled over rounds of RING groups, unrolled inside a round: the ring slots are static registers)
-    for (int g0 = 0; g0 < ng; g0 += RING) {
+    // (rolled over rounds of RING groups, unrolled inside a round: the ring slots are static registers.  No branch
+    // inside a round -- with one, hipcc stages every load through one temporary and waits vmcnt(0) per group; the
+    // groups past `ng` of the last round read the zero-filled rest of the super-block and their scores are not stored)
+    static_assert(16 % RING == 0, "rounds must not leave the super-block");
+    const int ngr = (ng + RING - 1) / RING * RING;
+    for (int g0 = 0; g0 < ngr; g0 += RING) {
 #pragma unroll
         for (int j = 0; j < RING; j++) {
-            const int g = g0 + j;
-            if (g < ng) {
-                const u32x4 w = wr[j];
-                wr[j] = buf_load<u32x4, true>(rk, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the super-block: zeros
-                group(g, w);
-            }
+            group(g0 + j, wr[j]);
+            // reload AFTER the last use: the slot's register is dead here, so the load lands in it directly (requested at
+            // the top of the group it would need a second register and a copy -- i.e. a vmcnt(0) -- at the loop edge)
+            wr[j] = buf_load<u32x4, true>(rk, (uint32_t)((g0 + j + RING) * 1024 + lane * 16), 0);   // past the codes: never used
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -482,13 +486,45 @@ struct GqaVArgs {
     int64_t out_sb, out_sh;
     float* ws;                  // [units][S + 1][R * 128] fp32 partial sums (slot S: the window part)
     int* counters;              // [units] arrival counters, zero between launches
+    unsigned long long* dbg;    // phase time stamps or null
 };
+
+// phase time stamps (kivi_debug_set_stamps; tools/gqa_phases.py): 16 slots per wave, DBG instantiations only
+template <bool DBG>
+__device__ __forceinline__ void gstamp(unsigned long long* dbg, int i) {
+    if constexpr (DBG) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i] = t;
+    }
+}
+
+template <int PAT>
+__device__ __forceinline__ uint32_t swz(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, PAT); }
 
 // softmax constants of the R rows of a unit from the segment statistics: M = max, 1 / sum exp(x - M).  Every lane of the
 // calling wave ends up with the same values.
 template <int R>
 __device__ __forceinline__ void gqa_row_consts(const GqaVArgs& a, int b, int h0, float* M, float* invS) {
     const int lane = threadIdx.x & 63;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    if (a.nseg <= 128) {
+        // all 2 R loads of the wave are requested before the first reduction: one memory round trip, not 2 R of them
+        f2 v0[R], v1[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const f2* st = reinterpret_cast<const f2*>(a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2);
+            v0[r] = lane < a.nseg ? st[lane] : f2{-__builtin_inff(), 0.f};
+            v1[r] = lane + 64 < a.nseg ? st[lane + 64] : f2{-__builtin_inff(), 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float m = wave_max(__builtin_fmaxf(v0[r][0], v1[r][0]));
+            const float l = wave_sum(v0[r][1] * kivi_exp(v0[r][0] - m) + v1[r][1] * kivi_exp(v1[r][0] - m));
+            M[r] = m;
+            invS[r] = 1.0f / l;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const float* st = a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2;
@@ -545,7 +581,7 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 
 // Window role: probs[..., -L:] @ V_window (llama_kivi.py:384) for the R heads of a unit, the V append (:377) and the
 // quantisation of the token that leaves the window (:386-399) into the VT layout.
-template <int R>
+template <int R, bool DBG>
 __device__ __forceinline__ void gqa_v_window(const GqaVArgs& a, int unit, float* lds_f) {
     constexpr int PW = 136;
     __shared__ uint16_t pw[R][PW];
@@ -561,6 +597,7 @@ __device__ __forceinline__ void gqa_v_window(const GqaVArgs& a, int unit, float*
     if (a.flush && threadIdx.x < 128) xflush = vwin[threadIdx.x];
     float M[R], invS[R];
     gqa_row_consts<R>(a, b, h0, M, invS);
+    gstamp<DBG>(a.dbg, 2);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int r = 0; r < R; r++) { cst[0][r] = M[r]; cst[1][r] = invS[r]; }
@@ -572,37 +609,49 @@ __device__ __forceinline__ void gqa_v_window(const GqaVArgs& a, int unit, float*
         pw[r][t] = f2h_bits(kivi_exp(x - cst[0][r]) * cst[1][r]);
     }
     __syncthreads();
-    float o[R][2];
+    // probs[-L:] @ V_window: a lane takes 8 channels (16 bytes) of a token, a wave-instruction covers 4 tokens, wave w the
+    // tokens 16 k + 4 w + (lane >> 4); all (<= 9) loads of a wave are requested before the first is used
+    constexpr int NLD = 9;                                         // 9 x 16 tokens >= 129 window tokens (+ the new one)
+    const int sub = lane >> 4, ch = (lane & 15) * 8;
+    u16x8 vv[NLD];
 #pragma unroll
-    for (int r = 0; r < R; r++) o[r][0] = o[r][1] = 0.f;
-    for (int t0 = wave; t0 < L; t0 += 16) {      // 4 tokens of this wave per round, their loads in flight together
-        uint32_t vv[4];
+    for (int k = 0; k < NLD; k++) {
+        const int t = 16 * k + 4 * wave + sub;
+        const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+        vv[k] = (t < L) ? *(const u16x8*)(vrow + ch) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float o[R][8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + 4 * u;
-            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
-            vv[u] = (t < L) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
-        }
+    for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + 4 * u;
-            if (t < L) {
-                const float v0 = h2f_bits((uint16_t)(vv[u] & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv[u] >> 16));
+        for (int e = 0; e < 8; e++) o[r][e] = 0.f;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const float p = h2f_bits(pw[r][t]);
-                    o[r][0] = __builtin_fmaf(p, v0, o[r][0]);
-                    o[r][1] = __builtin_fmaf(p, v1, o[r][1]);
-                }
-                if (t == a.res_len) *(uint32_t*)(vwin + (int64_t)t * a.vres_st + 2 * lane) = vv[u];   // V append
+    for (int k = 0; k < NLD; k++) {
+        const int t = 16 * k + 4 * wave + sub;
+        if (t < L) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float p = h2f_bits(pw[r][t]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[r][e] = __builtin_fmaf(p, h2f_bits(vv[k][e]), o[r][e]);
             }
+            if (t == a.res_len) *(u16x8*)(vwin + (int64_t)t * a.vres_st + ch) = vv[k];   // V append (llama_kivi.py:377)
         }
     }
-    // per-wave partials -> lds_f[wave][r][d]
+    // the 4 token sub-rows of a wave (lanes 16 apart), then per-wave partials -> lds_f[wave][r][d]
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        lds_f[(wave * R + r) * 128 + 2 * lane] = o[r][0];
-        lds_f[(wave * R + r) * 128 + 2 * lane + 1] = o[r][1];
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            o[r][e] += __shfl_xor(o[r][e], 16);
+            o[r][e] += __shfl_xor(o[r][e], 32);
+        }
+    gstamp<DBG>(a.dbg, 3);
+    if (sub == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) lds_f[(wave * R + r) * 128 + ch + e] = o[r][e];
     }
     if (a.flush && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
         const int d = threadIdx.x;
@@ -636,15 +685,20 @@ __device__ __forceinline__ void gqa_v_window(const GqaVArgs& a, int unit, float*
     for (int i = threadIdx.x; i < R * 128; i += 256)
         lds_f[4 * R * 128 + i] = (lds_f[i] + lds_f[R * 128 + i]) + (lds_f[2 * R * 128 + i] + lds_f[3 * R * 128 + i]);
     __syncthreads();
+    gstamp<DBG>(a.dbg, 4);
     gqa_arrive_and_combine<R>(a, unit, a.S, lds_f + 4 * R * 128, b, h0);
+    gstamp<DBG>(a.dbg, 5);
 }
 
 // Stream role: block (unit, slice) takes `spb` consecutive super-blocks of the unit's packed V, one per wave at a time.
-template <int R, bool HILO, int RING>
+template <int R, bool HILO, int RING, bool DBG = false>
 __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
     extern __shared__ uint32_t lds_all[];                          // 4 waves x 2048 words (scale | mn of the super-block)
+    gstamp<DBG>(a.dbg, 0);
+    if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
     if ((int)blockIdx.x < a.win_blocks) {
-        gqa_v_window<R>(a, (int)blockIdx.x, reinterpret_cast<float*>(lds_all));
+        gqa_v_window<R, DBG>(a, (int)blockIdx.x, reinterpret_cast<float*>(lds_all));
+        if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     const int bid = (int)blockIdx.x - a.win_blocks;
@@ -662,6 +716,7 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
 
     float M[R], invS[R];
     gqa_row_consts<R>(a, b, h0, M, invS);
+    gstamp<DBG>(a.dbg, 2);
     // per head: Sp = floor(log2(sum)) (<= 14): the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp before they enter
     // the A operand, so that p * scale * 2^(6 - 2 i) stays a normal fp16 whatever the row length
     int sp[R];
@@ -678,6 +733,11 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
         if (r == rr) { myM = M[rr]; myInv = invS[rr]; mySp = sp[rr]; }
     const uint32_t c1h = (uint32_t)(mySp + 15) << 10;              // fp16 2^Sp
     const uint32_t c1 = c1h | (c1h << 16);
+    // The 16 / R lanes that hold the same A row (head r: hi, lo and their duplicates) need the same 8 probabilities of a
+    // block: each computes 8 R / 16 of them (one token pair for R = 4, two for R = 8) and they exchange the packed
+    // results with ds_swizzle -- 2-4 v_exp per lane and block instead of 8.
+    constexpr int NCOPY = 16 / R, PPL = 4 / NCOPY;
+    const int q4 = n / R;
 
     f4 acc[4][2], zacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -686,7 +746,8 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
     // score rows of the unit's R heads as one buffer: lane (n, kb) reads 8 scores of its head r per 32-token block
     // (extent rounded up to whole 16-byte loads: the rows are padded to a multiple of 8 scores)
     const rsrc_t rx = make_rsrc(a.x + b * a.x_sb + (int64_t)h0 * a.x_sh, (uint32_t)((R - 1) * a.x_sh * 2 + ((a.Tv + 7) & ~(int64_t)7) * 2));
-    const uint32_t xoff = (uint32_t)((r * a.x_sh + 8 * kb) * 2);
+    const uint32_t xoff = (uint32_t)((r * a.x_sh + 8 * kb + 2 * PPL * q4) * 2);
+    typedef typename std::conditional<PPL == 1, uint32_t, u32x2>::type XV;
 
     const int sb_begin = slice * a.spb;
     const int sb_end = (sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb;
@@ -700,11 +761,12 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
         for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rv, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) mreg[j] = buf_load<u32x4, true>(rv, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + (j * 64 + lane) * 16), 0);
-        u32x4 wr[RING], xr[RING];
+        u32x4 wr[RING];
+        XV xr[RING];
 #pragma unroll
         for (int i = 0; i < RING; i++) {
             wr[i] = buf_load<u32x4, true>(rv, (uint32_t)(i * 1024 + lane * 16), 0);
-            xr[i] = buf_load<u32x4, false>(rx, xoff + (uint32_t)((tok0 + i * 32) * 2), 0);
+            xr[i] = buf_load<XV, false>(rx, xoff + (uint32_t)((tok0 + i * 32) * 2), 0);
         }
         __builtin_amdgcn_wave_barrier();                           // the previous super-block's LDS reads are over
 #pragma unroll
@@ -713,28 +775,42 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
             *(u32x4*)(lds_m + (j * 64 + lane) * 4) = mreg[j];
         }
         __builtin_amdgcn_wave_barrier();
-        for (int g0 = 0; g0 < ng; g0 += RING) {
+        // rounds of RING blocks without a branch inside (see gqa_k_kernel); blocks past `ng` of the last round lie inside
+        // the super-block, hold zeros (never-written slots) and get zero probabilities
+        static_assert(16 % RING == 0, "rounds must not leave the super-block");
+        const int ngr = (ng + RING - 1) / RING * RING;
+        const int64_t left = a.Tv - tok0;
+        const int lim = (int)(left > 512 ? 512 : left) - (8 * kb + 2 * PPL * q4);   // this lane's share: token offset < lim is valid
+        for (int g0 = 0; g0 < ngr; g0 += RING) {
 #pragma unroll
             for (int j = 0; j < RING; j++) {
                 const int g = g0 + j;
-                if (g >= ng) continue;
-                const u32x4 w = wr[j], xv = xr[j];
-                wr[j] = buf_load<u32x4, true>(rv, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the super-block: bounds-checked zeros
-                xr[j] = buf_load<u32x4, false>(rx, xoff + (uint32_t)((tok0 + (g + RING) * 32) * 2), 0);
-                // probabilities of this lane's 8 tokens: fp16(exp(x - M) / sum) as the reference casts them (llama_kivi.py:375),
-                // then the exact power-of-two scalings
-                const int64_t tl = tok0 + g * 32 + 8 * kb;
-                uint32_t pz[4], pp[4];
+                const u32x4& w = wr[j];
+                const XV& xv = xr[j];
+                // this lane's share of the probabilities: fp16(exp(x - M) / sum) as the reference casts them
+                // (llama_kivi.py:375), then the exact power-of-two scaling by 2^Sp; slots past the packed prefix get 0
+                uint32_t own[PPL];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float p0 = kivi_exp(h2f_bits((uint16_t)(xv[i] & 0xFFFFu)) - myM) * myInv;
-                    float p1 = kivi_exp(h2f_bits((uint16_t)(xv[i] >> 16)) - myM) * myInv;
-                    if (tl + 2 * i >= a.Tv) p0 = 0.f;              // slots past the packed prefix (last block only)
-                    if (tl + 2 * i + 1 >= a.Tv) p1 = 0.f;
-                    const uint32_t pk = (uint32_t)f2h_bits(p0) | ((uint32_t)f2h_bits(p1) << 16);
-                    pz[i] = pk_mul(pk, c1);
-                    pp[i] = pk_mul(pz[i], afac(i));
+                for (int jj = 0; jj < PPL; jj++) {
+                    uint32_t xw;
+                    if constexpr (PPL == 1) xw = xv;
+                    else xw = xv[jj];
+                    float p0 = kivi_exp(h2f_bits((uint16_t)(xw & 0xFFFFu)) - myM) * myInv;
+                    float p1 = kivi_exp(h2f_bits((uint16_t)(xw >> 16)) - myM) * myInv;
+                    const int t0 = g * 32 + 2 * jj;
+                    p0 = (t0 < lim) ? p0 : 0.f;
+                    p1 = (t0 + 1 < lim) ? p1 : 0.f;
+                    own[jj] = pk_mul((uint32_t)f2h_bits(p0) | ((uint32_t)f2h_bits(p1) << 16), c1);
                 }
+                // pz[i] <- the lane (same head, same kb) whose share holds pair i: lane' = (lane & 0x13) | (copy << 2)
+                uint32_t pz[4], pp[4];
+                constexpr int AND = (R == 4) ? 0x13 : 0x17;            // or_mask = copy index * R (sets the n / R bits)
+                pz[0] = swz<AND | (((0 / PPL) * R) << 5)>(own[0 % PPL]);
+                pz[1] = swz<AND | (((1 / PPL) * R) << 5)>(own[1 % PPL]);
+                pz[2] = swz<AND | (((2 / PPL) * R) << 5)>(own[2 % PPL]);
+                pz[3] = swz<AND | (((3 / PPL) * R) << 5)>(own[3 % PPL]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) pp[i] = pk_mul(pz[i], afac(i));
                 // Every MFMA starts from a ZERO accumulator and its result is added to the fp32 running sums on the VALU:
                 // the matrix pipe aligns the 32 products and C to the largest exponent and truncates what falls below
                 // ~2^-23 of it (tools/mfma_prec_probe.hip), so a long chain of same-sign products (codes >= 0, zero
@@ -754,10 +830,14 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
                 // zero-point term: Z[row, c] += sum_t p' * mn[t, c]  (columns n -> channel group n & 3)
                 const u32x4 bz = *(const u32x4*)(lds_m + g * 64 + kb * 16 + (n & 3) * 4);
                 zacc += __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(pz[0], pz[1], pz[2], pz[3]), as_h8(bz[0], bz[1], bz[2], bz[3]), zero4, 0, 0, 0);
+                // reload AFTER the last use (see gqa_k_kernel)
+                wr[j] = buf_load<u32x4, true>(rv, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the codes: never used
+                xr[j] = buf_load<XV, false>(rx, xoff + (uint32_t)((tok0 + (g + RING) * 32) * 2), 0);
             }
         }
     }
 
+    gstamp<DBG>(a.dbg, 3);
     // fold: O[r, d] = 2^-Sp * (2^12 * (hi + lo rows) + Z[r, d >> 5]); lane takes d = lane and lane + 64
     float zsel[R][2];
 #pragma unroll
@@ -804,7 +884,10 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
         if (i < R * 128) lf[i] = tot[k];
     }
     __syncthreads();
+    gstamp<DBG>(a.dbg, 4);
     gqa_arrive_and_combine<R>(a, unit, slice, lf, b, h0);
+    gstamp<DBG>(a.dbg, 5);
+    if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 }
 
 bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
@@ -907,6 +990,10 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
 
 template <int R, bool HILO, int RING>
 static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
+    if (a.dbg && RING == 4 && HILO) {
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, true>), dim3((unsigned)(a.win_blocks + units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        return;
+    }
     KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(a.win_blocks + units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
 }
 
@@ -931,9 +1018,9 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE(p->kres && p->knew && (uintptr_t)p->kres % 16 == 0 && (uintptr_t)p->knew % 16 == 0 && p->kres_sb % 8 == 0 &&
                      p->kres_sh % 8 == 0 && p->kres_st % 8 == 0 && p->knew_sb % 8 == 0 && p->knew_sh % 8 == 0,
                  KIVI_EALIGN, "kivi_gqa_decode: key rows must be 16-byte aligned");
-    KIVI_REQUIRE(p->vres && p->vnew && (uintptr_t)p->vres % 4 == 0 && (uintptr_t)p->vnew % 4 == 0 && p->vres_sb % 2 == 0 &&
-                     p->vres_sh % 2 == 0 && p->vres_st % 2 == 0 && p->vnew_sb % 2 == 0 && p->vnew_sh % 2 == 0,
-                 KIVI_EALIGN, "kivi_gqa_decode: value rows must be 4-byte aligned");
+    KIVI_REQUIRE(p->vres && p->vnew && (uintptr_t)p->vres % 16 == 0 && (uintptr_t)p->vnew % 16 == 0 && p->vres_sb % 8 == 0 &&
+                     p->vres_sh % 8 == 0 && p->vres_st % 8 == 0 && p->vnew_sb % 8 == 0 && p->vnew_sh % 8 == 0,
+                 KIVI_EALIGN, "kivi_gqa_decode: value rows must be 16-byte aligned");
     KIVI_REQUIRE(p->scores && (uintptr_t)p->scores % 16 == 0 && p->s_sb % 8 == 0 && p->s_sh % 8 == 0 && p->s_sh >= ((n + 7) & ~(int64_t)7),
                  KIVI_EALIGN, "kivi_gqa_decode: score rows must be 16-byte aligned and hold %lld scores", (long long)n);
     KIVI_REQUIRE((int64_t)(R - 1) * p->s_sh * 2 + n * 2 + 16 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_decode: score rows too long");
@@ -970,8 +1057,12 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
     static const char* skipk = getenv("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
+    static const char* timev = getenv("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
+    KiviLaunchEvents held = {nullptr, nullptr};
+    if (timev) held = kivi_take_launch_events();
     int rc = skipk ? 0 : run_gqa_k(k, units, s);
     if (rc) return rc;
+    if (timev) kivi_set_launch_events(held.start, held.stop);
 
     GqaVArgs v;
     v.x = (const uint16_t*)p->scores; v.x_sb = p->s_sb; v.x_sh = p->s_sh;
@@ -982,16 +1073,17 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.win_start = p->v_win_start; v.res_len = p->v_res_len;
     v.vnew = (const uint16_t*)p->vnew; v.vnew_sb = p->vnew_sb; v.vnew_sh = p->vnew_sh; v.flush = p->v_flush ? 1 : 0;
     v.out = (uint16_t*)p->out; v.out_sb = p->out_sb; v.out_sh = p->out_sh;
+    v.dbg = kivi_debug_stamps();
     v.counters = (int*)p->workspace;
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
     static const char* nohilo = getenv("KIVI_GQA_NO_HILO");
-    static const char* fr = getenv("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 3 or 4)
-    const int ring = fr ? atoi(fr) : 3;
+    static const char* fr = getenv("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 4 or 8)
+    const int ring = fr ? atoi(fr) : 4;
 #define KIVI_GV(RR, HL)                                          \
     do {                                                         \
         if (ring == 2) launch_gqa_v<RR, HL, 2>(v, units, s);     \
-        else if (ring == 4) launch_gqa_v<RR, HL, 4>(v, units, s); \
-        else launch_gqa_v<RR, HL, 3>(v, units, s);               \
+        else if (ring == 8) launch_gqa_v<RR, HL, 8>(v, units, s); \
+        else launch_gqa_v<RR, HL, 4>(v, units, s);               \
     } while (0)
     if (R == 4) { if (nohilo) KIVI_GV(4, false); else KIVI_GV(4, true); }
     else { if (nohilo) KIVI_GV(8, false); else KIVI_GV(8, true); }
