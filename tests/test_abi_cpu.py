@@ -269,3 +269,55 @@ def test_mistral_module_reads_a_mistral_config():
     assert isinstance(att, M.MistralAttention_KIVI) and M.MistralFlashAttention_KIVI is M.MistralAttention_KIVI
     assert att.sliding_window == 4096 and att.num_key_value_groups == 4 and att.q_proj.bias is None
     assert att.residual_length == 128 and att.k_proj.weight.shape == (2 * 64, 512)
+
+
+def _gqa_args(**over):
+    """kivi_gqa_decode_args over fake (never dereferenced) device pointers."""
+    from kivi_amd import _lib
+    f = dict(B=2, nh=8, nh_kv=2, D=128, group_size=32, bits=2, inv_scale=0.088,
+             q=0x1000, q_sb=8 * 128, q_sh=128, mask=None, mask_sb=0,
+             kt=0x1000, kt_sb=2 * 6144, kt_sh=6144, kt_ss=2 * 2 * 6144, Tq=512,
+             kres=0x1000, kres_sb=2 * 32 * 128, kres_sh=32 * 128, kres_st=128, knew=0x1000, knew_sb=2 * 128, knew_sh=128, k_res_len=7,
+             vt=0x1000, vt_sb=2 * 6144, vt_sh=6144, vt_ss=2 * 2 * 6144, Tv=487,
+             vres=0x1000, vres_sb=2 * 65 * 128, vres_sh=65 * 128, vres_st=128, v_win_start=0, v_res_len=32,
+             vnew=0x1000, vnew_sb=2 * 128, vnew_sh=128, v_flush=1,
+             scores=0x1000, s_sb=8 * 528, s_sh=528, stats=0x1000, stats_bytes=2 * 8 * 5 * 2 * 4,
+             workspace=0x1000, workspace_bytes=65536 + 2 * 2 * 2 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128)
+    f.update(over)
+    return _lib.GqaDecodeArgs(**f)
+
+
+@pytest.mark.parametrize("over,rc_expected,msg", [
+    (dict(nh=6), -3, b"nh / nh_kv"),                        # ratio 3: not on the matrix pipe (KIVI_EUNSUPPORTED)
+    (dict(bits=4), -3, b"2-bit"),
+    (dict(Tq=500), None, b"inconsistent lengths"),          # packed keys come in whole 32-token blocks
+    (dict(Tv=480), None, b"inconsistent lengths"),          # Tq + k_res != Tv + v_res
+    (dict(s_sh=516), None, b"score rows"),                  # rows must hold the step and be 16-byte aligned
+    (dict(stats_bytes=16), None, b"statistics buffer"),
+    (dict(workspace_bytes=65536), None, b"workspace"),
+    (dict(vnew=0x1004), None, b"value rows"),
+])
+def test_gqa_decode_validates_before_launching(lib, over, rc_expected, msg):
+    """kivi_gqa_decode (the grouped-query layer step, llama_kivi.py:314-399 / mistral_kivi.py:381-445) refuses bad shapes,
+    lengths and scratch sizes with a message before anything is enqueued -- callable without a GPU for that reason."""
+    import ctypes
+    a = _gqa_args(**over)
+    rc = lib.kivi_gqa_decode(ctypes.byref(a), None)
+    assert rc < 0 and (rc_expected is None or rc == rc_expected), rc
+    assert msg in lib.kivi_last_error(), lib.kivi_last_error()
+    assert lib.kivi_gqa_decode(None, None) < 0
+
+
+def test_layer_cache_factory_picks_the_layout():
+    """make_layer_cache: the matrix-pipe layout only for the shapes its kernels cover, the hook-state layout otherwise
+    (constructing either on the CPU allocates plain tensors; no kernel is involved)."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, KiviLayerCacheMF, make_layer_cache
+    mf = make_layer_cache(KiviConfig(2, 2, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32)
+    assert isinstance(mf, KiviLayerCacheMF) and mf.n_sb == 2 and mf.kt.shape == (1, 8, 2, 6144) and not mf.kt.any()
+    assert mf.kt.stride(2) == 8 * 6144 and mf.kt.stride(1) == 6144      # super-block index outside the head index in memory
+    for kw in (dict(num_heads=8), dict(num_heads=24), dict(num_heads=None)):
+        assert isinstance(make_layer_cache(KiviConfig(2, 2, 32, 128), 1, 8, 128, 1000, "cpu", **kw), KiviLayerCache)
+    assert isinstance(make_layer_cache(KiviConfig(4, 4, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
+    assert isinstance(make_layer_cache(KiviConfig(2, 2, 64, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
+    mf.reserve(3000)
+    assert mf.n_sb == 6 and mf.cap >= 3000
