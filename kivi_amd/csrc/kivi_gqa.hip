@@ -475,7 +475,6 @@ struct GqaVArgs {
     int64_t Tv;                 // packed tokens
     int nsb;                    // super-blocks holding them
     int S, spb;                 // stream blocks per (b, kv head), super-blocks per stream block
-    int win_blocks;             // = units: the FIRST blocks of the grid do the fp16 window, the V append and the flush
     uint16_t* vres;             // (B, nh_kv, W, D) fp16 window buffer
     int64_t vres_sb, vres_sh, vres_st;
     int win_start, res_len;     // live rows [win_start, win_start + res_len); the new token goes right after
@@ -484,7 +483,7 @@ struct GqaVArgs {
     int flush;                  // quantise the oldest window row into the layout at token Tv (llama_kivi.py:386-399)
     uint16_t* out;
     int64_t out_sb, out_sh;
-    float* ws;                  // [units][S + 1][R * 128] fp32 partial sums (slot S: the window part)
+    float* ws;                  // [units][S][2][R * 128] fp32 partial sums of every slice: quantised part, window part
     int* counters;              // [units] arrival counters, zero between launches
     unsigned long long* dbg;    // phase time stamps or null
 };
@@ -545,33 +544,37 @@ template <int R>
 __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0) {
     __shared__ int last_flag;
     constexpr int RD = R * 128;
-    const int nslot = a.S + 1;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * nslot + slot) * RD);
-    for (int i = threadIdx.x; i < RD; i += 256)
+    // part_lds = [quantised part | window part] of this block; workspace [unit][slice][2][RD]
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * a.S + slot) * 2 * RD);
+    for (int i = threadIdx.x; i < 2 * RD; i += 256)
         __hip_atomic_store(dst + i, __builtin_bit_cast(uint32_t, part_lds[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (old == nslot - 1);
+        const int last = (old == a.S - 1);
         if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
         last_flag = last;
     }
     __syncthreads();
     if (!last_flag) return;
-    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * nslot * RD);
+    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * a.S * 2 * RD);
     for (int i = threadIdx.x; i < RD; i += 256) {
         const int r = i >> 7, d = i & 127;
-        float q = 0.f;
-        for (int s0 = 0; s0 < a.S; s0 += 8) {   // 8 independent loads in flight, added in slice order
+        float q = 0.f, w = 0.f;
+        for (int s0 = 0; s0 < a.S; s0 += 4) {   // 8 independent loads in flight, added in slice order
             uint32_t v8[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                v8[k] = (s0 + k < a.S) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            for (int k = 0; k < 4; k++) {
+                v8[2 * k] = (s0 + k < a.S) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v8[2 * k + 1] = (s0 + k < a.S) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            }
 #pragma unroll
-            for (int k = 0; k < 8; k++) q += __builtin_bit_cast(float, v8[k]);
+            for (int k = 0; k < 4; k++) {
+                q += __builtin_bit_cast(float, v8[2 * k]);
+                w += __builtin_bit_cast(float, v8[2 * k + 1]);
+            }
         }
-        const float w = __builtin_bit_cast(float, __hip_atomic_load(p0 + (size_t)a.S * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (llama_kivi.py:382-384);
         // only the window part exists before anything is quantised (:380)
         const uint16_t o = (a.Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(q)) + h2f_bits(f2h_bits(w))) : f2h_bits(w);
@@ -579,129 +582,15 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
     }
 }
 
-// Window role: probs[..., -L:] @ V_window (llama_kivi.py:384) for the R heads of a unit, the V append (:377) and the
-// quantisation of the token that leaves the window (:386-399) into the VT layout.
-template <int R, bool DBG>
-__device__ __forceinline__ void gqa_v_window(const GqaVArgs& a, int unit, float* lds_f) {
-    constexpr int PW = 136;
-    __shared__ uint16_t pw[R][PW];
-    __shared__ float cst[2][R];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
-    const int h0 = hk * a.ratio;
-    const int L = a.res_len + 1;
-    uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
-    const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
-    // the token about to be quantised is requested first
-    uint16_t xflush = 0;
-    if (a.flush && threadIdx.x < 128) xflush = vwin[threadIdx.x];
-    float M[R], invS[R];
-    gqa_row_consts<R>(a, b, h0, M, invS);
-    gstamp<DBG>(a.dbg, 2);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int r = 0; r < R; r++) { cst[0][r] = M[r]; cst[1][r] = invS[r]; }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < R * L; idx += 256) {
-        const int r = idx / L, t = idx - r * L;
-        const float x = h2f_bits(a.x[b * a.x_sb + (int64_t)(h0 + r) * a.x_sh + a.Tv + t]);
-        pw[r][t] = f2h_bits(kivi_exp(x - cst[0][r]) * cst[1][r]);
-    }
-    __syncthreads();
-    // probs[-L:] @ V_window: a lane takes 8 channels (16 bytes) of a token, a wave-instruction covers 4 tokens, wave w the
-    // tokens 16 k + 4 w + (lane >> 4); all (<= 9) loads of a wave are requested before the first is used
-    constexpr int NLD = 9;                                         // 9 x 16 tokens >= 129 window tokens (+ the new one)
-    const int sub = lane >> 4, ch = (lane & 15) * 8;
-    u16x8 vv[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int t = 16 * k + 4 * wave + sub;
-        const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
-        vv[k] = (t < L) ? *(const u16x8*)(vrow + ch) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    float o[R][8];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[r][e] = 0.f;
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int t = 16 * k + 4 * wave + sub;
-        if (t < L) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const float p = h2f_bits(pw[r][t]);
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[r][e] = __builtin_fmaf(p, h2f_bits(vv[k][e]), o[r][e]);
-            }
-            if (t == a.res_len) *(u16x8*)(vwin + (int64_t)t * a.vres_st + ch) = vv[k];   // V append (llama_kivi.py:377)
-        }
-    }
-    // the 4 token sub-rows of a wave (lanes 16 apart), then per-wave partials -> lds_f[wave][r][d]
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            o[r][e] += __shfl_xor(o[r][e], 16);
-            o[r][e] += __shfl_xor(o[r][e], 32);
-        }
-    gstamp<DBG>(a.dbg, 3);
-    if (sub == 0) {
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) lds_f[(wave * R + r) * 128 + ch + e] = o[r][e];
-    }
-    if (a.flush && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
-        const int d = threadIdx.x;
-        const uint32_t key = h_key(xflush);
-        uint32_t kmin = key, kmax = key;
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
-            kmin = o1 < kmin ? o1 : kmin;
-            kmax = o2 > kmax ? o2 : kmax;
-        }
-        const GroupQ gq = make_group(kmin, kmax, 3);
-        const uint32_t code = quant_one<2>(xflush, gq);
-        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
-        const int e = tt & 7, kbq = tt >> 3;
-        const int c = d >> 5, tile = (d >> 4) & 1, n = d & 15;
-        uint32_t val = code << (mf_pos(tile, e >> 1) + 16 * (e & 1));
-        val |= (uint32_t)__shfl_xor((int)val, 16);
-        uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
-        if (tile == 0) {
-            uint32_t* wp = sbp + blk * KIVI_MF_BLOCK_WORDS + (n + 16 * kbq) * 4 + c;
-            *wp = *wp | val;                 // the slot of a token is written once, on zero-initialised storage
-        }
-        if ((d & 31) == 0) {
-            const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
-            ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
-            ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < R * 128; i += 256)
-        lds_f[4 * R * 128 + i] = (lds_f[i] + lds_f[R * 128 + i]) + (lds_f[2 * R * 128 + i] + lds_f[3 * R * 128 + i]);
-    __syncthreads();
-    gstamp<DBG>(a.dbg, 4);
-    gqa_arrive_and_combine<R>(a, unit, a.S, lds_f + 4 * R * 128, b, h0);
-    gstamp<DBG>(a.dbg, 5);
-}
-
 // Stream role: block (unit, slice) takes `spb` consecutive super-blocks of the unit's packed V, one per wave at a time.
-template <int R, bool HILO, int RING, bool DBG = false>
-__global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
+// DIAG (tools only, wrong results): 1 = the ring is never reloaded (no memory traffic in the loop), 2 = no MFMA / no
+// accumulate, 3 = no probability chain (constant p), 4 = no A build, 5 = no ds_swizzle, 6 = no LDS reads in the loop, 7 = 5 + 6
+template <int R, bool HILO, int RING, bool DBG = false, int OCC = 4, int DIAG = 0>
+__global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
     extern __shared__ uint32_t lds_all[];                          // 4 waves x 2048 words (scale | mn of the super-block)
     gstamp<DBG>(a.dbg, 0);
     if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
-    if ((int)blockIdx.x < a.win_blocks) {
-        gqa_v_window<R, DBG>(a, (int)blockIdx.x, reinterpret_cast<float*>(lds_all));
-        if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
-        return;
-    }
-    const int bid = (int)blockIdx.x - a.win_blocks;
+    const int bid = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_s = lds_all + wave * 2048;
@@ -787,6 +676,7 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
                 const int g = g0 + j;
                 const u32x4& w = wr[j];
                 const XV& xv = xr[j];
+                const u32x4 s_first = *(const u32x4*)(lds_s + g * 64 + kb * 16);      // scale of channel group 0: in flight during the exps
                 // this lane's share of the probabilities: fp16(exp(x - M) / sum) as the reference casts them
                 // (llama_kivi.py:375), then the exact power-of-two scaling by 2^Sp; slots past the packed prefix get 0
                 uint32_t own[PPL];
@@ -797,6 +687,7 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
                     else xw = xv[jj];
                     float p0 = kivi_exp(h2f_bits((uint16_t)(xw & 0xFFFFu)) - myM) * myInv;
                     float p1 = kivi_exp(h2f_bits((uint16_t)(xw >> 16)) - myM) * myInv;
+                    if constexpr (DIAG == 3) { p0 = myInv; p1 = myInv + __builtin_bit_cast(float, xw & 1u); }
                     const int t0 = g * 32 + 2 * jj;
                     p0 = (t0 < lim) ? p0 : 0.f;
                     p1 = (t0 + 1 < lim) ? p1 : 0.f;
@@ -805,10 +696,14 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
                 // pz[i] <- the lane (same head, same kb) whose share holds pair i: lane' = (lane & 0x13) | (copy << 2)
                 uint32_t pz[4], pp[4];
                 constexpr int AND = (R == 4) ? 0x13 : 0x17;            // or_mask = copy index * R (sets the n / R bits)
-                pz[0] = swz<AND | (((0 / PPL) * R) << 5)>(own[0 % PPL]);
-                pz[1] = swz<AND | (((1 / PPL) * R) << 5)>(own[1 % PPL]);
-                pz[2] = swz<AND | (((2 / PPL) * R) << 5)>(own[2 % PPL]);
-                pz[3] = swz<AND | (((3 / PPL) * R) << 5)>(own[3 % PPL]);
+                if constexpr (DIAG == 5 || DIAG == 7) {
+                    pz[0] = own[0]; pz[1] = own[0] + 1u; pz[2] = own[0] + 2u; pz[3] = own[0] + 3u;
+                } else {
+                    pz[0] = swz<AND | (((0 / PPL) * R) << 5)>(own[0 % PPL]);
+                    pz[1] = swz<AND | (((1 / PPL) * R) << 5)>(own[1 % PPL]);
+                    pz[2] = swz<AND | (((2 / PPL) * R) << 5)>(own[2 % PPL]);
+                    pz[3] = swz<AND | (((3 / PPL) * R) << 5)>(own[3 % PPL]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++) pp[i] = pk_mul(pz[i], afac(i));
                 // Every MFMA starts from a ZERO accumulator and its result is added to the fp32 running sums on the VALU:
@@ -816,28 +711,118 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
                 // ~2^-23 of it (tools/mfma_prec_probe.hip), so a long chain of same-sign products (codes >= 0, zero
                 // points < 0) through C loses ~2^-19 |C| per step -- 2e-3 of the output after the two sums cancel.
                 const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                // the LDS operands (scale of channel group c + 1, then the zero points) are requested one step ahead of their use
+                u32x4 s_next = s_first;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const u32x4 s = *(const u32x4*)(lds_s + g * 64 + kb * 16 + c * 4);
+                    const u32x4 s = s_next;
+                    if constexpr (DIAG == 6 || DIAG == 7) s_next = s_first + (uint32_t)c;
+                    else if (c < 3) s_next = *(const u32x4*)(lds_s + g * 64 + kb * 16 + (c + 1) * 4);
+                    else s_next = *(const u32x4*)(lds_m + g * 64 + kb * 16 + (n & 3) * 4);
                     uint32_t A[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) A[i] = a_elem<HILO>(pp[i], pp[i] & lomask, s[i]);
-                    f4 d0 = zero4, d1 = zero4;
-                    mfma_pair(A, w[c], d0, d1);
-                    acc[c][0] += d0;
-                    acc[c][1] += d1;
+                    for (int i = 0; i < 4; i++) A[i] = (DIAG == 4) ? (pp[i] ^ s[i]) : a_elem<HILO>(pp[i], pp[i] & lomask, s[i]);
+                    if constexpr (DIAG == 2) {
+                        acc[c][0][0] += __builtin_bit_cast(float, (A[0] ^ A[1] ^ A[2] ^ A[3] ^ w[c]) & 0x3FFFFFFFu);
+                    } else {
+                        f4 d0 = zero4, d1 = zero4;
+                        mfma_pair(A, w[c], d0, d1);
+                        acc[c][0] += d0;
+                        acc[c][1] += d1;
+                    }
                 }
                 // zero-point term: Z[row, c] += sum_t p' * mn[t, c]  (columns n -> channel group n & 3)
-                const u32x4 bz = *(const u32x4*)(lds_m + g * 64 + kb * 16 + (n & 3) * 4);
+                const u32x4 bz = s_next;
                 zacc += __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(pz[0], pz[1], pz[2], pz[3]), as_h8(bz[0], bz[1], bz[2], bz[3]), zero4, 0, 0, 0);
                 // reload AFTER the last use (see gqa_k_kernel)
-                wr[j] = buf_load<u32x4, true>(rv, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the codes: never used
-                xr[j] = buf_load<XV, false>(rx, xoff + (uint32_t)((tok0 + (g + RING) * 32) * 2), 0);
+                if constexpr (DIAG != 1) {
+                    wr[j] = buf_load<u32x4, true>(rv, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the codes: never used
+                    xr[j] = buf_load<XV, false>(rx, xoff + (uint32_t)((tok0 + (g + RING) * 32) * 2), 0);
+                }
             }
         }
     }
 
     gstamp<DBG>(a.dbg, 3);
+    // ---- this slice's share of the fp16 window: probs[..., Tv + t] * V_window[t] for t in [w0, w1) (llama_kivi.py:384), the
+    // V append (:377) by the slice that holds the new token, the quantisation of the token leaving the window (:386-399)
+    // by slice 0.  A lane owns two channels, wave w the tokens w0 + w, w0 + w + 4, ...; all loads of a batch in flight.
+    constexpr int PW = 136, WB = 12;
+    __shared__ uint16_t pw[R][PW];
+    const int Lw = a.res_len + 1;
+    const int wchunk = (Lw + a.S - 1) / a.S;
+    const int w0 = slice * wchunk;
+    const int w1 = (w0 + wchunk < Lw) ? w0 + wchunk : Lw;
+    const int nwt = w1 > w0 ? w1 - w0 : 0;
+    uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+    const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+    uint16_t xflush = 0;
+    if (a.flush && slice == 0 && threadIdx.x < 128) xflush = vwin[threadIdx.x];      // requested early, used last
+    for (int idx = threadIdx.x; idx < R * nwt; idx += 256) {
+        const int rr = idx / nwt, t = idx - rr * nwt;
+        float Mr = M[0], Ir = invS[0];
+#pragma unroll
+        for (int q = 1; q < R; q++)
+            if (rr == q) { Mr = M[q]; Ir = invS[q]; }
+        const float xw = h2f_bits(a.x[b * a.x_sb + (int64_t)(h0 + rr) * a.x_sh + a.Tv + w0 + t]);
+        pw[rr][t] = f2h_bits(kivi_exp(xw - Mr) * Ir);
+    }
+    __syncthreads();
+    float ow[R][2];
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
+    for (int tb = wave; tb < nwt; tb += 4 * WB) {
+        uint32_t vv[WB];
+#pragma unroll
+        for (int u = 0; u < WB; u++) {
+            const int t = w0 + tb + 4 * u;
+            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+            vv[u] = (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < WB; u++) {
+            const int t = w0 + tb + 4 * u;
+            if (t < w1) {
+                const float v0 = h2f_bits((uint16_t)(vv[u] & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv[u] >> 16));
+#pragma unroll
+                for (int rr = 0; rr < R; rr++) {
+                    const float p = h2f_bits(pw[rr][t - w0]);
+                    ow[rr][0] = __builtin_fmaf(p, v0, ow[rr][0]);
+                    ow[rr][1] = __builtin_fmaf(p, v1, ow[rr][1]);
+                }
+                if (t == a.res_len) *(uint32_t*)(vwin + (int64_t)t * a.vres_st + 2 * lane) = vv[u];   // V append
+            }
+        }
+    }
+    if (a.flush && slice == 0 && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
+        const int d = threadIdx.x;
+        const uint32_t key = h_key(xflush);
+        uint32_t kmin = key, kmax = key;
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
+            kmin = o1 < kmin ? o1 : kmin;
+            kmax = o2 > kmax ? o2 : kmax;
+        }
+        const GroupQ gq = make_group(kmin, kmax, 3);
+        const uint32_t code = quant_one<2>(xflush, gq);
+        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+        const int e = tt & 7, kbq = tt >> 3;
+        const int c = d >> 5, tile = (d >> 4) & 1, nn = d & 15;
+        uint32_t val = code << (mf_pos(tile, e >> 1) + 16 * (e & 1));
+        val |= (uint32_t)__shfl_xor((int)val, 16);
+        uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+        if (tile == 0) {
+            uint32_t* wp = sbp + blk * KIVI_MF_BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
+            *wp = *wp | val;                 // the slot of a token is written once, on zero-initialised storage
+        }
+        if ((d & 31) == 0) {
+            const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
+            ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
+            ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
+        }
+    }
+
     // fold: O[r, d] = 2^-Sp * (2^12 * (hi + lo rows) + Z[r, d >> 5]); lane takes d = lane and lane + 64
     float zsel[R][2];
 #pragma unroll
@@ -864,24 +849,28 @@ __global__ __launch_bounds__(256, 4) void gqa_v_kernel(const GqaVArgs a) {
             o[rr][half] = __builtin_ldexpf(__builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), zsel[rr][half]), -sp[rr]);
         }
     __builtin_amdgcn_wave_barrier();
+    // per-wave [quantised part (R x 128) | window part (R x 128)] at the start of the wave's region, then the 4 waves
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
         Lf[rr * 128 + lane] = o[rr][0];
         Lf[rr * 128 + lane + 64] = o[rr][1];
+        Lf[R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
+        Lf[R * 128 + rr * 128 + 2 * lane + 1] = ow[rr][1];
     }
     __syncthreads();
     float* lf = reinterpret_cast<float*>(lds_all);
-    float tot[(R * 128 + 255) / 256];
+    constexpr int NT = (2 * R * 128 + 255) / 256;
+    float tot[NT];
 #pragma unroll
-    for (int k = 0; k < (R * 128 + 255) / 256; k++) {
+    for (int k = 0; k < NT; k++) {
         const int i = threadIdx.x + 256 * k;
-        tot[k] = (i < R * 128) ? (lf[i] + lf[2048 + i]) + (lf[4096 + i] + lf[6144 + i]) : 0.f;
+        tot[k] = (i < 2 * R * 128) ? (lf[i] + lf[2048 + i]) + (lf[4096 + i] + lf[6144 + i]) : 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < (R * 128 + 255) / 256; k++) {
+    for (int k = 0; k < NT; k++) {
         const int i = threadIdx.x + 256 * k;
-        if (i < R * 128) lf[i] = tot[k];
+        if (i < 2 * R * 128) lf[i] = tot[k];
     }
     __syncthreads();
     gstamp<DBG>(a.dbg, 4);
@@ -990,11 +979,35 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
 
 template <int R, bool HILO, int RING>
 static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
-    if (a.dbg && RING == 4 && HILO) {
-        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, true>), dim3((unsigned)(a.win_blocks + units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+    static const char* occ = getenv("KIVI_GQA_V_OCC");            // tuning aid: 3 = let the kernel use up to 168 registers
+    if (occ && atoi(occ) == 3 && HILO && RING == 4) {
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 3>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
         return;
     }
-    KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(a.win_blocks + units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+    static const char* dg = getenv("KIVI_GQA_V_DIAG");
+    if (dg && HILO && RING == 4 && R == 4) {
+        const dim3 grid((unsigned)(units * a.S));
+        const size_t lds = 4 * 2048 * 4;
+        switch (atoi(dg)) {
+            case 1: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 1>), grid, dim3(256), lds, s, a); return;
+            case 2: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 2>), grid, dim3(256), lds, s, a); return;
+            case 3: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 3>), grid, dim3(256), lds, s, a); return;
+            case 4: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 4>), grid, dim3(256), lds, s, a); return;
+            case 5: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 5>), grid, dim3(256), lds, s, a); return;
+            case 6: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 6>), grid, dim3(256), lds, s, a); return;
+            case 7: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 7>), grid, dim3(256), lds, s, a); return;
+            default: break;
+        }
+    }
+    if (occ && atoi(occ) == 2 && HILO && RING == 4) {
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 2>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        return;
+    }
+    if (a.dbg && HILO && RING <= 4) {
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, RING, true>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        return;
+    }
+    KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
 }
 
 extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stream) {
@@ -1030,7 +1043,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE(p->stats && (uintptr_t)p->stats % 8 == 0 && p->stats_bytes >= (int64_t)B * nh * nseg * 2 * (int64_t)sizeof(float), KIVI_EINVAL,
                  "kivi_gqa_decode: statistics buffer too small (%lld bytes for %d segments)", (long long)p->stats_bytes, nseg);
     const int nsbv = (int)((p->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
-    int S = 0, spb = 0;
+    int S = 1, spb = 0;
     if (nsbv > 0) {
         // ~1024 stream blocks (4 per CU) of 4 waves: a wave then streams 1-2 super-blocks (24 KiB each)
         static const char* fs = getenv("KIVI_GQA_V_BLOCKS");     // tuning aid: target number of stream blocks
@@ -1041,7 +1054,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
         S = (nsbv + spb - 1) / spb;
     }
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
-    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * (S + 1) * R * 128 * 4;
+    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * S * 2 * R * 128 * 4;
     KIVI_REQUIRE(p->workspace && (uintptr_t)p->workspace % 16 == 0 && p->workspace_bytes >= need, KIVI_EINVAL,
                  "kivi_gqa_decode: workspace too small (%lld bytes needed)", (long long)need);
     hipStream_t s = (hipStream_t)stream;
@@ -1068,7 +1081,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.x = (const uint16_t*)p->scores; v.x_sb = p->s_sb; v.x_sh = p->s_sh;
     v.stats = (const float*)p->stats; v.nseg = nseg;
     v.vt = {(uint32_t*)p->vt, p->vt_sb, p->vt_sh, p->vt_ss};
-    v.nh_kv = nh_kv; v.ratio = R; v.nh = nh; v.Tv = p->Tv; v.nsb = nsbv; v.S = S; v.spb = spb; v.win_blocks = units;
+    v.nh_kv = nh_kv; v.ratio = R; v.nh = nh; v.Tv = p->Tv; v.nsb = nsbv; v.S = S; v.spb = spb;
     v.vres = (uint16_t*)p->vres; v.vres_sb = p->vres_sb; v.vres_sh = p->vres_sh; v.vres_st = p->vres_st;
     v.win_start = p->v_win_start; v.res_len = p->v_res_len;
     v.vnew = (const uint16_t*)p->vnew; v.vnew_sb = p->vnew_sb; v.vnew_sh = p->vnew_sh; v.flush = p->v_flush ? 1 : 0;
@@ -1078,7 +1091,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
     static const char* nohilo = getenv("KIVI_GQA_NO_HILO");
     static const char* fr = getenv("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 4 or 8)
-    const int ring = fr ? atoi(fr) : 4;
+    const int ring = fr ? atoi(fr) : (R == 4 ? 4 : 2);           // R = 8 spills at 4
 #define KIVI_GV(RR, HL)                                          \
     do {                                                         \
         if (ring == 2) launch_gqa_v<RR, HL, 2>(v, units, s);     \

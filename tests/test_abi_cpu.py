@@ -282,7 +282,7 @@ def _gqa_args(**over):
              vres=0x1000, vres_sb=2 * 65 * 128, vres_sh=65 * 128, vres_st=128, v_win_start=0, v_res_len=32,
              vnew=0x1000, vnew_sb=2 * 128, vnew_sh=128, v_flush=1,
              scores=0x1000, s_sb=8 * 528, s_sh=528, stats=0x1000, stats_bytes=2 * 8 * 5 * 2 * 4,
-             workspace=0x1000, workspace_bytes=65536 + 2 * 2 * 2 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128)
+             workspace=0x1000, workspace_bytes=65536 + 2 * 2 * 2 * 1 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128)
     f.update(over)
     return _lib.GqaDecodeArgs(**f)
 

@@ -34,17 +34,17 @@ s = st.cpu().numpy()
 used = s[:, 0, 0] != 0
 nb = int(used.sum())
 units = B * kv
-print(f"blocks stamped {nb} (window blocks {units})")
+print(f"blocks stamped {nb}")
 dt_rt = (s[used][:, :, 12] - s[used][:, :, 1]).astype(np.float64) * 0.01
 dt_sh = (s[used][:, :, 5] - s[used][:, :, 0]).astype(np.float64)
 mhz = float(np.median(dt_sh / np.maximum(dt_rt, 1e-3)))
 rt0 = s[used][:, :, 1].min()
-for name, sel in (("window blocks", slice(0, units)), ("stream blocks", slice(units, nb))):
+for name, sel in (("stream blocks", slice(0, nb)),):
     x = s[sel]
     beg = (x[:, :, 1] - rt0) * 0.01
     print(f"{name}: entry median {np.median(beg):.1f} us p90 {np.percentile(beg, 90):.1f};  exit median {np.median((x[:, :, 12] - rt0) * 0.01):.1f} max {((x[:, :, 12] - rt0) * 0.01).max():.1f} us   (clock {mhz:.0f} MHz)")
     prev = 0
-    for i, nm in ((2, "softmax constants"), (3, "stream loop / window sum"), (4, "fold + block partial"), (5, "arrival (+ combine)")):
+    for i, nm in ((2, "softmax constants"), (3, "stream loop"), (4, "window share + fold + block partial"), (5, "arrival (+ combine)")):
         d = (x[:, :, i] - x[:, :, prev]).reshape(-1) / mhz
         print(f"   {nm:26s} median {np.median(d):7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f} us")
         prev = i
