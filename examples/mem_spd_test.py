@@ -73,7 +73,12 @@ def main():
     ap.add_argument("--residual", type=int, default=32)
     ap.add_argument("--baseline", action="store_true", help="fp16 KV cache + torch SDPA instead of the KIVI hook")
     ap.add_argument("--graphs", action="store_true", help="replay the dense part of every decode step from hipGraphs")
+    ap.add_argument("--repeats", type=int, default=1, help="whole generations (prompt pass + gen steps) timed back to back")
+    ap.add_argument("--recipe", action="store_true",
+                    help="the reference's mem_spd_test.py:8-12, :53-70: batch 96, prompt 160, 338 new tokens, residual 128, 3 repeats")
     args = ap.parse_args()
+    if args.recipe:
+        args.batch, args.prompt, args.gen, args.residual, args.repeats = 96, 160, 338, 128, 3
     dev = torch.device("cuda:0")
     cfg = SimpleNamespace(hidden_size=args.hidden, num_attention_heads=args.heads, num_key_value_heads=args.kv_heads,
                           num_hidden_layers=args.layers, intermediate_size=args.intermediate, vocab_size=args.vocab,
@@ -94,24 +99,31 @@ def main():
     ids = torch.randint(0, args.vocab, (args.batch, args.prompt), device=dev)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
-    t0 = time.time()
-    logits, pasts = model(ids)
-    torch.cuda.synchronize()
-    t_prefill = time.time() - t0
-    tok = logits.argmax(-1)
-    if args.graphs:
-        assert not args.baseline, "--graphs drives the KIVI hook (the fp16 baseline cache grows in shape every step)"
-        model.prepare_graphs(args.batch, dev)
+    t_prefill = t_dec = 0.0
+    t_all0 = time.time()
+    for rep in range(args.repeats):
+        t0 = time.time()
+        logits, pasts = model(ids)
         torch.cuda.synchronize()
-    t1 = time.time()
-    if args.graphs:
-        model.decode_graphed(tok, pasts, args.prompt, args.gen)
-    else:
-        for _ in range(args.gen):
-            logits, pasts = model(tok, pasts)
-            tok = logits.argmax(-1)
-    torch.cuda.synchronize()
-    t_dec = time.time() - t1
+        t_prefill += time.time() - t0
+        tok = logits.argmax(-1)
+        if args.graphs:
+            assert not args.baseline, "--graphs drives the KIVI hook (the fp16 baseline cache grows in shape every step)"
+            if rep == 0:
+                model.prepare_graphs(args.batch, dev)
+            torch.cuda.synchronize()
+        t1 = time.time()
+        if args.graphs:
+            model.decode_graphed(tok, pasts, args.prompt, args.gen)
+        else:
+            for _ in range(args.gen):
+                logits, pasts = model(tok, pasts)
+                tok = logits.argmax(-1)
+        torch.cuda.synchronize()
+        t_dec += time.time() - t1
+    t_generate = (time.time() - t_all0) / args.repeats
+    t_prefill /= args.repeats
+    t_dec /= args.repeats
     if args.baseline:
         kv = kv_alloc = sum(p[0].numel() * 2 * 2 for p in pasts)
     else:
@@ -121,6 +133,7 @@ def main():
         "mode": "fp16 KV + SDPA" if args.baseline else f"KIVI {args.bits}-bit g={args.group} R={args.residual}" + (" + hipGraph dense" if args.graphs else ""),
         "model": f"llama-shaped random weights: L={args.layers} h={args.hidden} nh={args.heads}/{args.kv_heads} ffn={args.intermediate}",
         "batch": args.batch, "prompt": args.prompt, "gen": args.gen,
+        "repeats": args.repeats, "generate_ms": round(1e3 * t_generate, 1),     # what the reference prints as "used time"
         "prefill_s": round(t_prefill, 3), "decode_ms_per_step": round(1e3 * t_dec / args.gen, 3),
         "decode_tokens_per_s": round(args.batch * args.gen / t_dec, 1),
         "weights_bytes": weights, "kv_cache_bytes": kv, "kv_cache_allocated_bytes": kv_alloc,
