@@ -585,8 +585,14 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 // Stream role: block (unit, slice) takes `spb` consecutive super-blocks of the unit's packed V, one per wave at a time.
 // DIAG (tools only, wrong results): 1 = the ring is never reloaded (no memory traffic in the loop), 2 = no MFMA / no
 // accumulate, 3 = no probability chain (constant p), 4 = no A build, 5 = no ds_swizzle, 6 = no LDS reads in the loop, 7 = 5 + 6
-template <int R, bool HILO, int RING, bool DBG = false, int OCC = 4, int DIAG = 0>
+// V2 (R == 4): MFMA row = (channel group c, head r) instead of (hi / lo, head).  A lane then needs the scale / zero points of
+// ONE channel group (2 LDS reads per block instead of 5: the ablation's lever), builds hi and lo operands for it (16
+// packed ops instead of 36), and every (channel group c', tile) takes two chained MFMAs (hi, lo) whose rows are useful
+// where c == c' -- 18 MFMAs per block instead of 10 on a matrix pipe that is 8 % busy.  Rows (c, r) of column n land in
+// lane (n, kb = c), register r: the output fold needs no transposition.
+template <int R, bool HILO, int RING, bool DBG = false, int OCC = 4, int DIAG = 0, bool V2 = false>
 __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
+    static_assert(!V2 || (R == 4 && HILO), "row = (channel group, head) needs 4 x 4 rows");
     extern __shared__ uint32_t lds_all[];                          // 4 waves x 2048 words (scale | mn of the super-block)
     gstamp<DBG>(a.dbg, 0);
     if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -676,7 +682,8 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
                 const int g = g0 + j;
                 const u32x4& w = wr[j];
                 const XV& xv = xr[j];
-                const u32x4 s_first = *(const u32x4*)(lds_s + g * 64 + kb * 16);      // scale of channel group 0: in flight during the exps
+                // scale of channel group 0 (V2: of the lane's own channel group): in flight during the exps
+                const u32x4 s_first = *(const u32x4*)(lds_s + g * 64 + kb * 16 + (V2 ? (n >> 2) * 4 : 0));
                 // this lane's share of the probabilities: fp16(exp(x - M) / sum) as the reference casts them
                 // (llama_kivi.py:375), then the exact power-of-two scaling by 2^Sp; slots past the packed prefix get 0
                 uint32_t own[PPL];
@@ -711,6 +718,33 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
                 // ~2^-23 of it (tools/mfma_prec_probe.hip), so a long chain of same-sign products (codes >= 0, zero
                 // points < 0) through C loses ~2^-19 |C| per step -- 2e-3 of the output after the two sums cancel.
                 const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (V2) {
+                    const int cg = n >> 2;                                    // this lane's row: channel group cg, head n & 3
+                    const u32x4 m4 = *(const u32x4*)(lds_m + g * 64 + kb * 16 + cg * 4);
+                    uint32_t Ah[4], Al[4], Zh[4], Zl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        Ah[i] = pk_mul(pp[i], s_first[i]);
+                        Al[i] = pk_fms(pp[i], s_first[i], Ah[i]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        f4 d0 = zero4, d1 = zero4;
+                        mfma_pair(Ah, w[c], d0, d1);
+                        mfma_pair(Al, w[c], d0, d1);
+                        acc[c][0] += d0;
+                        acc[c][1] += d1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        Zh[i] = pk_mul(pz[i], m4[i]);
+                        Zl[i] = pk_fms(pz[i], m4[i], Zh[i]);
+                    }
+                    const h8 ones = as_h8(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+                    f4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(Zh[0], Zh[1], Zh[2], Zh[3]), ones, zero4, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(Zl[0], Zl[1], Zl[2], Zl[3]), ones, z, 0, 0, 0);
+                    zacc += z;
+                } else {
                 // the LDS operands (scale of channel group c + 1, then the zero points) are requested one step ahead of their use
                 u32x4 s_next = s_first;
 #pragma unroll
@@ -734,6 +768,7 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
                 // zero-point term: Z[row, c] += sum_t p' * mn[t, c]  (columns n -> channel group n & 3)
                 const u32x4 bz = s_next;
                 zacc += __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(pz[0], pz[1], pz[2], pz[3]), as_h8(bz[0], bz[1], bz[2], bz[3]), zero4, 0, 0, 0);
+                }
                 // reload AFTER the last use (see gqa_k_kernel)
                 if constexpr (DIAG != 1) {
                     wr[j] = buf_load<u32x4, true>(rv, (uint32_t)((g + RING) * 1024 + lane * 16), 0);   // past the codes: never used
@@ -823,6 +858,26 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
         }
     }
 
+    float* Lf = reinterpret_cast<float*>(lds_s);                   // the wave's own 8 KiB
+    if constexpr (V2) {
+        // rows (c, r) of column n sit in lane (n, kb = c), register r: O[r, 32 kb + 16 tile + n] = 2^-Sp (2^12 acc[kb] + Z[r, kb])
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = acc[0][tile][j];
+                if (kb == 1) v = acc[1][tile][j];
+                if (kb == 2) v = acc[2][tile][j];
+                if (kb == 3) v = acc[3][tile][j];
+                Lf[j * 128 + 32 * kb + 16 * tile + n] = __builtin_ldexpf(__builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), zacc[j]), -sp[j]);
+            }
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            Lf[R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
+            Lf[R * 128 + rr * 128 + 2 * lane + 1] = ow[rr][1];
+        }
+    } else {
     // fold: O[r, d] = 2^-Sp * (2^12 * (hi + lo rows) + Z[r, d >> 5]); lane takes d = lane and lane + 64
     float zsel[R][2];
 #pragma unroll
@@ -830,7 +885,6 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
 #pragma unroll
         for (int half = 0; half < 2; half++)
             zsel[rr][half] = __shfl(zacc[rr % 4], (rr / 4) * 16 + (lane >> 5) + 2 * half);
-    float* Lf = reinterpret_cast<float*>(lds_s);                   // [16 rows][128 columns], the wave's own 8 KiB
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -856,6 +910,7 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
         Lf[rr * 128 + lane + 64] = o[rr][1];
         Lf[R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
         Lf[R * 128 + rr * 128 + 2 * lane + 1] = ow[rr][1];
+    }
     }
     __syncthreads();
     float* lf = reinterpret_cast<float*>(lds_all);
@@ -982,6 +1037,16 @@ static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
     static const char* occ = getenv("KIVI_GQA_V_OCC");            // tuning aid: 3 = let the kernel use up to 168 registers
     if (occ && atoi(occ) == 3 && HILO && RING == 4) {
         KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 3>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        return;
+    }
+    static const char* v2 = getenv("KIVI_GQA_V2");                // tuning aid: 1 / 0 = row = (channel group, head) mapping on / off
+    if (R == 4 && HILO && (v2 ? atoi(v2) != 0 : true)) {
+        const dim3 grid((unsigned)(units * a.S));
+        static const char* occ2 = getenv("KIVI_GQA_V_OCC");
+        if (a.dbg) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, true, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
+        else if (occ2 && atoi(occ2) == 3) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 3, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
+        else if (RING == 2) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 2, false, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
+        else KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
         return;
     }
     static const char* dg = getenv("KIVI_GQA_V_DIAG");
