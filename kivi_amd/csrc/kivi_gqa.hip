@@ -193,6 +193,7 @@ struct GqaKArgs {
     int64_t mask_sb;
     // residual role (the FIRST res_blocks blocks of the grid): q . [fp16 K residual | new key] (:333-337) + the K append
     int res_blocks;             // units * KIVI_GQA_RES_SEGS or 0
+    int res_first;              // residual blocks at the head (1) or at the tail (0) of the grid
     uint16_t* kres;
     int64_t kres_sb, kres_sh, kres_st;
     const uint16_t* knew;
@@ -263,11 +264,14 @@ __device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
 template <int R, int W, bool HILO, int RING>
 __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
     extern __shared__ uint32_t lds_all[];
-    if ((int)blockIdx.x < a.res_blocks) {
-        gqa_k_residual<R>(a, (int)blockIdx.x);
+    // the short residual blocks come LAST or FIRST in the grid (res_first): last, they fill the slots the streaming blocks
+    // free up instead of delaying their start
+    const int main_blocks = (int)gridDim.x - a.res_blocks;
+    if (a.res_first ? (int)blockIdx.x < a.res_blocks : (int)blockIdx.x >= main_blocks) {
+        gqa_k_residual<R>(a, a.res_first ? (int)blockIdx.x : (int)blockIdx.x - main_blocks);
         return;
     }
-    const int bid = (int)blockIdx.x - a.res_blocks;
+    const int bid = a.res_first ? (int)blockIdx.x - a.res_blocks : (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_s = lds_all + wave * (1024 + R * 256);          // scale of the super-block: 16 groups x 64 words
@@ -1027,7 +1031,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.nsb = (int)((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
     a.nh = nh;
     a.stats = nullptr; a.nseg = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
-    a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
+    a.res_blocks = 0; a.res_first = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     return run_gqa_k(a, B * nh_kv, (hipStream_t)stream);
 }
@@ -1132,6 +1136,8 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.stats = (float*)p->stats; k.nseg = nseg; k.inv_scale = p->inv_scale;
     k.mask = (const uint16_t*)p->mask; k.mask_sb = p->mask_sb;
     k.res_blocks = units * KIVI_GQA_RES_SEGS;
+    static const char* rf = getenv("KIVI_GQA_RES_FIRST");        // tuning aid
+    k.res_first = rf ? atoi(rf) : 0;
     k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
     static const char* skipk = getenv("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats

@@ -72,15 +72,34 @@ __device__ __forceinline__ float fold_rows(float x, float y) {
     return x + y;
 }
 
+// Wave-wide max / sum with DPP inside the 16-lane rows and four v_readlane across them: no LDS round trips (the
+// __shfl_xor form is 6 dependent ds_bpermute, ~600 cycles per reduction; the softmax statistics need 2 R of them per
+// super-block).  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m));
-    return v;
+    v = __builtin_fmaxf(v, dpp_f<0xB1>(v));     // quad_perm [1,0,3,2]
+    v = __builtin_fmaxf(v, dpp_f<0x4E>(v));     // quad_perm [2,3,0,1]
+    v = __builtin_fmaxf(v, dpp_f<0x141>(v));    // row_half_mirror
+    v = __builtin_fmaxf(v, dpp_f<0x140>(v));    // row_mirror: every lane of a row holds the row's max
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (a + b) + (c + d);
 }
 
 }  // namespace
