@@ -81,6 +81,113 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim_kernel(const uint16_t*
     }
 }
 
+// 2-bit variant on packed 16-bit math (round 2).  The kernel above spends ~190 VALU instructions per 16-byte chunk and is
+// bound by them (332 us per GiB in), so this one keeps the same arithmetic but does it two halves at a time:
+//   * order-preserving keys, min / max: v_pk_ashrrev_i16 + xor, v_pk_min_u16 / v_pk_max_u16; the lanes of a group meet
+//     through DPP (no LDS round trips) while the group has <= 16 lanes;
+//   * d = fp16(x - mn): one v_pk_add_f16 per pair (IEEE, fp16 subnormals on) = the reference's fp32 subtract + round
+//     (24 >= 2 * 11 + 2 bits: the double rounding is innocuous);
+//   * the three decisions d > th0, d >= th1, d > th2 (kivi_quant.h) compare a NON-NEGATIVE fp16 with fp32 thresholds:
+//     they are equal to integer comparisons of the bit patterns with the thresholds rounded DOWN / UP to fp16 once per
+//     group (T0 = RD(th0), T1 = RU(th1) - 1 ulp, T2 = RD(th2)), i.e. sign(T - bits(d)) by v_pk_sub_i16 + v_pk_lshrrev_b16;
+//     groups with NaN thresholds -- scale 0, inf or NaN -- get code 0 by a mask, as before.
+// Bit-exact against the same fixtures as the kernel above (tests/test_pack_gpu.py).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// logical shift right by 15 of both halves (count in a register for both halves: see the key computation below)
+__device__ __forceinline__ uint32_t pk_lshr15(uint32_t v) {
+    uint32_t r;
+    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x000F000Fu), "v"(v));
+    return r;
+}
+// fp32 threshold -> fp16 bit pattern T with  (bits(d) > T)  ==  (d > th) [UP = false]  or  (d >= th) [UP = true]  for d >= +0
+template <bool UP>
+__device__ __forceinline__ uint32_t thr_bits(float th) {
+    if (!(th == th)) return 0x7FFFu;                              // NaN: never exceeded
+    const uint32_t h = f2h_bits(th);                              // round to nearest
+    const float back = h2f_bits((uint16_t)h);
+    if constexpr (!UP) return (back > th) ? h - 1u : h;           // RD(th): d > th  <=>  bits(d) > bits(RD(th))
+    else return ((back < th) ? h + 1u : h) - 1u;                  // RU(th) - 1 ulp: d >= th  <=>  bits(d) > bits(RU(th)) - 1
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t* __restrict__ x, uint32_t* __restrict__ code,
+                                                                  uint16_t* __restrict__ scale, uint16_t* __restrict__ mn,
+                                                                  int64_t nchunk, int lpg) {
+    const int64_t c0 = (int64_t)blockIdx.x * (256 * NU) + threadIdx.x;
+    const int lg = __builtin_ctz((unsigned)lpg);
+    u32x4 vv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int64_t c = c0 + 256 * u;
+        vv[u] = u32x4{0, 0, 0, 0};
+        if (c < nchunk) vv[u] = __builtin_nontemporal_load((const u32x4*)(x + c * 8));
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int64_t c = c0 + 256 * u;
+        const bool valid = c < nchunk;
+        const u32x4 v = vv[u];
+        uint32_t key[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t sgn;                                                                  // 0xFFFF for negative halves
+            asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[k]));    // shift count in BOTH halves (an inline 15 reaches only the low one)
+            key[k] = v[k] ^ (sgn | 0x80008000u);
+        }
+        us16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
+                                               __builtin_elementwise_min(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
+        us16x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
+                                               __builtin_elementwise_max(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
+        uint32_t kmin = mn2[0] < mn2[1] ? mn2[0] : mn2[1];
+        uint32_t kmax = mx2[0] > mx2[1] ? mx2[0] : mx2[1];
+        // the lpg lanes of a group (aligned, power of two): DPP inside a 16-lane row, shuffles beyond
+        if (lpg > 1) { const uint32_t a = dpp_u<0xB1>(kmin), b = dpp_u<0xB1>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+        if (lpg > 2) { const uint32_t a = dpp_u<0x4E>(kmin), b = dpp_u<0x4E>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+        if (lpg > 4) { const uint32_t a = dpp_u<0x141>(kmin), b = dpp_u<0x141>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+        if (lpg > 8) { const uint32_t a = dpp_u<0x140>(kmin), b = dpp_u<0x140>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+        for (int m = 16; m < lpg; m <<= 1) {
+            const uint32_t a = __shfl_xor(kmin, m), b = __shfl_xor(kmax, m);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        const GroupQ g = make_group(kmin, kmax, 3);
+        const uint32_t T0 = thr_bits<false>(g.th[0]), T1 = thr_bits<true>(g.th[1]), T2 = thr_bits<false>(g.th[2]);
+        const us16x2 t0 = {(unsigned short)T0, (unsigned short)T0}, t1 = {(unsigned short)T1, (unsigned short)T1},
+                     t2 = {(unsigned short)T2, (unsigned short)T2};
+        const _Float16 hmn = __builtin_bit_cast(_Float16, g.mn);
+        const hf2 mnv = {hmn, hmn};
+        uint32_t cq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t xk = v[k];   // by value: __builtin_bit_cast of a vector ELEMENT reads element 0 (hipcc 7.2)
+            const hf2 d = __builtin_bit_cast(hf2, xk) - mnv;                              // new_pack.py:239
+            const us16x2 db = __builtin_bit_cast(us16x2, d);
+            // 1 where bits(d) > T: the sign of T - bits(d) (both < 0x8000), per half
+            cq[k] = pk_lshr15(__builtin_bit_cast(uint32_t, t0 - db)) + pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db)) +
+                    pk_lshr15(__builtin_bit_cast(uint32_t, t2 - db));
+        }
+        // lo halves: codes 0, 2, 4, 6; hi halves: codes 1, 3, 5, 7
+        const uint32_t t = cq[0] | (cq[1] << 4) | (cq[2] << 8) | (cq[3] << 12);
+        // NaN thresholds (scale 0 / inf / NaN): code 0 whatever d is -- d itself may then be a NaN with the sign bit set
+        // (-inf - -inf), which the sign trick above would count
+        const uint32_t part = (t | (t >> 14)) & ((g.th[0] == g.th[0]) ? 0xFFFFu : 0u);
+        const uint32_t other = dpp_u<0xB1>(part);                                          // lane ^ 1
+        if (valid && !(threadIdx.x & 1)) code[c >> 1] = part | (other << 16);
+        if (valid && (c & (lpg - 1)) == 0) {                        // lpg is a power of two
+            const int64_t gi = c >> lg;
+            scale[gi] = g.scale;
+            mn[gi] = g.mn;
+        }
+    }
+}
+
 // Any group size (multiple of fpi): one thread per group, scalar loops.
 template <int BITS>
 __global__ __launch_bounds__(256) void quant_pack_lastdim_generic(const uint16_t* x, uint32_t* code, uint16_t* scale,
@@ -355,7 +462,13 @@ extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, v
         else hipLaunchKernelGGL((quant_pack_lastdim_kernel<BB, 1>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s,         \
                                 (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);                  \
     } while (0)
-        if (bits == 2) KIVI_QP(2);
+        static const char* nopk = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math 2-bit kernel
+        if (bits == 2 && !nopk) {
+            if (nu >= 4) hipLaunchKernelGGL((quant_pack_lastdim2_kernel<4>), dim3((unsigned)((nchunk + 1023) / 1024)), dim3(256), 0, s,
+                                            (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
+            else hipLaunchKernelGGL((quant_pack_lastdim2_kernel<1>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s,
+                                    (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
+        } else if (bits == 2) KIVI_QP(2);
         else if (bits == 4) KIVI_QP(4);
         else KIVI_QP(8);
 #undef KIVI_QP
