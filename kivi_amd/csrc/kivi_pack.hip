@@ -11,7 +11,9 @@
 // double rounding), with a correctly rounded fp32 division
 // (-fhip-fp32-correctly-rounded-divide-sqrt; never x * rcp(scale)).
 // A constant group has scale 0 -> 0/0 = NaN -> code 0 (the reference's CUDA
-// float->int conversion; its CPU run yields INT_MIN instead).
+// float->int conversion; its CPU run yields INT_MIN instead);
+// a group whose range is one fp16-subnormal ulp also has scale 0 and its
+// non-minimum elements quantise to d/0 = inf -> max code (kivi_quant.h).
 #include <stdlib.h>
 
 #include "kivi_common.h"
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim_kernel(const uint16_t*
 //   * d = fp16(x - mn): one v_pk_add_f16 per pair (IEEE, fp16 subnormals on) = the reference's fp32 subtract + round
 //     (24 >= 2 * 11 + 2 bits: the double rounding is innocuous);
 //   * the three decisions d > th0, d >= th1, d > th2 (kivi_quant.h) compare a NON-NEGATIVE fp16 with fp32 thresholds:
-//     they are equal to integer comparisons of the bit patterns with the thresholds rounded DOWN / UP to fp16 once per
-//     group (T0 = RD(th0), T1 = RU(th1) - 1 ulp, T2 = RD(th2)), i.e. sign(T - bits(d)) by v_pk_sub_i16 + v_pk_lshrrev_b16;
-//     groups with NaN thresholds -- scale 0, inf or NaN -- get code 0 by a mask, as before.
+//     they are equal to integer comparisons of the bit patterns with the thresholds rounded toward zero to fp16 once per
+//     group (make_group2), i.e. sign(T - bits(d)) by v_pk_sub_i16 + v_pk_lshrrev_b16; groups with scale inf or NaN
+//     get code 0 by a mask.
 // Bit-exact against the same fixtures as the kernel above (tests/test_pack_gpu.py).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
@@ -106,33 +108,51 @@ __device__ __forceinline__ uint32_t pk_lshr15(uint32_t v) {
     asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x000F000Fu), "v"(v));
     return r;
 }
-// fp32 threshold -> fp16 bit pattern T with  (bits(d) > T)  ==  (d > th) [UP = false]  or  (d >= th) [UP = true]  for d >= +0
-template <bool UP>
-__device__ __forceinline__ uint32_t thr_bits(float th) {
-    if (!(th == th)) return 0x7FFFu;                              // NaN: never exceeded
-    const uint32_t h = f2h_bits(th);                              // round to nearest
-    const float back = h2f_bits((uint16_t)h);
-    if constexpr (!UP) return (back > th) ? h - 1u : h;           // RD(th): d > th  <=>  bits(d) > bits(RD(th))
-    else return ((back < th) ? h + 1u : h) - 1u;                  // RU(th) - 1 ulp: d >= th  <=>  bits(d) > bits(RU(th)) - 1
+// One group of the 2-bit packed-math kernel: mn / scale as make_group does (kivi_quant.h), the three decision thresholds as
+// fp16 bit patterns.  Two shortcuts, both checked exhaustively on the CPU (tests/test_oracle_golden.py):
+//   * scale = fp16(range / 3) = fp16(range * fp32(1/3)): range / 3 is never within 2^-13 (relative) of an fp16 rounding
+//     boundary, the product is within 2^-23 of the quotient;
+//   * tau_k * scale (a 12-bit odd factor times an 11-bit mantissa) is never an fp16 value, so "d > th" and "d >= th"
+//     are both  bits(d) > bits(RTZ(th))  for d >= +0: v_cvt_pkrtz_f16_f32 makes two thresholds per instruction.
+struct Group2 {
+    uint32_t t02, t11;   // (T0 | T2 << 16), (T1 | T1 << 16)
+    uint16_t mn, scale;
+    bool live;           // false: scale inf / NaN -> every code 0
+};
+__device__ __forceinline__ Group2 make_group2(uint32_t kmin, uint32_t kmax) {
+    Group2 g;
+    g.mn = (uint16_t)h_unkey(kmin);
+    const uint16_t mx = (uint16_t)h_unkey(kmax);
+    const uint16_t range = f2h_bits(h2f_bits(mx) - h2f_bits(g.mn));          // new_pack.py:238 (mx - mn)
+    g.scale = f2h_bits(h2f_bits(range) * 0.3333333432674408f);               //                 / max_int
+    const float fs0 = h2f_bits(g.scale);
+    g.live = fs0 >= 0.0f && fs0 < __builtin_inff();                          // inf / NaN: every code 0
+    const float fs = fs0 == 0.0f ? 0x1p-30f : fs0;                           // scale 0: d > 0 -> d / 0 = inf -> 3 (kivi_quant.h)
+    g.t02 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(0.500244140625f * fs, 2.5009765625f * fs));
+    g.t11 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(1.49951171875f * fs, 1.49951171875f * fs));
+    return g;
 }
 
-template <int NU>
+// LPG = lanes per group when known at compile time (4 / 8 / 16 for group 32 / 64 / 128), 0 = the runtime value;
+// FULL = every block has all of its 256 * NU chunks (no bounds checks).
+template <int NU, int LPG, bool FULL>
 __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t* __restrict__ x, uint32_t* __restrict__ code,
                                                                   uint16_t* __restrict__ scale, uint16_t* __restrict__ mn,
-                                                                  int64_t nchunk, int lpg) {
+                                                                  int64_t nchunk, int lpg_rt) {
     const int64_t c0 = (int64_t)blockIdx.x * (256 * NU) + threadIdx.x;
-    const int lg = __builtin_ctz((unsigned)lpg);
+    const int lpg = LPG ? LPG : lpg_rt;
+    const int lg = LPG ? __builtin_ctz((unsigned)(LPG ? LPG : 1)) : __builtin_ctz((unsigned)lpg_rt);
     u32x4 vv[NU];
 #pragma unroll
     for (int u = 0; u < NU; u++) {
         const int64_t c = c0 + 256 * u;
         vv[u] = u32x4{0, 0, 0, 0};
-        if (c < nchunk) vv[u] = __builtin_nontemporal_load((const u32x4*)(x + c * 8));
+        if (FULL || c < nchunk) vv[u] = __builtin_nontemporal_load((const u32x4*)(x + c * 8));
     }
 #pragma unroll
     for (int u = 0; u < NU; u++) {
         const int64_t c = c0 + 256 * u;
-        const bool valid = c < nchunk;
+        const bool valid = FULL || c < nchunk;
         const u32x4 v = vv[u];
         uint32_t key[4];
 #pragma unroll
@@ -157,10 +177,9 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t
             kmin = a < kmin ? a : kmin;
             kmax = b > kmax ? b : kmax;
         }
-        const GroupQ g = make_group(kmin, kmax, 3);
-        const uint32_t T0 = thr_bits<false>(g.th[0]), T1 = thr_bits<true>(g.th[1]), T2 = thr_bits<false>(g.th[2]);
-        const us16x2 t0 = {(unsigned short)T0, (unsigned short)T0}, t1 = {(unsigned short)T1, (unsigned short)T1},
-                     t2 = {(unsigned short)T2, (unsigned short)T2};
+        const Group2 g = make_group2(kmin, kmax);
+        const us16x2 t02 = __builtin_bit_cast(us16x2, g.t02);
+        const us16x2 t0 = {t02[0], t02[0]}, t1 = __builtin_bit_cast(us16x2, g.t11), t2 = {t02[1], t02[1]};
         const _Float16 hmn = __builtin_bit_cast(_Float16, g.mn);
         const hf2 mnv = {hmn, hmn};
         uint32_t cq[4];
@@ -175,9 +194,9 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t
         }
         // lo halves: codes 0, 2, 4, 6; hi halves: codes 1, 3, 5, 7
         const uint32_t t = cq[0] | (cq[1] << 4) | (cq[2] << 8) | (cq[3] << 12);
-        // NaN thresholds (scale 0 / inf / NaN): code 0 whatever d is -- d itself may then be a NaN with the sign bit set
+        // dead groups (scale inf / NaN): code 0 whatever d is -- d itself may then be a NaN with the sign bit set
         // (-inf - -inf), which the sign trick above would count
-        const uint32_t part = (t | (t >> 14)) & ((g.th[0] == g.th[0]) ? 0xFFFFu : 0u);
+        const uint32_t part = (t | (t >> 14)) & (g.live ? 0xFFFFu : 0u);
         const uint32_t other = dpp_u<0xB1>(part);                                          // lane ^ 1
         if (valid && !(threadIdx.x & 1)) code[c >> 1] = part | (other << 16);
         if (valid && (c & (lpg - 1)) == 0) {                        // lpg is a power of two
@@ -464,10 +483,18 @@ extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, v
     } while (0)
         static const char* nopk = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math 2-bit kernel
         if (bits == 2 && !nopk) {
-            if (nu >= 4) hipLaunchKernelGGL((quant_pack_lastdim2_kernel<4>), dim3((unsigned)((nchunk + 1023) / 1024)), dim3(256), 0, s,
-                                            (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
-            else hipLaunchKernelGGL((quant_pack_lastdim2_kernel<1>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s,
-                                    (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);
+#define KIVI_QP2(NUU, LL, FF)                                                                                          \
+    hipLaunchKernelGGL((quant_pack_lastdim2_kernel<NUU, LL, FF>), dim3((unsigned)((nchunk + 256 * NUU - 1) / (256 * NUU))), dim3(256), 0, \
+                       s, (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg)
+            const int nu2 = nu >= 4 ? 4 : 1;
+            const bool full = nchunk % (256 * nu2) == 0;
+            if (nu2 == 4 && full && lpg == 4) KIVI_QP2(4, 4, true);
+            else if (nu2 == 4 && full && lpg == 8) KIVI_QP2(4, 8, true);
+            else if (nu2 == 4 && full && lpg == 16) KIVI_QP2(4, 16, true);
+            else if (nu2 == 4) KIVI_QP2(4, 0, false);
+            else if (lpg == 4) KIVI_QP2(1, 4, false);
+            else KIVI_QP2(1, 0, false);
+#undef KIVI_QP2
         } else if (bits == 2) KIVI_QP(2);
         else if (bits == 4) KIVI_QP(4);
         else KIVI_QP(8);

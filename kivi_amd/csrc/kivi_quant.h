@@ -28,9 +28,13 @@ __device__ __forceinline__ GroupQ make_group(uint32_t kmin, uint32_t kmax, int m
     // tau (12 bits) x scale (11 bits) is exact in fp32, so the comparison is exact and the result is identical to
     // rint(clamp(fp16(d / scale))): checked against the division for every scale and every d within 3 ulps of a
     // boundary (and 4e7 random pairs) -- tests/test_oracle_golden.py::test_threshold_quantiser_equals_division.
-    // scale 0 (constant group: 0/0) and scale inf (range overflow: x/inf or inf/inf) quantise to code 0 in the
-    // reference's CUDA path; NaN thresholds make every comparison false.
-    const float fsx = (g.fs > 0.0f && g.fs < __builtin_inff()) ? g.fs : __builtin_nanf("");
+    // Degenerate scales, as the reference's CUDA path resolves them (float -> int of NaN = 0):
+    //   scale inf / NaN (range overflow, NaN input): x / inf = 0, inf / inf = NaN -> every code 0: NaN thresholds make
+    //     every comparison false;
+    //   scale 0: a constant group (d = 0: 0 / 0 = NaN -> 0) OR a group whose range is ONE fp16-subnormal ulp (2^-24 / 3
+    //     rounds to 0): d > 0 there gives d / 0 = inf -> clamp -> 3.  Thresholds below the smallest positive fp16 do
+    //     both: d = 0 stays under them, any d > 0 passes all three.
+    const float fsx = (g.fs > 0.0f && g.fs < __builtin_inff()) ? g.fs : (g.fs == 0.0f ? 0x1p-30f : __builtin_nanf(""));
     g.th[0] = 0.500244140625f * fsx;
     g.th[1] = 1.49951171875f * fsx;
     g.th[2] = 2.5009765625f * fsx;

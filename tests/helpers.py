@@ -57,4 +57,10 @@ def make_kv(seed: int, B: int, nh_kv: int, T: int, D: int, kind: str = "randn"):
         x = torch.randn((B, nh_kv, T, D), generator=g)
         x[..., ::17] *= 12.0
         return x.half()
+    if kind == "tiny":     # fp16 subnormal neighbourhood: groups whose range is 0, 1 or a few subnormal ulps -- scale rounds to
+        # 0 for a one-ulp range and the reference's d / 0 = inf -> max code (kivi_quant.h)
+        base = torch.randint(0, 64, (B, nh_kv, 1, D), generator=g)
+        bits = (base + torch.randint(0, 2, (B, nh_kv, T, D), generator=g) * torch.randint(0, 4, (B, nh_kv, 1, D), generator=g))
+        sign = torch.randint(0, 2, (B, nh_kv, 1, D), generator=g) * 0x8000
+        return (bits + sign).to(torch.int32).to(torch.uint16).view(torch.float16)
     raise ValueError(kind)

@@ -15,12 +15,13 @@ def mods():
     return mfma, new_pack, matmul
 
 
-@pytest.mark.parametrize("B,nh_kv,T,off", [(1, 1, 32, 0), (2, 3, 544, 0), (1, 2, 128, 480), (2, 2, 1024, 64)])
-def test_kt_pack_equals_reference_pack(mods, oracle, B, nh_kv, T, off):
+@pytest.mark.parametrize("B,nh_kv,T,off,kind", [(1, 1, 32, 0, "outlier"), (2, 3, 544, 0, "outlier"), (1, 2, 128, 480, "outlier"),
+                                                  (2, 2, 1024, 64, "outlier"), (1, 2, 96, 32, "tiny")])
+def test_kt_pack_equals_reference_pack(mods, oracle, B, nh_kv, T, off, kind):
     """kivi_kt_pack (direct per-channel quantise into the layout) == the reference-layout pack (bit-exact vs the
     reference's new_pack.py through the golden fixtures) after kivi_kt_relayout, at a token offset too."""
     mfma, new_pack, _ = mods
-    k = make_kv(7, B, nh_kv, off + T, 128, "outlier").cuda()
+    k = make_kv(7, B, nh_kv, off + T, 128, kind).cuda()
     store = mfma.alloc_store(B, nh_kv, (off + T + 511) // 512, "cuda")
     if off:
         mfma.kt_pack(k[:, :, :off], store, 0)
@@ -206,3 +207,37 @@ def test_mf_cache_from_tuple_and_clone(oracle):
     assert c.kv_seq_len == T0 and a.kv_seq_len == T0 + 4
     for x, y in zip(a.as_tuple()[:8], b.as_tuple()[:8]):
         assert (x is None and y is None) or same_bits(x, y)
+
+
+@pytest.mark.parametrize("nh,nh_kv", [(4, 4), (8, 2)])
+def test_decode_flushes_of_subnormal_groups_are_bit_exact(oracle, nh, nh_kv):
+    """K / V values in the fp16-subnormal neighbourhood: groups whose range is 0 or ONE subnormal ulp have scale 0, and
+    the reference then gives code 0 to the minimum (0 / 0 = NaN) and the maximum code to everything above it (d / 0 = inf).
+    Every quantiser on the decode path (prefill packs, K flush, V leaving the window; hook layout for nh == nh_kv, matrix-
+    pipe layout for grouped heads) must reproduce that: the cache tuples stay bit-identical through a flush."""
+    from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
+    from oracle import hook_ref as H
+    B, D, g, R, T0 = 2, 128, 32, 32, 75
+    cfg = KiviConfig(2, 2, g, R)
+
+    def tiny_k(seed, T):      # one-ulp ranges along tokens (K groups)
+        return make_kv(seed, B, nh_kv, T, D, "tiny")
+
+    def tiny_v(seed, T):      # one-ulp ranges along channels (V groups)
+        return make_kv(seed, B, nh_kv, D, T, "tiny").transpose(2, 3).contiguous()
+
+    k0, v0 = tiny_k(1, T0), tiny_v(2, T0)
+    layer = make_layer_cache(cfg, B, nh_kv, D, T0 + R + 16, "cuda", num_heads=nh)
+    layer.prefill(k0.cuda(), v0.cuda())
+    past = H.prefill_cache(k0, v0, 2, 2, g, R)
+    _cmp_cache(layer.as_tuple(), past)
+    kseq, vseq = tiny_k(3, R + 9), tiny_v(4, R + 9)
+    for s in range(R + 9):
+        q = make_kv(100 + s, B, nh, 1, D)
+        kn, vn = kseq[:, :, s:s + 1].contiguous(), vseq[:, :, s:s + 1].contiguous()
+        out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer)
+        ref, past = H.decode_step(q, kn, vn, past, 2, 2, g, R)
+        assert torch.isfinite(out).all()
+        assert (out.cpu().float() - ref.float()).abs().max() <= 1e-6          # |V| < 4e-6
+        if s % 8 == 0 or s >= R - 2:
+            _cmp_cache(layer.as_tuple(), past)

@@ -149,7 +149,8 @@ def test_threshold_quantiser_equals_division():
 
     def thr_code(d, s):
         df, sf = d.astype(np.float32), s.astype(np.float32)
-        sf = np.where((sf > 0) & np.isfinite(sf), sf, np.float32(np.nan))   # scale 0 / inf -> code 0 (kivi_quant.h)
+        # scale inf -> code 0; scale 0 -> thresholds under the smallest fp16: 0/0 -> 0, d/0 = inf -> 3 (kivi_quant.h)
+        sf = np.where((sf > 0) & np.isfinite(sf), sf, np.where(sf == 0, np.float32(2.0 ** -30), np.float32(np.nan)))
         c = np.zeros(d.shape, np.int32)
         for t, st in zip(taus, strict):
             with np.errstate(invalid="ignore"):
@@ -176,3 +177,37 @@ def test_threshold_quantiser_equals_division():
             q = (d1.astype(np.float32) / s1.astype(np.float32)).astype(np.float16).astype(np.float32)
             ref = 0 if np.isnan(q[0]) else int(np.rint(np.clip(q, 0, 3))[0])
             assert thr_code(d1, s1)[0] == ref == 0
+        # scale 0 with d > 0: a group whose range is one subnormal ulp (2^-24 / 3 rounds to 0) -> d / 0 = inf -> code 3
+        for dv in (2.0 ** -24, 2.0 ** -23, 1.0):
+            d1, s1 = np.array([dv], np.float16), np.array([0.0], np.float16)
+            q = (d1.astype(np.float32) / s1.astype(np.float32)).astype(np.float16).astype(np.float32)
+            assert thr_code(d1, s1)[0] == int(np.rint(np.clip(q, 0, 3))[0]) == 3
+
+
+def test_packed_pack_kernel_shortcuts_are_exact():
+    """quant_pack_lastdim2_kernel (kivi_pack.hip, make_group2) takes two shortcuts; both hold for EVERY fp16 input:
+    (1) scale = fp16(range / 3) computed as fp16(range * fp32(1/3));
+    (2) tau_k * scale is never an fp16 value, so the three decisions  d > th0, d >= th1, d > th2  on a non-negative fp16 d
+        all equal  bits(d) > bits(RTZ_fp16(th))  (v_cvt_pkrtz_f16_f32)."""
+    b = np.arange(0, 0x7C01, dtype=np.uint16)                      # +0 .. +inf
+    r = b.view(np.float16).astype(np.float32)
+    with np.errstate(over="ignore"):
+        div = (r / np.float32(3.0)).astype(np.float16).view(np.uint16)
+        mul = (r * np.float32(0.3333333432674408)).astype(np.float16).view(np.uint16)
+    assert (div == mul).all()
+    s = b[1:0x7C00].view(np.float16).astype(np.float32)            # every positive finite scale
+    dbits = np.arange(0, 0x7C01, dtype=np.int32)                   # every d >= +0 (incl. +inf)
+    dval = dbits.astype(np.uint16).view(np.float16).astype(np.float32)
+    for tau, strict in ((0.500244140625, True), (1.49951171875, False), (2.5009765625, True)):
+        th = np.float32(tau) * s
+        assert (th.astype(np.float64) == np.float64(tau) * s.astype(np.float64)).all()       # exact product
+        with np.errstate(over="ignore"):
+            h = th.astype(np.float16)
+        hb = h.view(np.uint16).astype(np.int32)
+        rtz = np.where(h.astype(np.float32) > th, hb - 1, hb)      # round toward zero (never inf for a finite th)
+        assert (rtz < 0x7C00).all()
+        assert (rtz.astype(np.uint16).view(np.float16).astype(np.float32) < th).all()        # th is never representable
+        # the decision itself, on a sample of scales against every d
+        for i in range(0, s.size, 257):
+            ref = (dval > th[i]) if strict else (dval >= th[i])
+            assert ((dbits > rtz[i]) == ref).all(), (tau, i)

@@ -75,6 +75,8 @@ CASES = [
     (1, 1, 3, 48, 16, 2, "randn"),        # group 16 -> generic kernel
     (1, 1, 2, 96, 48, 4, "randn"),        # group not a power of two -> generic kernel
     (3, 2, 1, 128, 32, 2, "randn"),       # the per-step V shape (B, nh, 1, D)
+    (1, 2, 8, 128, 32, 2, "tiny"),        # subnormal neighbourhood: one-ulp ranges (scale 0, d / 0 = inf -> max code)
+    (1, 2, 8, 128, 32, 4, "tiny"),
 ]
 
 
@@ -106,8 +108,34 @@ def test_lastdim_hard_values(np_mod, oracle):
         assert same_bits(code, oc)
 
 
+@pytest.mark.parametrize("g", [32, 64, 128])
+def test_lastdim_2bit_every_exponent(np_mod, oracle, g):
+    """The packed-math 2-bit kernel (quant_pack_lastdim2_kernel: thresholds rounded toward zero to fp16, scale through a
+    multiply) on groups whose range sits at every fp16 exponent, subnormal scales included, values on a few-ulp grid so
+    that many d fall on or next to a decision boundary; full blocks (1024 chunks per block) and a ragged tail."""
+    gen = torch.Generator().manual_seed(17)
+    for rows in (4096 * 32 // g * 2, 37):
+        ngrp = rows * 128 // g
+        e = torch.randint(-24, 16, (ngrp, 1), generator=gen).float()
+        base = torch.randint(0, 2048, (ngrp, 1), generator=gen).float()
+        x = ((torch.randint(-24, 25, (ngrp, g), generator=gen).float() + base) * torch.exp2(e - 5)).half()
+        x = x.reshape(1, 1, rows, 128)
+        code, scale, mn = np_mod.triton_quantize_and_pack_along_last_dim(x.cuda(), g, 2)
+        oc, os_, om = oracle.quantize_and_pack_along_last_dim(x, g, 2)
+        for name, a, b in (("scale", scale, os_), ("mn", mn, om), ("code", code, oc)):
+            a, b = a.cpu().contiguous().view(torch.int16 if a.dtype == torch.float16 else torch.int32), b.contiguous().view(
+                torch.int16 if b.dtype == torch.float16 else torch.int32)
+            bad = (a.reshape(ngrp, -1) != b.reshape(ngrp, -1)).any(dim=1).nonzero().flatten()
+            if bad.numel():
+                gi = int(bad[0])
+                raise AssertionError(f"{name}: {bad.numel()} of {ngrp} groups differ; group {gi}: x bits "
+                                     f"{[hex(int(v) & 0xFFFF) for v in x.reshape(ngrp, g)[gi].view(torch.int16)]} "
+                                     f"kernel {a.reshape(ngrp, -1)[gi].tolist()} oracle {b.reshape(ngrp, -1)[gi].tolist()}")
+
+
 @pytest.mark.parametrize("B,nh,T,D,g,bits,kind", [
     (2, 2, 64, 128, 32, 2, "randn"), (1, 3, 128, 64, 64, 2, "outlier"), (1, 2, 256, 128, 128, 4, "randn"),
+    (1, 2, 64, 128, 32, 2, "tiny"), (1, 2, 64, 128, 32, 4, "tiny"),
     (1, 1, 32, 80, 32, 2, "randn"), (1, 2, 96, 128, 32, 4, "int"), (1, 1, 64, 128, 32, 8, "randn"),
     (1, 1, 48, 33, 16, 2, "randn"),
 ])

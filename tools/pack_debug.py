@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Debug aid: compare the packed-16-bit 2-bit last-dim pack kernel with the scalar one (KIVI_PACK_NO_PK16=1) on the
-hard-value tensor of tests/test_pack_gpu.py::test_lastdim_hard_values and print every group whose codes differ."""
+"""Debug aid for the 2-bit last-dim pack kernels: run the packed-16-bit kernel and the scalar one (KIVI_PACK_NO_PK16=1)
+on the tensors of tests/test_pack_gpu.py (hard values, every-exponent grid) and print every group whose scale / mn /
+codes differ from the CPU oracle."""
 import os, sys, subprocess
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from kivi_amd.quant import new_pack
 
 def hard():
@@ -19,21 +21,32 @@ def hard():
     x[0, 0, 6, :32] = torch.tensor([-0.0, 0.0] * 16)
     return x
 
-x = hard()
-if len(sys.argv) > 1:   # child: dump the codes of this mode
-    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(x.cuda(), 32, 2)
-    np.save(sys.argv[1], code.cpu().numpy())
+def grid(g=32, rows=37):
+    gen = torch.Generator().manual_seed(17)
+    ngrp = rows * 128 // g
+    e = torch.randint(-24, 16, (ngrp, 1), generator=gen).float()
+    base = torch.randint(0, 2048, (ngrp, 1), generator=gen).float()
+    x = ((torch.randint(-24, 25, (ngrp, g), generator=gen).float() + base) * torch.exp2(e - 5)).half()
+    return x.reshape(1, 1, rows, 128)
+
+G = int(os.environ.get("G", "32"))
+x = hard() if os.environ.get("CASE", "grid") == "hard" else grid(G)
+if len(sys.argv) > 1:   # child: dump the outputs of this mode
+    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(x.cuda(), G, 2)
+    np.savez(sys.argv[1], code=code.cpu().numpy(), scale=scale.cpu().view(torch.int16).numpy(), mn=mn.cpu().view(torch.int16).numpy())
     sys.exit(0)
-subprocess.check_call([sys.executable, __file__, "/tmp/_pk_new.npy"])
-subprocess.check_call([sys.executable, __file__, "/tmp/_pk_old.npy"], env=dict(os.environ, KIVI_PACK_NO_PK16="1"))
-new, old = np.load("/tmp/_pk_new.npy").reshape(-1, 2), np.load("/tmp/_pk_old.npy").reshape(-1, 2)
-xs = x.reshape(-1, 32)
-bad = np.nonzero((new != old).any(axis=1))[0]
-print(f"{len(bad)} of {len(new)} groups differ")
+subprocess.check_call([sys.executable, __file__, "/tmp/_pk_new.npz"])
+subprocess.check_call([sys.executable, __file__, "/tmp/_pk_old.npz"], env=dict(os.environ, KIVI_PACK_NO_PK16="1"))
+new, old = np.load("/tmp/_pk_new.npz"), np.load("/tmp/_pk_old.npz")
+wpg = G // 16
+cn, co = new["code"].reshape(-1, wpg), old["code"].reshape(-1, wpg)
+sn, so, mn_, mo = new["scale"].reshape(-1), old["scale"].reshape(-1), new["mn"].reshape(-1), old["mn"].reshape(-1)
+xs = x.reshape(-1, G)
+bad = np.nonzero((cn != co).any(axis=1) | (sn != so) | (mn_ != mo))[0]
+print(f"{len(bad)} of {len(cn)} groups differ")
 for gi in bad[:6]:
     xv = xs[gi]
-    print("group", gi, "x bits", [hex(int(b)) for b in xv.view(torch.int16).numpy().astype(np.uint16)])
-    cn = [(int(new[gi, i // 16]) >> (2 * (i % 16))) & 3 for i in range(32)]
-    co = [(int(old[gi, i // 16]) >> (2 * (i % 16))) & 3 for i in range(32)]
-    print("   new", cn)
-    print("   old", co)
+    print("group", gi, "scale new/old", hex(int(sn[gi]) & 0xFFFF), hex(int(so[gi]) & 0xFFFF), "mn", hex(int(mn_[gi]) & 0xFFFF), hex(int(mo[gi]) & 0xFFFF))
+    print("   x bits", [hex(int(b)) for b in xv.view(torch.int16).numpy().astype(np.uint16)])
+    print("   new", [(int(cn[gi, i // 16]) >> (2 * (i % 16))) & 3 for i in range(G)])
+    print("   old", [(int(co[gi, i // 16]) >> (2 * (i % 16))) & 3 for i in range(G)])
