@@ -54,8 +54,9 @@ unsigned long long* kivi_debug_stamps();         // kivi_debug_set_stamps buffer
     } while (0)
 #define KIVI_LAUNCH(kernel, grid, block, stream, ...) KIVI_LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)
 
-// max / sum over the 256 threads of a block through 4 floats of LDS (same tree in every kernel that uses it,
-// so the stand-alone softmax and the one fused into the sV kernel round identically)
+// max / sum over the NW * 64 threads of a block through NW floats of LDS (same tree in every kernel that uses it with
+// the same NW, so the stand-alone softmax and the one fused into the sV kernel round identically)
+template <int NW = 4>
 __device__ __forceinline__ float kivi_block_reduce(float v, bool is_max, float* lds) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -67,7 +68,13 @@ __device__ __forceinline__ float kivi_block_reduce(float v, bool is_max, float* 
     if ((threadIdx.x & 63) == 0) lds[wave] = v;
     __syncthreads();
     const float a = lds[0], b = lds[1], c = lds[2], d = lds[3];
-    return is_max ? __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)) : (a + b) + (c + d);
+    const float lo = is_max ? __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)) : (a + b) + (c + d);
+    if constexpr (NW == 8) {
+        const float e = lds[4], f = lds[5], g = lds[6], h = lds[7];
+        const float hi = is_max ? __builtin_fmaxf(__builtin_fmaxf(e, f), __builtin_fmaxf(g, h)) : (e + f) + (g + h);
+        return is_max ? __builtin_fmaxf(lo, hi) : lo + hi;
+    }
+    return lo;
 }
 
 // exp() of the softmax kernels: one v_exp_f32 on x * log2(e).  The argument product rounds at 2^-24 relative, i.e. the

@@ -45,7 +45,7 @@ template <bool DBG>
 __device__ __forceinline__ void kivi_stamp(unsigned long long* dbg, int i) {
     if constexpr (DBG) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i] = t;
+        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + i] = t;
     }
 }
 
@@ -142,7 +142,8 @@ __device__ __forceinline__ void k_residual_role(const GemvKArgs& a, int unit) {
 // One block's share of the product: TILES_PER_BLOCK tiles of 64*WPL words of one (b, head unit), `bid` = index among
 // the streaming blocks.  `lds_out` == nullptr: results go to a.out (the stand-alone kernel).  Otherwise (fused decode
 // row, R == 1): the fp16 scores of the tile's tokens are written to lds_out[token] and nothing goes to memory.
-template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT, bool DBG = false>
+// NW = waves of the block (4; 8 in the eight-wave decode-row kernel).
+template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT, bool DBG = false, int NW = 4>
 __device__ __forceinline__ void k_tile_body(const GemvKArgs& a, const int bid, uint16_t* lds_out) {
     constexpr int FPI = 32 / BITS;
     constexpr int TPL = WPL * FPI;                   // tokens per lane
@@ -150,14 +151,14 @@ __device__ __forceinline__ void k_tile_body(const GemvKArgs& a, const int bid, u
     static_assert(NGL == 1 || NGL == 2, "lane spans at most two groups");
     static_assert(G % FPI == 0, "a word never straddles two groups");
     constexpr int NACC = TPL;
-    constexpr int TILES_PER_BLOCK = 4 / DSPLIT;
+    constexpr int TILES_PER_BLOCK = NW / DSPLIT;
     constexpr int Q = NACC / DSPLIT;                 // tokens per lane each wave finalises
     static_assert(Q % 4 == 0, "finalisation stores 8 or 16 bytes per lane");
     typedef typename WordVec<WPL>::type WV;
     typedef typename std::conditional<NGL == 1, uint16_t, uint32_t>::type SV;
 
     // cross-wave exchange: every wave keeps 1/DSPLIT of its accumulators and hands the rest over
-    __shared__ float red[DSPLIT > 1 ? 4 * (DSPLIT - 1) * R * Q * 64 : 1];
+    __shared__ float red[DSPLIT > 1 ? NW * (DSPLIT - 1) * R * Q * 64 : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR

@@ -34,9 +34,12 @@ __global__ __launch_bounds__(256) void gemv_v_kernel(const GemvVArgs a) {
 // by tile (k_tile_body, the scores go to the LDS row instead of memory), then everything v_row_body does with them
 // (residual scores, softmax, window, packed sV).  Against the two-launch form this drops the 2 x 8 MB score round
 // trip through HBM, one launch ramp/drain and the cold start of the second kernel.
+// NW = 8 (round 2): the same row on eight waves, two blocks per CU.  Co-resident blocks are served oldest first (DESIGN.md
+// section 3.2b), so the last blocks of a launch stream alone, each wave bound by its own issue rate: with twice the waves
+// per row that tail is half as long.
 template <int BITS, int G, int DW, int KWPL, int KDS, int KU, int VWPL, int VU, bool PRE = true, bool DBG = false, int EARLY = 0,
-          int PRIO = 0>
-__global__ __launch_bounds__(256, (DBG || EARLY || PRIO) ? 4 : 1) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
+          int PRIO = 0, int NW = 4, int VDEPTH = 2>
+__global__ __launch_bounds__(NW * 64, (DBG || EARLY || PRIO || NW == 8 || VDEPTH == 3) ? 4 : 1) void decode_row_kernel(const GemvKArgs ak, const GemvVArgs av) {
     extern __shared__ uint16_t pl_row[];
     const int unit = (int)blockIdx.x;
     if constexpr (PRIO != 0) {   // experiment: issue priority by hardware wave slot (the SIMD arbiter is oldest-first otherwise)
@@ -48,20 +51,20 @@ __global__ __launch_bounds__(256, (DBG || EARLY || PRIO) ? 4 : 1) void decode_ro
     }
     kivi_stamp<DBG>(av.dbg, 0);
     if (DBG && (threadIdx.x & 63) == 0)
-        av.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 1] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
-    RowPre<DW * (32 / BITS)> pre;
+        av.dbg[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + 1] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
+    RowPre<DW * (32 / BITS), NW> pre;
     if constexpr (PRE) row_prefetch(av, pre);   // in flight during the whole qK^T phase (26 VGPRs, where they fit)
     kivi_stamp<DBG>(av.dbg, 2);
     for (int tb = 0; tb < ak.tile_blocks; tb++) {
-        k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true, DBG>(ak, unit * ak.tile_blocks + tb, pl_row);
+        k_tile_body<BITS, G, KWPL, KDS, 1, KU, KIVI_UNPACK_MIX, true, DBG, NW>(ak, unit * ak.tile_blocks + tb, pl_row);
         if (tb == 0) kivi_stamp<DBG>(av.dbg, 4);
         __syncthreads();   // the exchange buffer is reused by the next tile; the scores must be visible below
     }
     kivi_stamp<DBG>(av.dbg, 5);
-    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, PRE, DBG, true, EARLY>(av, &pre);
+    v_row_body<BITS, G, DW, VWPL, 1, VU, KIVI_UNPACK_MIX, true, false, PRE, DBG, true, EARLY, NW, VDEPTH>(av, &pre);
     kivi_stamp<DBG>(av.dbg, 11);
     if (DBG && (threadIdx.x & 63) == 0) {
-        unsigned long long* rec = av.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+        unsigned long long* rec = av.dbg + ((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16;
         rec[12] = __builtin_amdgcn_s_memrealtime();
         rec[13] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID: wave slot, SIMD, CU, SE
         rec[14] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // XCC_ID
@@ -310,23 +313,24 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const int selv = (rvv && !strcmp(rvv, "w2u4")) ? 1 : 0;
             ak.tile_blocks = (G != 32 || selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
             const dim3 grid((unsigned)units);
-            if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            if (G == 32 && rx && !strcmp(rx, "nw8ds4")) {          // eight waves: 2 tiles of 2048 tokens per pass, D over 4 waves
+                ak.tile_blocks = (tiles + 1) / 2;
+                if (a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, true, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
+                else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, false, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
+            }
+            else if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else if (G == 128) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else if (selv == 1 && a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4, true, true>), grid, dim3(256), lds, s, ak, a);
             else if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 0) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 1 && a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "e1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 2>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "u2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 2, true, false, 0>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "u2e1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 2, true, false, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "u2e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 2, true, false, 2>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "w2u4e1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4, true, false, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "p1")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "p2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 2>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "p1e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 2, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (rx && !strcmp(rx, "p2e2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 2, 2>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 1 && rx && !strcmp(rx, "d2") && a.dbg)   // the two-deep V ring (round 1 / first half of round 2)
+                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 1 && rx && !strcmp(rx, "d2"))
+                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 1 && a.dbg)
+                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
+            else if (sel == 1)   // default: three-deep V ring
+                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 2) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
             else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
             return kivi_launch_status("decode_row");

@@ -74,19 +74,19 @@ struct KSide {     // host only
 // Small operands of a row's step, requested ahead of time by the fused decode-row kernel (before its qK^T phase) so that
 // their memory round trips are over when v_row_body needs them: the first window rows of every wave, the window token
 // about to be quantised, and this thread's share of the residual keys / query.
-template <int D>
+template <int D, int NW = 4>
 struct RowPre {
     static constexpr int NP = (D / 2 + 63) / 64;
-    static constexpr int PWT = 9;
+    static constexpr int PWT = (NW == 8) ? 5 : 9;    // window tokens per wave requested ahead: NW * PWT - 1 >= 33
     static constexpr int NK = D / 64;                // 16-byte pieces of a thread's D/8 channels
     uint32_t vpre[PWT][NP];
     uint16_t xflush;
     u16x8 rk[NK], rq[NK];
 };
 
-template <int D>
-__device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D>& pre) {   // R = 1, not split
-    constexpr int NP = RowPre<D>::NP, PWT = RowPre<D>::PWT, NK = RowPre<D>::NK, CPL = D / 8;
+template <int D, int NW>
+__device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D, NW>& pre) {   // R = 1, not split
+    constexpr int NP = RowPre<D, NW>::NP, PWT = RowPre<D, NW>::PWT, NK = RowPre<D, NW>::NK, CPL = D / 8;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int unit = (int)blockIdx.x;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D>& pre)
     const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
 #pragma unroll
     for (int k = 0; k < PWT; k++) {
-        const int t = wave + 4 * k;
+        const int t = wave + NW * k;
         const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
 #pragma unroll
         for (int c = 0; c < NP; c++) {
@@ -128,8 +128,10 @@ __device__ __forceinline__ void row_prefetch(const GemvVArgs& a, RowPre<D>& pre)
 }
 
 template <int BITS, int G, int DW, int WPL, int R, int U, int MODE, bool NT, bool SPLIT, bool PRE = false, bool DBG = false,
-          bool FROW = false, int EARLY = 0>
-__device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW * (32 / BITS)>* pre = nullptr) {
+          bool FROW = false, int EARLY = 0, int NW = 4, int DEPTH = 2>
+__device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW * (32 / BITS), NW>* pre = nullptr) {
+    constexpr int NTH = NW * 64;                // threads of the block
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     constexpr int FPI = 32 / BITS;
     // R > 1 (grouped queries) and SPLIT kernels always get finished probabilities from the row-softmax launch (v_run):
     // the in-block softmax is compiled out of them
@@ -146,13 +148,18 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     static_assert(NFIN >= 1, "head_dim >= 64");
     typedef typename std::conditional<NGL == 1, uint16_t, uint32_t>::type SV;
 
-    __shared__ float red[4][R][D];
-    __shared__ float resl[4][R][D];   // fused decode step: per-wave partial sums over the fp16 V window
-    __shared__ float sm_lds[4];
+    __shared__ float red[NW][R][D];
+    __shared__ float resl[NW][R][D];   // fused decode step: per-wave partial sums over the fp16 V window
+    __shared__ float sm_lds[NW];
     extern __shared__ uint16_t pl[];  // [R][n_pad] fp16 probabilities when the softmax is folded in
     constexpr int RSMAX = 136;        // residual keys per row handled in LDS (R_k <= 128, + the new one)
     __shared__ uint16_t rs_lds[R][RSMAX];
     __shared__ int last_flag;
+    auto sum_waves = [](const float (*buf)[R][D], int r, int d) {   // fixed tree over the per-wave partial sums
+        const float lo = (buf[0][r][d] + buf[1][r][d]) + (buf[2][r][d] + buf[3][r][d]);
+        if constexpr (NW == 8) return lo + ((buf[4][r][d] + buf[5][r][d]) + (buf[6][r][d] + buf[7][r][d]));
+        else return lo;
+    };
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -227,9 +234,9 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         }
     };
 
-    // wave w owns chunks w, w+4, ... of the block's range; batch = U chunks of this wave
+    // wave w owns chunks w, w+NW, ... of the block's range; batch = U chunks of this wave
     const int nloc = c_end > c_begin ? c_end - c_begin : 0;
-    const int my_chunks = (nloc > wave) ? (nloc - wave + 3) / 4 : 0;
+    const int my_chunks = (nloc > wave) ? (nloc - wave + NW - 1) / NW : 0;
     const int nbatch = (my_chunks + U - 1) / U;  // out-of-range chunks read zeros (bounds check)
 
     // The chunk offset goes into the (bounds-checked) per-lane voffset: soffset is excluded
@@ -237,7 +244,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     auto load_wsm = [&](int bi, WV* wb, SV* sb, SV* mb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * 4 + wave);
+            const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * NW + wave);
             wb[u] = buf_load<WV, NT>(rc, coff + c * cstep, 0);
             sb[u] = buf_load<SV, NT>(rs, soff + c * sstep, 0);
             mb[u] = buf_load<SV, NT>(rm, soff + c * sstep, 0);
@@ -246,10 +253,13 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     auto load_a = [&](int bi, uint16_t (*ab)[R]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * 4 + wave);
+            const uint32_t c = (uint32_t)(c_begin + (bi * U + u) * NW + wave);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                if (CAN_SOFTMAX && a.softmax) {   // probabilities produced by this block, in LDS
+                if constexpr (FROW) {             // fused row (R = 1): always from this block's LDS row, 32-bit index, no branch
+                    const int t = (int)c * TPI + lt;
+                    ab[u][r] = (t < (int)a.Tv) ? pl[t] : (uint16_t)0;
+                } else if (CAN_SOFTMAX && a.softmax) {   // probabilities produced by this block, in LDS
                     const int64_t t = (int64_t)c * TPI + lt;
                     ab[u][r] = (t < a.Tv) ? pl[(size_t)r * a.n_pad + t] : (uint16_t)0;
                 } else {
@@ -272,20 +282,21 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     // round trip then costs several us): the score row(s), the fp16 V window, the window token about to be
     // quantised.  The consumers come later, in the order the data is needed.
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    constexpr int SMC = 8;
+    constexpr int SCH = NTH * 4;                // scores per softmax chunk (4 per thread)
+    constexpr int SMC = 8192 / SCH;             // chunks of a row of <= 8192 scores
     const bool owner = (h0 % a.ratio) == 0;   // the first head unit of a kv head owns its cache writes
     const bool do_win = a.fused && split == 0;
     const bool do_flush = do_win && a.flush && owner;
     const bool reg_softmax = CAN_SOFTMAX && a.softmax;
     const int n_sc = a.n_scores;
-    const int nch_sc = (n_sc + 1023) / 1024;
+    const int nch_sc = (n_sc + SCH - 1) / SCH;
     // (a) row 0 of the register-resident softmax: the part of the score row that is already in memory
     auto load_raw = [&](int r, u16x4* raw) {
         const uint16_t* srow = a.a + b * a.a_sb + (int64_t)(h0 + r) * a.a_sh;
         const int lim = a.rq ? (a.Tq < n_sc ? a.Tq : n_sc) : n_sc;   // scores from `lim` on are produced by this block
 #pragma unroll
         for (int c = 0; c < SMC; c++) {
-            const int j0 = c * 1024 + (int)threadIdx.x * 4;
+            const int j0 = c * SCH + (int)threadIdx.x * 4;
             raw[c] = u16x4{0, 0, 0, 0};
             if (c < nch_sc) {
                 // fused row: the packed scores are in LDS already (FROW: known at compile time, so no global load -- and no
@@ -309,7 +320,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     if (reg_softmax) load_raw(0, raw0);
     // (b) the first PWT window tokens of this wave (covers a window of 4*PWT-1 = 35 tokens; longer ones loop below)
     constexpr int NP = (D / 2 + 63) / 64;            // channel pairs per lane
-    constexpr int PWT = 9;
+    constexpr int PWT = RowPre<D, NW>::PWT;
     const int Lw = a.res_len + 1;
     uint32_t vpre[PWT][NP];
     if constexpr (PRE) {
@@ -322,7 +333,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
 #pragma unroll
         for (int k = 0; k < PWT; k++) {
-            const int t = wave + 4 * k;
+            const int t = wave + NW * k;
             const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
 #pragma unroll
             for (int c = 0; c < NP; c++) {
@@ -354,7 +365,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             uint16_t* kres = a.rkres + b * a.rk_sb + hk * a.rk_sh;
             // 8 lanes per (head, key): each takes D/8 channels with 16-byte loads, then a 3-step shuffle reduction
             constexpr int CPL = D / 8;                       // channels per lane (D % 64 == 0)
-            for (int idx = threadIdx.x; idx < R * L * 8; idx += 256) {
+            for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
                 const int sub = idx & 7, rt = idx >> 3;
                 const int r = rt / L, t = rt - r * L;
                 const uint16_t* krow = ((t < a.rk_len) ? kres + (int64_t)t * a.rk_st : knew) + sub * CPL;
@@ -403,7 +414,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             if (a.rq) {   // the residual range was produced by this block: take it from LDS
 #pragma unroll
                 for (int c = 0; c < SMC; c++) {
-                    const int j0 = c * 1024 + (int)threadIdx.x * 4;
+                    const int j0 = c * SCH + (int)threadIdx.x * 4;
                     if (c < nch && j0 + 4 > a.Tq) {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
@@ -417,14 +428,14 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             for (int c = 0; c < SMC; c++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int j = c * 1024 + (int)threadIdx.x * 4 + e;
+                    const int j = c * SCH + (int)threadIdx.x * 4 + e;
                     float v = -__builtin_inff();
                     if (c < nch && j < n)
                         v = h2f_bits(kivi_scaled_score(raw[c][e], a.inv_scale, mrow != nullptr, mrow ? mrow[j] : 0));
                     x[c][e] = v;
                     mx = __builtin_fmaxf(mx, v);
                 }
-            mx = kivi_block_reduce(mx, true, sm_lds);
+            mx = kivi_block_reduce<NW>(mx, true, sm_lds);
             float sum = 0.f;
 #pragma unroll
             for (int c = 0; c < SMC; c++)
@@ -434,12 +445,12 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
                         x[c][e] = kivi_exp(x[c][e] - mx);
                         sum += x[c][e];
                     }
-            sum = kivi_block_reduce(sum, false, sm_lds);
+            sum = kivi_block_reduce<NW>(sum, false, sm_lds);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int c = 0; c < SMC; c++)
                 if (c < nch) {
-                    const int j0 = c * 1024 + (int)threadIdx.x * 4;
+                    const int j0 = c * SCH + (int)threadIdx.x * 4;
                     u16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; e++) o[e] = f2h_bits(x[c][e] * inv);
@@ -488,16 +499,16 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         };
 #pragma unroll
         for (int k = 0; k < PWT; k++) {
-            const int t = wave + 4 * k;
+            const int t = wave + NW * k;
             if (t < Lw) win_tok(t, vpre[k]);
         }
         // longer windows (residual_length 64 / 128): PWT rows per round, all their loads in flight together
         constexpr int PW2 = (R >= 4) ? 4 : PWT;   // the R x EPL accumulators of the grouped-query kernels leave fewer registers
-        for (int k0 = PWT; wave + 4 * k0 < Lw; k0 += PW2) {
+        for (int k0 = PWT; wave + NW * k0 < Lw; k0 += PW2) {
             uint32_t vb[PW2][NP];
 #pragma unroll
             for (int k = 0; k < PW2; k++) {
-                const int t = wave + 4 * (k0 + k);
+                const int t = wave + NW * (k0 + k);
                 const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
 #pragma unroll
                 for (int c = 0; c < NP; c++) {
@@ -507,7 +518,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
             }
 #pragma unroll
             for (int k = 0; k < PW2; k++) {
-                const int t = wave + 4 * (k0 + k);
+                const int t = wave + NW * (k0 + k);
                 if (t < Lw) win_tok(t, vb[k]);
             }
         }
@@ -585,7 +596,36 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     }
 
     kivi_stamp<DBG>(a.dbg, 8);
-    {
+    if constexpr (DEPTH == 3) {
+        // Two batches ahead of the one being consumed.  A wave that streams ALONE (the last blocks of a launch: co-resident
+        // blocks are served oldest first) is bound by one memory round trip per batch; the third buffer halves that.
+        // Loads past the row's end are dropped by the buffer range check (zeros, no traffic).
+        static_assert(!SPLIT && EARLY == 0, "three-deep ring: unsplit rows only");
+        WV wC[U];
+        SV sC[U], mC[U];
+        uint16_t aC[U][R];
+        load_wsm(1, wB, sB, mB);
+        int it = 0;
+        for (; it + 3 <= nbatch; it += 3) {
+            load_wsm(it + 2, wC, sC, mC);
+            load_a(it, aA);
+            compute_batch(wA, sA, mA, aA);
+            load_wsm(it + 3, wA, sA, mA);
+            load_a(it + 1, aB);
+            compute_batch(wB, sB, mB, aB);
+            load_wsm(it + 4, wB, sB, mB);
+            load_a(it + 2, aC);
+            compute_batch(wC, sC, mC, aC);
+        }
+        if (it < nbatch) {
+            load_a(it, aA);
+            compute_batch(wA, sA, mA, aA);
+        }
+        if (it + 1 < nbatch) {
+            load_a(it + 1, aB);
+            compute_batch(wB, sB, mB, aB);
+        }
+    } else {
         if (nbatch > 0) load_a(0, aA);
         int it = 0;
         for (; it + 2 <= nbatch; it += 2) {
@@ -648,12 +688,12 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
     __syncthreads();
     kivi_stamp<DBG>(a.dbg, 10);
     if constexpr (!SPLIT) {
-        for (int i = threadIdx.x; i < R * D; i += 256) {
+        for (int i = threadIdx.x; i < R * D; i += NTH) {
             const int r = i / D, d = i - r * D;
-            const float s = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+            const float s = sum_waves(red, r, d);
             uint16_t o = f2h_bits(s);
             if (a.fused) {
-                const float res = (resl[0][r][d] + resl[1][r][d]) + (resl[2][r][d] + resl[3][r][d]);
+                const float res = sum_waves(resl, r, d);
                 // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (:382-384);
                 // only the window part exists before anything is quantised (:380)
                 o = (a.Tv > 0) ? f2h_bits(h2f_bits(o) + h2f_bits(f2h_bits(res))) : f2h_bits(res);
@@ -667,12 +707,12 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         // bumps the arrival counter; the last arriver reads them with agent-scope (sc1, L1-bypassing) loads.
         uint32_t* part = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * (nsplit + 1) + split) * (R * D));
         uint32_t* winp = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * (nsplit + 1) + nsplit) * (R * D));
-        for (int i = threadIdx.x; i < R * D; i += 256) {
+        for (int i = threadIdx.x; i < R * D; i += NTH) {
             const int r = i / D, d = i - r * D;
-            const float qs = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+            const float qs = sum_waves(red, r, d);
             __hip_atomic_store(part + i, __builtin_bit_cast(uint32_t, qs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.fused && split == 0) {
-                const float ws_ = (resl[0][r][d] + resl[1][r][d]) + (resl[2][r][d] + resl[3][r][d]);
+                const float ws_ = sum_waves(resl, r, d);
                 __hip_atomic_store(winp + i, __builtin_bit_cast(uint32_t, ws_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -687,7 +727,7 @@ __device__ __forceinline__ void v_row_body(const GemvVArgs& a, const RowPre<DW *
         __syncthreads();
         if (last_flag) {
             const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * (nsplit + 1) * (R * D));
-            for (int i = threadIdx.x; i < R * D; i += 256) {
+            for (int i = threadIdx.x; i < R * D; i += NTH) {
                 const int r = i / D, d = i - r * D;
                 float s = 0.f;
                 for (int sp0 = 0; sp0 < nsplit; sp0 += 8) {   // 8 independent loads in flight, added in split order

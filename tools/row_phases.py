@@ -39,7 +39,8 @@ for _ in range(STEPS):
         kivi_attention_decode(q, k, v, lc)
 torch.cuda.synchronize()
 nblk = B * nh
-stamps = torch.zeros((nblk, 4, 16), dtype=torch.int64, device=dev)
+NW = int(os.environ.get("NWAVES", "4"))   # waves per block of the instantiation under test (KIVI_ROW_X=nw8ds4: 8)
+stamps = torch.zeros((nblk, NW, 16), dtype=torch.int64, device=dev)
 lib.kivi_debug_set_stamps(stamps.data_ptr())
 # the stamped launch is the LAST layer of a full pass, so it runs behind a warm stream like in the bench
 for lc in layers:
@@ -85,7 +86,7 @@ print(f"finish  (shader clock, rel.): p10 {np.percentile(rel_end, 10):.2f}  medi
 edges = np.linspace(0, rel_end.max(), 41)
 k_in = at(2), at(3)
 v_in = at(8), at(9)
-print("t (us): waves in K stream / in V stream / elsewhere (of %d)" % (nblk * 4))
+print("t (us): waves in K stream / in V stream / elsewhere (of %d)" % (nblk * NW))
 for e in edges[:-1]:
     nk = int(((k_in[0] <= e) & (e < k_in[1])).sum())
     nv = int(((v_in[0] <= e) & (e < v_in[1])).sum())
@@ -94,7 +95,7 @@ for e in edges[:-1]:
 
 # who lags?  K-stream duration and finish time by dispatch position and by hardware placement
 kd = ((s[:, :, 3] - s[:, :, 2]) / mhz)
-fin = at(11).reshape(nblk, 4)
+fin = at(11).reshape(nblk, NW)
 hw = s[:, :, 13]
 groups = {
     "block index >> 8 (dispatch quarter)": (np.arange(nblk)[:, None] >> 8) + 0 * hw,
@@ -102,7 +103,7 @@ groups = {
     "XCC_ID": s[:, :, 14] & 15,
     "HW_ID wave slot [3:0]": hw & 15,
     "HW_ID SIMD [5:4]": (hw >> 4) & 3,
-    "wave in block": np.arange(4)[None, :] + 0 * hw,
+    "wave in block": np.arange(NW)[None, :] + 0 * hw,
 }
 for name, g in groups.items():
     print(name)
