@@ -278,17 +278,26 @@ def _attention_decode(query_states, key_states, value_states, layer: KiviLayerCa
 
 
 def kivi_attention_prefill(query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
-                           layer: KiviLayerCache) -> torch.Tensor:
-    """Prompt pass (:401-452): causal attention over fp16 q/k/v (the reference uses flash-attn with its mask
-    argument hard-wired to None, :420-423; here torch SDPA, outside the quantised hot path), then split K/V into
-    the quantised prefix and the fp16 residual."""
+                           layer: KiviLayerCache, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Prompt pass (:401-452): attention over fp16 q/k/v (torch SDPA, outside the quantised hot path), then split K/V
+    into the quantised prefix and the fp16 residual.
+
+    `attention_mask` None: causal -- the flash class, whose mask argument is hard-wired to None (:420-423).  Given
+    (additive, (bsz, 1, q_len, kv_len), causal structure included, as HF builds it): the eager class's
+    `attn_weights + attention_mask` (:228-237), e.g. for left-padded batches; a wrong shape raises like the reference."""
     B, nh, T, D = query_states.shape
     rep = nh // layer.nh_kv
     k, v = key_states, value_states
     if rep > 1:
         k = k.repeat_interleave(rep, dim=1)
         v = v.repeat_interleave(rep, dim=1)
-    attn_output = F.scaled_dot_product_attention(query_states, k, v, is_causal=True)
+    if attention_mask is None:
+        attn_output = F.scaled_dot_product_attention(query_states, k, v, is_causal=True)
+    else:
+        if tuple(attention_mask.shape) != (B, 1, T, key_states.shape[-2]):
+            raise ValueError(f"Attention mask should be of size {(B, 1, T, key_states.shape[-2])}, but is "
+                             f"{tuple(attention_mask.shape)}")
+        attn_output = F.scaled_dot_product_attention(query_states, k, v, attn_mask=attention_mask.to(query_states.dtype))
     layer.prefill(key_states, value_states)
     return attn_output
 
@@ -337,6 +346,9 @@ class LlamaAttention_KIVI(nn.Module):
     group_size, residual_length.  forward() keeps the reference signature and returns
     (attn_output, None, past_key_value) with past_key_value the 9-tuple of :454-455.
     """
+
+    # the eager class adds `attention_mask` to the prompt pass's scores (:228-237); the flash subclass does not (:420-423)
+    _prefill_uses_mask = True
 
     def __init__(self, config, layer_idx: Optional[int] = None):
         super().__init__()
@@ -408,7 +420,7 @@ class LlamaAttention_KIVI(nn.Module):
         else:
             layer = make_layer_cache(self.kivi, bsz, self.num_key_value_heads, self.head_dim, self._capacity(q_len),
                                      hidden_states.device, q.dtype, num_heads=self.num_heads)
-            attn_output = kivi_attention_prefill(q, k, v, layer)
+            attn_output = kivi_attention_prefill(q, k, v, layer, attention_mask if self._prefill_uses_mask else None)
         past = layer.as_tuple() if use_cache else None                                     # :454-455
         attn_output = attn_output.transpose(1, 2).reshape(bsz, q_len, self.num_heads * self.head_dim)
         return self.o_proj(attn_output), None, past
@@ -422,8 +434,11 @@ class LlamaAttention_KIVI(nn.Module):
         return max(needed + 4 * self.residual_length, reserve)
 
 
-# The reference has an eager and a flash class with identical cache logic; both names resolve here.
-LlamaFlashAttention_KIVI = LlamaAttention_KIVI
+class LlamaFlashAttention_KIVI(LlamaAttention_KIVI):
+    """Reference: LlamaFlashAttention_KIVI (models/llama_kivi.py:264-466): same cache logic as the eager class; its prompt
+    pass is causal flash attention with the mask argument hard-wired to None (:420-423), so `attention_mask` only
+    reaches the decode steps."""
+    _prefill_uses_mask = False
 
 
 class MistralAttention_KIVI(LlamaAttention_KIVI):
@@ -444,4 +459,6 @@ class MistralAttention_KIVI(LlamaAttention_KIVI):
         self.sliding_window = getattr(config, "sliding_window", None)
 
 
-MistralFlashAttention_KIVI = MistralAttention_KIVI
+class MistralFlashAttention_KIVI(MistralAttention_KIVI):
+    """Reference: MistralFlashAttention_KIVI (models/mistral_kivi.py:319-534): causal flash prompt pass, no mask."""
+    _prefill_uses_mask = False

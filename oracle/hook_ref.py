@@ -53,6 +53,24 @@ def prefill_cache(key_states, value_states, k_bits, v_bits, group_size, residual
     return (kc, k_full, ks, km, vc, v_full, vs, vm, T)
 
 
+def prefill_attention_eager(query_states, key_states, value_states, attention_mask=None):
+    """The eager class's prompt pass (llama_kivi.py:180-183, :222-240): fp16 q k^T / sqrt(D), + additive mask clamped at
+    the fp16 minimum, fp32 softmax cast back to fp16, fp16 probs @ V.  `attention_mask` (bsz, 1, q_len, kv_len) carries
+    the causal structure (HF builds it); None = no masking at all, as in the reference.  Inputs are fp16 CPU tensors;
+    the matmuls run in fp32 and round once to fp16 (what a CUDA fp16 matmul with fp32 accumulate returns)."""
+    nh, nh_kv = query_states.shape[1], key_states.shape[1]
+    k = repeat_kv(key_states, nh // nh_kv).float()
+    v = repeat_kv(value_states, nh // nh_kv).float()
+    w = (query_states.float() @ k.transpose(2, 3) / math.sqrt(query_states.shape[-1])).half()
+    if attention_mask is not None:
+        if tuple(attention_mask.shape) != (query_states.shape[0], 1, query_states.shape[2], key_states.shape[2]):
+            raise ValueError("Attention mask should be of size (bsz, 1, q_len, kv_seq_len)")
+        w = (w.float() + attention_mask.float()).half()
+        w = torch.max(w, torch.tensor(torch.finfo(torch.float16).min, dtype=torch.float16))
+    probs = torch.softmax(w.float(), dim=-1).half()
+    return (probs.float() @ v).half()
+
+
 def decode_step(query_states, key_states, value_states, past, k_bits, v_bits, group_size, residual_length,
                 attention_mask=None):
     """llama_kivi.py:314-399.  query (B,nh,1,D), key/value (B,nh_kv,1,D) -> (attn_output (B,nh,1,D), new 9-tuple)."""

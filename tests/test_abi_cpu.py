@@ -266,7 +266,8 @@ def test_mistral_module_reads_a_mistral_config():
     cfg.k_bits, cfg.v_bits, cfg.group_size, cfg.residual_length = 2, 2, 32, 128
     m = M.MistralForCausalLM_KIVI(cfg)
     att = m.model.layers[0].self_attn
-    assert isinstance(att, M.MistralAttention_KIVI) and M.MistralFlashAttention_KIVI is M.MistralAttention_KIVI
+    assert isinstance(att, M.MistralAttention_KIVI) and issubclass(M.MistralFlashAttention_KIVI, M.MistralAttention_KIVI)
+    assert M.MistralAttention_KIVI._prefill_uses_mask and not M.MistralFlashAttention_KIVI._prefill_uses_mask   # eager vs flash prompt pass
     assert att.sliding_window == 4096 and att.num_key_value_groups == 4 and att.q_proj.bias is None
     assert att.residual_length == 128 and att.k_proj.weight.shape == (2 * 64, 512)
 

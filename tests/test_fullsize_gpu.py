@@ -174,9 +174,9 @@ def test_mistral_7b_attention_module_vs_oracle(oracle):
         captured["qkv"] = (q.cpu(), k.cpu(), v.cpu())
         return orig_dec(q, k, v, layer, attention_mask, **kw)
 
-    def spy_pre(q, k, v, layer):
+    def spy_pre(q, k, v, layer, attention_mask=None):
         captured["qkv"] = (q.cpu(), k.cpu(), v.cpu())
-        return orig_pre(q, k, v, layer)
+        return orig_pre(q, k, v, layer, attention_mask)
 
     A.kivi_attention_decode, A.kivi_attention_prefill = spy_dec, spy_pre
     try:

@@ -331,3 +331,31 @@ def test_cache_grows_past_its_initial_capacity():
     assert small.cap > cap0 and small.kv_seq_len == big.kv_seq_len == T0 + 150
     for x, y in zip(small.as_tuple()[:8], big.as_tuple()[:8]):
         assert (x is None) == (y is None) and (x is None or same_bits(x, y))
+
+
+@pytest.mark.parametrize("nh,nh_kv", [(4, 4), (8, 2)])
+def test_eager_prompt_pass_applies_the_mask(oracle, nh, nh_kv):
+    """The eager class adds the additive mask to the prompt pass (llama_kivi.py:228-237; left-padded batches), the flash
+    class runs causal attention without it (:420-423).  Outputs vs the CPU restatement of the eager arithmetic, cache
+    tuples bit-identical either way (the cache never depends on the mask)."""
+    import types
+    from kivi_amd.attention import KiviConfig, kivi_attention_prefill, make_layer_cache
+    from oracle import hook_ref as H
+    B, T, D, g, R = 2, 75, 128, 32, 32
+    q, k, v = make_kv(1, B, nh, T, D), make_kv(2, B, nh_kv, T, D), make_kv(3, B, nh_kv, T, D)
+    neg = torch.finfo(torch.float16).min
+    mask = torch.full((T, T), neg, dtype=torch.float16).triu(1)[None, None].repeat(B, 1, 1, 1)
+    mask[1, :, :, :9] = neg                                   # batch row 1: nine left-padding positions
+    mask[1, 0, torch.arange(9), torch.arange(9)] = 0.0        # (padded queries still see themselves: no empty rows)
+    cfg = KiviConfig(2, 2, g, R)
+    for m in (mask, None):
+        layer = make_layer_cache(cfg, B, nh_kv, D, T + 64, "cuda", num_heads=nh)
+        out = kivi_attention_prefill(q.cuda(), k.cuda(), v.cuda(), layer, None if m is None else m.cuda())
+        causal = torch.full((T, T), neg, dtype=torch.float16).triu(1)[None, None].repeat(B, 1, 1, 1)
+        ref = H.prefill_attention_eager(q, k, v, m if m is not None else causal)
+        err = (out.cpu().float() - ref.float()).abs().max().item()
+        assert err <= 4e-3 * max(1.0, ref.float().abs().max().item()), err
+        _cmp_cache(layer.as_tuple(), H.prefill_cache(k, v, 2, 2, g, R))
+    with pytest.raises(ValueError):
+        kivi_attention_prefill(q.cuda(), k.cuda(), v.cuda(), make_layer_cache(cfg, B, nh_kv, D, T + 64, "cuda", num_heads=nh),
+                               mask[:, :, :1].cuda())
