@@ -297,8 +297,13 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
                 ak.tile_blocks = (int)(((ak.Tw + 255) / 256 + 1) / 2);
                 ak.res_blocks = 0;
                 a.scores_lds = 1;
-                KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false>), dim3((unsigned)units), dim3(256),
-                                (size_t)a.n_pad * sizeof(uint16_t), s, ak, a);
+                static const char* rx4 = getenv("KIVI_ROW_X");
+                if (rx4 && !strcmp(rx4, "d2"))
+                    KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false>), dim3((unsigned)units), dim3(256),
+                                    (size_t)a.n_pad * sizeof(uint16_t), s, ak, a);
+                else
+                    KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false, false, 0, 0, 4, 3>), dim3((unsigned)units),
+                                    dim3(256), (size_t)a.n_pad * sizeof(uint16_t), s, ak, a);
                 return kivi_launch_status("decode_row");
             }
             const int tiles = (int)((ak.Tw + 127) / 128);
@@ -318,8 +323,10 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
                 if (a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, true, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
                 else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, false, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
             }
-            else if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (G == 128) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (G == 64 && rx && !strcmp(rx, "d2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (G == 128 && rx && !strcmp(rx, "d2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
+            else if (G == 128) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
             else if (selv == 1 && a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4, true, true>), grid, dim3(256), lds, s, ak, a);
             else if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
             else if (sel == 0) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
