@@ -31,13 +31,15 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(DST, exist_ok=True)
     # ---- kernel stats of the bench command
-    rows = list(csv.DictReader(open(os.path.join(SRC, "bench_trace", "bench_kernel_stats.csv"))))
-    with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
-                        r["MaxNs"], r["StdDev"]])
+    stats = os.path.join(SRC, "bench_trace", "bench_kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats))) if os.path.exists(stats) else []    # absent in a PMC-only session
+    if rows:
+        with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                            r["MaxNs"], r["StdDev"]])
     kg = next((r for r in rows if "gemv_k_kernel" in r["Name"]), None)
     vg = next((r for r in rows if "gemv_v_kernel" in r["Name"]), None)
     rg = next((r for r in rows if "decode_row_kernel" in r["Name"]), None)   # the fused MHA decode step (one launch)
@@ -88,9 +90,7 @@ def main():
                              "launches": [m1, m2], "hbm_read_bytes": fr * unit, "hbm_write_bytes": wr * 1024,
                              "hbm_bytes_per_launch": fr * unit + wr * 1024}
         out["decode_row_hbm_bytes_per_launch"] = fr * unit + wr * 1024
-    with open(os.path.join(DST, f"{tag}_kgemv_pmc.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    with open(os.path.join(DST, "kgemv_pmc.json"), "w") as f:   # what bench.py reads for roofline.traffic
+    with open(os.path.join(DST, f"{tag}_kgemv_pmc.json"), "w") as f:   # bench.py reads the newest rNN_kgemv_pmc.json for roofline.traffic
         json.dump(out, f, indent=1)
     print(json.dumps(out["gemv_k"], indent=1))
     print(json.dumps(out["bench_kernel_trace"], indent=1))
