@@ -272,7 +272,8 @@ int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, i
  *      rows are cut into slices, partial sums meet in `workspace`.
  * Lengths: Tq packed keys (multiple of 32) + k_res_len residual keys == Tv packed values + v_res_len window values.
  * `stats`: >= B * nh * (ceil(Tq / 512) + 4) * 2 floats.  `workspace`: 64 KiB of arrival counters (zeroed once by the
- * caller) followed by B * nh_kv * 2 * slices * (nh / nh_kv) * 128 floats (1 <= slices <= max(1, ceil(Tv / 512))).
+ * caller) followed by B * nh_kv * 2 * (slices + 1) * (nh / nh_kv) * 128 floats (1 <= slices <= max(1, ceil(Tv / 512));
+ * + 1: the slot of the unit's window block).
  */
 typedef struct {
     int B, nh, nh_kv, D, group_size, bits;

@@ -46,7 +46,7 @@ def _scratch(device, B: int, nh: int, nh_kv: int, pitch: int, nseg: int, slices:
         st = torch.empty(need, dtype=torch.float32, device=device)
         d["stats"] = st
     ws = d.get("ws")
-    need = _WS_COUNTER_BYTES + B * nh_kv * 2 * max(slices, 1) * (nh // nh_kv) * 128 * 4
+    need = _WS_COUNTER_BYTES + B * nh_kv * 2 * (max(slices, 1) + 1) * (nh // nh_kv) * 128 * 4   # + 1: the window block's slot
     if ws is None or ws.numel() < need:
         ws = torch.zeros(need, dtype=torch.uint8, device=device)   # arrival counters start at zero; the kernel resets them
         d["ws"] = ws

@@ -479,6 +479,10 @@ struct GqaVArgs {
     int64_t Tv;                 // packed tokens
     int nsb;                    // super-blocks holding them
     int S, spb;                 // stream blocks per (b, kv head), super-blocks per stream block
+    int units;                  // B * nh_kv
+    int win_blocks;             // 0: every stream block takes a share of the fp16 window; else (= units): one window block per
+                                // unit at the TAIL of the grid does the window, the V append and the flush
+    int nslot;                  // partial-sum slots per unit: S (+ 1 for the window block)
     uint16_t* vres;             // (B, nh_kv, W, D) fp16 window buffer
     int64_t vres_sb, vres_sh, vres_st;
     int win_start, res_len;     // live rows [win_start, win_start + res_len); the new token goes right after
@@ -487,7 +491,7 @@ struct GqaVArgs {
     int flush;                  // quantise the oldest window row into the layout at token Tv (llama_kivi.py:386-399)
     uint16_t* out;
     int64_t out_sb, out_sh;
-    float* ws;                  // [units][S][2][R * 128] fp32 partial sums of every slice: quantised part, window part
+    float* ws;                  // [units][nslot][2][R * 128] fp32 partial sums of every block: quantised part, window part
     int* counters;              // [units] arrival counters, zero between launches
     unsigned long long* dbg;    // phase time stamps or null
 };
@@ -548,30 +552,30 @@ template <int R>
 __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0) {
     __shared__ int last_flag;
     constexpr int RD = R * 128;
-    // part_lds = [quantised part | window part] of this block; workspace [unit][slice][2][RD]
-    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * a.S + slot) * 2 * RD);
+    // part_lds = [quantised part | window part] of this block; workspace [unit][slot][2][RD]
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * a.nslot + slot) * 2 * RD);
     for (int i = threadIdx.x; i < 2 * RD; i += 256)
         __hip_atomic_store(dst + i, __builtin_bit_cast(uint32_t, part_lds[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (old == a.S - 1);
+        const int last = (old == a.nslot - 1);
         if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
         last_flag = last;
     }
     __syncthreads();
     if (!last_flag) return;
-    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * a.S * 2 * RD);
+    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * a.nslot * 2 * RD);
     for (int i = threadIdx.x; i < RD; i += 256) {
         const int r = i >> 7, d = i & 127;
         float q = 0.f, w = 0.f;
-        for (int s0 = 0; s0 < a.S; s0 += 4) {   // 8 independent loads in flight, added in slice order
+        for (int s0 = 0; s0 < a.nslot; s0 += 4) {   // 8 independent loads in flight, added in slot order
             uint32_t v8[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                v8[2 * k] = (s0 + k < a.S) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                v8[2 * k + 1] = (s0 + k < a.S) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v8[2 * k] = (s0 + k < a.nslot) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v8[2 * k + 1] = (s0 + k < a.nslot) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -605,7 +609,12 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_s = lds_all + wave * 2048;
     uint32_t* lds_m = lds_s + 1024;
-    const int unit = bid / a.S, slice = bid - unit * a.S;
+    // window role (a.win_blocks): the last `units` blocks of the grid stream nothing; they run when the CUs drain, next to
+    // the youngest stream blocks (co-resident blocks are served oldest first), instead of 8 us at the end of EVERY stream block
+    const int nstream = a.units * a.S;
+    const bool win_role = bid >= nstream;
+    const int unit = win_role ? bid - nstream : bid / a.S;
+    const int slice = win_role ? a.S : bid - unit * a.S;           // = the block's partial-sum slot
     const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
     const int h0 = hk * a.ratio;
     const int n = lane & 15, kb = lane >> 4;
@@ -648,8 +657,8 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
     const uint32_t xoff = (uint32_t)((r * a.x_sh + 8 * kb + 2 * PPL * q4) * 2);
     typedef typename std::conditional<PPL == 1, uint32_t, u32x2>::type XV;
 
-    const int sb_begin = slice * a.spb;
-    const int sb_end = (sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb;
+    const int sb_begin = win_role ? 0 : slice * a.spb;
+    const int sb_end = win_role ? 0 : ((sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb);
     for (int sb = sb_begin + wave; sb < sb_end; sb += 4) {
         const int64_t tok0 = (int64_t)sb * KIVI_MF_SB_TOKENS;
         int ng = (int)((a.Tv - tok0 + 31) / 32);
@@ -789,14 +798,15 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
     constexpr int PW = 136, WB = 12;
     __shared__ uint16_t pw[R][PW];
     const int Lw = a.res_len + 1;
-    const int wchunk = (Lw + a.S - 1) / a.S;
-    const int w0 = slice * wchunk;
-    const int w1 = (w0 + wchunk < Lw) ? w0 + wchunk : Lw;
+    const int wchunk = a.win_blocks ? Lw : (Lw + a.S - 1) / a.S;
+    const int w0 = a.win_blocks ? 0 : slice * wchunk;
+    const int w1 = a.win_blocks ? (win_role ? Lw : 0) : ((w0 + wchunk < Lw) ? w0 + wchunk : Lw);
+    const bool flusher = a.flush && (a.win_blocks ? win_role : slice == 0);
     const int nwt = w1 > w0 ? w1 - w0 : 0;
     uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
     const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
     uint16_t xflush = 0;
-    if (a.flush && slice == 0 && threadIdx.x < 128) xflush = vwin[threadIdx.x];      // requested early, used last
+    if (flusher && threadIdx.x < 128) xflush = vwin[threadIdx.x];      // requested early, used last
     for (int idx = threadIdx.x; idx < R * nwt; idx += 256) {
         const int rr = idx / nwt, t = idx - rr * nwt;
         float Mr = M[0], Ir = invS[0];
@@ -833,7 +843,7 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
             }
         }
     }
-    if (a.flush && slice == 0 && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
+    if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
         const int d = threadIdx.x;
         const uint32_t key = h_key(xflush);
         uint32_t kmin = key, kmax = key;
@@ -1040,12 +1050,12 @@ template <int R, bool HILO, int RING>
 static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
     static const char* occ = getenv("KIVI_GQA_V_OCC");            // tuning aid: 3 = let the kernel use up to 168 registers
     if (occ && atoi(occ) == 3 && HILO && RING == 4) {
-        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 3>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 3>), dim3((unsigned)(units * a.S + a.win_blocks)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
         return;
     }
     static const char* v2 = getenv("KIVI_GQA_V2");                // tuning aid: 1 / 0 = row = (channel group, head) mapping on / off
     if (R == 4 && HILO && (v2 ? atoi(v2) != 0 : true)) {
-        const dim3 grid((unsigned)(units * a.S));
+        const dim3 grid((unsigned)(units * a.S + a.win_blocks));
         static const char* occ2 = getenv("KIVI_GQA_V_OCC");
         if (a.dbg) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, true, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
         else if (occ2 && atoi(occ2) == 3) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 3, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
@@ -1055,7 +1065,7 @@ static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
     }
     static const char* dg = getenv("KIVI_GQA_V_DIAG");
     if (dg && HILO && RING == 4 && R == 4) {
-        const dim3 grid((unsigned)(units * a.S));
+        const dim3 grid((unsigned)(units * a.S + a.win_blocks));
         const size_t lds = 4 * 2048 * 4;
         switch (atoi(dg)) {
             case 1: KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 1>), grid, dim3(256), lds, s, a); return;
@@ -1069,14 +1079,14 @@ static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
         }
     }
     if (occ && atoi(occ) == 2 && HILO && RING == 4) {
-        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 2>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 2>), dim3((unsigned)(units * a.S + a.win_blocks)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
         return;
     }
     if (a.dbg && HILO && RING <= 4) {
-        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, RING, true>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+        KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, RING, true>), dim3((unsigned)(units * a.S + a.win_blocks)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
         return;
     }
-    KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(units * a.S)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
+    KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(units * a.S + a.win_blocks)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
 }
 
 extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stream) {
@@ -1123,7 +1133,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
         S = (nsbv + spb - 1) / spb;
     }
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
-    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * S * 2 * R * 128 * 4;
+    static const char* wt = getenv("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
+    const int win_blocks = (nsbv > 0 && !(wt && atoi(wt) == 0)) ? units : 0;
+    const int nslot = S + (win_blocks ? 1 : 0);
+    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * nslot * 2 * R * 128 * 4;
     KIVI_REQUIRE(p->workspace && (uintptr_t)p->workspace % 16 == 0 && p->workspace_bytes >= need, KIVI_EINVAL,
                  "kivi_gqa_decode: workspace too small (%lld bytes needed)", (long long)need);
     hipStream_t s = (hipStream_t)stream;
@@ -1153,6 +1166,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.stats = (const float*)p->stats; v.nseg = nseg;
     v.vt = {(uint32_t*)p->vt, p->vt_sb, p->vt_sh, p->vt_ss};
     v.nh_kv = nh_kv; v.ratio = R; v.nh = nh; v.Tv = p->Tv; v.nsb = nsbv; v.S = S; v.spb = spb;
+    v.units = units; v.win_blocks = win_blocks; v.nslot = nslot;
     v.vres = (uint16_t*)p->vres; v.vres_sb = p->vres_sb; v.vres_sh = p->vres_sh; v.vres_st = p->vres_st;
     v.win_start = p->v_win_start; v.res_len = p->v_res_len;
     v.vnew = (const uint16_t*)p->vnew; v.vnew_sb = p->vnew_sb; v.vnew_sh = p->vnew_sh; v.flush = p->v_flush ? 1 : 0;
