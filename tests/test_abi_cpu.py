@@ -283,7 +283,7 @@ def _gqa_args(**over):
              vres=0x1000, vres_sb=2 * 65 * 128, vres_sh=65 * 128, vres_st=128, v_win_start=0, v_res_len=32,
              vnew=0x1000, vnew_sb=2 * 128, vnew_sh=128, v_flush=1,
              scores=0x1000, s_sb=8 * 528, s_sh=528, stats=0x1000, stats_bytes=2 * 8 * 5 * 2 * 4,
-             workspace=0x1000, workspace_bytes=65536 + 2 * 2 * 2 * 1 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128)
+             workspace=0x1000, workspace_bytes=65536 + 4 * (1 + 1) * 2 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128)
     f.update(over)
     return _lib.GqaDecodeArgs(**f)
 
@@ -296,6 +296,7 @@ def _gqa_args(**over):
     (dict(s_sh=516), None, b"score rows"),                  # rows must hold the step and be 16-byte aligned
     (dict(stats_bytes=16), None, b"statistics buffer"),
     (dict(workspace_bytes=65536), None, b"workspace"),
+    (dict(workspace_bytes=65536 + 4 * 1 * 2 * 4 * 128 * 4), None, b"workspace"),   # one slot per slice is not enough: + the window block's
     (dict(vnew=0x1004), None, b"value rows"),
 ])
 def test_gqa_decode_validates_before_launching(lib, over, rc_expected, msg):
