@@ -133,6 +133,33 @@ __device__ __forceinline__ Group2 make_group2(uint32_t kmin, uint32_t kmax) {
     return g;
 }
 
+// Front end shared by the packed-math kernels: order-preserving keys of the 8 halves of a chunk (-0 < +0), their min / max,
+// then the lpg lanes of a group (aligned, power of two) meet through DPP inside a 16-lane row and shuffles beyond.
+__device__ __forceinline__ void pk16_group_minmax(const u32x4& v, int lpg, uint32_t& kmin, uint32_t& kmax) {
+    uint32_t key[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t sgn;                                                                  // 0xFFFF for negative halves
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[k]));    // shift count in BOTH halves (an inline 15 reaches only the low one)
+        key[k] = v[k] ^ (sgn | 0x80008000u);
+    }
+    us16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
+                                           __builtin_elementwise_min(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
+    us16x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
+                                           __builtin_elementwise_max(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
+    kmin = mn2[0] < mn2[1] ? mn2[0] : mn2[1];
+    kmax = mx2[0] > mx2[1] ? mx2[0] : mx2[1];
+    if (lpg > 1) { const uint32_t a = dpp_u<0xB1>(kmin), b = dpp_u<0xB1>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    if (lpg > 2) { const uint32_t a = dpp_u<0x4E>(kmin), b = dpp_u<0x4E>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    if (lpg > 4) { const uint32_t a = dpp_u<0x141>(kmin), b = dpp_u<0x141>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    if (lpg > 8) { const uint32_t a = dpp_u<0x140>(kmin), b = dpp_u<0x140>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    for (int m = 16; m < lpg; m <<= 1) {
+        const uint32_t a = __shfl_xor(kmin, m), b = __shfl_xor(kmax, m);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+}
+
 // LPG = lanes per group when known at compile time (4 / 8 / 16 for group 32 / 64 / 128), 0 = the runtime value;
 // FULL = every block has all of its 256 * NU chunks (no bounds checks).
 template <int NU, int LPG, bool FULL>
@@ -154,29 +181,8 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t
         const int64_t c = c0 + 256 * u;
         const bool valid = FULL || c < nchunk;
         const u32x4 v = vv[u];
-        uint32_t key[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t sgn;                                                                  // 0xFFFF for negative halves
-            asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[k]));    // shift count in BOTH halves (an inline 15 reaches only the low one)
-            key[k] = v[k] ^ (sgn | 0x80008000u);
-        }
-        us16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
-                                               __builtin_elementwise_min(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
-        us16x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
-                                               __builtin_elementwise_max(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
-        uint32_t kmin = mn2[0] < mn2[1] ? mn2[0] : mn2[1];
-        uint32_t kmax = mx2[0] > mx2[1] ? mx2[0] : mx2[1];
-        // the lpg lanes of a group (aligned, power of two): DPP inside a 16-lane row, shuffles beyond
-        if (lpg > 1) { const uint32_t a = dpp_u<0xB1>(kmin), b = dpp_u<0xB1>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-        if (lpg > 2) { const uint32_t a = dpp_u<0x4E>(kmin), b = dpp_u<0x4E>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-        if (lpg > 4) { const uint32_t a = dpp_u<0x141>(kmin), b = dpp_u<0x141>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-        if (lpg > 8) { const uint32_t a = dpp_u<0x140>(kmin), b = dpp_u<0x140>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-        for (int m = 16; m < lpg; m <<= 1) {
-            const uint32_t a = __shfl_xor(kmin, m), b = __shfl_xor(kmax, m);
-            kmin = a < kmin ? a : kmin;
-            kmax = b > kmax ? b : kmax;
-        }
+        uint32_t kmin, kmax;
+        pk16_group_minmax(v, lpg, kmin, kmax);
         const Group2 g = make_group2(kmin, kmax);
         const us16x2 t02 = __builtin_bit_cast(us16x2, g.t02);
         const us16x2 t0 = {t02[0], t02[0]}, t1 = __builtin_bit_cast(us16x2, g.t11), t2 = {t02[1], t02[1]};
@@ -203,6 +209,77 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t
             const int64_t gi = c >> lg;
             scale[gi] = g.scale;
             mn[gi] = g.mn;
+        }
+    }
+}
+
+// 4- and 8-bit on packed 16-bit math (round 2): the front end of the kernel above (keys, min / max, DPP group reduce), then
+//   q    = fp16(d * r),  r = fp32(1 / scale) once per chunk (IEEE division), instead of one IEEE division per element;
+//   code = low bits of  fp16(min(max(q, 0), maxq) + 1024)   -- the fp16 add rounds to nearest even at ulp 1 = rint().
+// q itself is NOT always the reference's fp16(d / scale) (1 495 of the 10^9 (d, scale) pairs differ by an ulp with the
+// product rounded twice, 17 069 with v_fma_mixlo_f16's single rounding) but the CODE is, for every fp16 d >= 0, every
+// positive fp16 scale and maxq in {3, 15, 255}: checked exhaustively on the CPU for both roundings
+// (tests/test_oracle_golden.py::test_reciprocal_quantiser_codes_are_exact).  Degenerate scales need no special case:
+// scale 0 -> r = inf: d > 0 -> inf -> maxq, d = 0 -> NaN -> 0; scale inf -> r = 0: 0, inf * 0 = NaN -> 0 (v_pk_max_f16
+// returns the non-NaN operand) -- the reference's CUDA results (kivi_quant.h).
+template <int BITS, int NU, int LPG, bool FULL>
+__global__ __launch_bounds__(256) void quant_pack_lastdimN_kernel(const uint16_t* __restrict__ x, uint32_t* __restrict__ code,
+                                                                  uint16_t* __restrict__ scale, uint16_t* __restrict__ mn,
+                                                                  int64_t nchunk, int lpg_rt) {
+    static_assert(BITS == 4 || BITS == 8, "2 bits: quant_pack_lastdim2_kernel");
+    constexpr int MAXQ = (1 << BITS) - 1;
+    const int64_t c0 = (int64_t)blockIdx.x * (256 * NU) + threadIdx.x;
+    const int lpg = LPG ? LPG : lpg_rt;
+    const int lg = LPG ? __builtin_ctz((unsigned)(LPG ? LPG : 1)) : __builtin_ctz((unsigned)lpg_rt);
+    u32x4 vv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int64_t c = c0 + 256 * u;
+        vv[u] = u32x4{0, 0, 0, 0};
+        if (FULL || c < nchunk) vv[u] = __builtin_nontemporal_load((const u32x4*)(x + c * 8));
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int64_t c = c0 + 256 * u;
+        const bool valid = FULL || c < nchunk;
+        const u32x4 v = vv[u];
+        uint32_t kmin, kmax;
+        pk16_group_minmax(v, lpg, kmin, kmax);
+        const uint16_t gmn = (uint16_t)h_unkey(kmin), gmx = (uint16_t)h_unkey(kmax);
+        const uint16_t range = f2h_bits(h2f_bits(gmx) - h2f_bits(gmn));                       // new_pack.py:238 (mx - mn)
+        const uint16_t gscale = f2h_bits(h2f_bits(range) * (1.0f / (float)MAXQ));             //   / max_int (equal to the division for every fp16 range)
+        const float r = 1.0f / h2f_bits(gscale);                                              // IEEE; inf for scale 0, 0 for scale inf
+        const _Float16 hmn = __builtin_bit_cast(_Float16, gmn);
+        const hf2 mnv = {hmn, hmn};
+        const hf2 zero2 = {(_Float16)0.0f, (_Float16)0.0f}, maxq2 = {(_Float16)(float)MAXQ, (_Float16)(float)MAXQ};
+        const hf2 magic = {(_Float16)1024.0f, (_Float16)1024.0f};
+        uint32_t cb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t xk = v[k];   // by value (see quant_pack_lastdim2_kernel)
+            const hf2 d = __builtin_bit_cast(hf2, xk) - mnv;                                  // new_pack.py:239
+            hf2 q;
+            q[0] = (_Float16)((float)d[0] * r);                                               // :240 through the reciprocal
+            q[1] = (_Float16)((float)d[1] * r);
+            const hf2 cl = __builtin_elementwise_min(__builtin_elementwise_max(q, zero2), maxq2);   // :241 clamp_ (NaN -> 0)
+            cb[k] = __builtin_bit_cast(uint32_t, cl + magic) & (BITS == 4 ? 0x000F000Fu : 0x00FF00FFu);   // round_ + to(int32)
+        }
+        if constexpr (BITS == 4) {
+            // element 2k + h -> nibble 2k + h: byte k = lo | hi << 4
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) w |= ((cb[k] | (cb[k] >> 12)) & 0xFFu) << (8 * k);
+            if (valid) code[c] = w;
+        } else {
+            u32x2 w;
+            w[0] = ((cb[0] | (cb[0] >> 8)) & 0xFFFFu) | (((cb[1] | (cb[1] >> 8)) & 0xFFFFu) << 16);
+            w[1] = ((cb[2] | (cb[2] >> 8)) & 0xFFFFu) | (((cb[3] | (cb[3] >> 8)) & 0xFFFFu) << 16);
+            if (valid) *(u32x2*)(code + c * 2) = w;
+        }
+        if (valid && (c & (lpg - 1)) == 0) {
+            const int64_t gi = c >> lg;
+            scale[gi] = gscale;
+            mn[gi] = gmn;
         }
     }
 }
@@ -481,7 +558,7 @@ extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, v
         else hipLaunchKernelGGL((quant_pack_lastdim_kernel<BB, 1>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s,         \
                                 (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);                  \
     } while (0)
-        static const char* nopk = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math 2-bit kernel
+        static const char* nopk = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math kernels
         if (bits == 2 && !nopk) {
 #define KIVI_QP2(NUU, LL, FF)                                                                                          \
     hipLaunchKernelGGL((quant_pack_lastdim2_kernel<NUU, LL, FF>), dim3((unsigned)((nchunk + 256 * NUU - 1) / (256 * NUU))), dim3(256), 0, \
@@ -496,7 +573,25 @@ extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, v
             else KIVI_QP2(1, 0, false);
 #undef KIVI_QP2
         } else if (bits == 2) KIVI_QP(2);
-        else if (bits == 4) KIVI_QP(4);
+        else if (!nopk) {
+#define KIVI_QPN(BB, NUU, LL, FF)                                                                                      \
+    hipLaunchKernelGGL((quant_pack_lastdimN_kernel<BB, NUU, LL, FF>), dim3((unsigned)((nchunk + 256 * NUU - 1) / (256 * NUU))), dim3(256), \
+                       0, s, (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg)
+            const int nu2 = nu >= 4 ? 4 : 1;
+            const bool full = nchunk % (256 * nu2) == 0;
+            if (bits == 4) {
+                if (nu2 == 4 && full && lpg == 4) KIVI_QPN(4, 4, 4, true);
+                else if (nu2 == 4 && full && lpg == 8) KIVI_QPN(4, 4, 8, true);
+                else if (nu2 == 4 && full && lpg == 16) KIVI_QPN(4, 4, 16, true);
+                else if (nu2 == 4) KIVI_QPN(4, 4, 0, false);
+                else KIVI_QPN(4, 1, 0, false);
+            } else {
+                if (nu2 == 4 && full && lpg == 4) KIVI_QPN(8, 4, 4, true);
+                else if (nu2 == 4) KIVI_QPN(8, 4, 0, false);
+                else KIVI_QPN(8, 1, 0, false);
+            }
+#undef KIVI_QPN
+        } else if (bits == 4) KIVI_QP(4);
         else KIVI_QP(8);
 #undef KIVI_QP
         return kivi_launch_status("quant_pack_lastdim");

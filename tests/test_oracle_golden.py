@@ -211,3 +211,59 @@ def test_packed_pack_kernel_shortcuts_are_exact():
         for i in range(0, s.size, 257):
             ref = (dval > th[i]) if strict else (dval >= th[i])
             assert ((dbits > rtz[i]) == ref).all(), (tau, i)
+
+
+def test_reciprocal_quantiser_codes_are_exact():
+    """quant_pack_lastdimN_kernel (kivi_pack.hip) quantises through ONE reciprocal per group: code = low bits of
+    fp16(min(max(fp16(d * fp32(1 / s)), 0), maxq) + 1024) instead of rint(clamp(fp16(d / s))) (new_pack.py:240-241).
+    Exhaustive over every fp16 d >= +0 (incl. +inf) and every positive finite fp16 scale -- 10^9 pairs -- for maxq in
+    {3, 15, 255}, with the product rounded twice (fp32, then fp16: v_mul_f32 + v_cvt) and once (v_fma_mixlo_f16): the
+    quotient differs by an ulp in a few thousand pairs, the CODE never.  Also: scale = fp16(range * fp32(1 / maxq)) equals
+    fp16(range / maxq) for every fp16 range, both roundings."""
+    allb = np.arange(0, 0x7C01, dtype=np.uint16)
+    d32 = allb.view(np.float16).astype(np.float32)[None, :]
+    d64 = d32.astype(np.float64)
+    sb = np.arange(1, 0x7C00, dtype=np.uint16)
+    s_all = sb.view(np.float16).astype(np.float32)
+
+    def magic_code(q16, mq):
+        q = q16.astype(np.float32)
+        q = np.clip(np.where(np.isnan(q), np.float32(0), q), 0, mq)
+        return ((q + np.float32(1024.0)).astype(np.float16).view(np.uint16) & 0x3FF).astype(np.int32)   # fp16 add = exact sum, one RNE
+
+    differ = [0, 0]
+    with np.errstate(over="ignore", invalid="ignore"):
+        for i in range(0, s_all.size, 128):
+            s = s_all[i:i + 128, None]
+            qr = (d32 / s).astype(np.float16)
+            r = np.float32(1.0) / s
+            q_twice = (d32 * r).astype(np.float16)
+            q_once = (d64 * r.astype(np.float64)).astype(np.float16)        # 11 x 24-bit product is exact in a double
+            for j, q in enumerate((q_twice, q_once)):
+                m = q.view(np.uint16) != qr.view(np.uint16)
+                differ[j] += int(m.sum())
+                if m.any():
+                    a = np.nan_to_num(qr[m].astype(np.float32), nan=0.0)
+                    for mq in (3, 15, 255):
+                        assert (np.rint(np.clip(a, 0, mq)).astype(np.int32) == magic_code(q[m], mq)).all(), (hex(sb[i]), j, mq)
+            if i % 4096 == 0:   # where the quotients agree the magic-number rint must agree with rint too: a sample of scales
+                a = np.nan_to_num(qr.astype(np.float32), nan=0.0)
+                for mq in (3, 15, 255):
+                    assert (np.rint(np.clip(a, 0, mq)).astype(np.int32) == magic_code(qr, mq)).all(), (hex(sb[i]), mq)
+    assert differ[0] > 0 and differ[1] > 0          # the shortcut is NOT the division; only the codes agree
+    # the magic-number rint on every clamped fp16 value (ties to even at .5)
+    q_all = allb.view(np.float16)
+    for mq in (3, 15, 255):
+        a = q_all.astype(np.float32)
+        assert (np.rint(np.clip(a, 0, mq)).astype(np.int32) == magic_code(q_all, mq)).all()
+    # degenerate scales, as the kernel meets them: r = inf (scale 0), r = 0 (scale inf)
+    with np.errstate(over="ignore", invalid="ignore"):
+        for r_, dv, want in ((np.inf, 0.0, 0), (np.inf, 6e-8, 15), (0.0, 1.0, 0), (0.0, np.inf, 0)):
+            q = (np.array([dv], np.float16).astype(np.float32) * np.float32(r_)).astype(np.float16)
+            assert magic_code(q, 15)[0] == want
+        rng = allb.view(np.float16).astype(np.float32)
+        for mq in (15, 255):
+            ref = (rng / np.float32(mq)).astype(np.float16).view(np.uint16)
+            rq = np.float32(1.0) / np.float32(mq)
+            assert ((rng * rq).astype(np.float16).view(np.uint16) == ref).all()
+            assert ((rng.astype(np.float64) * np.float64(rq)).astype(np.float16).view(np.uint16) == ref).all()

@@ -108,11 +108,12 @@ def test_lastdim_hard_values(np_mod, oracle):
         assert same_bits(code, oc)
 
 
-@pytest.mark.parametrize("g", [32, 64, 128])
-def test_lastdim_2bit_every_exponent(np_mod, oracle, g):
-    """The packed-math 2-bit kernel (quant_pack_lastdim2_kernel: thresholds rounded toward zero to fp16, scale through a
-    multiply) on groups whose range sits at every fp16 exponent, subnormal scales included, values on a few-ulp grid so
-    that many d fall on or next to a decision boundary; full blocks (1024 chunks per block) and a ragged tail."""
+@pytest.mark.parametrize("g,bits", [(32, 2), (64, 2), (128, 2), (32, 4), (64, 4), (128, 4), (32, 8), (16, 4)])
+def test_lastdim_every_exponent(np_mod, oracle, g, bits):
+    """The packed-math kernels (2 bits: quant_pack_lastdim2_kernel, thresholds rounded toward zero to fp16, scale through a
+    multiply; 4 / 8 bits: quant_pack_lastdimN_kernel, one reciprocal per group + magic-number rint) on groups whose range
+    sits at every fp16 exponent, subnormal scales included, values on a few-ulp grid so that many d fall on or next to a
+    decision boundary; full blocks (1024 chunks per block) and a ragged tail."""
     gen = torch.Generator().manual_seed(17)
     for rows in (4096 * 32 // g * 2, 37):
         ngrp = rows * 128 // g
@@ -120,8 +121,8 @@ def test_lastdim_2bit_every_exponent(np_mod, oracle, g):
         base = torch.randint(0, 2048, (ngrp, 1), generator=gen).float()
         x = ((torch.randint(-24, 25, (ngrp, g), generator=gen).float() + base) * torch.exp2(e - 5)).half()
         x = x.reshape(1, 1, rows, 128)
-        code, scale, mn = np_mod.triton_quantize_and_pack_along_last_dim(x.cuda(), g, 2)
-        oc, os_, om = oracle.quantize_and_pack_along_last_dim(x, g, 2)
+        code, scale, mn = np_mod.triton_quantize_and_pack_along_last_dim(x.cuda(), g, bits)
+        oc, os_, om = oracle.quantize_and_pack_along_last_dim(x, g, bits)
         for name, a, b in (("scale", scale, os_), ("mn", mn, om), ("code", code, oc)):
             a, b = a.cpu().contiguous().view(torch.int16 if a.dtype == torch.float16 else torch.int32), b.contiguous().view(
                 torch.int16 if b.dtype == torch.float16 else torch.int32)

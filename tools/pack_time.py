@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kivi_amd.quant import new_pack
 x = [torch.randn((32, 32, 4096, 128), device="cuda", dtype=torch.float16) for _ in range(3)]
-for bits in (2, 4):
+for bits in (2, 4, 8):
     ts = []
     for it in range(4):
         for xi in x:
