@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void quant_pack_k_tmajor_kernel(const uint16_t*
 // g = 32) of one (b, h); each wave quantises 4 of them exactly like the kernel above, but the packed words and the
 // scale / mn go through an LDS tile so that every channel row is written as one contiguous 128-byte (codes) and
 // 32-byte (scale, mn) segment instead of 64 scattered 8-byte stores.  D <= 128 per block column (blockIdx.y).
-template <int BITS, int G>
+template <int BITS, int G, bool PK16 = true>
 __global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t* __restrict__ k, int64_t k_sb, int64_t k_sh,
                                                                  int64_t k_st, uint32_t* __restrict__ code,
                                                                  int64_t code_sb, int64_t code_sh, int64_t code_sr,
@@ -389,6 +389,74 @@ __global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t*
             uint32_t v[G];
 #pragma unroll
             for (int t = 0; t < G; t++) v[t] = __builtin_nontemporal_load((const uint32_t*)(kp + t * k_st));
+            if constexpr (PK16) {
+                // packed 16-bit math (round 2): the lane's two channels are the two halves of every register, so min / max,
+                // d = x - mn, the threshold compares (2 bits) or the reciprocal quantiser (4 / 8 bits) and the word assembly
+                // run on both channels at once and nothing crosses lanes; the arithmetic of quant_pack_lastdim2_kernel /
+                // quant_pack_lastdimN_kernel (bit-exact, see there)
+                uint32_t kmin2 = 0xFFFFFFFFu, kmax2 = 0u;
+#pragma unroll
+                for (int t = 0; t < G; t++) {
+                    uint32_t sgn;
+                    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[t]));
+                    const uint32_t key = v[t] ^ (sgn | 0x80008000u);
+                    kmin2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, kmin2), __builtin_bit_cast(us16x2, key)));
+                    kmax2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us16x2, kmax2), __builtin_bit_cast(us16x2, key)));
+                }
+                constexpr int TPR = 16 / BITS;           // tokens per 16-bit half of an accumulation register
+                uint32_t W[G / TPR];
+#pragma unroll
+                for (int i = 0; i < G / TPR; i++) W[i] = 0u;
+                uint16_t sc0, sc1, mn0, mn1;
+                uint32_t livemask = 0xFFFFFFFFu;
+                if constexpr (BITS == 2) {
+                    const Group2 g0 = make_group2(kmin2 & 0xFFFFu, kmax2 & 0xFFFFu), g1 = make_group2(kmin2 >> 16, kmax2 >> 16);
+                    sc0 = g0.scale; sc1 = g1.scale; mn0 = g0.mn; mn1 = g1.mn;
+                    livemask = (g0.live ? 0x0000FFFFu : 0u) | (g1.live ? 0xFFFF0000u : 0u);
+                    const us16x2 t0 = __builtin_bit_cast(us16x2, (g0.t02 & 0xFFFFu) | (g1.t02 << 16));
+                    const us16x2 t2 = __builtin_bit_cast(us16x2, (g0.t02 >> 16) | (g1.t02 & 0xFFFF0000u));
+                    const us16x2 t1 = __builtin_bit_cast(us16x2, (g0.t11 & 0xFFFFu) | (g1.t11 & 0xFFFF0000u));
+                    const hf2 mnv = {__builtin_bit_cast(_Float16, mn0), __builtin_bit_cast(_Float16, mn1)};
+#pragma unroll
+                    for (int t = 0; t < G; t++) {
+                        const uint32_t xt = v[t];
+                        const us16x2 db = __builtin_bit_cast(us16x2, __builtin_bit_cast(hf2, xt) - mnv);
+                        const uint32_t cq = pk_lshr15(__builtin_bit_cast(uint32_t, t0 - db)) + pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db)) +
+                                            pk_lshr15(__builtin_bit_cast(uint32_t, t2 - db));
+                        W[t / TPR] |= cq << (BITS * (t % TPR));
+                    }
+                } else {
+                    constexpr int MAXQ = (1 << BITS) - 1;
+                    mn0 = (uint16_t)h_unkey(kmin2 & 0xFFFFu); mn1 = (uint16_t)h_unkey(kmin2 >> 16);
+                    const uint16_t r0 = f2h_bits(h2f_bits((uint16_t)h_unkey(kmax2 & 0xFFFFu)) - h2f_bits(mn0));
+                    const uint16_t r1 = f2h_bits(h2f_bits((uint16_t)h_unkey(kmax2 >> 16)) - h2f_bits(mn1));
+                    sc0 = f2h_bits(h2f_bits(r0) * (1.0f / (float)MAXQ));
+                    sc1 = f2h_bits(h2f_bits(r1) * (1.0f / (float)MAXQ));
+                    const float rc0 = 1.0f / h2f_bits(sc0), rc1 = 1.0f / h2f_bits(sc1);
+                    const hf2 mnv = {__builtin_bit_cast(_Float16, mn0), __builtin_bit_cast(_Float16, mn1)};
+                    const hf2 zero2 = {(_Float16)0.0f, (_Float16)0.0f}, maxq2 = {(_Float16)(float)MAXQ, (_Float16)(float)MAXQ};
+                    const hf2 magic = {(_Float16)1024.0f, (_Float16)1024.0f};
+#pragma unroll
+                    for (int t = 0; t < G; t++) {
+                        const uint32_t xt = v[t];
+                        const hf2 d = __builtin_bit_cast(hf2, xt) - mnv;
+                        hf2 q;
+                        q[0] = (_Float16)((float)d[0] * rc0);
+                        q[1] = (_Float16)((float)d[1] * rc1);
+                        const hf2 cl = __builtin_elementwise_min(__builtin_elementwise_max(q, zero2), maxq2);
+                        const uint32_t cb = __builtin_bit_cast(uint32_t, cl + magic) & (BITS == 4 ? 0x000F000Fu : 0x00FF00FFu);
+                        W[t / TPR] |= cb << (BITS * (t % TPR));
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const uint32_t a = W[2 * w] & livemask, bq = W[2 * w + 1] & livemask;
+                    codeL[dl * CP + gl * NW + w] = (a & 0xFFFFu) | (bq << 16);
+                    codeL[(dl + 1) * CP + gl * NW + w] = (a >> 16) | (bq & 0xFFFF0000u);
+                }
+                scaleL[dl * NG + gl] = sc0; scaleL[(dl + 1) * NG + gl] = sc1;
+                mnL[dl * NG + gl] = mn0; mnL[(dl + 1) * NG + gl] = mn1;
+            } else {
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 uint32_t kmin = 0xFFFFu, kmax = 0u;
@@ -409,6 +477,7 @@ __global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t*
                 }
                 scaleL[(dl + ch) * NG + gl] = gq.scale;
                 mnL[(dl + ch) * NG + gl] = gq.mn;
+            }
             }
         }
     }
@@ -635,9 +704,11 @@ extern "C" int kivi_quant_pack_k_tmajor(const void* k, int64_t k_sb, int64_t k_s
     if (fast && ngroups >= 8) {   // store-coalescing tile kernel (prefill-sized calls)
         const int64_t nchunks = (ngroups + 15) / 16;
         dim3 grid((unsigned)(nchunks * B * nh), (unsigned)((D + 127) / 128));
+        static const char* nopk_k = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math instantiation
 #define KIVI_KT_CASE(BITS, G)                                                                                   \
     if (bits == BITS && group_size == G) {                                                                      \
-        hipLaunchKernelGGL((quant_pack_k_tmajor_tiled<BITS, G>), grid, dim3(256), 0, s, KIVI_K_ARGS, nchunks);  \
+        if (nopk_k) hipLaunchKernelGGL((quant_pack_k_tmajor_tiled<BITS, G, false>), grid, dim3(256), 0, s, KIVI_K_ARGS, nchunks); \
+        else hipLaunchKernelGGL((quant_pack_k_tmajor_tiled<BITS, G, true>), grid, dim3(256), 0, s, KIVI_K_ARGS, nchunks);         \
         return kivi_launch_status("quant_pack_k_tmajor_tiled");                                                 \
     }
         KIVI_KT_CASE(2, 32) KIVI_KT_CASE(2, 64) KIVI_KT_CASE(4, 32) KIVI_KT_CASE(4, 64)
