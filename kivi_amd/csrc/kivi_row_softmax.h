@@ -33,7 +33,6 @@ struct RowSoftmaxArgs {
 template <int MODE>
 __global__ __launch_bounds__(256) void row_softmax_kernel(const RowSoftmaxArgs p) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    __shared__ float sm_lds[4];
     __shared__ uint16_t rs_lds[136];
     const int row = (MODE == 0) ? (int)blockIdx.x : (int)blockIdx.x / p.P;
     const int c = (MODE == 0) ? 0 : (int)blockIdx.x - row * p.P;
