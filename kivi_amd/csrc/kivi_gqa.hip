@@ -31,6 +31,10 @@ constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of
 // llama_kivi.py:436, and the flush of the fp16 residual every R tokens, :343-356).  Reference arithmetic through the
 // shared quantiser (kivi_quant.h = new_pack.py:236-241 op for op); group_size == 32 == the block.
 // One wave per block; lane l owns channels 2l, 2l+1 over the 32 tokens (min / max without any cross-lane step).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or(uint32_t v) {     // the value of the quad neighbour (quad_perm), for an OR across a quad
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
 __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
                                                      int64_t blk0, int nblk, int nh_kv) {
     const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
@@ -40,24 +44,17 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
     uint32_t x[32];
 #pragma unroll
     for (int t = 0; t < 32; t++) x[t] = *(const uint32_t*)(src + (int64_t)t * k_st);
-    uint32_t mn0 = 0xFFFFu, mx0 = 0u, mn1 = 0xFFFFu, mx1 = 0u;
-#pragma unroll
-    for (int t = 0; t < 32; t++) {
-        const uint32_t k0 = h_key(x[t] & 0xFFFFu), k1 = h_key(x[t] >> 16);
-        mn0 = k0 < mn0 ? k0 : mn0; mx0 = k0 > mx0 ? k0 : mx0;
-        mn1 = k1 < mn1 ? k1 : mn1; mx1 = k1 > mx1 ? k1 : mx1;
-    }
-    const GroupQ g0 = make_group(mn0, mx0, 3), g1 = make_group(mn1, mx1, 3);
+    // both channels of the lane at once on packed 16-bit math (kivi_quant.h): cq[t] = code(2l) | code(2l + 1) << 16
+    uint32_t cq[32], scale2, mn2;
+    pk16_pair_quant2<32>(x, cq, scale2, mn2);
     const int i = lane & 3;
+    const int p0 = mf_pos(0, i), p1 = mf_pos(1, i);
     uint32_t pw[16];
 #pragma unroll
     for (int n = 0; n < 16; n++) {
-        const uint32_t ce = quant_one<2>((uint16_t)(x[n] & 0xFFFFu), g0), co = quant_one<2>((uint16_t)(x[n] >> 16), g1);
-        const uint32_t ce2 = quant_one<2>((uint16_t)(x[n + 16] & 0xFFFFu), g0), co2 = quant_one<2>((uint16_t)(x[n + 16] >> 16), g1);
-        const int p0 = mf_pos(0, i), p1 = mf_pos(1, i);
-        uint32_t w = (ce << p0) | (co << (p0 + 16)) | (ce2 << p1) | (co2 << (p1 + 16));
-        w |= (uint32_t)__shfl_xor((int)w, 1);      // the 4 lanes of a quad hold the 4 channel pairs of one word
-        w |= (uint32_t)__shfl_xor((int)w, 2);
+        uint32_t w = (cq[n] << p0) | (cq[n + 16] << p1);     // tokens n (tile 0) and n + 16 (tile 1); even channel low half, odd high
+        w |= dpp_or<0xB1>(w);                                // the 4 lanes of a quad hold the 4 channel pairs of one word
+        w |= dpp_or<0x4E>(w);
         pw[n] = w;
     }
     const int c = lane >> 4, kb = (lane >> 2) & 3;
@@ -68,8 +65,8 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
     for (int n = 0; n < 16; n++)
         if ((n >> 2) == i) cw[(n + 16 * kb) * 4 + c] = pw[n];
     const int hidx = kb * 32 + c * 8 + 2 * i;    // kt_half of channel 2l (even): the pair (2l, 2l+1) is one word
-    (sb + KIVI_MF_SB_SCALE_WORD0 + (blk & 15) * 64)[hidx >> 1] = (uint32_t)g0.scale | ((uint32_t)g1.scale << 16);
-    (sb + KIVI_MF_SB_MN_WORD0 + (blk & 15) * 64)[hidx >> 1] = (uint32_t)g0.mn | ((uint32_t)g1.mn << 16);
+    (sb + KIVI_MF_SB_SCALE_WORD0 + (blk & 15) * 64)[hidx >> 1] = scale2;
+    (sb + KIVI_MF_SB_MN_WORD0 + (blk & 15) * 64)[hidx >> 1] = mn2;
 }
 
 // KT <-> reference layout K_code_T (B, nh_kv, D, T/16), K_scale_T / K_mn_T (B, nh_kv, D, T/32) (llama_kivi.py:454-455).

@@ -94,45 +94,10 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim_kernel(const uint16_t*
 //     group (make_group2), i.e. sign(T - bits(d)) by v_pk_sub_i16 + v_pk_lshrrev_b16; groups with scale inf or NaN
 //     get code 0 by a mask.
 // Bit-exact against the same fixtures as the kernel above (tests/test_pack_gpu.py).
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
-
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-// logical shift right by 15 of both halves (count in a register for both halves: see the key computation below)
-__device__ __forceinline__ uint32_t pk_lshr15(uint32_t v) {
-    uint32_t r;
-    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x000F000Fu), "v"(v));
-    return r;
-}
-// One group of the 2-bit packed-math kernel: mn / scale as make_group does (kivi_quant.h), the three decision thresholds as
-// fp16 bit patterns.  Two shortcuts, both checked exhaustively on the CPU (tests/test_oracle_golden.py):
-//   * scale = fp16(range / 3) = fp16(range * fp32(1/3)): range / 3 is never within 2^-13 (relative) of an fp16 rounding
-//     boundary, the product is within 2^-23 of the quotient;
-//   * tau_k * scale (a 12-bit odd factor times an 11-bit mantissa) is never an fp16 value, so "d > th" and "d >= th"
-//     are both  bits(d) > bits(RTZ(th))  for d >= +0: v_cvt_pkrtz_f16_f32 makes two thresholds per instruction.
-struct Group2 {
-    uint32_t t02, t11;   // (T0 | T2 << 16), (T1 | T1 << 16)
-    uint16_t mn, scale;
-    bool live;           // false: scale inf / NaN -> every code 0
-};
-__device__ __forceinline__ Group2 make_group2(uint32_t kmin, uint32_t kmax) {
-    Group2 g;
-    g.mn = (uint16_t)h_unkey(kmin);
-    const uint16_t mx = (uint16_t)h_unkey(kmax);
-    const uint16_t range = f2h_bits(h2f_bits(mx) - h2f_bits(g.mn));          // new_pack.py:238 (mx - mn)
-    g.scale = f2h_bits(h2f_bits(range) * 0.3333333432674408f);               //                 / max_int
-    const float fs0 = h2f_bits(g.scale);
-    g.live = fs0 >= 0.0f && fs0 < __builtin_inff();                          // inf / NaN: every code 0
-    const float fs = fs0 == 0.0f ? 0x1p-30f : fs0;                           // scale 0: d > 0 -> d / 0 = inf -> 3 (kivi_quant.h)
-    g.t02 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(0.500244140625f * fs, 2.5009765625f * fs));
-    g.t11 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(1.49951171875f * fs, 1.49951171875f * fs));
-    return g;
-}
-
 // Front end shared by the packed-math kernels: order-preserving keys of the 8 halves of a chunk (-0 < +0), their min / max,
 // then the lpg lanes of a group (aligned, power of two) meet through DPP inside a 16-lane row and shuffles beyond.
 __device__ __forceinline__ void pk16_group_minmax(const u32x4& v, int lpg, uint32_t& kmin, uint32_t& kmax) {
@@ -394,46 +359,35 @@ __global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t*
                 // d = x - mn, the threshold compares (2 bits) or the reciprocal quantiser (4 / 8 bits) and the word assembly
                 // run on both channels at once and nothing crosses lanes; the arithmetic of quant_pack_lastdim2_kernel /
                 // quant_pack_lastdimN_kernel (bit-exact, see there)
-                uint32_t kmin2 = 0xFFFFFFFFu, kmax2 = 0u;
-#pragma unroll
-                for (int t = 0; t < G; t++) {
-                    uint32_t sgn;
-                    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[t]));
-                    const uint32_t key = v[t] ^ (sgn | 0x80008000u);
-                    kmin2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, kmin2), __builtin_bit_cast(us16x2, key)));
-                    kmax2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us16x2, kmax2), __builtin_bit_cast(us16x2, key)));
-                }
                 constexpr int TPR = 16 / BITS;           // tokens per 16-bit half of an accumulation register
                 uint32_t W[G / TPR];
 #pragma unroll
                 for (int i = 0; i < G / TPR; i++) W[i] = 0u;
-                uint16_t sc0, sc1, mn0, mn1;
-                uint32_t livemask = 0xFFFFFFFFu;
+                uint32_t scale2, mn2;
                 if constexpr (BITS == 2) {
-                    const Group2 g0 = make_group2(kmin2 & 0xFFFFu, kmax2 & 0xFFFFu), g1 = make_group2(kmin2 >> 16, kmax2 >> 16);
-                    sc0 = g0.scale; sc1 = g1.scale; mn0 = g0.mn; mn1 = g1.mn;
-                    livemask = (g0.live ? 0x0000FFFFu : 0u) | (g1.live ? 0xFFFF0000u : 0u);
-                    const us16x2 t0 = __builtin_bit_cast(us16x2, (g0.t02 & 0xFFFFu) | (g1.t02 << 16));
-                    const us16x2 t2 = __builtin_bit_cast(us16x2, (g0.t02 >> 16) | (g1.t02 & 0xFFFF0000u));
-                    const us16x2 t1 = __builtin_bit_cast(us16x2, (g0.t11 & 0xFFFFu) | (g1.t11 & 0xFFFF0000u));
-                    const hf2 mnv = {__builtin_bit_cast(_Float16, mn0), __builtin_bit_cast(_Float16, mn1)};
+                    uint32_t cq[G];
+                    pk16_pair_quant2<G>(v, cq, scale2, mn2);
 #pragma unroll
-                    for (int t = 0; t < G; t++) {
-                        const uint32_t xt = v[t];
-                        const us16x2 db = __builtin_bit_cast(us16x2, __builtin_bit_cast(hf2, xt) - mnv);
-                        const uint32_t cq = pk_lshr15(__builtin_bit_cast(uint32_t, t0 - db)) + pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db)) +
-                                            pk_lshr15(__builtin_bit_cast(uint32_t, t2 - db));
-                        W[t / TPR] |= cq << (BITS * (t % TPR));
-                    }
+                    for (int t = 0; t < G; t++) W[t / TPR] |= cq[t] << (BITS * (t % TPR));
                 } else {
                     constexpr int MAXQ = (1 << BITS) - 1;
-                    mn0 = (uint16_t)h_unkey(kmin2 & 0xFFFFu); mn1 = (uint16_t)h_unkey(kmin2 >> 16);
+                    uint32_t kmin2 = 0xFFFFFFFFu, kmax2 = 0u;
+#pragma unroll
+                    for (int t = 0; t < G; t++) {
+                        uint32_t sgn;
+                        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[t]));
+                        const uint32_t key = v[t] ^ (sgn | 0x80008000u);
+                        kmin2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, kmin2), __builtin_bit_cast(us16x2, key)));
+                        kmax2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us16x2, kmax2), __builtin_bit_cast(us16x2, key)));
+                    }
+                    const uint16_t mn0 = (uint16_t)h_unkey(kmin2 & 0xFFFFu), mn1 = (uint16_t)h_unkey(kmin2 >> 16);
                     const uint16_t r0 = f2h_bits(h2f_bits((uint16_t)h_unkey(kmax2 & 0xFFFFu)) - h2f_bits(mn0));
                     const uint16_t r1 = f2h_bits(h2f_bits((uint16_t)h_unkey(kmax2 >> 16)) - h2f_bits(mn1));
-                    sc0 = f2h_bits(h2f_bits(r0) * (1.0f / (float)MAXQ));
-                    sc1 = f2h_bits(h2f_bits(r1) * (1.0f / (float)MAXQ));
+                    const uint16_t sc0 = f2h_bits(h2f_bits(r0) * (1.0f / (float)MAXQ)), sc1 = f2h_bits(h2f_bits(r1) * (1.0f / (float)MAXQ));
+                    scale2 = (uint32_t)sc0 | ((uint32_t)sc1 << 16);
+                    mn2 = (uint32_t)mn0 | ((uint32_t)mn1 << 16);
                     const float rc0 = 1.0f / h2f_bits(sc0), rc1 = 1.0f / h2f_bits(sc1);
-                    const hf2 mnv = {__builtin_bit_cast(_Float16, mn0), __builtin_bit_cast(_Float16, mn1)};
+                    const hf2 mnv = __builtin_bit_cast(hf2, mn2);
                     const hf2 zero2 = {(_Float16)0.0f, (_Float16)0.0f}, maxq2 = {(_Float16)(float)MAXQ, (_Float16)(float)MAXQ};
                     const hf2 magic = {(_Float16)1024.0f, (_Float16)1024.0f};
 #pragma unroll
@@ -450,12 +404,12 @@ __global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t*
                 }
 #pragma unroll
                 for (int w = 0; w < NW; w++) {
-                    const uint32_t a = W[2 * w] & livemask, bq = W[2 * w + 1] & livemask;
+                    const uint32_t a = W[2 * w], bq = W[2 * w + 1];
                     codeL[dl * CP + gl * NW + w] = (a & 0xFFFFu) | (bq << 16);
                     codeL[(dl + 1) * CP + gl * NW + w] = (a >> 16) | (bq & 0xFFFF0000u);
                 }
-                scaleL[dl * NG + gl] = sc0; scaleL[(dl + 1) * NG + gl] = sc1;
-                mnL[dl * NG + gl] = mn0; mnL[(dl + 1) * NG + gl] = mn1;
+                scaleL[dl * NG + gl] = (uint16_t)scale2; scaleL[(dl + 1) * NG + gl] = (uint16_t)(scale2 >> 16);
+                mnL[dl * NG + gl] = (uint16_t)mn2; mnL[(dl + 1) * NG + gl] = (uint16_t)(mn2 >> 16);
             } else {
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {

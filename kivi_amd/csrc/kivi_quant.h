@@ -61,3 +61,69 @@ __device__ __forceinline__ uint32_t quant_one(uint16_t x, const GroupQ& g) {
     return (uint32_t)__builtin_rintf(fq);                         //      round_ (half to even), to(int32)
 }
 
+// ---- packed 16-bit forms (round 2): two fp16 values per register through the same arithmetic (kivi_pack.hip has the derivation)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+
+// logical shift right by 15 of both halves (count in a register for both halves: see the key computation below)
+__device__ __forceinline__ uint32_t pk_lshr15(uint32_t v) {
+    uint32_t r;
+    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x000F000Fu), "v"(v));
+    return r;
+}
+// One group of the 2-bit packed-math kernel: mn / scale as make_group does (kivi_quant.h), the three decision thresholds as
+// fp16 bit patterns.  Two shortcuts, both checked exhaustively on the CPU (tests/test_oracle_golden.py):
+//   * scale = fp16(range / 3) = fp16(range * fp32(1/3)): range / 3 is never within 2^-13 (relative) of an fp16 rounding
+//     boundary, the product is within 2^-23 of the quotient;
+//   * tau_k * scale (a 12-bit odd factor times an 11-bit mantissa) is never an fp16 value, so "d > th" and "d >= th"
+//     are both  bits(d) > bits(RTZ(th))  for d >= +0: v_cvt_pkrtz_f16_f32 makes two thresholds per instruction.
+struct Group2 {
+    uint32_t t02, t11;   // (T0 | T2 << 16), (T1 | T1 << 16)
+    uint16_t mn, scale;
+    bool live;           // false: scale inf / NaN -> every code 0
+};
+__device__ __forceinline__ Group2 make_group2(uint32_t kmin, uint32_t kmax) {
+    Group2 g;
+    g.mn = (uint16_t)h_unkey(kmin);
+    const uint16_t mx = (uint16_t)h_unkey(kmax);
+    const uint16_t range = f2h_bits(h2f_bits(mx) - h2f_bits(g.mn));          // new_pack.py:238 (mx - mn)
+    g.scale = f2h_bits(h2f_bits(range) * 0.3333333432674408f);               //                 / max_int
+    const float fs0 = h2f_bits(g.scale);
+    g.live = fs0 >= 0.0f && fs0 < __builtin_inff();                          // inf / NaN: every code 0
+    const float fs = fs0 == 0.0f ? 0x1p-30f : fs0;                           // scale 0: d > 0 -> d / 0 = inf -> 3 (kivi_quant.h)
+    g.t02 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(0.500244140625f * fs, 2.5009765625f * fs));
+    g.t11 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(1.49951171875f * fs, 1.49951171875f * fs));
+    return g;
+}
+
+
+// The 2-bit codes of the TWO channels (or rows) a lane holds in the halves of x[0..N): min / max, groups and threshold
+// compares on both halves at once.  cq[t] = code of the low half | code of the high half << 16; scale2 / mn2 likewise.
+template <int N>
+__device__ __forceinline__ void pk16_pair_quant2(const uint32_t* x, uint32_t* cq, uint32_t& scale2, uint32_t& mn2) {
+    uint32_t kmin2 = 0xFFFFFFFFu, kmax2 = 0u;
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        uint32_t sgn;
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(x[t]));   // shift count in BOTH halves
+        const uint32_t key = x[t] ^ (sgn | 0x80008000u);                                  // order-preserving, -0 < +0
+        kmin2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, kmin2), __builtin_bit_cast(us16x2, key)));
+        kmax2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us16x2, kmax2), __builtin_bit_cast(us16x2, key)));
+    }
+    const Group2 g0 = make_group2(kmin2 & 0xFFFFu, kmax2 & 0xFFFFu), g1 = make_group2(kmin2 >> 16, kmax2 >> 16);
+    scale2 = (uint32_t)g0.scale | ((uint32_t)g1.scale << 16);
+    mn2 = (uint32_t)g0.mn | ((uint32_t)g1.mn << 16);
+    const uint32_t live = (g0.live ? 0x00000003u : 0u) | (g1.live ? 0x00030000u : 0u);   // scale inf / NaN: code 0
+    const us16x2 t0 = __builtin_bit_cast(us16x2, (g0.t02 & 0xFFFFu) | (g1.t02 << 16));
+    const us16x2 t2 = __builtin_bit_cast(us16x2, (g0.t02 >> 16) | (g1.t02 & 0xFFFF0000u));
+    const us16x2 t1 = __builtin_bit_cast(us16x2, (g0.t11 & 0xFFFFu) | (g1.t11 & 0xFFFF0000u));
+    const hf2 mnv = __builtin_bit_cast(hf2, mn2);
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        const uint32_t xt = x[t];
+        const us16x2 db = __builtin_bit_cast(us16x2, __builtin_bit_cast(hf2, xt) - mnv);
+        cq[t] = (pk_lshr15(__builtin_bit_cast(uint32_t, t0 - db)) + pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db)) +
+                 pk_lshr15(__builtin_bit_cast(uint32_t, t2 - db))) & live;
+    }
+}
