@@ -244,6 +244,9 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  * kivi_kt_pack: per-channel K quantise + pack of whole 32-token blocks (T % 32 == 0) from un-transposed keys
  *   k[b, h, t, :] = k + b*k_sb + h*k_sh + t*k_st straight into the layout at token_offset (prompt pass
  *   models/llama_kivi.py:436, residual flush :343-356); bit-identical to kivi_quant_pack_k_tmajor + relayout.
+ * kivi_vt_pack: per-token V quantise + pack of tokens [0, T) of a prompt (any T; 16-byte aligned rows) into the VT
+ *   layout at token 0 -- triton_quantize_and_pack_along_last_dim (new_pack.py:217-252) as llama_kivi.py:441-448 applies
+ *   it to value_states[:, :, :-R], without the intermediate hook-state tensors.
  * kivi_kt_relayout / kivi_vt_relayout: to_ref != 0 writes tokens [0, T) of the hook-state tensors
  *   (K_code_T (B,nh_kv,D,T/16) / V_code (B,nh_kv,T,D/16) + scale, mn) from the layout, to_ref == 0 the reverse.
  * kivi_gqa_scores: out[b, h, :T] = packed qK^T (the arithmetic of kivi_gemv_k: fp32 accumulate, one fp16 rounding; the
@@ -252,6 +255,8 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
 int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* kt, int64_t kt_sb, int64_t kt_sh,
                  int64_t kt_ss, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
                  kivi_stream_t stream);
+int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v_st, void* vt, int64_t vt_sb, int64_t vt_sh,
+                 int64_t vt_ss, int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
 int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* code, int64_t code_sb,
                      int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
                      int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);

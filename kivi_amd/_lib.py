@@ -110,6 +110,7 @@ SIGNATURES = {
     "kivi_decode_layer": (_i32, [ctypes.POINTER(LayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
                                  _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "kivi_kt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_vt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "kivi_kt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                 _i64, _i32, _i32, _i32, _vp]),
     "kivi_vt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,

@@ -160,8 +160,12 @@ class KiviLayerCacheMF:
             self.k_res[:, :, : self.k_res_len].copy_(key_states[:, :, nq:])
         nv = max(T - R, 0)
         if nv:
-            code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(value_states[:, :, :nv].contiguous(), g, cfg.v_bits)
-            mfma.vt_from_ref(self.vt, code, scale, mn, g, cfg.v_bits)
+            vq = value_states[:, :, :nv]
+            if vq.stride(3) == 1 and vq.data_ptr() % 16 == 0 and all(st % 8 == 0 for st in vq.stride()[:3]):
+                mfma.vt_pack(vq, self.vt, g, cfg.v_bits)           # one pass, straight into the layout
+            else:                                                   # odd strides: through the hook-state tensors
+                code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(vq.contiguous(), g, cfg.v_bits)
+                mfma.vt_from_ref(self.vt, code, scale, mn, g, cfg.v_bits)
         self.v_quant_len = nv
         self.v_res_start = 0
         self.v_res_len = T - nv

@@ -69,6 +69,53 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
     (sb + KIVI_MF_SB_MN_WORD0 + (blk & 15) * 64)[hidx >> 1] = mn2;
 }
 
+// Per-token V quantise + pack of a prompt straight into the VT layout (prompt pass, models/llama_kivi.py:441-448: the
+// reference quantises value_states[:, :, :-R] along the channel axis, new_pack.py:217-252); replaces the last-dim pack
+// into hook-state tensors followed by kivi_vt_relayout (two passes, the second one all bit moves).
+// One wave per 32-token block.  Lane (kb, c, ee) = 16 kb + 4 c + ee owns the token PAIR (8 kb + 2 ee, + 1) of channel
+// group c: even token in the low halves, odd token in the high halves of x[j], j = channel inside the group -- exactly
+// the VT word's halves -- so the pair quantiser (kivi_quant.h) gives both groups at once, the 4 lanes of a quad (ee)
+// complete a word with two DPP ORs, and the lane index is the index of the pair's scale / zero-point word.  Tokens at
+// or past T read as zeros (constant group: scale 0, zero point 0, codes 0 = never-written storage).
+__global__ __launch_bounds__(64) void vt_pack_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
+                                                     int64_t T, int nblk, int nh_kv) {
+    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+    const int b = unit / nh_kv, hk = unit - b * nh_kv;
+    const int lane = threadIdx.x;
+    const int kb = lane >> 4, c = (lane >> 2) & 3, ee = lane & 3;
+    const int64_t t0 = (int64_t)bi * 32 + 8 * kb + 2 * ee;
+    const uint16_t* src = v + b * v_sb + hk * v_sh + t0 * v_st + 32 * c;
+    u32x4 ra[4], rb[4];                                   // 32 channels of the even / odd token
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ra[i] = (t0 < T) ? *(const u32x4*)(src + 8 * i) : u32x4{0, 0, 0, 0};
+        rb[i] = (t0 + 1 < T) ? *(const u32x4*)(src + v_st + 8 * i) : u32x4{0, 0, 0, 0};
+    }
+    uint32_t x[32];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t a = ra[i][k], bq = rb[i][k];   // channels 8 i + 2 k, + 1
+            x[8 * i + 2 * k] = __builtin_amdgcn_perm(bq, a, 0x05040100u);       // (a.lo, b.lo)
+            x[8 * i + 2 * k + 1] = __builtin_amdgcn_perm(bq, a, 0x07060302u);   // (a.hi, b.hi)
+        }
+    uint32_t cq[32], scale2, mn2;
+    pk16_pair_quant2<32>(x, cq, scale2, mn2);
+    const int p0 = mf_pos(0, ee), p1 = mf_pos(1, ee);
+    uint32_t* sb = mf_sb(st, b, hk, bi >> 4);
+    uint32_t* cw = sb + (bi & 15) * KIVI_MF_BLOCK_WORDS;
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        uint32_t w = (cq[n] << p0) | (cq[n + 16] << p1);   // channels n (tile 0) and 16 + n (tile 1) of the group
+        w |= dpp_or<0xB1>(w);
+        w |= dpp_or<0x4E>(w);
+        if ((n >> 2) == ee) cw[(n + 16 * kb) * 4 + c] = w;
+    }
+    (sb + KIVI_MF_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;    // vt_half(8 kb + 2 ee, c) / 2 == lane
+    (sb + KIVI_MF_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
+}
+
 // KT <-> reference layout K_code_T (B, nh_kv, D, T/16), K_scale_T / K_mn_T (B, nh_kv, D, T/32) (llama_kivi.py:454-455).
 // Pure bit moves; one 128-thread block per 32-token block (thread = channel).
 template <bool TO_REF>
@@ -976,6 +1023,21 @@ extern "C" int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     hipLaunchKernelGGL(kt_pack_kernel, dim3((unsigned)((int64_t)B * nh_kv * nblk)), dim3(64), 0, (hipStream_t)stream,
                        (const uint16_t*)k, k_sb, k_sh, k_st, st, token_offset / 32, nblk, nh_kv);
     return kivi_launch_status("kt_pack");
+}
+
+extern "C" int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v_st, void* vt, int64_t vt_sb, int64_t vt_sh,
+                            int64_t vt_ss, int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream) {
+    KIVI_MF_SHAPE_CHECK("kivi_vt_pack");
+    KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_vt_pack: negative length");
+    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss), KIVI_EALIGN, "kivi_vt_pack: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(v && (uintptr_t)v % 16 == 0 && v_sb % 8 == 0 && v_sh % 8 == 0 && v_st % 8 == 0, KIVI_EALIGN,
+                 "kivi_vt_pack: value rows must be 16-byte aligned");
+    if (T == 0) return 0;
+    const int nblk = (int)((T + 31) / 32);
+    const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
+    hipLaunchKernelGGL(vt_pack_kernel, dim3((unsigned)((int64_t)B * nh_kv * nblk)), dim3(64), 0, (hipStream_t)stream,
+                       (const uint16_t*)v, v_sb, v_sh, v_st, st, T, nblk, nh_kv);
+    return kivi_launch_status("vt_pack");
 }
 
 extern "C" int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* code,

@@ -42,6 +42,16 @@ def kt_pack(k: torch.Tensor, store: torch.Tensor, token_offset: int = 0, group_s
                                 group_size, bits, _lib.stream_ptr(k)), "kivi_kt_pack")
 
 
+def vt_pack(v: torch.Tensor, store: torch.Tensor, group_size: int = 32, bits: int = 2) -> None:
+    """v (B, nh_kv, T, 128) fp16, any T -> quantised per token (groups along the channel axis) into `store` from token 0:
+    the prompt-pass V quantisation (llama_kivi.py:441-448) without the intermediate hook-state tensors."""
+    _lib.require_gpu(v, "v")
+    B, nh_kv, T, D = v.shape
+    assert v.dtype == torch.float16 and v.stride(3) == 1 and T <= store.shape[2] * SB_TOKENS
+    _lib.check(_lib.load().kivi_vt_pack(_lib.ptr(v), v.stride(0), v.stride(1), v.stride(2), *_st(store), B, nh_kv, T, D,
+                                        group_size, bits, _lib.stream_ptr(v)), "kivi_vt_pack")
+
+
 def _relayout(fn, name, to_ref, store, code, scale, mn, T, D, group_size, bits):
     B, nh_kv = store.shape[0], store.shape[1]
     assert code.dtype == torch.int32 and scale.dtype == mn.dtype == torch.float16

@@ -37,6 +37,34 @@ def test_kt_pack_equals_reference_pack(mods, oracle, B, nh_kv, T, off, kind):
     assert torch.equal(store2, store)
 
 
+@pytest.mark.parametrize("B,nh_kv,T,kind", [(1, 1, 1, "randn"), (2, 2, 33, "outlier"), (1, 3, 512, "randn"), (2, 1, 1000, "outlier"),
+                                             (1, 2, 75, "tiny_rows"), (3, 8, 2049, "randn")])
+def test_vt_pack_equals_reference_pack(mods, oracle, B, nh_kv, T, kind):
+    """kivi_vt_pack (per-token V quantise straight into the VT layout, llama_kivi.py:441-448) == the last-dim pack
+    (bit-exact vs the reference through the golden fixtures) followed by kivi_vt_relayout, word for word, for whole and
+    ragged 32-token blocks; and == the oracle after the reverse relayout.  Also through a strided view (the prompt's
+    value_states[:, :, :-R])."""
+    mfma, new_pack, _ = mods
+    if kind == "tiny_rows":      # one-ulp ranges along the channel axis (V groups): scale 0 with the max code
+        v = make_kv(9, B, nh_kv, 128, T, "tiny").transpose(2, 3).contiguous().cuda()
+    else:
+        v = make_kv(9, B, nh_kv, T, 128, kind).cuda()
+    nsb = (T + 511) // 512
+    a, b_ = mfma.alloc_store(B, nh_kv, nsb, "cuda"), mfma.alloc_store(B, nh_kv, nsb, "cuda")
+    mfma.vt_pack(v, a)
+    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(v, 32, 2)
+    mfma.vt_from_ref(b_, code, scale, mn)
+    assert torch.equal(a, b_)
+    oc, os_, om = oracle.quantize_and_pack_along_last_dim(v.cpu(), 32, 2)
+    c2, s2, m2 = mfma.vt_to_ref(a, T)
+    assert same_bits(c2, oc) and same_bits(s2, os_) and same_bits(m2, om)
+    big = torch.zeros((B, nh_kv, T + 40, 128), dtype=torch.float16, device="cuda")
+    big[:, :, :T] = v
+    c = mfma.alloc_store(B, nh_kv, nsb, "cuda")
+    mfma.vt_pack(big[:, :, :T], c)                       # strided view: rows of the longer tensor
+    assert torch.equal(c, a)
+
+
 @pytest.mark.parametrize("B,nh_kv,T", [(1, 1, 1), (2, 2, 33), (1, 3, 512), (2, 1, 1000)])
 def test_vt_relayout_round_trip(mods, B, nh_kv, T):
     mfma, new_pack, _ = mods

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Prefill of the matrix-pipe cache layout at the config-4 shape (B=64, 8 kv heads, 8192 tokens, D=128 = 1 GiB of K and of V):
-kivi_kt_pack (per-channel K quantise straight into the KT layout), the last-dim V pack and its relayout into VT."""
+kivi_kt_pack / kivi_vt_pack (quantise straight into the KT / VT layouts), and the two-pass V route they replace (last-dim
+pack + relayout)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kivi_amd.quant import mfma, new_pack
@@ -24,6 +25,8 @@ n = k.numel()
 alg = n * 2 + n // 4 + n // 32 * 4
 t, _ = timed(lambda: mfma.kt_pack(k, store, 0))
 print(f"kt_pack            {t:8.1f} us  {alg / t / 1e6:.2f} TB/s algorithmic = {alg / t / 8e6:.3f}")
+t, _ = timed(lambda: mfma.vt_pack(k, store))
+print(f"vt_pack            {t:8.1f} us  {alg / t / 1e6:.2f} TB/s algorithmic = {alg / t / 8e6:.3f}")
 t, out = timed(lambda: new_pack.triton_quantize_and_pack_along_last_dim(k, 32, 2))
 print(f"V last-dim pack    {t:8.1f} us  {alg / t / 1e6:.2f} TB/s algorithmic = {alg / t / 8e6:.3f}")
 vc, vs, vm = out
