@@ -194,7 +194,9 @@ def test_packed_pack_kernel_shortcuts_are_exact():
     with np.errstate(over="ignore"):
         div = (r / np.float32(3.0)).astype(np.float16).view(np.uint16)
         mul = (r * np.float32(0.3333333432674408)).astype(np.float16).view(np.uint16)
+        mul_once = (r.astype(np.float64) * np.float64(np.float32(0.3333333432674408))).astype(np.float16).view(np.uint16)
     assert (div == mul).all()
+    assert (div == mul_once).all()      # the compiler may fuse the product and the rounding (v_fma_mixlo_f16: one rounding)
     s = b[1:0x7C00].view(np.float16).astype(np.float32)            # every positive finite scale
     dbits = np.arange(0, 0x7C01, dtype=np.int32)                   # every d >= +0 (incl. +inf)
     dval = dbits.astype(np.uint16).view(np.float16).astype(np.float32)
