@@ -318,7 +318,11 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             const int selv = (rvv && !strcmp(rvv, "w2u4")) ? 1 : 0;
             ak.tile_blocks = (G != 32 || selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
             const dim3 grid((unsigned)units);
-            if (G == 32 && rx && !strcmp(rx, "nw8ds4")) {          // eight waves: 2 tiles of 2048 tokens per pass, D over 4 waves
+            // Eight waves per row (2 tiles of 2048 tokens per pass, D over 4 waves): with fewer than ~1.75 four-wave blocks per
+            // CU the chip is under-occupied and the row's own waves are what hides latency -- 256 rows: 37.8 -> 32.5 us,
+            // 512 rows: equal, 768 rows: 65.9 vs 72.8 us (profiles/r02_row_nw8_small_batch.log); "d3" / "d2" force four waves
+            const bool few_rows = units < 448 && !(rx && (!strcmp(rx, "d3") || !strcmp(rx, "d2")));
+            if (G == 32 && ((rx && !strcmp(rx, "nw8ds4")) || few_rows)) {
                 ak.tile_blocks = (tiles + 1) / 2;
                 if (a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, true, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
                 else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, false, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
