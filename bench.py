@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="reference-style composition (one launch per reference op)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the K-GEMV launches with HIP events")
     ap.add_argument("--event-every", type=int, default=9, help="bracket the dominant kernel of every n-th layer step of the timed region")
+    ap.add_argument("--no-hook-kgemv", action="store_true", help="skip the hook-state-layout K-GEMV comparison line")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: a sleep per step (launcher / reduction / JSON plumbing on CPU, gloo)")
     args = ap.parse_args()
 
@@ -307,30 +308,35 @@ def main():
         if kev:
             us = [klib.kivi_event_elapsed_us(a, b) for a, b, _, _ in kev]
             timed = (klib.kivi_last_timed_kernel() or b"").decode()
-            row_fused = "decode_row_kernel" in timed and all(r is not None for _, _, _, r in kev)
+            row_fused = ("decode_row_kernel" in timed or "mf_row_kernel" in timed) and all(r is not None for _, _, _, r in kev)
+            kname = timed.split("<")[0].strip("( ")
             tot_bytes = sum((r if row_fused else n) for _, _, n, r in kev)
             avg_us = sum(us) / len(us)
             achieved = tot_bytes / (sum(us) * 1e-6) / 1e9
             traffic = None
             traffic_src = None
-            profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kgemv_pmc.json")))
+            profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
             if profs:           # HBM bytes per launch from the newest rocprofv3 --pmc passes of the same command (profiles/)
                 try:
                     pj = json.load(open(profs[-1]))
-                    traffic = pj.get("decode_row_hbm_bytes_per_launch") if row_fused else pj.get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/" + os.path.basename(profs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 correction)"
+                    ent = pj.get("kernels", {}).get(kname)
+                    if ent and ent.get("config") == {"B": B, "nh": nh, "nh_kv": nh_kv, "prompt": T0, "bits": bits, "group": g, "residual": R}:
+                        traffic = ent["hbm_bytes_per_launch"]
+                        traffic_src = ("profiles/" + os.path.basename(profs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                       "passes of this command, x2 gfx950 FETCH_SIZE correction; a tracked measurement, not collected in this run)")
                 except Exception:
                     traffic = None
             mf = getattr(layers[0], "layout", "hook") == "mfma"
-            if mf:
-                traffic, traffic_src = None, None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": ("decode_row_kernel (one launch per layer: packed qK^T of the row -> LDS scores -> residual "
-                               "scores + softmax + window + packed sV + cache update)" if row_fused
-                               else "gqa_k_kernel (grouped-query packed qK^T on the matrix pipe + residual scores + softmax "
-                                    "statistics; first of the two launches of a layer step)" if mf
-                               else "gemv_k_kernel (fused int2 qK^T over packed K)"), "launches": len(us),
+                    "kernel": kname, "kernel_role": (
+                        "one launch per layer: packed qK^T of the row on the matrix pipe -> LDS scores -> residual scores + softmax + "
+                        "window + packed sV + cache update" if "mf_row_kernel" in timed else
+                        "one launch per layer (VALU unpack): packed qK^T of the row -> LDS scores -> residual scores + softmax + window + "
+                        "packed sV + cache update" if row_fused else
+                        "packed qK^T on the matrix pipe + residual scores + softmax statistics; first of the two launches of a layer step"
+                        if mf else "fused int2 qK^T over packed K"),
+                    "launches": len(us),
                     "sampled": f"every {args.event_every}th layer step of the timed region (an event pair costs ~10 us of stream time)",
                     "avg_launch_us": round(avg_us, 2), "median_launch_us": round(sorted(us)[len(us) // 2], 2),
                     "min_launch_us": round(min(us), 2),
@@ -340,24 +346,53 @@ def main():
         # reads a different ~200 MiB cache, L x 200 MiB >> the 256 MiB Infinity Cache), every dispatch timed -- the
         # isolated single-layer K-GEMV number, without the decode loop's kernel alternation
         single = None
-        if roof is not None and layers[0].k_quant_len and hasattr(layers[0], "k_code"):
-            scratch = torch.empty((B, nh, 1, layers[0].k_quant_len), device=dev, dtype=torch.float16)
+        single_hook = None
+
+        def time_kgemv(launch, ncaches, nbytes, label):
+            """`launch(layer_index)` enqueues one qK^T launch with a pending event pair; 6 passes over the layer caches, the
+            first is warm-up."""
             ev1 = []
             for rep in range(6):
-                for lc in layers:
+                for i in range(ncaches):
                     pair = (klib.kivi_event_create(), klib.kivi_event_create())
                     klib.kivi_set_launch_events(*pair)
-                    matmul.gemv_k_paged(g, qs[0], lc.k_code, lc.k_scale, lc.k_mn, lc.k_quant_len, bits, out=scratch)
-                    if rep:          # first pass = warm-up
+                    launch(i)
+                    if rep:
                         ev1.append(pair)
             torch.cuda.synchronize()
             us1 = sorted(klib.kivi_event_elapsed_us(a, b) for a, b in ev1)
-            nbytes = kgemv_bytes(B, nh, nh_kv, D, layers[0].k_quant_len, g, bits)
             med = us1[len(us1) // 2]
-            single = {"workload": "BASELINE configs[1]: single-layer packed-K qK^T GEMV, back-to-back over the layer caches",
-                      "launches": len(us1), "median_launch_us": round(med, 2), "min_launch_us": round(us1[0], 2),
-                      "achieved": round(nbytes / (med * 1e-6) / 1e9, 1), "unit": "GB/s",
-                      "frac": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            return {"workload": label, "kernel": (klib.kivi_last_timed_kernel() or b"").decode().split("<")[0].strip("( "),
+                    "launches": len(us1), "median_launch_us": round(med, 2), "min_launch_us": round(us1[0], 2),
+                    "achieved": round(nbytes / (med * 1e-6) / 1e9, 1), "unit": "GB/s",
+                    "frac": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+        if roof is not None and layers[0].k_quant_len:
+            Tq = layers[0].k_quant_len
+            scratch = torch.empty((B, nh, 1, Tq + 8), device=dev, dtype=torch.float16)
+            nbytes = kgemv_bytes(B, nh, nh_kv, D, Tq, g, bits)
+            label = ("BASELINE configs[1]: single-layer packed-K qK^T GEMV, back-to-back over the layer caches "
+                     f"({L} x {nbytes / 2**20:.0f} MiB >> the 256 MiB Infinity Cache)")
+            if hasattr(layers[0], "k_code"):
+                single = time_kgemv(lambda i: matmul.gemv_k_paged(g, qs[0], layers[i].k_code, layers[i].k_scale, layers[i].k_mn,
+                                                                  Tq, bits, out=scratch[..., :Tq]), L, nbytes, label + ", hook-state layout")
+            else:
+                from kivi_amd.quant import mfma
+                single = time_kgemv(lambda i: mfma.gqa_scores(qs[0], layers[i].kt, Tq, scratch), L, nbytes,
+                                    label + ", matrix-pipe layout (raw fp16 scores to memory)")
+                if not args.no_hook_kgemv and nh == nh_kv:
+                    # the same GEMV on the reference's hook-state layout (K_code_T (B,nh,D,T/16): kivi_gemv_k, the VALU kernel
+                    # behind quant.matmul.cuda_bmm_fA_qB_outer): 12 caches of ~200 MiB, rotating
+                    from kivi_amd.quant import new_pack
+                    hk = []
+                    for _ in range(12):
+                        kk = torch.randn((B, nh_kv, Tq, D), device=dev, dtype=torch.float16)
+                        hk.append(new_pack.quantize_and_pack_k_tmajor(kk, g, bits))
+                        del kk
+                    single_hook = time_kgemv(lambda i: matmul.cuda_bmm_fA_qB_outer(g, qs[0], hk[i][0], hk[i][1], hk[i][2], bits), len(hk),
+                                             nbytes, "the same GEMV on the reference's hook-state layout (kivi_gemv_k behind "
+                                             "quant.matmul.cuda_bmm_fA_qB_outer, output allocated per call), 12 rotating caches")
+                    del hk
         # cost of one K flush per layer (the launch of kivi_quant_pack_k_tmajor over the R residual tokens), timed apart
         flush_us = None
         try:
@@ -379,7 +414,9 @@ def main():
         kv_bytes = sum(lc.nbytes() for lc in layers)
         fp16_bytes = 2 * L * B * nh_kv * layers[0].kv_seq_len * D * 2
         out = {
-            "metric": "decode-step tokens/sec (KIVI attention hot path, Llama-2-7B shape, B=32/GPU, seq=4k, 2b/2b g=32)",
+            "metric": ("decode-step tokens/sec (KIVI attention hot path, "
+                       + ("Llama-2-7B shape" if (nh, nh_kv, D, L) == (32, 32, 128, 32) else f"{nh}/{nh_kv} heads x {D}, {L} layers")
+                       + f", B={B}/GPU, seq={'4k' if T0 in (4080, 4096) else T0}, {bits}b/{bits}b g={g})"),
             "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "per_rank_ms_per_step": [round(x * 1e3 / args.steps, 4) for x in per_rank],
@@ -387,7 +424,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
-                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (MHA rows <= 8192 keys: 1 decode-row launch; nh / nh_kv in {4, 8}: 2 launches on the matrix-pipe layout; else qK^T + [row softmax] + sV; +1 K flush every R steps)",
+                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (2-bit g=32 D=128 on the matrix-pipe layout: nh == nh_kv and rows <= 8192 keys 1 launch, else 2; other shapes on the hook-state layout: 1 decode-row launch or qK^T + [row softmax] + sV; +1 K flush every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
                        "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)",
@@ -398,6 +435,7 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / args.steps, 4),
             "roofline": roof,
             "roofline_single_layer_kgemv": single,
+            "roofline_single_layer_kgemv_hook_layout": single_hook,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, nh, (T0 // R) * R, D, g, bits, L)   # the packed K prefix holds floor(T0 / R) * R tokens

@@ -232,7 +232,9 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
 /* ------------------------------------ grouped queries on the matrix pipe --- */
 
 /*
- * MFMA-friendly cache layout for grouped-query models (nh / nh_kv in {4, 8}; 2-bit, group_size 32, head_dim 128).
+ * MFMA-friendly cache layout (nh / nh_kv in {1, 4, 8}; 2-bit, group_size 32, head_dim 128): round 2 introduced it for
+ * grouped-query models, round 3 uses it for multi-head models too (the matrix pipe takes the per-code multiply-adds
+ * off the vector ALU, which is what bounds the hook-layout kernels).
  * Same codes, scales and zero points as the hook-state tensors above -- kivi_kt_relayout / kivi_vt_relayout convert
  * both ways bit for bit -- stored so that one masked code word IS a B-operand register of v_mfma_f32_16x16x32_f16
  * (kivi_amd/csrc/kivi_mfma_layout.h): per (batch row, kv head) a sequence of super-blocks of 512 tokens,
@@ -250,7 +252,12 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  * kivi_kt_relayout / kivi_vt_relayout: to_ref != 0 writes tokens [0, T) of the hook-state tensors
  *   (K_code_T (B,nh_kv,D,T/16) / V_code (B,nh_kv,T,D/16) + scale, mn) from the layout, to_ref == 0 the reverse.
  * kivi_gqa_scores: out[b, h, :T] = packed qK^T (the arithmetic of kivi_gemv_k: fp32 accumulate, one fp16 rounding; the
- *   q * scale products enter the matrix pipe as exact hi + lo fp16 pairs).
+ *   q * scale products enter the matrix pipe as exact hi + lo fp16 pairs).  = cuda_bmm_fA_qB_outer at llama_kivi.py:324.
+ * kivi_gqa_output (nh / nh_kv in {1, 4}): out[b, h, :128] = packed sV for given fp16 attention weights
+ *   probs[b, h, :T] = probs + b*p_sb + h*p_sh (rows 16-byte aligned, pitch >= T rounded up to 8) -- cuda_bmm_fA_qB_outer
+ *   at llama_kivi.py:382 on the VT layout: fp32 accumulate of exact products, one fp16 rounding.  `workspace`: 64 KiB of
+ *   arrival counters (zeroed once by the caller) + 4 * B * nh bytes (rounded up to 256) + B * nh_kv * slices * 2 *
+ *   (nh / nh_kv) * 128 floats, slices <= max(1, ceil(T / 512)).
  */
 int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* kt, int64_t kt_sb, int64_t kt_sh,
                  int64_t kt_ss, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
@@ -266,9 +273,14 @@ int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_sh, int64_t
 int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss,
                     void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
                     int bits, kivi_stream_t stream);
+int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss,
+                    void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
+                    int bits, void* workspace, int64_t workspace_bytes, kivi_stream_t stream);
 
 /*
- * kivi_gqa_decode: the whole decode step of one layer for grouped queries over the KT / VT layouts, two launches:
+ * kivi_gqa_decode: the whole decode step of one layer over the KT / VT layouts.  nh == nh_kv, rows of <= 8192 keys and
+ * >= 192 (batch row, head) rows: ONE launch (mf_row_kernel: packed qK^T -> LDS scores -> residual scores -> softmax ->
+ * window -> packed sV; `scores` / `stats` / `workspace` are not touched).  Otherwise two launches:
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies
  *      1/sqrt(D) and the mask (:339, :364-372), writes the scaled scores to `scores` and (max, sum exp) of every
  *      512-token segment to `stats`;
@@ -279,7 +291,14 @@ int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, i
  * `stats`: >= B * nh * (ceil(Tq / 512) + 4) * 2 floats.  `workspace`: 64 KiB of arrival counters (zeroed once by the
  * caller) followed by B * nh_kv * 2 * (slices + 1) * (nh / nh_kv) * 128 floats (1 <= slices <= max(1, ceil(Tv / 512));
  * + 1: the slot of the unit's window block).
+ * Bounds the step writes against: residual_length (k_res_len < residual_length: the K append goes to row k_res_len of
+ * kres), v_window_rows (v_win_start + v_res_len + 1 <= v_window_rows: the V append), vt_superblocks (Tv + 1 <= 512 *
+ * vt_superblocks when v_flush), kt_superblocks (Tq <= 512 * kt_superblocks).
+ * flags: KIVI_GQA_FORCE_SPLIT = the two-launch form even where the one-launch form applies, KIVI_GQA_FORCE_ROW = the
+ * one-launch form for any number of rows (nh == nh_kv, <= 8192 keys) -- tests and tuning.
  */
+#define KIVI_GQA_FORCE_SPLIT 1
+#define KIVI_GQA_FORCE_ROW 2
 typedef struct {
     int B, nh, nh_kv, D, group_size, bits;
     float inv_scale;
@@ -294,6 +313,8 @@ typedef struct {
     void* stats; int64_t stats_bytes;
     void* workspace; int64_t workspace_bytes;
     void* out; int64_t out_sb, out_sh;
+    int residual_length; int64_t v_window_rows, kt_superblocks, vt_superblocks;
+    int flags;
 } kivi_gqa_decode_args;
 int kivi_gqa_decode(const kivi_gqa_decode_args* args, kivi_stream_t stream);
 
@@ -328,6 +349,27 @@ typedef struct {
 int kivi_decode_layer(const kivi_layer_desc* layer, int64_t* state, const void* q, int64_t q_sb, int64_t q_sh, int nh,
                       const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb, int64_t vn_sh,
                       const void* mask, int64_t mask_sb, void* out, int64_t out_sb, int64_t out_sh, kivi_stream_t stream);
+
+/*
+ * The same for a cache in the KT / VT layouts (kivi_gqa_decode + bookkeeping + the K flush through kivi_kt_pack every
+ * residual_length steps + window compaction), same state array and the same atomicity contract.
+ */
+typedef struct {
+    int B, nh_kv, D, bits, group_size, residual_length;
+    float inv_scale;
+    int64_t cap, v_window_rows, s_pitch;               /* cap: tokens the stores can hold (512 * super-blocks) */
+    void* kt; int64_t kt_sb, kt_sh, kt_ss;
+    void* vt; int64_t vt_sb, vt_sh, vt_ss;
+    void* k_res; int64_t kr_sb, kr_sh, kr_st;          /* (B, nh_kv, R, D) fp16 */
+    void* v_res; int64_t vr_sb, vr_sh, vr_st;          /* (B, nh_kv, v_window_rows, D) fp16, contiguous */
+    void* scores; int64_t s_sb, s_sh;                  /* (B, nh, s_pitch) fp16 scratch rows */
+    void* stats; int64_t stats_bytes;
+    void* workspace; int64_t workspace_bytes;
+    int flags;                                         /* KIVI_GQA_FORCE_* */
+} kivi_mf_layer_desc;
+int kivi_mf_decode_layer(const kivi_mf_layer_desc* layer, int64_t* state, const void* q, int64_t q_sb, int64_t q_sh, int nh,
+                         const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb, int64_t vn_sh,
+                         const void* mask, int64_t mask_sb, void* out, int64_t out_sb, int64_t out_sh, kivi_stream_t stream);
 
 /* ------------------------------------------------- tuning / bench hooks --- */
 

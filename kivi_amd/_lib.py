@@ -79,6 +79,28 @@ class GqaDecodeArgs(ctypes.Structure):
         ("stats", _vp), ("stats_bytes", _i64),
         ("workspace", _vp), ("workspace_bytes", _i64),
         ("out", _vp), ("out_sb", _i64), ("out_sh", _i64),
+        ("residual_length", _i32), ("v_window_rows", _i64), ("kt_superblocks", _i64), ("vt_superblocks", _i64),
+        ("flags", _i32),
+    ]
+
+
+GQA_FORCE_SPLIT, GQA_FORCE_ROW = 1, 2
+
+
+class MfLayerDesc(ctypes.Structure):
+    """kivi_mf_layer_desc (include/kivi_hip.h), field for field."""
+    _fields_ = [
+        ("B", _i32), ("nh_kv", _i32), ("D", _i32), ("bits", _i32), ("group_size", _i32), ("residual_length", _i32),
+        ("inv_scale", ctypes.c_float),
+        ("cap", _i64), ("v_window_rows", _i64), ("s_pitch", _i64),
+        ("kt", _vp), ("kt_sb", _i64), ("kt_sh", _i64), ("kt_ss", _i64),
+        ("vt", _vp), ("vt_sb", _i64), ("vt_sh", _i64), ("vt_ss", _i64),
+        ("k_res", _vp), ("kr_sb", _i64), ("kr_sh", _i64), ("kr_st", _i64),
+        ("v_res", _vp), ("vr_sb", _i64), ("vr_sh", _i64), ("vr_st", _i64),
+        ("scores", _vp), ("s_sb", _i64), ("s_sh", _i64),
+        ("stats", _vp), ("stats_bytes", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64),
+        ("flags", _i32),
     ]
 
 
@@ -117,7 +139,11 @@ SIGNATURES = {
                                 _i64, _i32, _i32, _i32, _vp]),
     "kivi_gqa_scores": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
                                _i32, _vp]),
+    "kivi_gqa_output": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
+                               _i32, _vp, _i64, _vp]),
     "kivi_gqa_decode": (_i32, [ctypes.POINTER(GqaDecodeArgs), _vp]),
+    "kivi_mf_decode_layer": (_i32, [ctypes.POINTER(MfLayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
+                                    _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),

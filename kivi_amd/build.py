@@ -17,8 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkivi_hip.so")
 SOURCES = ["kivi_abi.hip", "kivi_pack.hip", "kivi_gemv_k.hip", "kivi_gemv_v.hip", "kivi_gemv_compat.hip",
-           "kivi_softmax.hip", "kivi_layer.hip", "kivi_gqa.hip"]
-HEADERS = [os.path.join(CSRC, "kivi_common.h"), os.path.join(CSRC, "kivi_quant.h"), os.path.join(CSRC, "kivi_gemv_k_dev.h"), os.path.join(CSRC, "kivi_gemv_v_dev.h"), os.path.join(CSRC, "kivi_row_softmax.h"), os.path.join(CSRC, "kivi_mfma_layout.h"), os.path.join(os.path.dirname(HERE), "include", "kivi_hip.h")]
+           "kivi_softmax.hip", "kivi_layer.hip", "kivi_gqa.hip", "kivi_mf.hip"]
+import glob
+
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "kivi_hip.h")]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -1,4 +1,5 @@
-"""Per-layer KIVI cache for grouped-query models in the matrix-pipe layout (kivi_amd/csrc/kivi_mfma_layout.h).
+"""Per-layer KIVI cache in the matrix-pipe layout (kivi_amd/csrc/kivi_mfma_layout.h): grouped-query models (round 2) and
+multi-head models (round 3).
 
 Same state machine and the same bits as KiviLayerCache (cache.py; reference contract models/llama_kivi.py:454-455, read
 back at :315-322; Mistral: models/mistral_kivi.py:381-385, :441-445): the 9-tuple members are reproduced bit for bit by
@@ -6,8 +7,10 @@ the relayout kernels.  What differs is where the packed codes live: super-blocks
 of v_mfma_f32_16x16x32_f16, so that the nh / nh_kv query heads of a kv head share every code on the matrix pipe instead of
 costing one FMA each (the shared-unpack VALU kernels run at ~0.35 of the HBM roofline for nh / nh_kv = 4).
 
-A decode step is two launches (kivi_gqa_decode): packed qK^T + residual scores + K append + softmax statistics, then
-softmax-on-the-fly + packed sV + fp16 window + V append / quantise; + one kivi_kt_pack every R steps (the K flush).
+A decode step is ONE library call (kivi_mf_decode_layer: lengths, window compaction, the launches, the K flush through
+kivi_kt_pack every R steps).  Launches: multi-head rows of <= 8192 keys -> one (mf_row_kernel); otherwise two (packed
+qK^T + residual scores + K append + softmax statistics, then softmax-on-the-fly + packed sV + fp16 window + V append /
+quantise).
 """
 from __future__ import annotations
 
@@ -22,12 +25,15 @@ from .cache import KiviCacheTuple, KiviConfig
 from .quant import mfma, new_pack
 
 SB = mfma.SB_TOKENS
-_SCRATCH = {}   # device -> dict(scores, stats, ws): shared by every layer on the device (launches are stream-ordered)
+_SCRATCH = {}   # (device, stream) -> dict(scores, stats, ws): shared by the layers that decode on that stream (launches are
+                # stream-ordered; two streams must not share score rows or arrival counters)
 _WS_COUNTER_BYTES = 65536
 
 
 def supported(cfg: KiviConfig, head_dim: int, num_heads: int, num_kv_heads: int) -> bool:
-    if os.environ.get("KIVI_NO_MFMA_LAYOUT"):     # tuning aid: keep grouped-query models on the hook-state layout
+    if os.environ.get("KIVI_NO_MFMA_LAYOUT"):     # tuning aid: keep every model on the hook-state layout
+        return False
+    if num_heads == num_kv_heads and os.environ.get("KIVI_NO_MFMA_MHA"):   # tuning aid (A/B): multi-head models on the hook-state layout
         return False
     return num_heads % num_kv_heads == 0 and mfma.supported(cfg.k_bits, cfg.v_bits, cfg.group_size, head_dim,
                                                             cfg.residual_length, num_heads // num_kv_heads) \
@@ -35,10 +41,12 @@ def supported(cfg: KiviConfig, head_dim: int, num_heads: int, num_kv_heads: int)
 
 
 def _scratch(device, B: int, nh: int, nh_kv: int, pitch: int, nseg: int, slices: int):
-    d = _SCRATCH.setdefault(device, {})
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    d = _SCRATCH.setdefault((str(device), stream), {})
     sc = d.get("scores")
     if sc is None or sc.shape[0] < B or sc.shape[1] < nh or sc.shape[3] < pitch:
-        sc = torch.empty((B, nh, 1, pitch), dtype=torch.float16, device=device)
+        shape = (B, nh, 1, pitch) if sc is None else (max(B, sc.shape[0]), max(nh, sc.shape[1]), 1, max(pitch, sc.shape[3]))
+        sc = torch.empty(shape, dtype=torch.float16, device=device)      # every dimension grows monotonically
         d["scores"] = sc
     st = d.get("stats")
     need = B * nh * nseg * 2
@@ -54,7 +62,7 @@ def _scratch(device, B: int, nh: int, nh_kv: int, pitch: int, nseg: int, slices:
 
 
 class KiviLayerCacheMF:
-    """One layer's quantised KV cache (capacity `max_len` tokens, appended in place) for nh / nh_kv in {4, 8}."""
+    """One layer's quantised KV cache (capacity `max_len` tokens, appended in place) for nh / nh_kv in {1, 4, 8}."""
 
     layout = "mfma"
 
@@ -62,7 +70,7 @@ class KiviLayerCacheMF:
                  dtype=torch.float16, num_heads: int = None):
         assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
         assert num_heads is not None and supported(cfg, head_dim, num_heads, num_kv_heads), \
-            "matrix-pipe layout: 2-bit, group 32, head_dim 128, nh / nh_kv in {4, 8}, residual_length <= 128"
+            "matrix-pipe layout: 2-bit, group 32, head_dim 128, nh / nh_kv in {1, 4, 8}, residual_length <= 128"
         self.cfg = cfg
         R = cfg.residual_length
         self.B, self.nh_kv, self.D, self.nh = batch, num_kv_heads, head_dim, num_heads
@@ -78,6 +86,8 @@ class KiviLayerCacheMF:
         self.v_res_start = 0
         self.v_res_len = 0
         self.kv_seq_len = 0
+        self._native = None       # (descriptor, state array, scratch tensors) of kivi_mf_decode_layer
+        self.flags = 0            # _lib.GQA_FORCE_SPLIT / GQA_FORCE_ROW (tests, tuning)
 
     # ------------------------------------------------------------------ capacity
     def reserve(self, max_len: int) -> None:
@@ -94,6 +104,7 @@ class KiviLayerCacheMF:
                 setattr(self, name, new)
             self.n_sb = n_sb
         self.cap = cap
+        self._native = None
 
     def ensure_room(self, tokens: int = 1) -> None:
         need = self.kv_seq_len + tokens
@@ -108,6 +119,7 @@ class KiviLayerCacheMF:
             dst = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device)
             dst.copy_(src)
             setattr(other, name, dst)
+        other._native = None
         return other
 
     # ------------------------------------------------------------------ the 9-tuple
@@ -151,6 +163,9 @@ class KiviLayerCacheMF:
         R, g = cfg.residual_length, cfg.group_size
         T = key_states.shape[2]
         self.reserve(T)
+        if self.kv_seq_len:        # reuse of the object: the V slots are filled token by token later, start from clean storage
+            self.kt.zero_()
+            self.vt.zero_()
         nq = (T // R) * R
         if nq:
             mfma.kt_pack(key_states[:, :, :nq], self.kt, 0, g, cfg.k_bits)
@@ -198,12 +213,35 @@ class KiviLayerCacheMF:
         return self
 
     # ------------------------------------------------------------------ decode step (llama_kivi.py:314-399)
+    def _desc(self, nh: int, device):
+        """kivi_mf_layer_desc of this cache (rebuilt when the stores were reallocated or the stream changed)."""
+        stream = torch.cuda.current_stream(device).cuda_stream
+        nat = self._native
+        if nat is not None and nat[2] == (nh, stream):
+            return nat
+        pitch = ((self.cap + 1 + 7) // 8) * 8
+        scores, stats, ws = _scratch(device, self.B, nh, self.nh_kv, pitch, self.n_sb + 4, self.n_sb)
+        kt, vt, kr, vr = self.kt, self.vt, self.k_res, self.v_res
+        d = _lib.MfLayerDesc(
+            B=self.B, nh_kv=self.nh_kv, D=self.D, bits=self.cfg.k_bits, group_size=self.cfg.group_size,
+            residual_length=self.cfg.residual_length, inv_scale=1.0 / math.sqrt(self.D),
+            cap=self.n_sb * SB, v_window_rows=vr.shape[2], s_pitch=scores.shape[3],
+            kt=kt.data_ptr(), kt_sb=kt.stride(0), kt_sh=kt.stride(1), kt_ss=kt.stride(2),
+            vt=vt.data_ptr(), vt_sb=vt.stride(0), vt_sh=vt.stride(1), vt_ss=vt.stride(2),
+            k_res=kr.data_ptr(), kr_sb=kr.stride(0), kr_sh=kr.stride(1), kr_st=kr.stride(2),
+            v_res=vr.data_ptr(), vr_sb=vr.stride(0), vr_sh=vr.stride(1), vr_st=vr.stride(2),
+            scores=scores.data_ptr(), s_sb=scores.stride(0), s_sh=scores.stride(1),
+            stats=stats.data_ptr(), stats_bytes=stats.numel() * 4,
+            workspace=ws.data_ptr(), workspace_bytes=ws.numel(), flags=self.flags)
+        state = (ctypes.c_int64 * 6)()
+        self._native = (d, state, (nh, stream), _lib.load().kivi_mf_decode_layer, (scores, stats, ws))
+        return self._native
+
     def decode_step(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
                     attention_mask: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
-        cfg = self.cfg
-        R = cfg.residual_length
         B, nh, _, D = query_states.shape
         assert nh == self.nh and B == self.B and D == self.D
+
         def rows16(x):   # 16-byte loads of whole rows: unit inner stride, 16-byte aligned rows
             ok = x.stride(3) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0
             return x if ok else x.contiguous()
@@ -215,48 +253,27 @@ class KiviLayerCacheMF:
                 raise ValueError(f"Attention mask should be of size {(B, 1, 1, kv_seq_len)}, but is {attention_mask.size()}")
             assert attention_mask.dtype == torch.float16 and attention_mask.stride(3) == 1
             mask_ptr, mask_sb = attention_mask.data_ptr(), attention_mask.stride(0)
-        if self.v_res_start + self.v_res_len + 1 > self.v_res.shape[2]:
-            self.compact_v_window()
         if out is None:
             out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=q.device)
-        pitch = ((self.cap + 1 + 7) // 8) * 8
-        nseg = (self.k_quant_len + SB - 1) // SB + 4
-        scores, stats, ws = _scratch(q.device, B, nh, self.nh_kv, pitch, max(nseg, self.n_sb + 4), self.n_sb)
-        flush = self.v_res_len + 1 > R
-        kt, vt, kr, vr = self.kt, self.vt, self.k_res, self.v_res
-        a = _lib.GqaDecodeArgs(
-            B=B, nh=nh, nh_kv=self.nh_kv, D=D, group_size=cfg.group_size, bits=cfg.k_bits, inv_scale=1.0 / math.sqrt(D),
-            q=q.data_ptr(), q_sb=q.stride(0), q_sh=q.stride(1), mask=mask_ptr, mask_sb=mask_sb,
-            kt=kt.data_ptr(), kt_sb=kt.stride(0), kt_sh=kt.stride(1), kt_ss=kt.stride(2), Tq=self.k_quant_len,
-            kres=kr.data_ptr(), kres_sb=kr.stride(0), kres_sh=kr.stride(1), kres_st=kr.stride(2),
-            knew=k.data_ptr(), knew_sb=k.stride(0), knew_sh=k.stride(1), k_res_len=self.k_res_len,
-            vt=vt.data_ptr(), vt_sb=vt.stride(0), vt_sh=vt.stride(1), vt_ss=vt.stride(2), Tv=self.v_quant_len,
-            vres=vr.data_ptr(), vres_sb=vr.stride(0), vres_sh=vr.stride(1), vres_st=vr.stride(2),
-            v_win_start=self.v_res_start, v_res_len=self.v_res_len,
-            vnew=v.data_ptr(), vnew_sb=v.stride(0), vnew_sh=v.stride(1), v_flush=int(flush),
-            scores=scores.data_ptr(), s_sb=scores.stride(0), s_sh=scores.stride(1),
-            stats=stats.data_ptr(), stats_bytes=stats.numel() * 4,
-            workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
-            out=out.data_ptr(), out_sb=out.stride(0), out_sh=out.stride(1))
+        else:
+            assert out.shape == (B, nh, 1, D) and out.dtype == torch.float16 and out.stride(3) == 1
+        d, state, _, fn, _ = self._desc(nh, q.device)
+        d.flags = self.flags
+        state[0], state[1], state[2] = self.k_quant_len, self.k_res_len, self.v_quant_len
+        state[3], state[4], state[5] = self.v_res_start, self.v_res_len, self.kv_seq_len
         hook = _launch_hook()
         if hook is not None and self.k_quant_len:
-            hook("pre", "k", dict(B=B, nh=nh, nh_kv=self.nh_kv, K=D, N=self.k_quant_len, bits=cfg.k_bits,
-                                  group_size=cfg.group_size, v_bits=cfg.v_bits, Tv=self.v_quant_len,
+            hook("pre", "k", dict(B=B, nh=nh, nh_kv=self.nh_kv, K=D, N=self.k_quant_len, bits=self.cfg.k_bits,
+                                  group_size=self.cfg.group_size, v_bits=self.cfg.v_bits, Tv=self.v_quant_len,
                                   k_res=self.k_res_len + 1, v_res=self.v_res_len + 1))
-        _lib.check(_lib.load().kivi_gqa_decode(ctypes.byref(a), _lib.stream_ptr(q)), "kivi_gqa_decode")
-        # committed: the launches appended the new key (:333-336) and value (:377) and, when the window was full,
-        # quantised the token leaving it (:386-399)
-        self.k_res_len += 1
-        self.v_res_len += 1
-        if flush:
-            self.v_quant_len += 1
-            self.v_res_start += 1
-            self.v_res_len -= 1
-        self.kv_seq_len = kv_seq_len
-        if self.k_res_len == R:              # :343-356
-            mfma.kt_pack(self.k_res, self.kt, self.k_quant_len, cfg.group_size, cfg.k_bits)
-            self.k_quant_len += R
-            self.k_res_len = 0
+        rc = fn(ctypes.byref(d), state, q.data_ptr(), q.stride(0), q.stride(1), nh, k.data_ptr(), k.stride(0), k.stride(1),
+                v.data_ptr(), v.stride(0), v.stride(1), mask_ptr, mask_sb, out.data_ptr(), out.stride(0), out.stride(1),
+                torch.cuda.current_stream(q.device).cuda_stream)
+        # the library writes `state` after every phase it has enqueued: read the lengths back whether or not the call succeeded
+        self.k_quant_len, self.k_res_len, self.v_quant_len = state[0], state[1], state[2]
+        self.v_res_start, self.v_res_len, self.kv_seq_len = state[3], state[4], state[5]
+        if rc:
+            _lib.check(rc, "kivi_mf_decode_layer")
         return out
 
 

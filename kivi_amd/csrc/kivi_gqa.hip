@@ -18,12 +18,12 @@
 #include "kivi_common.h"
 #include "kivi_gqa_dev.h"
 #include "kivi_quant.h"
+#include "kivi_gqa_roles.h"
 
 #include <type_traits>
 
 namespace {
 
-constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per unit)
 
 // ------------------------------------------------------------------------------------------------ pack / relayout
 
@@ -219,89 +219,6 @@ __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* 
 
 // ------------------------------------------------------------------------------------------------ qK^T
 
-struct GqaKArgs {
-    const uint16_t* q;
-    int64_t q_sb, q_sh;
-    MfStore kt;
-    uint16_t* out;              // score rows: raw fp16 scores (stats == null) or scaled + masked scores (decode step)
-    int64_t out_sb, out_sh;
-    int nh_kv, ratio, nh;
-    int64_t Tq;                 // packed tokens (multiple of 32)
-    int nsb, sb_blocks;         // super-blocks of a row, thread blocks per (b, kv head)
-    // decode step (kivi_gqa_decode): the epilogue applies 1/sqrt(D) + mask exactly as the reference feeds its softmax
-    // (llama_kivi.py:339, :364-372) and leaves (max, sum exp(x - max)) of every segment of the row in `stats`
-    float* stats;               // [B][nh][nseg][2] or null
-    int nseg;                   // nsb + KIVI_GQA_RES_SEGS
-    float inv_scale;
-    const uint16_t* mask;       // (B, 1, 1, n) additive fp16 mask or null
-    int64_t mask_sb;
-    // residual role (the FIRST res_blocks blocks of the grid): q . [fp16 K residual | new key] (:333-337) + the K append
-    int res_blocks;             // units * KIVI_GQA_RES_SEGS or 0
-    int res_first;              // residual blocks at the head (1) or at the tail (0) of the grid
-    uint16_t* kres;
-    int64_t kres_sb, kres_sh, kres_st;
-    const uint16_t* knew;
-    int64_t knew_sb, knew_sh;
-    int res_len;                // keys already in the residual; the new one becomes index res_len
-};
-
-// Residual role of the decode step: block (unit, j) scores keys [j c, (j + 1) c) of the residual (c = ceil(L / 4), L =
-// res_len + 1 incl. the new key) for the R query heads of the unit, 8 lanes per (head, key) with 16-byte loads, fp32
-// accumulate, one rounding (the reference's fp16 torch.matmul, llama_kivi.py:337), writes the scaled scores and the
-// statistics of its segment, and appends the new key (:333-336).  Short, latency-bound blocks: first in the grid.
-template <int R>
-__device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
-    constexpr int CH = 36;                                         // keys per segment: L <= 129 -> c <= 33
-    __shared__ float xs[R][CH];
-    const int unit = bid / KIVI_GQA_RES_SEGS, j = bid - unit * KIVI_GQA_RES_SEGS;
-    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
-    const int h0 = hk * a.ratio;
-    const int L = a.res_len + 1;
-    const int c = (L + KIVI_GQA_RES_SEGS - 1) / KIVI_GQA_RES_SEGS;
-    const int t0 = j * c;
-    const int nt = (t0 + c <= L ? c : L - t0) > 0 ? (t0 + c <= L ? c : L - t0) : 0;
-    const uint16_t* knew = a.knew + b * a.knew_sb + hk * a.knew_sh;
-    uint16_t* kres = a.kres + b * a.kres_sb + hk * a.kres_sh;
-    const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb : nullptr;
-    const int nthr = (int)blockDim.x;
-    for (int idx = threadIdx.x; idx < R * nt * 8; idx += nthr) {
-        const int sub = idx & 7, rt = idx >> 3;
-        const int r = rt / nt, t = t0 + (rt - r * nt);
-        const uint16_t* krow = ((t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew) + sub * 16;
-        const uint16_t* qrow = a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + sub * 16;
-        const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
-        const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
-        float sc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
-#pragma unroll
-        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
-        if (t == a.res_len && r == 0) {                             // append the new key
-            *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16) = k0;
-            *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16 + 8) = k1;
-        }
-        sc += __shfl_xor(sc, 1);
-        sc += __shfl_xor(sc, 2);
-        sc += __shfl_xor(sc, 4);
-        if (sub == 0) {
-            const uint16_t x = kivi_scaled_score(f2h_bits(sc), a.inv_scale, mrow != nullptr, mrow ? mrow[a.Tq + t] : 0);
-            a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.Tq + t] = x;
-            xs[r][t - t0] = h2f_bits(x);
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthr >> 6;
-    for (int r = wave; r < R; r += nw) {
-        const float v = lane < nt ? xs[r][lane] : -__builtin_inff();
-        const float m = wave_max(v);
-        const float l = wave_sum(lane < nt ? kivi_exp(v - m) : 0.f);
-        if (lane == 0) {
-            float* st = a.stats + (((int64_t)b * a.nh + h0 + r) * a.nseg + a.nsb + j) * 2;
-            st[0] = m;
-            st[1] = l;
-        }
-    }
-}
 
 // W waves per thread block, one super-block each; nothing is shared between the waves of a block.
 // RING = code blocks requested ahead of the one being multiplied (1 KiB per wave each).
@@ -513,126 +430,6 @@ int run_gqa_k(GqaKArgs& a, int units, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ sV (+ softmax, window)
 
-struct GqaVArgs {
-    const uint16_t* x;          // scaled + masked scores of the row (written by the qK^T launch)
-    int64_t x_sb, x_sh;
-    const float* stats;         // [B][nh][nseg][2]
-    int nseg;
-    MfStore vt;
-    int nh_kv, ratio, nh;
-    int64_t Tv;                 // packed tokens
-    int nsb;                    // super-blocks holding them
-    int S, spb;                 // stream blocks per (b, kv head), super-blocks per stream block
-    int units;                  // B * nh_kv
-    int win_blocks;             // 0: every stream block takes a share of the fp16 window; else (= units): one window block per
-                                // unit at the TAIL of the grid does the window, the V append and the flush
-    int nslot;                  // partial-sum slots per unit: S (+ 1 for the window block)
-    uint16_t* vres;             // (B, nh_kv, W, D) fp16 window buffer
-    int64_t vres_sb, vres_sh, vres_st;
-    int win_start, res_len;     // live rows [win_start, win_start + res_len); the new token goes right after
-    const uint16_t* vnew;
-    int64_t vnew_sb, vnew_sh;
-    int flush;                  // quantise the oldest window row into the layout at token Tv (llama_kivi.py:386-399)
-    uint16_t* out;
-    int64_t out_sb, out_sh;
-    float* ws;                  // [units][nslot][2][R * 128] fp32 partial sums of every block: quantised part, window part
-    int* counters;              // [units] arrival counters, zero between launches
-    unsigned long long* dbg;    // phase time stamps or null
-};
-
-// phase time stamps (kivi_debug_set_stamps; tools/gqa_phases.py): 16 slots per wave, DBG instantiations only
-template <bool DBG>
-__device__ __forceinline__ void gstamp(unsigned long long* dbg, int i) {
-    if constexpr (DBG) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i] = t;
-    }
-}
-
-template <int PAT>
-__device__ __forceinline__ uint32_t swz(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, PAT); }
-
-// softmax constants of the R rows of a unit from the segment statistics: M = max, 1 / sum exp(x - M).  Every lane of the
-// calling wave ends up with the same values.
-template <int R>
-__device__ __forceinline__ void gqa_row_consts(const GqaVArgs& a, int b, int h0, float* M, float* invS) {
-    const int lane = threadIdx.x & 63;
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    if (a.nseg <= 128) {
-        // all 2 R loads of the wave are requested before the first reduction: one memory round trip, not 2 R of them
-        f2 v0[R], v1[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const f2* st = reinterpret_cast<const f2*>(a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2);
-            v0[r] = lane < a.nseg ? st[lane] : f2{-__builtin_inff(), 0.f};
-            v1[r] = lane + 64 < a.nseg ? st[lane + 64] : f2{-__builtin_inff(), 0.f};
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const float m = wave_max(__builtin_fmaxf(v0[r][0], v1[r][0]));
-            const float l = wave_sum(v0[r][1] * kivi_exp(v0[r][0] - m) + v1[r][1] * kivi_exp(v1[r][0] - m));
-            M[r] = m;
-            invS[r] = 1.0f / l;
-        }
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const float* st = a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2;
-        float m = -__builtin_inff();
-        for (int i = lane; i < a.nseg; i += 64) m = __builtin_fmaxf(m, st[2 * i]);
-        m = wave_max(m);
-        float l = 0.f;
-        for (int i = lane; i < a.nseg; i += 64) l += st[2 * i + 1] * kivi_exp(st[2 * i] - m);
-        l = wave_sum(l);
-        M[r] = m;
-        invS[r] = 1.0f / l;
-    }
-}
-
-// Combine of a unit's partial sums by the block that arrives last (hand-off as in gemv_v_kernel<SPLIT>: write-through
-// payload, drained, one relaxed arrival counter; cdna_hip_programming.md G16).
-template <int R>
-__device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0) {
-    __shared__ int last_flag;
-    constexpr int RD = R * 128;
-    // part_lds = [quantised part | window part] of this block; workspace [unit][slot][2][RD]
-    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * a.nslot + slot) * 2 * RD);
-    for (int i = threadIdx.x; i < 2 * RD; i += 256)
-        __hip_atomic_store(dst + i, __builtin_bit_cast(uint32_t, part_lds[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (old == a.nslot - 1);
-        if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-        last_flag = last;
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * a.nslot * 2 * RD);
-    for (int i = threadIdx.x; i < RD; i += 256) {
-        const int r = i >> 7, d = i & 127;
-        float q = 0.f, w = 0.f;
-        for (int s0 = 0; s0 < a.nslot; s0 += 4) {   // 8 independent loads in flight, added in slot order
-            uint32_t v8[8];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                v8[2 * k] = (s0 + k < a.nslot) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                v8[2 * k + 1] = (s0 + k < a.nslot) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                q += __builtin_bit_cast(float, v8[2 * k]);
-                w += __builtin_bit_cast(float, v8[2 * k + 1]);
-            }
-        }
-        // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (llama_kivi.py:382-384);
-        // only the window part exists before anything is quantised (:380)
-        const uint16_t o = (a.Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(q)) + h2f_bits(f2h_bits(w))) : f2h_bits(w);
-        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
-    }
-}
 
 // Stream role: block (unit, slice) takes `spb` consecutive super-blocks of the unit's packed V, one per wave at a time.
 // DIAG (tools only, wrong results): 1 = the ring is never reloaded (no memory traffic in the loop), 2 = no MFMA / no
@@ -1080,12 +877,23 @@ extern "C" int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_
     return kivi_launch_status("vt_relayout");
 }
 
+// round-3 kernels for nh / nh_kv in {1, 4} (kivi_mf.hip); the argument blocks cross the translation-unit boundary as void*
+int kivi_mf_run_k(void* k_args, int units, hipStream_t s);
+int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s);
+int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int64_t T, int* sp, hipStream_t s);
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream_t s);
+
+static bool mf_new_path(int ratio) {
+    static const char* old = getenv("KIVI_MF_OLD");              // tuning aid (A/B): nh / nh_kv = 4 on the round-2 kernels
+    return ratio == 1 || (ratio == 4 && !(old && atoi(old)));
+}
+
 extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh,
                                int64_t kt_ss, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D,
                                int64_t T, int group_size, int bits, kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_gqa_scores");
-    KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
-                 "kivi_gqa_scores: nh / nh_kv must be 4 or 8 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
+                 "kivi_gqa_scores: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
     KIVI_REQUIRE(T >= 0 && T % 32 == 0, KIVI_EINVAL, "kivi_gqa_scores: T=%lld must be a multiple of 32", (long long)T);
     KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss), KIVI_EALIGN, "kivi_gqa_scores: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(q && (uintptr_t)q % 16 == 0 && q_sb % 8 == 0 && q_sh % 8 == 0, KIVI_EALIGN, "kivi_gqa_scores: q rows must be 16-byte aligned");
@@ -1102,7 +910,59 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.stats = nullptr; a.nseg = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
     a.res_blocks = 0; a.res_first = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
+    if (mf_new_path(a.ratio)) return kivi_mf_run_k(&a, B * nh_kv, (hipStream_t)stream);
     return run_gqa_k(a, B * nh_kv, (hipStream_t)stream);
+}
+
+// slices of the sV launch: ~1024 stream blocks (4 per CU) of 4 waves, a wave then streams 1-2 super-blocks (24 KiB each)
+static void gqa_v_slices(int units, int nsbv, int& S, int& spb) {
+    S = 1; spb = 0;
+    if (nsbv <= 0) return;
+    static const char* fs = getenv("KIVI_GQA_V_BLOCKS");         // tuning aid: target number of stream blocks
+    const int target = fs ? atoi(fs) : 1024;
+    S = (target + units - 1) / units;
+    S = S < 1 ? 1 : (S > nsbv ? nsbv : S);
+    spb = (nsbv + S - 1) / S;
+    S = (nsbv + spb - 1) / spb;
+}
+
+extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* vt, int64_t vt_sb, int64_t vt_sh,
+                               int64_t vt_ss, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D,
+                               int64_t T, int group_size, int bits, void* workspace, int64_t workspace_bytes,
+                               kivi_stream_t stream) {
+    KIVI_MF_SHAPE_CHECK("kivi_gqa_output");
+    KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4), KIVI_EUNSUPPORTED,
+                 "kivi_gqa_output: nh / nh_kv must be 1 or 4 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_gqa_output: negative length");
+    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss), KIVI_EALIGN, "kivi_gqa_output: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(probs && (uintptr_t)probs % 16 == 0 && p_sb % 8 == 0 && p_sh % 8 == 0 && p_sh >= ((T + 7) & ~(int64_t)7), KIVI_EALIGN,
+                 "kivi_gqa_output: probability rows must be 16-byte aligned and padded to a multiple of 8");
+    KIVI_REQUIRE(out != nullptr, KIVI_EINVAL, "kivi_gqa_output: null output");
+    const int R = nh / nh_kv, units = B * nh_kv;
+    KIVI_REQUIRE((int64_t)(R - 1) * p_sh * 2 + T * 2 + 16 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_output: rows too long");
+    KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_output: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
+    const int nsbv = (int)((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
+    KIVI_REQUIRE((int64_t)nsbv * vt_ss * 4 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_output: store too large for one descriptor");
+    int S, spb;
+    gqa_v_slices(units, nsbv, S, spb);
+    const int64_t sp_bytes = ((int64_t)B * nh * 4 + 255) / 256 * 256;
+    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + sp_bytes + (int64_t)units * S * 2 * R * 128 * 4;
+    KIVI_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && workspace_bytes >= need, KIVI_EINVAL,
+                 "kivi_gqa_output: workspace too small (%lld bytes needed)", (long long)need);
+    hipStream_t s = (hipStream_t)stream;
+    GqaVArgs v;
+    memset(&v, 0, sizeof(v));
+    v.x = (const uint16_t*)probs; v.x_sb = p_sb; v.x_sh = p_sh;
+    v.vt = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
+    v.nh_kv = nh_kv; v.ratio = R; v.nh = nh; v.Tv = T; v.nsb = nsbv; v.S = S; v.spb = spb;
+    v.units = units; v.win_blocks = 0; v.nslot = S;
+    v.out = (uint16_t*)out; v.out_sb = out_sb; v.out_sh = out_sh;
+    v.counters = (int*)workspace;
+    v.sp_rows = (const int*)((char*)workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
+    v.ws = (float*)((char*)workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4 + sp_bytes);
+    int rc = kivi_mf_run_row_sp(probs, p_sb, p_sh, B, nh, T, (int*)v.sp_rows, s);
+    if (rc) return rc;
+    return kivi_mf_run_v(&v, 1, s);
 }
 
 template <int R, bool HILO, int RING>
@@ -1153,8 +1013,8 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     const int B = p->B, nh = p->nh, nh_kv = p->nh_kv, D = p->D, group_size = p->group_size, bits = p->bits;
     const int64_t T = p->Tq > p->Tv ? p->Tq : p->Tv;
     KIVI_MF_SHAPE_CHECK("kivi_gqa_decode");
-    KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
-                 "kivi_gqa_decode: nh / nh_kv must be 4 or 8 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
+                 "kivi_gqa_decode: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
     const int R = nh / nh_kv;
     const int units = B * nh_kv;
     KIVI_REQUIRE(p->Tq >= 0 && p->Tq % 32 == 0 && p->Tv >= 0 && p->k_res_len >= 0 && p->k_res_len <= 128 && p->v_res_len >= 0 &&
@@ -1162,6 +1022,20 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
                  KIVI_EINVAL, "kivi_gqa_decode: inconsistent lengths (Tq=%lld k_res=%d Tv=%lld v_res=%d)", (long long)p->Tq,
                  p->k_res_len, (long long)p->Tv, p->v_res_len);
     const int64_t n = p->Tq + p->k_res_len + 1;
+    // what the step WRITES: the K append (row k_res_len of kres), the V append (row v_win_start + v_res_len of vres), the
+    // slot of the token leaving the window (token Tv of the VT store)
+    KIVI_REQUIRE(p->residual_length > 0 && p->residual_length <= 128 && p->k_res_len < p->residual_length &&
+                     p->v_res_len <= p->residual_length,
+                 KIVI_EINVAL, "kivi_gqa_decode: residual of %d keys / window of %d values do not fit residual_length %d",
+                 p->k_res_len, p->v_res_len, p->residual_length);
+    KIVI_REQUIRE(p->v_win_start >= 0 && (int64_t)p->v_win_start + p->v_res_len + 1 <= p->v_window_rows, KIVI_EINVAL,
+                 "kivi_gqa_decode: window rows [%d, %d] exceed the %lld rows of the buffer", p->v_win_start,
+                 p->v_win_start + p->v_res_len, (long long)p->v_window_rows);
+    KIVI_REQUIRE(p->Tq <= p->kt_superblocks * KIVI_MF_SB_TOKENS && p->Tv + (p->v_flush ? 1 : 0) <= p->vt_superblocks * KIVI_MF_SB_TOKENS,
+                 KIVI_EINVAL, "kivi_gqa_decode: Tq=%lld / Tv=%lld exceed the stores (%lld / %lld super-blocks)", (long long)p->Tq,
+                 (long long)p->Tv, (long long)p->kt_superblocks, (long long)p->vt_superblocks);
+    KIVI_REQUIRE(!p->v_flush || p->v_res_len == p->residual_length, KIVI_EINVAL,
+                 "kivi_gqa_decode: v_flush with a window of %d values (residual_length %d)", p->v_res_len, p->residual_length);
     KIVI_REQUIRE(mf_store_ok(p->kt, p->kt_sb, p->kt_sh, p->kt_ss) && mf_store_ok(p->vt, p->vt_sb, p->vt_sh, p->vt_ss), KIVI_EALIGN,
                  "kivi_gqa_decode: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(p->q && (uintptr_t)p->q % 16 == 0 && p->q_sb % 8 == 0 && p->q_sh % 8 == 0, KIVI_EALIGN,
@@ -1181,16 +1055,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE(p->stats && (uintptr_t)p->stats % 8 == 0 && p->stats_bytes >= (int64_t)B * nh * nseg * 2 * (int64_t)sizeof(float), KIVI_EINVAL,
                  "kivi_gqa_decode: statistics buffer too small (%lld bytes for %d segments)", (long long)p->stats_bytes, nseg);
     const int nsbv = (int)((p->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
-    int S = 1, spb = 0;
-    if (nsbv > 0) {
-        // ~1024 stream blocks (4 per CU) of 4 waves: a wave then streams 1-2 super-blocks (24 KiB each)
-        static const char* fs = getenv("KIVI_GQA_V_BLOCKS");     // tuning aid: target number of stream blocks
-        const int target = fs ? atoi(fs) : 1024;
-        S = (target + units - 1) / units;
-        S = S < 1 ? 1 : (S > nsbv ? nsbv : S);
-        spb = (nsbv + S - 1) / S;
-        S = (nsbv + spb - 1) / spb;
-    }
+    int S, spb;
+    gqa_v_slices(units, nsbv, S, spb);
+    KIVI_REQUIRE((int64_t)(nsbv > nsbk ? nsbv : nsbk) * (p->kt_ss > p->vt_ss ? p->kt_ss : p->vt_ss) * 4 < ((int64_t)1 << 32), KIVI_EINVAL,
+                 "kivi_gqa_decode: store too large for one descriptor");
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
     static const char* wt = getenv("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
     const int win_blocks = (nsbv > 0 && !(wt && atoi(wt) == 0)) ? units : 0;
@@ -1216,11 +1084,9 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     static const char* timev = getenv("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};
     if (timev) held = kivi_take_launch_events();
-    int rc = skipk ? 0 : run_gqa_k(k, units, s);
-    if (rc) return rc;
-    if (timev) kivi_set_launch_events(held.start, held.stop);
-
+    const bool newp = mf_new_path(R);
     GqaVArgs v;
+    memset(&v, 0, sizeof(v));
     v.x = (const uint16_t*)p->scores; v.x_sb = p->s_sb; v.x_sh = p->s_sh;
     v.stats = (const float*)p->stats; v.nseg = nseg;
     v.vt = {(uint32_t*)p->vt, p->vt_sb, p->vt_sh, p->vt_ss};
@@ -1233,6 +1099,18 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.dbg = kivi_debug_stamps();
     v.counters = (int*)p->workspace;
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
+    if (newp && R == 1 && n <= 8192) {
+        // MHA rows that fit the LDS: the whole step of a (batch row, head) in one launch
+        static const char* norow = getenv("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
+        const bool split = (p->flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow));
+        // fewer than 192 rows: the split two-launch form fills the chip better
+        if (!split && (units >= 192 || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, s);
+    }
+    int rc = skipk ? 0 : (newp ? kivi_mf_run_k(&k, units, s) : run_gqa_k(k, units, s));
+    if (rc) return rc;
+    if (timev) kivi_set_launch_events(held.start, held.stop);
+    if (newp) return kivi_mf_run_v(&v, 0, s);
+
     static const char* nohilo = getenv("KIVI_GQA_NO_HILO");
     static const char* fr = getenv("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 4 or 8)
     const int ring = fr ? atoi(fr) : (R == 4 ? 4 : 2);           // R = 8 spills at 4

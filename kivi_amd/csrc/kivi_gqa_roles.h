@@ -1,0 +1,293 @@
+// Roles shared by the matrix-pipe decode kernels (kivi_gqa.hip: round-2 bodies, kept for nh / nh_kv = 8; kivi_mf.hip:
+// round-3 bodies for nh / nh_kv in {1, 4}): argument blocks, the fp16 K-residual role of the qK^T launch, the softmax
+// constants of a row from its segment statistics, the hand-off of partial sums between the blocks of a unit.
+#pragma once
+#include "kivi_common.h"
+#include "kivi_gqa_dev.h"
+#include "kivi_quant.h"
+
+namespace {
+
+constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per unit)
+
+struct GqaKArgs {
+    const uint16_t* q;
+    int64_t q_sb, q_sh;
+    MfStore kt;
+    uint16_t* out;              // score rows: raw fp16 scores (stats == null) or scaled + masked scores (decode step)
+    int64_t out_sb, out_sh;
+    int nh_kv, ratio, nh;
+    int64_t Tq;                 // packed tokens (multiple of 32)
+    int nsb, sb_blocks;         // super-blocks of a row, thread blocks per (b, kv head)
+    // decode step (kivi_gqa_decode): the epilogue applies 1/sqrt(D) + mask exactly as the reference feeds its softmax
+    // (llama_kivi.py:339, :364-372) and leaves (max, sum exp(x - max)) of every segment of the row in `stats`
+    float* stats;               // [B][nh][nseg][2] or null
+    int nseg;                   // nsb + KIVI_GQA_RES_SEGS
+    float inv_scale;
+    const uint16_t* mask;       // (B, 1, 1, n) additive fp16 mask or null
+    int64_t mask_sb;
+    // residual role (the FIRST res_blocks blocks of the grid): q . [fp16 K residual | new key] (:333-337) + the K append
+    int res_blocks;             // units * KIVI_GQA_RES_SEGS or 0
+    int res_first;              // residual blocks at the head (1) or at the tail (0) of the grid
+    uint16_t* kres;
+    int64_t kres_sb, kres_sh, kres_st;
+    const uint16_t* knew;
+    int64_t knew_sb, knew_sh;
+    int res_len;                // keys already in the residual; the new one becomes index res_len
+};
+
+// Residual role of the decode step: block (unit, j) scores keys [j c, (j + 1) c) of the residual (c = ceil(L / 4), L =
+// res_len + 1 incl. the new key) for the R query heads of the unit, 8 lanes per (head, key) with 16-byte loads, fp32
+// accumulate, one rounding (the reference's fp16 torch.matmul, llama_kivi.py:337), writes the scaled scores and the
+// statistics of its segment, and appends the new key (:333-336).  Short, latency-bound blocks: first in the grid.
+template <int R>
+__device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
+    constexpr int CH = 36;                                         // keys per segment: L <= 129 -> c <= 33
+    __shared__ float xs[R][CH];
+    const int unit = bid / KIVI_GQA_RES_SEGS, j = bid - unit * KIVI_GQA_RES_SEGS;
+    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
+    const int h0 = hk * a.ratio;
+    const int L = a.res_len + 1;
+    const int c = (L + KIVI_GQA_RES_SEGS - 1) / KIVI_GQA_RES_SEGS;
+    const int t0 = j * c;
+    const int nt = (t0 + c <= L ? c : L - t0) > 0 ? (t0 + c <= L ? c : L - t0) : 0;
+    const uint16_t* knew = a.knew + b * a.knew_sb + hk * a.knew_sh;
+    uint16_t* kres = a.kres + b * a.kres_sb + hk * a.kres_sh;
+    const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb : nullptr;
+    const int nthr = (int)blockDim.x;
+    for (int idx = threadIdx.x; idx < R * nt * 8; idx += nthr) {
+        const int sub = idx & 7, rt = idx >> 3;
+        const int r = rt / nt, t = t0 + (rt - r * nt);
+        const uint16_t* krow = ((t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew) + sub * 16;
+        const uint16_t* qrow = a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + sub * 16;
+        const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
+        const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
+        float sc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
+        if (t == a.res_len && r == 0) {                             // append the new key
+            *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16) = k0;
+            *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16 + 8) = k1;
+        }
+        sc += __shfl_xor(sc, 1);
+        sc += __shfl_xor(sc, 2);
+        sc += __shfl_xor(sc, 4);
+        if (sub == 0) {
+            const uint16_t x = kivi_scaled_score(f2h_bits(sc), a.inv_scale, mrow != nullptr, mrow ? mrow[a.Tq + t] : 0);
+            a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.Tq + t] = x;
+            xs[r][t - t0] = h2f_bits(x);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthr >> 6;
+    for (int r = wave; r < R; r += nw) {
+        const float v = lane < nt ? xs[r][lane] : -__builtin_inff();
+        const float m = wave_max(v);
+        const float l = wave_sum(lane < nt ? kivi_exp(v - m) : 0.f);
+        if (lane == 0) {
+            float* st = a.stats + (((int64_t)b * a.nh + h0 + r) * a.nseg + a.nsb + j) * 2;
+            st[0] = m;
+            st[1] = l;
+        }
+    }
+}
+
+struct GqaVArgs {
+    const uint16_t* x;          // scaled + masked scores of the row (written by the qK^T launch)
+    int64_t x_sb, x_sh;
+    const float* stats;         // [B][nh][nseg][2]
+    int nseg;
+    MfStore vt;
+    int nh_kv, ratio, nh;
+    int64_t Tv;                 // packed tokens
+    int nsb;                    // super-blocks holding them
+    int S, spb;                 // stream blocks per (b, kv head), super-blocks per stream block
+    int units;                  // B * nh_kv
+    int win_blocks;             // 0: every stream block takes a share of the fp16 window; else (= units): one window block per
+                                // unit at the TAIL of the grid does the window, the V append and the flush
+    int nslot;                  // partial-sum slots per unit: S (+ 1 for the window block)
+    uint16_t* vres;             // (B, nh_kv, W, D) fp16 window buffer
+    int64_t vres_sb, vres_sh, vres_st;
+    int win_start, res_len;     // live rows [win_start, win_start + res_len); the new token goes right after
+    const uint16_t* vnew;
+    int64_t vnew_sb, vnew_sh;
+    int flush;                  // quantise the oldest window row into the layout at token Tv (llama_kivi.py:386-399)
+    uint16_t* out;
+    int64_t out_sb, out_sh;
+    float* ws;                  // [units][nslot][2][R * 128] fp32 partial sums of every block: quantised part, window part
+    int* counters;              // [units] arrival counters, zero between launches
+    unsigned long long* dbg;    // phase time stamps or null
+    const int* sp_rows;         // kivi_gqa_output: [B][nh] exponent Sp of every probability row (mf_row_sp_kernel)
+};
+
+// phase time stamps (kivi_debug_set_stamps; tools/gqa_phases.py): 16 slots per wave, DBG instantiations only
+template <bool DBG>
+__device__ __forceinline__ void gstamp(unsigned long long* dbg, int i) {
+    if constexpr (DBG) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i] = t;
+    }
+}
+
+template <int PAT>
+__device__ __forceinline__ uint32_t swz(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, PAT); }
+
+// softmax constants of the R rows of a unit from the segment statistics: M = max, 1 / sum exp(x - M).  Every lane of the
+// calling wave ends up with the same values.
+template <int R>
+__device__ __forceinline__ void gqa_row_consts(const GqaVArgs& a, int b, int h0, float* M, float* invS) {
+    const int lane = threadIdx.x & 63;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    if (a.nseg <= 128) {
+        // all 2 R loads of the wave are requested before the first reduction: one memory round trip, not 2 R of them
+        f2 v0[R], v1[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const f2* st = reinterpret_cast<const f2*>(a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2);
+            v0[r] = lane < a.nseg ? st[lane] : f2{-__builtin_inff(), 0.f};
+            v1[r] = lane + 64 < a.nseg ? st[lane + 64] : f2{-__builtin_inff(), 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float m = wave_max(__builtin_fmaxf(v0[r][0], v1[r][0]));
+            const float l = wave_sum(v0[r][1] * kivi_exp(v0[r][0] - m) + v1[r][1] * kivi_exp(v1[r][0] - m));
+            M[r] = m;
+            invS[r] = 1.0f / l;
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float* st = a.stats + ((int64_t)b * a.nh + h0 + r) * a.nseg * 2;
+        float m = -__builtin_inff();
+        for (int i = lane; i < a.nseg; i += 64) m = __builtin_fmaxf(m, st[2 * i]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int i = lane; i < a.nseg; i += 64) l += st[2 * i + 1] * kivi_exp(st[2 * i] - m);
+        l = wave_sum(l);
+        M[r] = m;
+        invS[r] = 1.0f / l;
+    }
+}
+
+// Combine of a unit's partial sums by the block that arrives last (hand-off as in gemv_v_kernel<SPLIT>: write-through
+// payload, drained, one relaxed arrival counter; cdna_hip_programming.md G16).
+template <int R>
+__device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0) {
+    __shared__ int last_flag;
+    constexpr int RD = R * 128;
+    // part_lds = [quantised part | window part] of this block; workspace [unit][slot][2][RD]
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * a.nslot + slot) * 2 * RD);
+    for (int i = threadIdx.x; i < 2 * RD; i += 256)
+        __hip_atomic_store(dst + i, __builtin_bit_cast(uint32_t, part_lds[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == a.nslot - 1);
+        if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * a.nslot * 2 * RD);
+    for (int i = threadIdx.x; i < RD; i += 256) {
+        const int r = i >> 7, d = i & 127;
+        float q = 0.f, w = 0.f;
+        for (int s0 = 0; s0 < a.nslot; s0 += 4) {   // 8 independent loads in flight, added in slot order
+            uint32_t v8[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v8[2 * k] = (s0 + k < a.nslot) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v8[2 * k + 1] = (s0 + k < a.nslot) ? __hip_atomic_load(p0 + (size_t)(s0 + k) * 2 * RD + RD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                q += __builtin_bit_cast(float, v8[2 * k]);
+                w += __builtin_bit_cast(float, v8[2 * k + 1]);
+            }
+        }
+        // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (llama_kivi.py:382-384);
+        // only the window part exists before anything is quantised (:380)
+        const uint16_t o = (a.Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(q)) + h2f_bits(f2h_bits(w))) : f2h_bits(w);
+        a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + d] = o;
+    }
+}
+
+// Window role of the sV launch: out_w[r][2 lane, 2 lane + 1] += probs[r, Tv + t] * V_window[t] for the window tokens
+// t in [w0, w1) (llama_kivi.py:384; the last token is the new value, appended here, :377), and -- `flusher` -- the
+// quantisation of the token leaving the window into its VT slot (:386-399).  NTH threads; `pw`: R x >= 136 halves of LDS
+// that already hold the fp16 probabilities of tokens [w0, w1) (index t - w0).  A lane owns two channels, wave w takes
+// tokens w0 + w, w0 + w + NW, ...; all loads of a batch in flight.
+template <int R, int NTH, int PW>
+__device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
+                                                const uint16_t (*pw)[PW], float (*ow)[2]) {
+    constexpr int NW = NTH / 64, WB = 12;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+    const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+    uint16_t xflush = 0;
+    if (flusher && threadIdx.x < 128) xflush = vwin[threadIdx.x];      // requested early, used last
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
+    const int nwt = w1 > w0 ? w1 - w0 : 0;
+    for (int tb = wave; tb < nwt; tb += NW * WB) {
+        uint32_t vv[WB];
+#pragma unroll
+        for (int u = 0; u < WB; u++) {
+            const int t = w0 + tb + NW * u;
+            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+            vv[u] = (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < WB; u++) {
+            const int t = w0 + tb + NW * u;
+            if (t < w1) {
+                const float v0 = h2f_bits((uint16_t)(vv[u] & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv[u] >> 16));
+#pragma unroll
+                for (int rr = 0; rr < R; rr++) {
+                    const float p = h2f_bits(pw[rr][t - w0]);
+                    ow[rr][0] = __builtin_fmaf(p, v0, ow[rr][0]);
+                    ow[rr][1] = __builtin_fmaf(p, v1, ow[rr][1]);
+                }
+                if (t == a.res_len) *(uint32_t*)(vwin + (int64_t)t * a.vres_st + 2 * lane) = vv[u];   // V append
+            }
+        }
+    }
+    if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
+        const int d = threadIdx.x;
+        const uint32_t key = h_key(xflush);
+        uint32_t kmin = key, kmax = key;
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
+            kmin = o1 < kmin ? o1 : kmin;
+            kmax = o2 > kmax ? o2 : kmax;
+        }
+        const GroupQ gq = make_group(kmin, kmax, 3);
+        const uint32_t code = quant_one<2>(xflush, gq);
+        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+        const int e = tt & 7, kbq = tt >> 3;
+        const int c = d >> 5, tile = (d >> 4) & 1, nn = d & 15;
+        const int sh = 16 * (e & 1);
+        uint32_t val = code << (mf_pos(tile, e >> 1) + sh);
+        val |= (uint32_t)__shfl_xor((int)val, 16);
+        uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+        if (tile == 0) {
+            // the two fields of this token (channel tiles 0 / 1) are cleared first: a slot may hold stale codes of an earlier,
+            // longer sequence that used the same storage
+            const uint32_t clr = (3u << (mf_pos(0, e >> 1) + sh)) | (3u << (mf_pos(1, e >> 1) + sh));
+            uint32_t* wp = sbp + blk * KIVI_MF_BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
+            *wp = (*wp & ~clr) | val;
+        }
+        if ((d & 31) == 0) {
+            const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
+            ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
+            ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
+        }
+    }
+}
+
+}  // namespace

@@ -110,3 +110,95 @@ extern "C" int kivi_decode_layer(const kivi_layer_desc* L, int64_t* st, const vo
     }
     return 0;
 }
+
+// The same for a cache in the KT / VT layouts (kivi_mfma_layout.h): kivi_gqa_decode (one launch for multi-head rows that fit
+// the LDS, two launches otherwise) + lengths + the K flush through kivi_kt_pack every residual_length steps
+// (llama_kivi.py:343-356) + window compaction.  Same state array, same atomicity contract as kivi_decode_layer.
+extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, const void* q, int64_t q_sb, int64_t q_sh, int nh,
+                                    const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb,
+                                    int64_t vn_sh, const void* mask, int64_t mask_sb, void* out, int64_t out_sb,
+                                    int64_t out_sh, kivi_stream_t stream) {
+    KIVI_REQUIRE(L && st && q && knew && vnew && out, KIVI_EINVAL, "kivi_mf_decode_layer: null argument");
+    int64_t Tq = st[0], kres = st[1], Tv = st[2], wstart = st[3], vres = st[4], kv = st[5];
+    const int R = L->residual_length;
+    KIVI_REQUIRE(R > 0 && R % 32 == 0 && R <= 128 && Tq >= 0 && Tq % 32 == 0 && kres >= 0 && kres <= R && Tv >= 0 && wstart >= 0 &&
+                     vres >= 0 && vres <= R && kv == Tq + kres && kv == Tv + vres,
+                 KIVI_EINVAL, "kivi_mf_decode_layer: inconsistent lengths (Tq=%lld kres=%lld Tv=%lld vres=%lld kv=%lld R=%d)",
+                 (long long)Tq, (long long)kres, (long long)Tv, (long long)vres, (long long)kv, R);
+    // everything the K flush (kivi_kt_pack, below) can reject is checked before anything is launched
+    KIVI_REQUIRE(L->bits == 2 && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
+                 "kivi_mf_decode_layer: the MFMA cache layout covers 2-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
+                 L->bits, L->group_size, L->D);
+    KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL, "kivi_mf_decode_layer: bad shape (B=%d nh=%d nh_kv=%d)",
+                 L->B, nh, L->nh_kv);
+    KIVI_REQUIRE(L->kt && L->vt && L->k_res && L->v_res && L->scores && L->stats && L->workspace, KIVI_EINVAL,
+                 "kivi_mf_decode_layer: null cache buffer in the descriptor");
+    KIVI_REQUIRE(L->cap % 512 == 0 && kv + 1 <= L->cap, KIVI_EINVAL, "kivi_mf_decode_layer: cache capacity %lld exceeded", (long long)L->cap);
+    KIVI_REQUIRE((uintptr_t)L->kt % 16 == 0 && L->kt_sb % 4 == 0 && L->kt_sh % 4 == 0 && L->kt_ss % 4 == 0 && L->kt_ss >= 6144 &&
+                     (uintptr_t)L->k_res % 4 == 0 && L->kr_sb % 2 == 0 && L->kr_sh % 2 == 0 && L->kr_st % 2 == 0,
+                 KIVI_EALIGN, "kivi_mf_decode_layer: K store / residual alignment");
+    KIVI_REQUIRE((int64_t)L->B * L->nh_kv * (R / 32) < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_mf_decode_layer: K flush grid too large");
+    KIVI_REQUIRE(kv + 1 <= L->s_pitch, KIVI_EINVAL, "kivi_mf_decode_layer: score rows too short");
+    hipStream_t s = (hipStream_t)stream;
+
+    auto flush_k = [&]() -> int {
+        const int rc = kivi_kt_pack(L->k_res, L->kr_sb, L->kr_sh, L->kr_st, L->kt, L->kt_sb, L->kt_sh, L->kt_ss, Tq, L->B, L->nh_kv,
+                                    R, L->D, L->group_size, L->bits, stream);
+        if (rc) return rc;
+        Tq += R;
+        kres = 0;
+        st[0] = Tq; st[1] = 0;
+        return 0;
+    };
+    if (kres == R) {   // a previous call committed its attend phase but its K flush launch failed: finish that first
+        const int rc = flush_k();
+        if (rc) return rc;
+    }
+    if (wstart + vres + 1 > L->v_window_rows) {
+        KIVI_REQUIRE(L->vr_sb == (int64_t)L->nh_kv * L->vr_sh && wstart >= vres, KIVI_EUNSUPPORTED,
+                     "kivi_mf_decode_layer: window buffer layout not compactable in place");
+        const size_t pitch = (size_t)L->vr_sh * 2, width = (size_t)vres * L->vr_st * 2;
+        if (vres) {
+            const hipError_t e = hipMemcpy2DAsync(L->v_res, pitch, (const char*)L->v_res + (size_t)wstart * L->vr_st * 2,
+                                                  pitch, width, (size_t)L->B * L->nh_kv, hipMemcpyDeviceToDevice, s);
+            KIVI_REQUIRE(e == hipSuccess, (int)e, "kivi_mf_decode_layer: window compaction: %s", hipGetErrorString(e));
+        }
+        wstart = 0;
+        st[3] = 0;
+    }
+    const int flush = vres + 1 > R;
+    kivi_gqa_decode_args a;
+    a.B = L->B; a.nh = nh; a.nh_kv = L->nh_kv; a.D = L->D; a.group_size = L->group_size; a.bits = L->bits;
+    a.inv_scale = L->inv_scale;
+    a.q = q; a.q_sb = q_sb; a.q_sh = q_sh;
+    a.mask = mask; a.mask_sb = mask_sb;
+    a.kt = L->kt; a.kt_sb = L->kt_sb; a.kt_sh = L->kt_sh; a.kt_ss = L->kt_ss; a.Tq = Tq;
+    a.kres = L->k_res; a.kres_sb = L->kr_sb; a.kres_sh = L->kr_sh; a.kres_st = L->kr_st;
+    a.knew = knew; a.knew_sb = kn_sb; a.knew_sh = kn_sh; a.k_res_len = (int)kres;
+    a.vt = L->vt; a.vt_sb = L->vt_sb; a.vt_sh = L->vt_sh; a.vt_ss = L->vt_ss; a.Tv = Tv;
+    a.vres = L->v_res; a.vres_sb = L->vr_sb; a.vres_sh = L->vr_sh; a.vres_st = L->vr_st;
+    a.v_win_start = (int)wstart; a.v_res_len = (int)vres;
+    a.vnew = vnew; a.vnew_sb = vn_sb; a.vnew_sh = vn_sh; a.v_flush = flush;
+    a.scores = L->scores; a.s_sb = L->s_sb; a.s_sh = L->s_sh;
+    a.stats = L->stats; a.stats_bytes = L->stats_bytes;
+    a.workspace = L->workspace; a.workspace_bytes = L->workspace_bytes;
+    a.out = out; a.out_sb = out_sb; a.out_sh = out_sh;
+    a.residual_length = R; a.v_window_rows = L->v_window_rows;
+    a.kt_superblocks = L->cap / 512; a.vt_superblocks = L->cap / 512;
+    a.flags = L->flags;
+    int rc = kivi_gqa_decode(&a, stream);
+    if (rc) return rc;            // nothing of the step has been committed
+    kres += 1;
+    vres += 1;
+    if (flush) {
+        Tv += 1;
+        wstart += 1;
+        vres -= 1;
+    }
+    st[1] = kres; st[2] = Tv; st[3] = wstart; st[4] = vres; st[5] = kv + 1;
+    if (kres == R) {              // :343-356; on a launch failure the state says "R residual tokens, flush pending"
+        rc = flush_k();
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,508 @@
+// Round-3 matrix-pipe decode kernels over the KT / VT cache layouts (kivi_mfma_layout.h) for nh / nh_kv = R in {1, 4}:
+// the packed qK^T and sV of models/llama_kivi.py:324 / :382 (kernel quant/csrc/gemv_cuda.cu:348-427, head mapping
+// :361-365) and the whole decode step around them (:314-399).  Device bodies and the reasoning: kivi_mf_dev.h.
+//
+//   mf_k_kernel    one wave per super-block: scores (raw, or scaled + masked with softmax statistics per segment) + the
+//                  fp16 K-residual role (q . K_full, K append) in short blocks at the tail of the grid
+//   mf_v_kernel    slices of a unit's packed V: probabilities from the score rows + segment statistics (or given fp16
+//                  probabilities: kivi_gqa_output), packed sV, fp16 window + V append + quantisation of the token leaving
+//                  the window, partial sums meet in the workspace
+//   mf_row_kernel  R = 1 (MHA), rows <= 8192 keys: the whole step of a (batch row, head) in ONE block -- packed qK^T ->
+//                  LDS scores -> residual scores -> softmax -> window -> packed sV -> output; nothing but the output
+//                  and the cache appends goes to memory
+#include <stdlib.h>
+#include <string.h>
+
+#include "kivi_common.h"
+#include "kivi_gqa_dev.h"
+#include "kivi_quant.h"
+#include "kivi_gqa_roles.h"
+#include "kivi_mf_dev.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ qK^T launch
+
+// per-wave LDS words of mf_k_kernel: [scale of the super-block: 1024 words, R = 4 only | R x 512 fp16 scores]
+template <int R>
+constexpr int mf_k_lds_words() { return (R == 4 ? 1024 : 0) + R * 256; }
+
+template <int R, int W, int RING>
+__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a) {
+    extern __shared__ uint32_t lds_all[];
+    const int main_blocks = (int)gridDim.x - a.res_blocks;
+    if ((int)blockIdx.x >= main_blocks) {                            // short residual blocks at the tail of the grid
+        gqa_k_residual<R>(a, (int)blockIdx.x - main_blocks);
+        return;
+    }
+    const int bid = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* lds_w = lds_all + wave * mf_k_lds_words<R>();
+    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 4 ? 1024 : 0));
+    const int unit = bid / a.sb_blocks;
+    const int sb = (bid - unit * a.sb_blocks) * W + wave;
+    if (sb >= a.nsb) return;
+    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
+    const int h0 = hk * a.ratio;
+    int ng = (int)((a.Tq - (int64_t)sb * KIVI_MF_SB_TOKENS) / 32);
+    ng = ng > 16 ? 16 : ng;
+
+    const uint32_t* sbp = mf_sb(a.kt, b, hk, sb);
+    const rsrc_t rk = make_rsrc(sbp, KIVI_MF_SB_WORDS * 4);
+    auto sink = [&](int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); };
+    if constexpr (R == 1) {
+        MfQ<1> Q;
+        mf_load_q<1>(a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, Q);
+        mf_k_run1<RING>(rk, 0u, 0, ng, Q, sink);
+    } else {
+        const int n = lane & 15, kb = lane >> 4;
+        u32x4 sreg[4], zreg[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
+#pragma unroll
+        for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + n * 256 + kb * 64 + c * 16), 0);
+        MfQ<4> Q;
+        mf_load_q<4>(a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, Q);
+        float zmul[4], cmul[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sqj = __shfl(Q.sq, j);                        // lane j (kb = 0, row j) holds head j's exponent
+            zmul[j] = __builtin_ldexpf(1.0f, -sqj);
+            cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) *(u32x4*)(lds_w + (j * 64 + lane) * 4) = sreg[j];
+        float zz[4];
+        mf_k_zero4(Q, zreg, zmul, zz);
+        __builtin_amdgcn_wave_barrier();
+        mf_k_run4<RING>(rk, 0u, 0, ng, Q, lds_w, zz, cmul, sink);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 512 tokens x R heads of fp16 scores: one 16-byte store per lane and head
+    const bool valid = lane * 8 < ng * 32;
+    const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8 : nullptr;
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) {
+        u16x8 v = valid ? *(const u16x8*)(lds_o + rr * 512 + lane * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.stats) {
+            float x[8], m = -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[e] = kivi_scaled_score(v[e], a.inv_scale, mrow != nullptr, (mrow && valid) ? mrow[e] : 0);
+                x[e] = h2f_bits(v[e]);
+                m = __builtin_fmaxf(m, x[e]);
+            }
+            m = wave_max(valid ? m : -__builtin_inff());
+            float l = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) l += kivi_exp(x[e] - m);
+            l = wave_sum(valid ? l : 0.f);
+            if (lane == 0) {
+                float* st = a.stats + (((int64_t)b * a.nh + h0 + rr) * a.nseg + sb) * 2;
+                st[0] = m;
+                st[1] = l;
+            }
+        }
+        if (valid)
+            *(u16x8*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
+    }
+}
+
+template <int R, int W, int RING>
+void launch_mf_k(const GqaKArgs& a, int units, hipStream_t s) {
+    const size_t lds = (size_t)W * mf_k_lds_words<R>() * 4;
+    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a);
+}
+
+int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
+    const int W = ((int64_t)units * a.nsb >= 2048) ? 4 : 1;        // few super-blocks: one wave per block spreads them over the CUs
+    a.sb_blocks = (a.nsb + W - 1) / W;
+    if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
+    static const char* fr = getenv("KIVI_MF_RING");                // tuning aid: code blocks in flight (2 or 4)
+    const int ring = fr ? atoi(fr) : 4;
+    if (a.ratio == 1) {
+        if (W == 4) { if (ring == 2) launch_mf_k<1, 4, 2>(a, units, s); else launch_mf_k<1, 4, 4>(a, units, s); }
+        else { if (ring == 2) launch_mf_k<1, 1, 2>(a, units, s); else launch_mf_k<1, 1, 4>(a, units, s); }
+    } else {
+        if (W == 4) { if (ring == 2) launch_mf_k<4, 4, 2>(a, units, s); else launch_mf_k<4, 4, 4>(a, units, s); }
+        else { if (ring == 2) launch_mf_k<4, 1, 2>(a, units, s); else launch_mf_k<4, 1, 4>(a, units, s); }
+    }
+    return kivi_launch_status("mf_k");
+}
+
+// ------------------------------------------------------------------------------------------------ sV launch
+
+// One super-block's R x 512 scaled probabilities p'' into this wave's LDS rows (pitch 512 halves): lane l owns tokens
+// 8 l .. 8 l + 7 of every head.  PROB: the score rows already hold fp16 probabilities (kivi_gqa_output); otherwise
+// p = fp16(exp(x - M) / sum) exactly as the reference casts them (llama_kivi.py:375).  Tokens at or past Tv get 0.
+template <int R, bool PROB>
+__device__ __forceinline__ void mf_probs_to_lds(rsrc_t rx, uint32_t x_row_bytes, int64_t tok0, int64_t Tv, const float* M,
+                                                const float* invS, const int* sp, uint16_t* lds_p) {
+    const int lane = threadIdx.x & 63;
+    u16x8 xv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) xv[r] = buf_load<u16x8, false>(rx, (uint32_t)(r * x_row_bytes + (tok0 + lane * 8) * 2), 0);
+    const int64_t left = Tv - tok0 - lane * 8;                      // tokens e < left are inside the packed prefix
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            uint16_t p;
+            if constexpr (PROB) p = xv[r][e];
+            else p = f2h_bits(kivi_exp(h2f_bits(xv[r][e]) - M[r]) * invS[r]);
+            p = (e < left) ? p : (uint16_t)0;
+            o[e] = f2h_bits(__builtin_ldexpf(h2f_bits(p), sp[r] + ((e & 4) ? 6 : 4)));
+        }
+        *(u16x8*)(lds_p + r * 512 + lane * 8) = o;
+    }
+}
+
+// PW: window probabilities per head kept in LDS
+constexpr int MF_PW = 136;
+
+template <int R, int RING, bool PROB>
+__global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
+    extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 64 words of dot sums)
+    __shared__ uint16_t pw[R][MF_PW];
+    const int bid = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WW = R * 256 + 64;                               // per-wave words
+    uint16_t* lds_p = (uint16_t*)(lds_all + wave * WW);
+    float* zl = (float*)(lds_all + wave * WW + R * 256);
+    const int nstream = a.units * a.S;
+    const bool win_role = bid >= nstream;
+    const int unit = win_role ? bid - nstream : bid / a.S;
+    const int slice = win_role ? a.S : bid - unit * a.S;           // = the block's partial-sum slot
+    const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
+    const int h0 = hk * a.ratio;
+
+    float M[R], invS[R];
+    int sp[R];
+    if constexpr (PROB) {
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            M[rr] = 0.f;
+            invS[rr] = 1.f;
+            sp[rr] = a.sp_rows[(int64_t)b * a.nh + h0 + rr];
+        }
+    } else {
+        gqa_row_consts<R>(a, b, h0, M, invS);
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) sp[rr] = mf_sp(1.0f / invS[rr]);
+    }
+
+    const rsrc_t rx = make_rsrc(a.x + b * a.x_sb + (int64_t)h0 * a.x_sh, (uint32_t)((R - 1) * a.x_sh * 2 + ((a.Tv + 7) & ~(int64_t)7) * 2));
+    const rsrc_t rv = make_rsrc(mf_sb(a.vt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.vt.sb_s * 4));
+    const uint32_t sb_bytes = (uint32_t)(a.vt.sb_s * 4);
+
+    MfVAcc<R> A;
+    mf_v_init<R>(A);
+    const int sb_begin = win_role ? 0 : slice * a.spb;
+    const int sb_end = win_role ? 0 : ((sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb);
+    for (int sb = sb_begin + wave; sb < sb_end; sb += 4) {
+        const int64_t tok0 = (int64_t)sb * KIVI_MF_SB_TOKENS;
+        int nb = (int)((a.Tv - tok0 + 31) / 32);
+        nb = nb > 16 ? 16 : nb;
+        __builtin_amdgcn_wave_barrier();                           // the previous super-block's LDS reads are over
+        mf_probs_to_lds<R, PROB>(rx, (uint32_t)(a.x_sh * 2), tok0, a.Tv, M, invS, sp, lds_p);
+        __builtin_amdgcn_wave_barrier();
+        mf_v_run<R, RING>(A, rv, sb_bytes, sb * 16, sb * 16 + nb, lds_p, 512, (int)tok0);
+    }
+
+    // ---- fp16 window (+ V append + flush): the window block of the unit (tail of the grid), or shares inside the stream blocks
+    float ow[R][2];
+    {
+        const int Lw = a.res_len + 1;
+        const int wchunk = a.win_blocks ? Lw : (Lw + a.S - 1) / a.S;
+        const int w0 = a.win_blocks ? 0 : slice * wchunk;
+        const int w1 = a.win_blocks ? (win_role ? Lw : 0) : ((w0 + wchunk < Lw) ? w0 + wchunk : Lw);
+        const bool flusher = a.flush && (a.win_blocks ? win_role : slice == 0);
+        const int nwt = w1 > w0 ? w1 - w0 : 0;
+        if (a.vres) {
+            for (int idx = threadIdx.x; idx < R * nwt; idx += 256) {
+                const int rr = idx / nwt, t = idx - rr * nwt;
+                float Mr = M[0], Ir = invS[0];
+#pragma unroll
+                for (int q = 1; q < R; q++)
+                    if (rr == q) { Mr = M[q]; Ir = invS[q]; }
+                const uint16_t xw = a.x[b * a.x_sb + (int64_t)(h0 + rr) * a.x_sh + a.Tv + w0 + t];
+                pw[rr][t] = PROB ? xw : f2h_bits(kivi_exp(h2f_bits(xw) - Mr) * Ir);
+            }
+            __syncthreads();
+            gqa_window_part<R, 256, MF_PW>(a, b, hk, w0, w1, flusher, pw, ow);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
+        }
+    }
+
+    // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
+    __syncthreads();                                               // every wave is done with its p'' rows
+    float* Lf = (float*)(lds_all + wave * WW);
+    mf_v_finish<R>(A, zl, Lf);                                     // Lf[r * 128 + d], before 2^-Sp
+    // the p'' region of a wave holds R x 256 words = R x 128 floats twice: quantised part first, window part second
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) {
+        Lf[R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
+        Lf[R * 128 + rr * 128 + 2 * lane + 1] = ow[rr][1];
+    }
+    __syncthreads();
+    float* lf = (float*)lds_all;
+    constexpr int NT = (2 * R * 128 + 255) / 256;
+    float tot[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = threadIdx.x + 256 * k;
+        float v = 0.f;
+        if (i < 2 * R * 128) {
+            v = (lf[i] + lf[WW + i]) + (lf[2 * WW + i] + lf[3 * WW + i]);
+            if (i < R * 128) {                                     // quantised part: undo the 2^Sp of its head
+                int s_ = sp[0];
+#pragma unroll
+                for (int q = 1; q < R; q++)
+                    if ((i >> 7) == q) s_ = sp[q];
+                v = __builtin_ldexpf(v, -s_);
+            }
+        }
+        tot[k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < 2 * R * 128) lf[i] = tot[k];
+    }
+    __syncthreads();
+    gqa_arrive_and_combine<R>(a, unit, slice, lf, b, h0);
+}
+
+// row maximum of given fp16 probabilities -> Sp of the row (kivi_gqa_output): 2^Sp * max p in [1, 2) (clamped to [0, 14])
+__global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64_t p_sb, int64_t p_sh, int nh, int64_t T, int* sp) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int b = row / nh, h = row - b * nh;
+    const uint16_t* pr = p + b * p_sb + (int64_t)h * p_sh;
+    float m = 0.f;
+    for (int64_t t = threadIdx.x; t < T; t += 256) m = __builtin_fmaxf(m, __builtin_fabsf(h2f_bits(pr[t])));
+    m = kivi_block_reduce<4>(m, true, red);
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (m > 0.f && m < __builtin_inff()) e = -((int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u) - 127);
+        sp[row] = e < 0 ? 0 : (e > 14 ? 14 : e);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused row (R = 1)
+
+// The whole decode step of one (batch row, head) in one block of NW waves.  Dynamic LDS: the score / p'' row (n_pad halves).
+template <int KRING, int VRING, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad, int chunk_groups) {
+    constexpr int NTH = NW * 64;
+    extern __shared__ uint16_t row[];                              // [n_pad] fp16 scores, then p''
+    __shared__ float red[NW][128], resl[NW][128];
+    __shared__ float zl[NW][64];
+    __shared__ uint16_t pw[1][MF_PW];
+    __shared__ float sm_lds[NW];
+    const int unit = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = unit / ak.nh_kv, hk = unit - b * ak.nh_kv;       // nh == nh_kv
+    const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
+    const int L = ak.res_len + 1;                                  // residual keys incl. the new one
+    const int n = Tq + L;                                          // row length
+
+    const uint16_t* qrow = ak.q + b * ak.q_sb + (int64_t)hk * ak.q_sh;
+    uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
+    const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
+
+    // ---- packed qK^T: chunks of `chunk_groups` groups, wave w takes chunks w, w + NW, ...
+    {
+        MfQ<1> Q;
+        mf_load_q<1>(qrow, ak.q_sh, Q);
+        const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
+        const uint32_t sb_bytes = (uint32_t)(ak.kt.sb_s * 4);
+        const int NG = Tq >> 5;
+        const int nchunk = (NG + chunk_groups - 1) / chunk_groups;
+        for (int ci = wave; ci < nchunk; ci += NW) {
+            const int gs = ci * chunk_groups;
+            const int sb = gs >> 4, g_lo = gs & 15;
+            int g_hi = g_lo + chunk_groups;
+            const int lim = NG - sb * 16;
+            g_hi = g_hi < lim ? g_hi : lim;
+            uint16_t* rsb = row + sb * KIVI_MF_SB_TOKENS;
+            mf_k_run1<KRING>(rk, (uint32_t)sb * sb_bytes, g_lo, g_hi, Q, [&](int tt, int, float v) { rsb[tt] = f2h_bits(v); });
+        }
+    }
+    // ---- residual scores q . [K_full | k_new] (fp32 accumulate, one rounding: the reference's fp16 matmul, :337) + K append
+    for (int idx = threadIdx.x; idx < L * 8; idx += NTH) {
+        const int sub = idx & 7, t = idx >> 3;
+        const uint16_t* krow = ((t < ak.res_len) ? kres + (int64_t)t * ak.kres_st : knew) + sub * 16;
+        const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
+        const u16x8 q0 = *(const u16x8*)(qrow + sub * 16), q1 = *(const u16x8*)(qrow + sub * 16 + 8);
+        float sc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
+        if (t == ak.res_len) {                                      // append the new key (:333-336)
+            *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = k0;
+            *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = k1;
+        }
+        sc += __shfl_xor(sc, 1);
+        sc += __shfl_xor(sc, 2);
+        sc += __shfl_xor(sc, 4);
+        if (sub == 0) row[Tq + t] = f2h_bits(sc);
+    }
+    __syncthreads();
+
+    // ---- scale + mask + fp32 softmax of the row (llama_kivi.py:339, :364-375); each thread owns 4 consecutive scores per
+    // chunk of 4 NTH; the probabilities of the packed prefix go back into the row as p'', the window's into pw
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    constexpr int SCH = NTH * 4, SMC = 8192 / SCH;
+    const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
+    float x[SMC][4];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < SMC; c++) {
+        const int j0 = c * SCH + (int)threadIdx.x * 4;
+        u16x4 raw = {0, 0, 0, 0};
+        if (j0 < n) raw = *(const u16x4*)(row + j0);               // n_pad >= n rounded up to 8: whole vectors stay inside the row
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float v = -__builtin_inff();
+            if (j0 + e < n) v = h2f_bits(kivi_scaled_score(raw[e], ak.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
+            x[c][e] = v;
+            mx = __builtin_fmaxf(mx, v);
+        }
+    }
+    mx = kivi_block_reduce<NW>(mx, true, sm_lds);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < SMC; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            x[c][e] = kivi_exp(x[c][e] - mx);                      // exp(-inf) = 0 past the row
+            sum += x[c][e];
+        }
+    sum = kivi_block_reduce<NW>(sum, false, sm_lds);
+    const float inv = 1.0f / sum;
+    const int sp = mf_sp(sum);
+#pragma unroll
+    for (int c = 0; c < SMC; c++) {
+        const int j0 = c * SCH + (int)threadIdx.x * 4;
+        if (j0 < n_pad) {
+            const int ex = sp + ((j0 & 4) ? 6 : 4);
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint16_t p = f2h_bits(x[c][e] * inv);
+                const int j = j0 + e;
+                if (j >= Tv && j < n) pw[0][j - Tv] = p;
+                o[e] = (j < Tv) ? f2h_bits(__builtin_ldexpf(h2f_bits(p), ex)) : (uint16_t)0;
+            }
+            *(u16x4*)(row + j0) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- fp16 window: probs[-Lw:] . V_full, V append, quantisation of the token leaving the window (:377-399)
+    float ow[1][2];
+    gqa_window_part<1, NTH, MF_PW>(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+    resl[wave][2 * lane] = ow[0][0];
+    resl[wave][2 * lane + 1] = ow[0][1];
+
+    // ---- packed sV: contiguous block ranges per wave
+    {
+        const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
+        const uint32_t sb_bytes = (uint32_t)(av.vt.sb_s * 4);
+        const int NB = (Tv + 31) >> 5;
+        const int nbw = (NB + NW - 1) / NW;
+        const int b_lo = wave * nbw;
+        const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
+        MfVAcc<1> A;
+        mf_v_init<1>(A);
+        mf_v_run<1, VRING>(A, rv, sb_bytes, b_lo, b_hi, row, 0, 0);
+        mf_v_finish<1>(A, zl[wave], red[wave]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int d = threadIdx.x;
+        float qs = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+        float ws = (resl[0][d] + resl[1][d]) + (resl[2][d] + resl[3][d]);
+        if constexpr (NW == 8) {
+            qs += (red[4][d] + red[5][d]) + (red[6][d] + red[7][d]);
+            ws += (resl[4][d] + resl[5][d]) + (resl[6][d] + resl[7][d]);
+        }
+        qs = __builtin_ldexpf(qs, -sp);
+        // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (llama_kivi.py:382-384);
+        // only the window part exists before anything is quantised (:380)
+        const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
+        av.out[b * av.out_sb + (int64_t)hk * av.out_sh + d] = o;
+    }
+}
+
+bool mf_store_ok2(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
+    return base && (uintptr_t)base % 16 == 0 && sb_b % 4 == 0 && sb_h % 4 == 0 && sb_s % 4 == 0 && sb_s >= KIVI_MF_SB_WORDS;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side (called from kivi_gqa.hip)
+
+// qK^T launch of the decode step / kivi_gqa_scores for nh / nh_kv in {1, 4}
+// (the argument blocks live in an anonymous namespace of a shared header: they cross the translation-unit boundary as void*)
+int kivi_mf_run_k(void* k_args, int units, hipStream_t s) { return run_mf_k(*(GqaKArgs*)k_args, units, s); }
+
+// sV launch of the decode step (prob == 0) or of kivi_gqa_output (prob != 0: a.x rows hold fp16 probabilities, a.sp_rows
+// their exponents)
+int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
+    const GqaVArgs& a = *(const GqaVArgs*)v_args;
+    static const char* fr = getenv("KIVI_MF_RING");                // tuning aid
+    const int ring = fr ? atoi(fr) : 4;
+    const int R = a.ratio;
+    const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
+    const size_t lds = (size_t)4 * (R * 256 + 64) * 4;
+#define KIVI_MV(RR, RG, PB) KIVI_LAUNCH_LDS((mf_v_kernel<RR, RG, PB>), grid, dim3(256), lds, s, a)
+    if (R == 1) {
+        if (prob) { if (ring == 2) KIVI_MV(1, 2, true); else KIVI_MV(1, 4, true); }
+        else { if (ring == 2) KIVI_MV(1, 2, false); else KIVI_MV(1, 4, false); }
+    } else {
+        if (prob) { if (ring == 2) KIVI_MV(4, 2, true); else KIVI_MV(4, 4, true); }
+        else { if (ring == 2) KIVI_MV(4, 2, false); else KIVI_MV(4, 4, false); }
+    }
+#undef KIVI_MV
+    return kivi_launch_status("mf_v");
+}
+
+int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int64_t T, int* sp, hipStream_t s) {
+    hipLaunchKernelGGL(mf_row_sp_kernel, dim3((unsigned)(B * nh)), dim3(256), 0, s, (const uint16_t*)p, p_sb, p_sh, nh, T, sp);
+    return kivi_launch_status("mf_row_sp");
+}
+
+// the whole step in one launch (R = 1, rows <= 8192 keys); returns KIVI_EUNSUPPORTED when the shape does not qualify
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream_t s) {
+    const GqaKArgs& k = *(const GqaKArgs*)k_args;
+    const GqaVArgs& v = *(const GqaVArgs*)v_args;
+    const int64_t n = k.Tq + k.res_len + 1;
+    if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
+    const int n_pad = (int)((n + 31) / 32 * 32);
+    const int NG = (int)(k.Tq / 32);
+    // whole super-blocks per wave when every wave gets at least two of them, smaller chunks for short rows
+    int cg = 16;
+    if (NG < 2 * 4 * 16) cg = 8;
+    if (NG < 2 * 4 * 8) cg = 4;
+    static const char* fc = getenv("KIVI_MF_ROW_CHUNK");          // tuning aid: groups per qK^T chunk (4, 8, 16)
+    if (fc) cg = atoi(fc);
+    static const char* fr = getenv("KIVI_MF_ROW_RINGS");          // tuning aid: "<K ring><V ring>", e.g. 42
+    const int rings = fr ? atoi(fr) : 42;
+    const size_t lds = (size_t)n_pad * 2;
+    const dim3 grid((unsigned)units);
+    if (rings == 22) KIVI_LAUNCH_LDS((mf_row_kernel<2, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
+    else if (rings == 43) KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
+    else if (rings == 23) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
+    else KIVI_LAUNCH_LDS((mf_row_kernel<4, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
+    return kivi_launch_status("mf_row");
+}

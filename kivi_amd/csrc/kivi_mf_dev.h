@@ -1,0 +1,483 @@
+// Round-3 device bodies of the matrix-pipe kernels over the KT / VT cache layouts (kivi_mfma_layout.h): the packed qK^T
+// and sV products of quant/csrc/gemv_cuda.cu:348-427 (call sites models/llama_kivi.py:324 / :382) for R = nh / nh_kv
+// in {1, 4} query heads per kv head.
+//
+// What changed against the round-2 bodies (kivi_gqa.hip), per 32-token block of 128 channels (64 codes per lane):
+//   * qK^T: an MFMA ROW is a quantisation GROUP (R = 1: the 16 groups of a super-block; R = 4: 4 groups x 4 heads), not
+//     a (hi / lo, head) pair.  The A operand q * scale[., group] is then built ONCE per 16 / R groups by the one lane
+//     that owns the row -- 2 packed ops per group instead of 32 -- and every group multiplies its own code words with it;
+//     row g of the result is the group's scores, the other rows (codes of group g against the scales of other groups)
+//     are never read.  hi and lo (the exact fp16 split of the 22-bit product) are two chained MFMAs.  The zero-point term
+//     sum_d q * mn[d, g] comes out of 4 MFMAs per super-block in exactly the lanes / registers of the useful rows.
+//   * sV: an MFMA row is a CHANNEL GROUP (R = 1: (channel group, hi | lo); R = 4: (channel group, head) with hi and lo
+//     chained), the codes enter CENTRED: every tile first accumulates A x (-1.5) and then A x code, so the running sums
+//     through the C operand stay at the size of the output instead of growing to sum p * scale * code ~ 100x larger
+//     (the matrix pipe aligns its 32 products to the largest addend and drops what falls ~2^-26 below it: with the
+//     uncentred sums that loss, accumulated over 128 blocks, was 2e-3 of the output once code sum and zero-point sum
+//     cancelled, which is why round 2 started every MFMA from zero and added 32 registers on the VALU per block).
+//     The matching +1.5 * sum p * scale and the zero-point sum p * mn are v_dot2_f32_f16 on the operands the lane holds
+//     anyway.
+// VALU instructions per block: qK^T 106 -> ~50 (R = 1) / ~70 (R = 4), sV 115 -> ~62; matrix instructions 9-18 -> 16-24
+// on a pipe that was under 10 % busy.
+#pragma once
+#include "kivi_gqa_dev.h"
+
+namespace {
+
+// fp16 constants in both halves
+constexpr uint32_t MF_ONE2 = 0x3C003C00u;      // 1.0
+constexpr uint32_t MF_M1 = 0x03000300u, MF_M2 = 0x00C000C0u;
+// -1.5 in the units of a masked code (kivi_mfma_layout.h): registers 0, 1 hold code * 2^-16, registers 2, 3 code * 2^-18
+constexpr uint32_t MF_C15A = 0x81808180u, MF_C15B = 0x80608060u;
+
+__device__ __forceinline__ float dot2_f16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// the two B operands (token tile 0 / 1 for K, channel tile 0 / 1 for V) of one code word: 3 views + 8 masks
+struct MfB { h8 b0, b1; };
+__device__ __forceinline__ MfB mf_views(uint32_t w) {
+    const uint32_t x1 = w << 4, x2 = w >> 4, x3 = __builtin_amdgcn_perm(w, w, 0x02030001u);
+    MfB r;
+    r.b0 = as_h8(w & MF_M1, x1 & MF_M1, w & MF_M2, x1 & MF_M2);
+    r.b1 = as_h8(x2 & MF_M1, x3 & MF_M1, x2 & MF_M2, x3 & MF_M2);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ q operand
+// Lane (m, kb) of a wave, m = lane & 15: the query of head r = m % R, channels 32 c + 8 kb + 2 i (+ 1) as fp16 pairs,
+// normalised to max |q| in [1, 2) (exponent sq, so A = q'' * scale stays a normal fp16 for any realistic scale) and
+// pre-multiplied by 2^aexp(i).  The same registers are the A operand's q factor (row m) and, because a lane's A row and
+// B column have the same index, the B operand of the zero-point product (column m -> head m % R).
+template <int R>
+struct MfQ {
+    uint32_t qq[4][4];
+    int sq;
+};
+
+template <int R>
+__device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, MfQ<R>& Q) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    const uint16_t* qrow = q_h0 + (int64_t)(m % R) * q_sh + 8 * kb;
+    u16x8 qv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) qv[c] = *(const u16x8*)(qrow + 32 * c);
+    uint32_t amax = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t v = qv[c][e] & 0x7FFFu;
+            amax = v > amax ? v : amax;
+        }
+    amax = max(amax, (uint32_t)__shfl_xor((int)amax, 16));
+    amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32));
+    const int ex = (int)(amax >> 10);                              // biased exponent of the row maximum (0: zero / subnormal)
+    Q.sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);               // inf / nan rows: no scaling (they poison the row anyway)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), Q.sq + aexp(i));
+            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), Q.sq + aexp(i));
+            Q.qq[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ qK^T
+// A operands of one row set: rows m -> (group ga + m / R of the super-block, head m % R).  hi = fp16(q'' * scale), lo = its
+// exact remainder.  Zs[j] = the zero-point term of output register j in score units: lane (n, kb'), register j holds row
+// 4 kb' + j of every column n.
+template <int R>
+struct MfKSet {
+    uint32_t Ah[4][4], Al[4][4];
+    float Zs[4];
+};
+
+// `sv` / `mv`: this lane's 4 x 16 bytes of scale / zero points (channels 32 c + 8 kb + e of the row's group) -- loaded by
+// the caller (from the super-block: byte kt_row_off(m / R + ga, kb) + 16 c of the scale / mn region).
+// zmul[j] = 2^-sq of the head of output register j.
+template <int R>
+__device__ __forceinline__ void mf_k_build(const MfQ<R>& Q, const u32x4* sv, const u32x4* mv, const float* zmul, MfKSet<R>& S) {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            S.Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
+            S.Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], S.Ah[c][i]);
+        }
+    // Z[row, col] = sum_d mn[d, group(row)] * q''[head(col), d]: A = the raw zero points (row layout = the scale's), B = q''
+    // without the 2^aexp(i) (exact power-of-two scaling of a normalised row)
+    f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const h8 bq = as_h8(pk_mul(Q.qq[c][0], zfac(0)), pk_mul(Q.qq[c][1], zfac(1)), pk_mul(Q.qq[c][2], zfac(2)),
+                            pk_mul(Q.qq[c][3], zfac(3)));
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), bq, z, 0, 0, 0);
+    }
+    if constexpr (R == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) S.Zs[j] = z[j] * zmul[j];
+    } else {
+        // column n carries head n % 4; register j belongs to head j: take quad lane j (every quad of the row holds the same)
+        static_assert(R == 4, "row sets: R = 1 or 4");
+        S.Zs[0] = dpp_mov_f<0x00>(z[0]) * zmul[0];     // quad_perm [0,0,0,0]
+        S.Zs[1] = dpp_mov_f<0x55>(z[1]) * zmul[1];     // [1,1,1,1]
+        S.Zs[2] = dpp_mov_f<0xAA>(z[2]) * zmul[2];     // [2,2,2,2]
+        S.Zs[3] = dpp_mov_f<0xFF>(z[3]) * zmul[3];     // [3,3,3,3]
+    }
+}
+
+// one 32-token group: 16 MFMAs (4 channel chunks x {hi, lo} x 2 token tiles), fp32 accumulate from zero.
+// acc0 / acc1: rows x tokens n / 16 + n of the group.
+template <int R>
+__device__ __forceinline__ void mf_k_group(const MfKSet<R>& S, const u32x4& w, f4& acc0, f4& acc1) {
+    acc0 = f4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const MfB b = mf_views(w[c]);
+        const h8 ah = as_h8(S.Ah[c][0], S.Ah[c][1], S.Ah[c][2], S.Ah[c][3]);
+        const h8 al = as_h8(S.Al[c][0], S.Al[c][1], S.Al[c][2], S.Al[c][3]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, acc1, 0, 0, 0);
+    }
+}
+
+// Groups [g_lo, g_hi) of one super-block (g_lo a multiple of 4), R = 1: rows = the 16 groups of the super-block.
+// `rk`: buffer over the unit's K store, `sb_off`: byte offset of the super-block inside it (wave-uniform).
+// Scores: token tt of the super-block -> sink(tt, head 0, fp32 score).  RING = code blocks in flight (2 or 4).
+template <int RING, typename Sink>
+__device__ __forceinline__ void mf_k_run1(rsrc_t rk, uint32_t sb_off, int g_lo, int g_hi, const MfQ<1>& Q, Sink&& sink) {
+    static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    // requests first: scale / zero points of the lane's row (group m), then the ring
+    u32x4 sv[4], mv[4];
+    const uint32_t row_off = (uint32_t)(m * 256 + kb * 64);
+#pragma unroll
+    for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_SCALE_WORD0 * 4 + row_off + c * 16, sb_off);
+#pragma unroll
+    for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_MN_WORD0 * 4 + row_off + c * 16, sb_off);
+    u32x4 wr[RING];
+    const int g_last = g_hi - 1;
+#pragma unroll
+    for (int i = 0; i < RING; i++) {
+        const int g = (g_lo + i < g_last) ? g_lo + i : g_last;
+        wr[i] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)g * 1024u);
+        // the slots are requested in the order the loop re-requests them: hipcc merges the wait counters of the loop's two
+        // entries, and a different order here makes every wait inside the loop a vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    MfKSet<1> S;
+    const float zm = __builtin_ldexpf(1.0f, -Q.sq);
+    const float zmul[4] = {zm, zm, zm, zm};
+    mf_k_build<1>(Q, sv, mv, zmul, S);
+    const float cmul = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - Q.sq);
+    float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
+        const bool mine = kb == (g0 >> 2);            // this lane's output rows 4 kb .. 4 kb + 3 are these four groups
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f4 a0, a1;
+            mf_k_group<1>(S, wr[j % RING], a0, a1);
+            o0[j] = mine ? a0[j] : o0[j];
+            o1[j] = mine ? a1[j] : o1[j];
+            // reload AFTER the last use (the slot's register is dead here, the load lands in it directly); clamped to the
+            // chunk's last group: no branch inside the round
+            const int gn = (g0 + j + RING < g_last) ? g0 + j + RING : g_last;
+            wr[j % RING] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)gn * 1024u);
+        }
+    }
+    // lane (n, kb), register j: group 4 kb + j, tokens n and 16 + n
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int g = 4 * kb + j;
+        if (g >= g_lo && g < g_hi) {
+            sink(g * 32 + m, 0, __builtin_fmaf(o0[j], cmul, S.Zs[j]));
+            sink(g * 32 + 16 + m, 0, __builtin_fmaf(o1[j], cmul, S.Zs[j]));
+        }
+    }
+}
+
+// R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups.  `lds_s`: the super-block's scale region staged
+// in this wave's LDS (4 KiB, kt_half order, filled by the caller); `zz`: zero-point sums of the whole super-block, lane
+// (group, any kb), register j = head j, already in score units (mf_k_zero4).
+template <int RING, typename Sink>
+__device__ __forceinline__ void mf_k_run4(rsrc_t rk, uint32_t sb_off, int g_lo, int g_hi, const MfQ<4>& Q, const uint32_t* lds_s,
+                                          const float* zz, const float* cmul, Sink&& sink) {
+    static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    u32x4 wr[RING];
+    const int g_last = g_hi - 1;
+#pragma unroll
+    for (int i = 0; i < RING; i++) {
+        const int g = (g_lo + i < g_last) ? g_lo + i : g_last;
+        wr[i] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)g * 1024u);
+        // the slots are requested in the order the loop re-requests them: hipcc merges the wait counters of the loop's two
+        // entries, and a different order here makes every wait inside the loop a vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
+        // A operands of this round: row m -> group g0 + (m >> 2), head m & 3
+        const uint32_t* sp = lds_s + (g0 + (m >> 2)) * 64 + kb * 16;
+        uint32_t Ah[4][4], Al[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const u32x4 s = *(const u32x4*)(sp + c * 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Ah[c][i] = pk_mul(Q.qq[c][i], s[i]);
+                Al[c][i] = pk_fms(Q.qq[c][i], s[i], Ah[c][i]);
+            }
+        }
+        // zero points of (group g0 + kb, head j) from lane (g0 + kb) of this 16-lane row
+        float zs[4];
+        const int src = ((lane & 48) + g0 + kb) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) zs[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zz[j])));
+        float o0[4], o1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const MfB b = mf_views(wr[j % RING][c]);
+                const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
+                const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
+            }
+            const bool mine = kb == j;                 // rows 4 kb .. 4 kb + 3 = group g0 + kb, heads 0 .. 3
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                o0[r] = (j == 0 || mine) ? a0[r] : o0[r];
+                o1[r] = (j == 0 || mine) ? a1[r] : o1[r];
+            }
+            const int gn = (g0 + j + RING < g_last) ? g0 + j + RING : g_last;
+            wr[j % RING] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)gn * 1024u);
+        }
+        const int g = g0 + kb;
+        if (g < g_hi) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                sink(g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
+                sink(g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
+            }
+        }
+    }
+}
+
+// Zero-point sums of a whole super-block for R = 4: zz[j] at lane (n = group, any kb) = sum_d q[head j, d] * mn[d, group n]
+// in score units.  `mv`: this lane's 4 x 16 bytes of the zero points of group n (B layout = the row layout).
+__device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, const float* zmul, float* zz) {
+    f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        // rows = heads (A = q'' without the 2^aexp), columns = groups
+        const h8 aq = as_h8(pk_mul(Q.qq[c][0], zfac(0)), pk_mul(Q.qq[c][1], zfac(1)), pk_mul(Q.qq[c][2], zfac(2)),
+                            pk_mul(Q.qq[c][3], zfac(3)));
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq, as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), z, 0, 0, 0);
+    }
+    // row 4 kb' + j carries head (4 kb' + j) % 4 = j for every kb': register j = head j in every lane
+#pragma unroll
+    for (int j = 0; j < 4; j++) zz[j] = z[j] * zmul[j];
+}
+
+// ------------------------------------------------------------------------------------------------ sV
+// Accumulators of a wave over its token blocks: acc[c][tile] = rows x channels 32 c + 16 tile + n.
+// R = 1: row 4 cg + j, j even = hi, j odd = lo part of p'' * scale[t, cg]; the lanes of rows j >= 2 load the ZERO POINTS
+//        instead of the scale (their rows are never read) and so accumulate sum p'' * mn while rows j < 2 accumulate
+//        sum p'' * scale -- one 16-byte load per lane brings both.
+// R = 4: row 4 cg + r = (channel group cg, head r); hi and lo are two operands; z = sum p'' * mn, hs = sum hi.
+// p'' = the fp16 probability times 2^(Sp + aexp(i)) (exact), i = ((t & 7) >> 1): written that way into LDS by the softmax.
+template <int R>
+struct MfVAcc {
+    f4 acc[4][2];
+    float z4, z6, h4, h6;      // dot-product sums of the registers with 2^4 / 2^6
+};
+
+template <int R>
+__device__ __forceinline__ void mf_v_init(MfVAcc<R>& A) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) A.acc[c][0] = A.acc[c][1] = f4{0.f, 0.f, 0.f, 0.f};
+    A.z4 = A.z6 = A.h4 = A.h6 = 0.f;
+}
+
+// one 32-token block.  w: code words; ps: the lane's 8 scaled probabilities (tokens 8 kb + e of its row's head);
+// R = 1: sm = scale (rows j < 2) or zero points (rows j >= 2), lomask = all ones in lo rows;  R = 4: sm = scale, mn = zero points.
+template <int R>
+__device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u32x4& ps, const u32x4& sm, const u32x4& mn,
+                                           uint32_t lomask) {
+    const h8 bc = as_h8(MF_C15A, MF_C15A, MF_C15B, MF_C15B);
+    if constexpr (R == 1) {
+        uint32_t a[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t hi = pk_mul(ps[i], sm[i]);
+            a[i] = pk_fms(ps[i], sm[i], hi & lomask);          // hi rows: fp16(p'' s); lo rows: the exact remainder
+        }
+        A.z4 = dot2_f16(ps[0], sm[0], A.z4);
+        A.z4 = dot2_f16(ps[1], sm[1], A.z4);
+        A.z6 = dot2_f16(ps[2], sm[2], A.z6);
+        A.z6 = dot2_f16(ps[3], sm[3], A.z6);
+        const h8 av = as_h8(a[0], a[1], a[2], a[3]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const MfB b = mf_views(w[c]);
+            f4 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, A.acc[c][0], 0, 0, 0);
+            f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, A.acc[c][1], 0, 0, 0);
+            A.acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b0, x0, 0, 0, 0);
+            A.acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, x1, 0, 0, 0);
+        }
+    } else {
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hi[i] = pk_mul(ps[i], sm[i]);
+            lo[i] = pk_fms(ps[i], sm[i], hi[i]);
+        }
+        A.z4 = dot2_f16(ps[0], mn[0], A.z4);
+        A.z4 = dot2_f16(ps[1], mn[1], A.z4);
+        A.z6 = dot2_f16(ps[2], mn[2], A.z6);
+        A.z6 = dot2_f16(ps[3], mn[3], A.z6);
+        A.h4 = dot2_f16(hi[0], MF_ONE2, A.h4);
+        A.h4 = dot2_f16(hi[1], MF_ONE2, A.h4);
+        A.h6 = dot2_f16(hi[2], MF_ONE2, A.h6);
+        A.h6 = dot2_f16(hi[3], MF_ONE2, A.h6);
+        const h8 ah = as_h8(hi[0], hi[1], hi[2], hi[3]), al = as_h8(lo[0], lo[1], lo[2], lo[3]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const MfB b = mf_views(w[c]);
+            f4 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, A.acc[c][0], 0, 0, 0);
+            f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, A.acc[c][1], 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, x1, 0, 0, 0);
+            A.acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, x0, 0, 0, 0);
+            A.acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, x1, 0, 0, 0);
+        }
+    }
+}
+
+// Token blocks [b_lo, b_hi) of one unit's V store.  `rv`: buffer over the unit's V store (all its super-blocks), sb_bytes =
+// byte stride between consecutive super-blocks; ps_lds: the R rows of scaled probabilities (halves), row pitch `pitch`
+// halves, indexed by token - tok0.
+template <int R, int RING>
+__device__ __forceinline__ void mf_v_run(MfVAcc<R>& A, rsrc_t rv, uint32_t sb_bytes, int b_lo, int b_hi, const uint16_t* ps_lds,
+                                         int pitch, int tok0) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    // R = 1: row 4 cg + j; R = 4: row 4 cg + r
+    const int cg = m >> 2, j = m & 3;
+    const uint32_t lomask = (R == 1 && (j & 1)) ? 0xFFFFFFFFu : 0u;
+    const uint32_t sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
+    const uint32_t mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
+    const uint16_t* prow = ps_lds + (R == 1 ? 0 : j * pitch) + 8 * kb - tok0;
+    if (b_hi <= b_lo) return;
+    const int b_last = b_hi - 1;
+    u32x4 wr[RING], sr[RING], mr[R == 1 ? 1 : RING];
+    auto request = [&](int slot, int bl) {
+        const int bc = bl < b_last ? bl : b_last;                  // clamped: no branch, no out-of-range address
+        const uint32_t so = (uint32_t)(bc >> 4) * sb_bytes;
+        wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16), so + (uint32_t)(bc & 15) * 1024u);
+        sr[slot] = buf_load<u32x4, true>(rv, sm_off, so + (uint32_t)(bc & 15) * 256u);
+        if constexpr (R != 1) mr[slot] = buf_load<u32x4, true>(rv, mn_off, so + (uint32_t)(bc & 15) * 256u);
+    };
+#pragma unroll
+    for (int i = 0; i < RING; i++) {
+        request(i, b_lo + i);
+        __builtin_amdgcn_sched_barrier(0);             // same request order as inside the loop (see mf_k_run1)
+    }
+    for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
+#pragma unroll
+        for (int s = 0; s < RING; s++) {
+            const int bl = b0 + s;
+            // blocks past the range repeat the last block with zero probabilities
+            u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_last) * 32);
+            if (bl >= b_hi) ps = u32x4{0, 0, 0, 0};
+            mf_v_block<R>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+            request(s, bl + RING);
+            // memory operations stay on their side of this point (ALU / MFMA / LDS may cross): without it hipcc moves all
+            // RING re-requests to the end of the round, i.e. a block's data is asked for one block before its use
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]) -- 2^12 * (hi + lo sums) + zero-point
+// term + 1.5 * sum p'' s.  `zl`: 64 floats of scratch LDS of this wave.
+template <int R>
+__device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float* dst) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, kb = lane >> 4;
+    // per-lane dot sums -> LDS -> every lane gathers the four kb partials of the rows it needs
+    if constexpr (R == 1) {
+        zl[lane] = A.z4 * 0.0625f + A.z6 * 0.015625f;
+        __builtin_amdgcn_wave_barrier();
+        // output lane (n, kb' = cg): bracket = sum_kb zl[row 4 cg + 2] + 1.5 * sum_kb zl[row 4 cg]
+        float zs = 0.f, zm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            zs += zl[4 * kb + 16 * k];
+            zm += zl[4 * kb + 2 + 16 * k];
+        }
+        const float br = __builtin_fmaf(1.5f, zs, zm);
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++) {
+            // (scalar selects: an `if (kb == c) v = acc[c]` chain over the vectors becomes a scratch array indexed by kb)
+            float v0 = A.acc[0][tile][0], v1 = A.acc[0][tile][1];
+#pragma unroll
+            for (int c = 1; c < 4; c++) {
+                v0 = (kb == c) ? A.acc[c][tile][0] : v0;
+                v1 = (kb == c) ? A.acc[c][tile][1] : v1;
+            }
+            dst[32 * kb + 16 * tile + n] = __builtin_fmaf(v0 + v1, (float)(1 << KIVI_MF_PROD_SHIFT), br);
+        }
+    } else {
+        zl[lane] = __builtin_fmaf(1.5f, A.h4 * 0.0625f + A.h6 * 0.015625f, A.z4 * 0.0625f + A.z6 * 0.015625f);
+        __builtin_amdgcn_wave_barrier();
+        float br[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            br[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) br[r] += zl[4 * kb + r + 16 * k];
+        }
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = A.acc[0][tile][r];
+#pragma unroll
+                for (int c = 1; c < 4; c++) v = (kb == c) ? A.acc[c][tile][r] : v;
+                dst[r * 128 + 32 * kb + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = clamp(floor(log2 sum), 0, 14),
+// so that p'' * scale stays a normal fp16 whatever the row length
+__device__ __forceinline__ int mf_sp(float sum) {
+    const int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
+    return e < 0 ? 0 : (e > 14 ? 14 : e);
+}
+// fp16 p -> p'' for token t: 2^(Sp + 4) for (t & 7) < 4, 2^(Sp + 6) otherwise (the register i = (t & 7) >> 1 of the operand)
+__device__ __forceinline__ uint16_t mf_scale_p(uint16_t p, int sp, int t) {
+    const int e = sp + ((t & 4) ? 6 : 4);
+    return f2h_bits(__builtin_ldexpf(h2f_bits(p), e));
+}
+
+}  // namespace

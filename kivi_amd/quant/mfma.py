@@ -1,4 +1,4 @@
-"""The MFMA-friendly cache layout for grouped-query decode (include/kivi_hip.h, "grouped queries on the matrix pipe").
+"""The MFMA-friendly cache layout (grouped-query decode since round 2, multi-head decode since round 3) (include/kivi_hip.h, "grouped queries on the matrix pipe").
 
 Not part of the reference's Python surface: the reference keeps the hook-state tensors (models/llama_kivi.py:454-455)
 and, for grouped queries, expands them nh / nh_kv times per call (models/mistral_kivi.py:58-67) or lets the CUDA kernel
@@ -18,7 +18,7 @@ BLOCK_TOKENS = 32
 
 def supported(k_bits: int, v_bits: int, group_size: int, head_dim: int, residual_length: int, ratio: int) -> bool:
     return (k_bits == 2 and v_bits == 2 and group_size == 32 and head_dim == 128 and residual_length % 32 == 0
-            and ratio in (4, 8))
+            and ratio in (1, 4, 8))
 
 
 def alloc_store(B: int, nh_kv: int, n_sb: int, device) -> torch.Tensor:
@@ -99,3 +99,28 @@ def gqa_scores(q: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tensor, 
     _lib.check(_lib.load().kivi_gqa_scores(_lib.ptr(q), q.stride(0), q.stride(1), *_st(store), _lib.ptr(out), out.stride(0),
                                            out.stride(1), B, nh, nh_kv, D, T, group_size, bits, _lib.stream_ptr(q)),
                "kivi_gqa_scores")
+
+
+_OUT_WS = {}
+
+
+def gqa_output(probs: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tensor = None, group_size: int = 32, bits: int = 2) -> torch.Tensor:
+    """out[b, h, 0, :] = packed sV over tokens [0, T) of a VT store for given fp16 attention weights probs (B, nh, 1, >= T)
+    (rows 16-byte aligned, pitch a multiple of 8): cuda_bmm_fA_qB_outer at llama_kivi.py:382 on the matrix-pipe layout,
+    nh / nh_kv in {1, 4}."""
+    B, nh = probs.shape[0], probs.shape[1]
+    nh_kv = store.shape[1]
+    assert probs.dtype == torch.float16 and probs.stride(3) == 1
+    if out is None:
+        out = torch.empty((B, nh, 1, 128), dtype=torch.float16, device=probs.device)
+    nsb = max(1, (T + SB_TOKENS - 1) // SB_TOKENS)
+    need = 65536 + ((B * nh * 4 + 255) // 256) * 256 + B * nh_kv * nsb * 2 * (nh // nh_kv) * 128 * 4
+    key = (str(probs.device), torch.cuda.current_stream(probs.device).cuda_stream)
+    ws = _OUT_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=probs.device)
+        _OUT_WS[key] = ws
+    _lib.check(_lib.load().kivi_gqa_output(_lib.ptr(probs), probs.stride(0), probs.stride(1), *_st(store), _lib.ptr(out),
+                                           out.stride(0), out.stride(1), B, nh, nh_kv, 128, T, group_size, bits, _lib.ptr(ws),
+                                           ws.numel(), _lib.stream_ptr(probs)), "kivi_gqa_output")
+    return out

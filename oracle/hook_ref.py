@@ -72,8 +72,12 @@ def prefill_attention_eager(query_states, key_states, value_states, attention_ma
 
 
 def decode_step(query_states, key_states, value_states, past, k_bits, v_bits, group_size, residual_length,
-                attention_mask=None):
-    """llama_kivi.py:314-399.  query (B,nh,1,D), key/value (B,nh_kv,1,D) -> (attn_output (B,nh,1,D), new 9-tuple)."""
+                attention_mask=None, scores_override=None, return_scores=False):
+    """llama_kivi.py:314-399.  query (B,nh,1,D), key/value (B,nh_kv,1,D) -> (attn_output (B,nh,1,D), new 9-tuple).
+
+    Two-stage checks of a fused implementation (tests/test_mfma_gpu.py): `return_scores` also returns the fp16 row the
+    reference feeds its softmax (scores / sqrt(D) + mask, :339, :364-372); `scores_override` replaces that row (e.g. by
+    the row the implementation under test produced) before the softmax, everything after it (:375-399) unchanged."""
     B, nh, q_len, D = query_states.shape
     nh_kv = key_states.shape[1]
     groups = nh // nh_kv
@@ -101,6 +105,10 @@ def decode_step(query_states, key_states, value_states, past, k_bits, v_bits, gr
     if attention_mask is not None:
         attn_weights = attn_weights + attention_mask
         attn_weights = torch.max(attn_weights, torch.tensor(torch.finfo(attn_weights.dtype).min))
+    pre_softmax = attn_weights
+    if scores_override is not None:
+        assert scores_override.shape == attn_weights.shape and scores_override.dtype == attn_weights.dtype
+        attn_weights = scores_override
     attn_weights = torch.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)         # :375
     v_full = torch.cat([v_full, value_states], dim=2)                                                     # :377
     Lv = v_full.shape[-2]
@@ -118,4 +126,7 @@ def decode_step(query_states, key_states, value_states, past, k_bits, v_bits, gr
             vc, vs, vm = torch.cat([vc, vc_n], 2), torch.cat([vs, vs_n], 2), torch.cat([vm, vm_n], 2)
         else:
             vc, vs, vm = vc_n, vs_n, vm_n
-    return attn_output, (kc, k_full, ks, km, vc, v_full, vs, vm, kv_seq_len)
+    new_past = (kc, k_full, ks, km, vc, v_full, vs, vm, kv_seq_len)
+    if return_scores:
+        return attn_output, new_past, pre_softmax
+    return attn_output, new_past

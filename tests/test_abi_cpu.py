@@ -283,7 +283,8 @@ def _gqa_args(**over):
              vres=0x1000, vres_sb=2 * 65 * 128, vres_sh=65 * 128, vres_st=128, v_win_start=0, v_res_len=32,
              vnew=0x1000, vnew_sb=2 * 128, vnew_sh=128, v_flush=1,
              scores=0x1000, s_sb=8 * 528, s_sh=528, stats=0x1000, stats_bytes=2 * 8 * 5 * 2 * 4,
-             workspace=0x1000, workspace_bytes=65536 + 4 * (1 + 1) * 2 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128)
+             workspace=0x1000, workspace_bytes=65536 + 4 * (1 + 1) * 2 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128,
+             residual_length=32, v_window_rows=65, kt_superblocks=2, vt_superblocks=2, flags=0)
     f.update(over)
     return _lib.GqaDecodeArgs(**f)
 
@@ -298,6 +299,15 @@ def _gqa_args(**over):
     (dict(workspace_bytes=65536), None, b"workspace"),
     (dict(workspace_bytes=65536 + 4 * 1 * 2 * 4 * 128 * 4), None, b"workspace"),   # one slot per slice is not enough: + the window block's
     (dict(vnew=0x1004), None, b"value rows"),
+    # what the step writes must lie inside the caller's buffers: K append row, V append row, the VT slot of the
+    # token leaving the window, the packed prefix
+    (dict(k_res_len=32, Tq=480, Tv=480), None, b"residual_length"),
+    (dict(residual_length=16), None, b"residual_length"),
+    (dict(v_win_start=33), None, b"window rows"),
+    (dict(v_window_rows=32), None, b"window rows"),
+    (dict(vt_superblocks=0), None, b"exceed the stores"),
+    (dict(Tq=1024, Tv=999, kt_superblocks=1), None, b"exceed the stores"),
+    (dict(v_res_len=31, Tv=488), None, b"v_flush"),
 ])
 def test_gqa_decode_validates_before_launching(lib, over, rc_expected, msg):
     """kivi_gqa_decode (the grouped-query layer step, llama_kivi.py:314-399 / mistral_kivi.py:381-445) refuses bad shapes,
@@ -317,7 +327,9 @@ def test_layer_cache_factory_picks_the_layout():
     mf = make_layer_cache(KiviConfig(2, 2, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32)
     assert isinstance(mf, KiviLayerCacheMF) and mf.n_sb == 2 and mf.kt.shape == (1, 8, 2, 6144) and not mf.kt.any()
     assert mf.kt.stride(2) == 8 * 6144 and mf.kt.stride(1) == 6144      # super-block index outside the head index in memory
-    for kw in (dict(num_heads=8), dict(num_heads=24), dict(num_heads=None)):
+    mha = make_layer_cache(KiviConfig(2, 2, 32, 32), 1, 8, 128, 1000, "cpu", num_heads=8)       # round 3: multi-head models too
+    assert isinstance(mha, KiviLayerCacheMF) and mha.n_sb == 2
+    for kw in (dict(num_heads=24), dict(num_heads=16), dict(num_heads=None)):
         assert isinstance(make_layer_cache(KiviConfig(2, 2, 32, 128), 1, 8, 128, 1000, "cpu", **kw), KiviLayerCache)
     assert isinstance(make_layer_cache(KiviConfig(4, 4, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
     assert isinstance(make_layer_cache(KiviConfig(2, 2, 64, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)

@@ -36,9 +36,11 @@ class LaunchProbe:
         return (self.lib.kivi_last_timed_kernel() or b"").decode()
 
 
-def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False, expect_kernel=None, D=128):
-    """Full-size decode steps on the GPU; hook_ref on the sampled (b, kv head) slices.  Returns the kernels seen."""
-    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False, expect_kernel=None, D=128, layout="hook"):
+    """Full-size decode steps on the GPU; hook_ref on the sampled (b, kv head) slices.  Returns the kernels seen.
+    layout "hook": the hook-state layout (KiviLayerCache, VALU kernels); "auto": what make_layer_cache picks for the shape
+    (the matrix-pipe layout for 2-bit / g=32 / D=128 with nh / nh_kv in {1, 4, 8})."""
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode, make_layer_cache
     from oracle import hook_ref as H
     ratio = nh // nh_kv
     cfg = KiviConfig(bits, bits, g, R)
@@ -47,7 +49,10 @@ def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False
     v0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
     # plain randn: with large-magnitude K channels the fp16 scores reach |s| ~ 100, where ONE ulp of a dominant score
     # (0.0625 / sqrt(D)) moves its probability by 0.5 % -- summation-order flips would then exceed any output bar
-    layer = KiviLayerCache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda")
+    if layout == "hook":
+        layer = KiviLayerCache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda")
+    else:
+        layer = make_layer_cache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda", num_heads=nh)
     layer.prefill(k0, v0)
     pasts = {}
     for (b, hk) in samples:
@@ -101,6 +106,23 @@ def test_bench_shape_decode_row_kernel_vs_oracle(oracle, bits, masked):
     print("worst ratio vs the 3e-3 hook bar:", worst)
 
 
+@pytest.mark.parametrize("T0,masked", [(4096, False), (4080, True)])
+def test_bench_shape_mf_row_kernel_vs_oracle(oracle, T0, masked):
+    """The shape bench.py runs since round 3: B=32, 32 heads, 2-bit g=32 R=32 on the matrix-pipe layout, one launch per layer
+    (mf_row_kernel); 40 steps across the K flush (kivi_kt_pack at 4096 + 32 / 4080 + 16), the V flush of every step, a
+    window compaction and the growth into a ninth super-block.  The launch probe proves which kernel was checked."""
+    seen, worst = run_sampled(B=32, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=40, samples=[(0, 0), (13, 7), (31, 31)],
+                              seed=11, masked=masked, expect_kernel="mf_row_kernel", layout="auto")
+    print("worst ratio vs the 3e-3 hook bar:", worst)
+
+
+@pytest.mark.parametrize("B,T0", [(1, 32768 + 13), (4, 4080), (16, 4080)])
+def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0):
+    """Few (batch row, head) rows (B = 1 x 32k keys, B = 4 / 16 x 4k): rows longer than the LDS row or fewer than 192 rows
+    run the two-launch form with the rows cut into slices."""
+    run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=6, samples=[(0, 0), (B - 1, 31)], seed=15, layout="auto")
+
+
 def test_bench_shape_prompt_4080_k_flush_mid_page(oracle):
     """bench.py's default prompt (4080 tokens: K residual starts at 16, the flush lands inside the timed region)."""
     run_sampled(B=32, nh=32, nh_kv=32, T0=4080, R=32, bits=2, g=32, steps=20, samples=[(5, 3), (30, 17)], seed=12,
@@ -115,6 +137,8 @@ def test_config4_shape_gqa_8k_vs_oracle(oracle, B, steps):
     samples = [(0, 0), (B - 1, 7), (B // 2, 3)]
     run_sampled(B=B, nh=32, nh_kv=8, T0=8192 + 124, R=128, bits=2, g=32, steps=steps, samples=samples, seed=13,
                 masked=(B == 2))
+    if B == 64:      # the layout the hook uses for this shape since round 2 (matrix pipe), round-3 kernels
+        run_sampled(B=B, nh=32, nh_kv=8, T0=8192 + 124, R=128, bits=2, g=32, steps=steps, samples=samples, seed=13, layout="auto")
 
 
 @pytest.mark.parametrize("B", [1, 2])

@@ -1,6 +1,7 @@
-"""GPU: the MFMA-friendly cache layout for grouped queries (kivi_amd/quant/mfma.py, kivi_amd/csrc/kivi_gqa.hip):
-relayout kernels are bit-exact inverses and reproduce the hook-state tensors of the reference pack; the matrix-pipe
-qK^T / sV agree with the oracle's restatement of gemv_cuda.cu:348-427 within the GEMV bar."""
+"""GPU: the MFMA-friendly cache layout (kivi_amd/quant/mfma.py, kivi_amd/csrc/kivi_gqa.hip, kivi_mf.hip; nh / nh_kv in
+{1, 4, 8}): relayout kernels are bit-exact inverses and reproduce the hook-state tensors of the reference pack; the
+matrix-pipe qK^T AND sV each agree with the oracle's restatement of gemv_cuda.cu:348-427 within the north_star GEMV bar
+(1e-3), in isolation and stage by stage inside the decode step."""
 import pytest
 import torch
 
@@ -82,10 +83,11 @@ def test_vt_relayout_round_trip(mods, B, nh_kv, T):
 
 
 @pytest.mark.parametrize("B,nh,nh_kv,T", [(1, 4, 1, 32), (2, 8, 2, 544), (1, 8, 1, 1024), (3, 16, 2, 96), (16, 32, 8, 8192),
-                                          (1, 32, 8, 4096)])
+                                          (1, 32, 8, 4096), (1, 1, 1, 32), (2, 3, 3, 544), (1, 2, 2, 480), (32, 32, 32, 4096),
+                                          (1, 32, 32, 32768)])
 def test_gqa_scores_vs_oracle(mods, oracle, B, nh, nh_kv, T):
-    """Matrix-pipe qK^T (ratio 4 and 8; partial super-blocks; both block shapes) against the oracle on sampled heads and
-    against the VALU kernel of the paged layout everywhere."""
+    """Matrix-pipe qK^T (ratio 1, 4 and 8; partial super-blocks; both block shapes; the BASELINE configs[1] size) against
+    the oracle on sampled heads and against the VALU kernel of the hook-state layout everywhere."""
     mfma, new_pack, matmul = mods
     k = make_kv(3, B, nh_kv, T, 128, "outlier").cuda()
     q = (make_kv(4, B, nh, 1, 128) * 1.5).half().cuda()
@@ -107,11 +109,12 @@ def test_gqa_scores_vs_oracle(mods, oracle, B, nh, nh_kv, T):
         assert ok, (b, hk, ratio)
 
 
-def test_gqa_scores_exact_arithmetic(mods):
+@pytest.mark.parametrize("nh,nh_kv", [(8, 2), (2, 2), (16, 2)])
+def test_gqa_scores_exact_arithmetic(mods, nh, nh_kv):
     """Integer-valued inputs (quant/test.py:182-183 style): every product and sum is exact in fp32, so head mapping, the
     layout's bit positions and the hi / lo operand split must reproduce the dequantised matmul exactly."""
     mfma, new_pack, _ = mods
-    B, nh, nh_kv, T = 2, 8, 2, 1056
+    B, T = 2, 1056
     g = torch.Generator().manual_seed(0)
     k = torch.randint(0, 4, (B, nh_kv, T, 128), generator=g).half().cuda()     # groups span 0..3 -> scale 1 or less, exact
     k[:, :, ::32] = 0
@@ -123,6 +126,71 @@ def test_gqa_scores_exact_arithmetic(mods):
     mfma.gqa_scores(q, store, T, out)
     ref = torch.matmul(q.float(), k.float().repeat_interleave(nh // nh_kv, dim=1).transpose(2, 3))
     assert torch.equal(out.float(), ref.half().float())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the matrix-pipe sV in isolation (VERDICT r2 #1a): kivi_gqa_output vs oracle.bmm_fA_qB_outer at the north_star GEMV bar
+
+def _probs(kind, B, nh, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "softmax":        # peaked rows: a few dominant keys
+        return torch.softmax(torch.randn((B, nh, 1, T), generator=g) * 3, -1).half()
+    if kind == "uniform":        # the worst cancellation between the code sum and the zero-point sum
+        return torch.full((B, nh, 1, T), 1.0 / T).half()
+    if kind == "sparse":         # exact zeros and probabilities down to the fp16 subnormals
+        p = torch.softmax(torch.randn((B, nh, 1, T), generator=g) * 12, -1)
+        return p.half()
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["softmax", "uniform", "sparse"])
+@pytest.mark.parametrize("B,nh,nh_kv,T", [(2, 4, 1, 33), (1, 8, 2, 544), (2, 32, 8, 8192), (1, 32, 8, 32768),
+                                          (2, 2, 2, 33), (1, 3, 3, 544), (4, 32, 32, 4064), (1, 4, 4, 32768)])
+def test_gqa_output_vs_oracle(mods, oracle, B, nh, nh_kv, T, kind):
+    """out = probs @ dequant(V) on the VT layout (ratio 1 and 4; ragged last block; one to 64 super-blocks; rows cut into
+    slices) against the oracle's restatement of the reference kernel (gemv_cuda.cu:348-427 at llama_kivi.py:382) on
+    sampled kv heads with gemv_close(rtol=1e-3), and against the VALU kernel of the hook-state layout everywhere."""
+    mfma, new_pack, matmul = mods
+    v = make_kv(21, B, nh_kv, T, 128, "outlier" if kind == "softmax" else "randn").cuda()
+    store = mfma.alloc_store(B, nh_kv, (T + 511) // 512, "cuda")
+    mfma.vt_pack(v, store)
+    pitch = (T + 7) // 8 * 8 + 8
+    probs = torch.zeros((B, nh, 1, pitch), dtype=torch.float16, device="cuda")
+    probs[..., :T] = _probs(kind, B, nh, T, 5).cuda()
+    probs[..., T:] = 1.0                                             # beyond the row: must not be read as a probability
+    out = mfma.gqa_output(probs, store, T)
+    assert torch.isfinite(out).all()
+    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(v, 32, 2)
+    ref_gpu = matmul.cuda_bmm_fA_qB_outer(32, probs[..., :T], code, scale, mn, 2)
+    ok, ratio = gemv_close(out, ref_gpu.cpu(), rtol=1.5e-3)          # two roundings of the same exact sum apart
+    assert ok, ratio
+    ratio_h = nh // nh_kv
+    for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
+        hs = slice(hk * ratio_h, (hk + 1) * ratio_h)
+        ref = oracle.bmm_fA_qB_outer(32, probs[b:b + 1, hs, :, :T].cpu().contiguous(), code[b:b + 1, hk:hk + 1].cpu(),
+                                     scale[b:b + 1, hk:hk + 1].cpu(), mn[b:b + 1, hk:hk + 1].cpu(), 2)
+        ok, ratio = gemv_close(out[b:b + 1, hs], ref, rtol=1e-3)
+        assert ok, (b, hk, ratio)
+
+
+def test_gqa_output_exact_arithmetic(mods):
+    """Integer-valued V and power-of-two probabilities: every product and sum is exact, so the layout's bit positions, the
+    centring of the codes (A x (code - 1.5) + 1.5 sum A) and the hi / lo split must reproduce the dequantised matmul
+    exactly."""
+    mfma, new_pack, _ = mods
+    for nh, nh_kv in ((4, 1), (2, 2)):
+        B, T = 2, 700
+        g = torch.Generator().manual_seed(0)
+        v = torch.randint(0, 4, (B, nh_kv, T, 128), generator=g).half()
+        v[..., ::32] = 0
+        v[..., 1::32] = 3                                               # every group: min 0, max 3 -> scale 1, codes = values
+        v = v.cuda()
+        p = (torch.randint(0, 3, (B, nh, 1, 704), generator=g).float() * 2.0 ** -10).half().cuda()
+        store = mfma.alloc_store(B, nh_kv, 2, "cuda")
+        mfma.vt_pack(v, store)
+        out = mfma.gqa_output(p, store, T)
+        ref = torch.matmul(p[..., :T].float(), v.float().repeat_interleave(nh // nh_kv, dim=1))
+        assert torch.equal(out.float(), ref.half().float())
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -141,14 +209,22 @@ def _cmp_cache(t_gpu, t_ref):
 
 
 @pytest.mark.parametrize("nh,nh_kv,T0,R,masked", [(4, 1, 5, 32, False), (8, 2, 70, 32, True), (8, 1, 33, 32, False),
-                                                    (16, 2, 600, 64, False), (8, 2, 1100, 128, True), (32, 8, 300, 128, False)])
+                                                    (16, 2, 600, 64, False), (8, 2, 1100, 128, True), (32, 8, 300, 128, False),
+                                                    (2, 2, 5, 32, False), (3, 3, 70, 32, True), (4, 4, 600, 64, False),
+                                                    (2, 2, 1100, 128, True)])
 def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked):
-    """Every step: outputs within the hook bar, and after R + 9 steps (one K flush, V flushes, a window compaction, a
-    partial last super-block) the 9-tuple is bit-identical to the reference logic's.
-    The hook bar (3e-3 of max(|ref|, rms)) is the size of ONE fp16 ulp flip in the score of a dominant key (the fp32 sums of
-    two correct implementations round differently for ~0.2 % of the scores, tools/mf_stage_error.py): with 32 heads x 137
-    steps such a flip lands on a heavy token now and then, for either layout (tools/mf_ratio.py shows the hook-layout
-    kernels at 0.9 of the bar on the same inputs).  So: every step within 2x the bar, at most 2 % of the steps above it."""
+    """Every step of R + 9 (one K flush, V flushes, a window compaction, cache growth, a partial last super-block), stage by
+    stage against the reference logic (oracle/hook_ref.py), no step-level escape:
+      A. the fp16 row fed to the softmax (packed qK^T | residual scores, / sqrt(D), + mask; llama_kivi.py:324-372) within
+         the north_star GEMV bar (1e-3 of max(|ref|, rms) + 1 ulp) of the reference's row;
+      B. the output within 2e-3 of the reference's attend half (:375-399) run ON THE ROW THE GPU PRODUCED: the GEMV bar
+         for the packed sV + one fp16 ulp (4.9e-4) of the probability of a dominant key (the row sum of exp is added in a
+         different order) + the roundings of the two partial sums.
+    A and B bound the end-to-end difference by the triangle inequality; what they leave out -- how a one-ulp difference in
+    a dominant score moves its probability -- is the reference softmax itself, run on the CPU in stage B.
+    After R + 9 steps the 9-tuple is bit-identical to the reference logic's.  nh == nh_kv: the two-launch form is forced
+    (the one-launch row kernel keeps its scores in LDS; test_mf_row_kernel_matches_two_launch_form ties it to this)."""
+    from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, KiviLayerCacheMF, kivi_attention_decode, make_layer_cache
     from oracle import hook_ref as H
     B, D, g = 2, 128, 32
@@ -157,28 +233,84 @@ def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked)
     k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
     layer = make_layer_cache(cfg, B, nh_kv, D, T0 + 8, "cuda", num_heads=nh)    # small capacity: the cache must grow
     assert isinstance(layer, KiviLayerCacheMF)
+    layer.flags = _lib.GQA_FORCE_SPLIT
     layer.prefill(k0.cuda(), v0.cuda())
     past = H.prefill_cache(k0, v0, 2, 2, g, R)
     _cmp_cache(layer.as_tuple(), past)
     gen = torch.Generator().manual_seed(5)
-    over = 0
+    worst_a = worst_b = 0.0
     for s in range(steps):
         q = make_kv(100 + s, B, nh, 1, D)
         kn, vn = make_kv(200 + s, B, nh_kv, 1, D), make_kv(300 + s, B, nh_kv, 1, D)
         mask = None
+        n = T0 + s + 1
         if masked:
-            n = T0 + s + 1
             mask = torch.zeros((B, 1, 1, n), dtype=torch.float16)
             mask[0, ..., : min(7, n - 1)] = torch.finfo(torch.float16).min          # left padding of batch row 0
             mask[1, ..., torch.randint(0, n - 1, (3,), generator=gen)] = -3.0
         out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer, attention_mask=None if mask is None else mask.cuda())
-        ref, past = H.decode_step(q, kn, vn, past, 2, 2, g, R, attention_mask=mask)
-        ok, ratio = gemv_close(out, ref, rtol=3e-3)
-        assert ratio <= 2.0, (s, ratio)
-        over += (not ok)
+        x_gpu = layer._native[4][0][:B, :nh, :, :n].cpu()                            # the row the sV launch consumed
+        ref, past_ref, x_ref = H.decode_step(q, kn, vn, past, 2, 2, g, R, attention_mask=mask, return_scores=True)
+        live = x_ref.float() > -60000                                                # fully masked keys: both sides at the fp16 minimum
+        ok, ra = gemv_close(torch.where(live, x_gpu.float(), 0.0), torch.where(live, x_ref.float(), 0.0), rtol=1e-3)
+        assert ok, ("scores", s, ra)
+        assert torch.equal(x_gpu[~live], x_ref[~live])
+        ref_b, past_b = H.decode_step(q, kn, vn, past, 2, 2, g, R, attention_mask=mask, scores_override=x_gpu)
+        ok, rb = gemv_close(out, ref_b, rtol=2e-3)
+        assert ok, ("attend", s, rb)
+        worst_a, worst_b = max(worst_a, ra), max(worst_b, rb)
+        past = past_ref
         if s in (0, R - 1, R, steps - 1):
             _cmp_cache(layer.as_tuple(), past)
-    assert over <= max(1, steps // 50), over
+    print(f"worst ratio: scores {worst_a:.3f} of the 1e-3 bar, attend {worst_b:.3f} of the 2e-3 bar")
+
+
+@pytest.mark.parametrize("B,nh,T0,R,masked", [(2, 4, 5, 32, False), (8, 32, 1500, 32, True), (2, 2, 8100, 32, False),
+                                               (4, 8, 4080, 128, False)])
+def test_mf_row_kernel_matches_two_launch_form(oracle, B, nh, T0, R, masked):
+    """nh == nh_kv: the one-launch row kernel (mf_row_kernel: scores never leave the LDS) against the two-launch form of
+    the same step (stage-checked above) on cloned caches: same packed qK^T body -> same scores; the softmax sum and the
+    sV partial sums are added in a different order -> outputs within 1.5e-3 (GEMV bar + one fp16 ulp of a dominant
+    probability); every cache write identical: 9-tuples bit-identical after a K flush and V flushes.  Also vs the
+    reference logic end to end at the hook bar."""
+    from kivi_amd import _lib
+    from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
+    from oracle import hook_ref as H
+    D, g = 128, 32
+    cfg = KiviConfig(2, 2, g, R)
+    k0, v0 = make_kv(1, B, nh, T0, D), make_kv(2, B, nh, T0, D)
+    a = make_layer_cache(cfg, B, nh, D, T0 + 2 * R + 8, "cuda", num_heads=nh)
+    a.prefill(k0.cuda(), v0.cuda())
+    b_ = a.clone()
+    a.flags, b_.flags = _lib.GQA_FORCE_ROW, _lib.GQA_FORCE_SPLIT
+    samples = sorted({(0, 0), (B - 1, nh - 1)})
+    pasts = {(b, h): H.prefill_cache(k0[b:b + 1, h:h + 1], v0[b:b + 1, h:h + 1], 2, 2, g, R) for b, h in samples}
+    probe_lib = _lib.load()
+    for s in range(R + 3):
+        q, kn, vn = make_kv(100 + s, B, nh, 1, D).cuda(), make_kv(200 + s, B, nh, 1, D).cuda(), make_kv(300 + s, B, nh, 1, D).cuda()
+        mask = None
+        if masked:
+            mask = torch.zeros((B, 1, 1, T0 + s + 1), dtype=torch.float16, device="cuda")
+            mask[0, ..., :9] = torch.finfo(torch.float16).min
+        e0, e1 = probe_lib.kivi_event_create(), probe_lib.kivi_event_create()
+        probe_lib.kivi_set_launch_events(e0, e1)
+        oa = kivi_attention_decode(q, kn, vn, a, attention_mask=mask)
+        torch.cuda.synchronize()
+        assert b"mf_row_kernel" in (probe_lib.kivi_last_timed_kernel() or b"")
+        ob = kivi_attention_decode(q, kn, vn, b_, attention_mask=mask)
+        ok, r = gemv_close(oa, ob, rtol=1.5e-3)
+        assert ok, (s, r)
+        for (bb, h) in samples:
+            ref, pasts[(bb, h)] = H.decode_step(q[bb:bb + 1, h:h + 1].cpu(), kn[bb:bb + 1, h:h + 1].cpu(), vn[bb:bb + 1, h:h + 1].cpu(),
+                                                pasts[(bb, h)], 2, 2, g, R, attention_mask=None if mask is None else mask[bb:bb + 1].cpu())
+            ok, r = gemv_close(oa[bb:bb + 1, h:h + 1], ref, rtol=3e-3)
+            assert ok, (s, bb, h, r)
+    ta, tb = a.as_tuple(), b_.as_tuple()
+    for x, y in zip(ta[:8], tb[:8]):
+        assert (x is None and y is None) or same_bits(x, y)
+    for (bb, h) in samples:
+        sl = tuple(None if x is None else x[bb:bb + 1, h:h + 1] for x in ta[:8]) + (ta[8],)
+        _cmp_cache(sl, pasts[(bb, h)])
 
 
 @pytest.mark.parametrize("B,nh,nh_kv,T0,R", [(64, 32, 8, 8192 - 128, 128), (2, 32, 8, 8192 - 128, 128), (2, 32, 8, 32768 - 128, 128),
@@ -241,8 +373,8 @@ def test_mf_cache_from_tuple_and_clone(oracle):
 def test_decode_flushes_of_subnormal_groups_are_bit_exact(oracle, nh, nh_kv):
     """K / V values in the fp16-subnormal neighbourhood: groups whose range is 0 or ONE subnormal ulp have scale 0, and
     the reference then gives code 0 to the minimum (0 / 0 = NaN) and the maximum code to everything above it (d / 0 = inf).
-    Every quantiser on the decode path (prefill packs, K flush, V leaving the window; hook layout for nh == nh_kv, matrix-
-    pipe layout for grouped heads) must reproduce that: the cache tuples stay bit-identical through a flush."""
+    Every quantiser on the decode path (prefill packs, K flush, V leaving the window; matrix-pipe layout, one-launch row
+    kernel for nh == nh_kv) must reproduce that: the cache tuples stay bit-identical through a flush."""
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
     from oracle import hook_ref as H
     B, D, g, R, T0 = 2, 128, 32, 32, 75
