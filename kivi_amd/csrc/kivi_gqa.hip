@@ -64,9 +64,9 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
 #pragma unroll
     for (int n = 0; n < 16; n++)
         if ((n >> 2) == i) cw[(n + 16 * kb) * 4 + c] = pw[n];
-    const int hidx = kb * 32 + c * 8 + 2 * i;    // kt_half of channel 2l (even): the pair (2l, 2l+1) is one word
-    (sb + KIVI_MF_SB_SCALE_WORD0 + (blk & 15) * 64)[hidx >> 1] = scale2;
-    (sb + KIVI_MF_SB_MN_WORD0 + (blk & 15) * 64)[hidx >> 1] = mn2;
+    const int hidx = kt_sm_half((int)(blk & 15), 2 * lane);    // channel 2l (even): the pair (2l, 2l+1) is one word
+    (sb + KIVI_MF_SB_SCALE_WORD0)[hidx >> 1] = scale2;
+    (sb + KIVI_MF_SB_MN_WORD0)[hidx >> 1] = mn2;
 }
 
 // Per-token V quantise + pack of a prompt straight into the VT layout (prompt pass, models/llama_kivi.py:441-448: the
@@ -128,8 +128,9 @@ __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* 
     const int d = threadIdx.x;
     uint32_t* sb = mf_sb(st, b, hk, blk >> 4);
     uint32_t* cw = sb + (blk & 15) * KIVI_MF_BLOCK_WORDS;
-    uint16_t* ks = (uint16_t*)(sb + KIVI_MF_SB_SCALE_WORD0) + (blk & 15) * 128;
-    uint16_t* km = (uint16_t*)(sb + KIVI_MF_SB_MN_WORD0) + (blk & 15) * 128;
+    uint16_t* ks = (uint16_t*)(sb + KIVI_MF_SB_SCALE_WORD0);
+    uint16_t* km = (uint16_t*)(sb + KIVI_MF_SB_MN_WORD0);
+    const int gsb = blk & 15;
     uint32_t* cref = code + b * code_sb + hk * code_sh + (int64_t)d * code_sr + (int64_t)blk * 2;
     const int64_t sidx = b * sm_sb + hk * sm_sh + (int64_t)d * sm_sr + blk;
     if constexpr (TO_REF) {
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* 
             for (int n = 0; n < 16; n++) w |= ((lds[kt_word(n + 16 * tile, d)] >> kt_bit(n + 16 * tile, d)) & 3u) << (2 * n);
             cref[tile] = w;
         }
-        scale[sidx] = ks[kt_half(d)];
-        mn[sidx] = km[kt_half(d)];
+        scale[sidx] = ks[kt_sm_half(gsb, d)];
+        mn[sidx] = km[kt_sm_half(gsb, d)];
     } else {
         lds[2 * d] = cref[0];
         lds[2 * d + 1] = cref[1];
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* 
                 }
             cw[wi] = w;
         }
-        ks[kt_half(d)] = scale[sidx];
-        km[kt_half(d)] = mn[sidx];
+        ks[kt_sm_half(gsb, d)] = scale[sidx];
+        km[kt_sm_half(gsb, d)] = mn[sidx];
     }
 }
 
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
 #pragma unroll
-    for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + n * 256 + kb * 64 + c * 16), 0);
+    for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(n, kb, c) * 4), 0);
     u32x4 wr[RING];
 #pragma unroll
     for (int i = 0; i < RING; i++) wr[i] = buf_load<u32x4, true>(rk, (uint32_t)(i * 1024 + lane * 16), 0);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(64 * W) void gqa_k_kernel(const GqaKArgs a) {
     auto group = [&](int g, const u32x4& w) {
         u32x4 s[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) s[c] = *(const u32x4*)(lds_s + g * 64 + kb * 16 + c * 4);
+        for (int c = 0; c < 4; c++) s[c] = *(const u32x4*)(lds_s + kt_sm_word4(g, kb, c));
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; c++) {

@@ -25,10 +25,10 @@ namespace {
 
 // per-wave LDS words of mf_k_kernel: [scale of the super-block: 1024 words, R = 4 only | R x 512 fp16 scores]
 template <int R>
-constexpr int mf_k_lds_words() { return (R == 4 ? 1024 : 0) + R * 256; }
+constexpr int mf_k_lds_words() { return (R == 4 ? 1024 : 64) + R * 256; }   // R = 1: 64 words for the q operand
 
 template <int R, int W, int RING>
-__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a) {
+__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
     extern __shared__ uint32_t lds_all[];
     const int main_blocks = (int)gridDim.x - a.res_blocks;
     if ((int)blockIdx.x >= main_blocks) {                            // short residual blocks at the tail of the grid
@@ -39,29 +39,60 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_w = lds_all + wave * mf_k_lds_words<R>();
-    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 4 ? 1024 : 0));
+    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 4 ? 1024 : 64));
     const int unit = bid / a.sb_blocks;
-    const int sb = (bid - unit * a.sb_blocks) * W + wave;
-    if (sb >= a.nsb) return;
+    const int sb0 = ((bid - unit * a.sb_blocks) * W + wave) * spw;  // this wave: super-blocks sb0 .. sb0 + spw - 1
+    if (sb0 >= a.nsb) return;
     const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
     const int h0 = hk * a.ratio;
-    int ng = (int)((a.Tq - (int64_t)sb * KIVI_MF_SB_TOKENS) / 32);
-    ng = ng > 16 ? 16 : ng;
 
-    const uint32_t* sbp = mf_sb(a.kt, b, hk, sb);
-    const rsrc_t rk = make_rsrc(sbp, KIVI_MF_SB_WORDS * 4);
-    auto sink = [&](int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); };
+    // scores of one finished super-block (R x 512 fp16 in lds_o) -> memory: one 16-byte store per lane and head; the decode
+    // step scales + masks them as the reference feeds its softmax (llama_kivi.py:339, :364-372) and leaves (max, sum exp)
+    auto flush_sb = [&](int sb, int ng) {
+        __builtin_amdgcn_wave_barrier();
+        const bool valid = lane * 8 < ng * 32;
+        const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8 : nullptr;
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            u16x8 v = valid ? *(const u16x8*)(lds_o + rr * 512 + lane * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.stats) {
+                float x[8], m = -__builtin_inff();
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    v[e] = kivi_scaled_score(v[e], a.inv_scale, mrow != nullptr, (mrow && valid) ? mrow[e] : 0);
+                    x[e] = h2f_bits(v[e]);
+                    m = __builtin_fmaxf(m, x[e]);
+                }
+                m = wave_max(valid ? m : -__builtin_inff());
+                float l = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) l += kivi_exp(x[e] - m);
+                l = wave_sum(valid ? l : 0.f);
+                if (lane == 0) {
+                    float* st = a.stats + (((int64_t)b * a.nh + h0 + rr) * a.nseg + sb) * 2;
+                    st[0] = m;
+                    st[1] = l;
+                }
+            }
+            if (valid)
+                *(u16x8*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
     if constexpr (R == 1) {
-        MfQ<1> Q;
-        mf_load_q<1>(a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, Q);
-        mf_k_run1<RING>(rk, 0u, 0, ng, Q, sink);
+        const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.kt.sb_s * 4));
+        MfKSeq seq;
+        seq.sb_bytes = (uint32_t)(a.kt.sb_s * 4);
+        seq.sb_first = sb0;
+        seq.sb_stride = 1;
+        seq.n_sb = (sb0 + spw <= a.nsb) ? spw : a.nsb - sb0;
+        const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
+        seq.ng_total = (int)(((a.Tq < tok_end ? a.Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
+        mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w,
+                        [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
         const int n = lane & 15, kb = lane >> 4;
-        u32x4 sreg[4], zreg[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
-#pragma unroll
-        for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + n * 256 + kb * 64 + c * 16), 0);
         MfQ<4> Q;
         mf_load_q<4>(a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, Q);
         float zmul[4], cmul[4];
@@ -71,62 +102,52 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a) {
             zmul[j] = __builtin_ldexpf(1.0f, -sqj);
             cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
         }
+        auto sink = [&](int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); };
+        for (int sb = sb0; sb < sb0 + spw && sb < a.nsb; sb++) {
+            int ng = (int)((a.Tq - (int64_t)sb * KIVI_MF_SB_TOKENS) / 32);
+            ng = ng > 16 ? 16 : ng;
+            const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, sb), KIVI_MF_SB_WORDS * 4);
+            u32x4 sreg[4], zreg[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) *(u32x4*)(lds_w + (j * 64 + lane) * 4) = sreg[j];
-        float zz[4];
-        mf_k_zero4(Q, zreg, zmul, zz);
-        __builtin_amdgcn_wave_barrier();
-        mf_k_run4<RING>(rk, 0u, 0, ng, Q, lds_w, zz, cmul, sink);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // 512 tokens x R heads of fp16 scores: one 16-byte store per lane and head
-    const bool valid = lane * 8 < ng * 32;
-    const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8 : nullptr;
+            for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
 #pragma unroll
-    for (int rr = 0; rr < R; rr++) {
-        u16x8 v = valid ? *(const u16x8*)(lds_o + rr * 512 + lane * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (a.stats) {
-            float x[8], m = -__builtin_inff();
+            for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(n, kb, c) * 4), 0);
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                v[e] = kivi_scaled_score(v[e], a.inv_scale, mrow != nullptr, (mrow && valid) ? mrow[e] : 0);
-                x[e] = h2f_bits(v[e]);
-                m = __builtin_fmaxf(m, x[e]);
-            }
-            m = wave_max(valid ? m : -__builtin_inff());
-            float l = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) l += kivi_exp(x[e] - m);
-            l = wave_sum(valid ? l : 0.f);
-            if (lane == 0) {
-                float* st = a.stats + (((int64_t)b * a.nh + h0 + rr) * a.nseg + sb) * 2;
-                st[0] = m;
-                st[1] = l;
-            }
+            for (int j = 0; j < 4; j++) *(u32x4*)(lds_w + (j * 64 + lane) * 4) = sreg[j];
+            float zz[4];
+            mf_k_zero4(Q, zreg, zmul, zz);
+            __builtin_amdgcn_wave_barrier();
+            mf_k_run4<RING>(rk, 0u, 0, ng, Q, lds_w, zz, cmul, sink);
+            flush_sb(sb, ng);
         }
-        if (valid)
-            *(u16x8*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
     }
 }
 
 template <int R, int W, int RING>
-void launch_mf_k(const GqaKArgs& a, int units, hipStream_t s) {
+void launch_mf_k(const GqaKArgs& a, int units, int spw, hipStream_t s) {
     const size_t lds = (size_t)W * mf_k_lds_words<R>() * 4;
-    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a);
+    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a, spw);
 }
 
 int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
-    const int W = ((int64_t)units * a.nsb >= 2048) ? 4 : 1;        // few super-blocks: one wave per block spreads them over the CUs
-    a.sb_blocks = (a.nsb + W - 1) / W;
+    // a wave walks `spw` consecutive super-blocks of its unit (the next one's operands are requested while the current one is
+    // multiplied): 2 when that still leaves >= 4 waves per SIMD, else 1; few super-blocks: one wave per block spreads them
+    const int64_t total = (int64_t)units * a.nsb;
+    int spw = (total >= 8192 && a.nsb >= 2) ? 2 : 1;
+    static const char* fs = getenv("KIVI_MF_SPW");                 // tuning aid
+    if (fs) spw = atoi(fs) > 0 ? atoi(fs) : 1;
+    const int chunks = (a.nsb + spw - 1) / spw;                     // waves per unit
+    const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
+    a.sb_blocks = (chunks + W - 1) / W;
     if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
     static const char* fr = getenv("KIVI_MF_RING");                // tuning aid: code blocks in flight (2 or 4)
     const int ring = fr ? atoi(fr) : 4;
     if (a.ratio == 1) {
-        if (W == 4) { if (ring == 2) launch_mf_k<1, 4, 2>(a, units, s); else launch_mf_k<1, 4, 4>(a, units, s); }
-        else { if (ring == 2) launch_mf_k<1, 1, 2>(a, units, s); else launch_mf_k<1, 1, 4>(a, units, s); }
+        if (W == 4) { if (ring == 2) launch_mf_k<1, 4, 2>(a, units, spw, s); else launch_mf_k<1, 4, 4>(a, units, spw, s); }
+        else { if (ring == 2) launch_mf_k<1, 1, 2>(a, units, spw, s); else launch_mf_k<1, 1, 4>(a, units, spw, s); }
     } else {
-        if (W == 4) { if (ring == 2) launch_mf_k<4, 4, 2>(a, units, s); else launch_mf_k<4, 4, 4>(a, units, s); }
-        else { if (ring == 2) launch_mf_k<4, 1, 2>(a, units, s); else launch_mf_k<4, 1, 4>(a, units, s); }
+        if (W == 4) { if (ring == 2) launch_mf_k<4, 4, 2>(a, units, spw, s); else launch_mf_k<4, 4, 4>(a, units, spw, s); }
+        else { if (ring == 2) launch_mf_k<4, 1, 2>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
     }
     return kivi_launch_status("mf_k");
 }
@@ -164,12 +185,12 @@ constexpr int MF_PW = 136;
 
 template <int R, int RING, bool PROB>
 __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
-    extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 64 words of dot sums)
+    extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
     __shared__ uint16_t pw[R][MF_PW];
     const int bid = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int WW = R * 256 + 64;                               // per-wave words
+    constexpr int WW = R * 256 + 128;                              // per-wave words
     uint16_t* lds_p = (uint16_t*)(lds_all + wave * WW);
     float* zl = (float*)(lds_all + wave * WW + R * 256);
     const int nstream = a.units * a.S;
@@ -206,10 +227,12 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
         const int64_t tok0 = (int64_t)sb * KIVI_MF_SB_TOKENS;
         int nb = (int)((a.Tv - tok0 + 31) / 32);
         nb = nb > 16 ? 16 : nb;
+        MfVStream<R, RING> vs;
+        vs.prime(rv, sb_bytes, sb * 16, sb * 16 + nb);              // the first code blocks fly while the probabilities are made
         __builtin_amdgcn_wave_barrier();                           // the previous super-block's LDS reads are over
         mf_probs_to_lds<R, PROB>(rx, (uint32_t)(a.x_sh * 2), tok0, a.Tv, M, invS, sp, lds_p);
         __builtin_amdgcn_wave_barrier();
-        mf_v_run<R, RING>(A, rv, sb_bytes, sb * 16, sb * 16 + nb, lds_p, 512, (int)tok0);
+        vs.run(A, rv, sb * 16, sb * 16 + nb, lds_p, 512, (int)tok0);
     }
 
     // ---- fp16 window (+ V append + flush): the window block of the unit (tail of the grid), or shares inside the stream blocks
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R>(A, zl, Lf);                                     // Lf[r * 128 + d], before 2^-Sp
+    mf_v_finish<R, RING>(A, zl, Lf);                               // Lf[r * 128 + d], before 2^-Sp
     // the p'' region of a wave holds R x 256 words = R x 128 floats twice: quantised part first, window part second
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
@@ -298,17 +321,27 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 // ------------------------------------------------------------------------------------------------ fused row (R = 1)
 
 // The whole decode step of one (batch row, head) in one block of NW waves.  Dynamic LDS: the score / p'' row (n_pad halves).
-template <int KRING, int VRING, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad, int chunk_groups) {
+// DBG (tools/mf_row_phases.py): every wave stamps the shader clock at its phase boundaries into av.dbg
+template <int KRING, int VRING, int NW, bool DBG = false>
+__global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int NTH = NW * 64;
     extern __shared__ uint16_t row[];                              // [n_pad] fp16 scores, then p''
     __shared__ float red[NW][128], resl[NW][128];
-    __shared__ float zl[NW][64];
+    __shared__ float zl[NW][128];
+    __shared__ uint32_t q_lds[NW][64];
     __shared__ uint16_t pw[1][MF_PW];
     __shared__ float sm_lds[NW];
     const int unit = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto stamp = [&](int i) {
+        if constexpr (DBG) {
+            const unsigned long long tck = __builtin_amdgcn_s_memtime();
+            if (lane == 0) av.dbg[((size_t)blockIdx.x * NW + wave) * 16 + i] = tck;
+        }
+    };
+    stamp(0);
+    if (DBG && lane == 0) av.dbg[((size_t)blockIdx.x * NW + wave) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
     const int b = unit / ak.nh_kv, hk = unit - b * ak.nh_kv;       // nh == nh_kv
     const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
     const int L = ak.res_len + 1;                                  // residual keys incl. the new one
@@ -318,24 +351,29 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
 
-    // ---- packed qK^T: chunks of `chunk_groups` groups, wave w takes chunks w, w + NW, ...
+    // ---- packed qK^T: wave w walks super-blocks w, w + NW, ... of the row (mf_k_seq1: one memory round trip up front, the next
+    // half's operands requested while the current one is multiplied)
     {
-        MfQ<1> Q;
-        mf_load_q<1>(qrow, ak.q_sh, Q);
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
-        const uint32_t sb_bytes = (uint32_t)(ak.kt.sb_s * 4);
+        MfKSeq seq;
+        seq.sb_bytes = (uint32_t)(ak.kt.sb_s * 4);
+        seq.sb_first = wave;
+        seq.sb_stride = NW;
+        seq.n_sb = ak.nsb > wave ? (ak.nsb - wave + NW - 1) / NW : 0;
+        const int last = wave + (seq.n_sb - 1) * NW;                // this wave's last super-block
         const int NG = Tq >> 5;
-        const int nchunk = (NG + chunk_groups - 1) / chunk_groups;
-        for (int ci = wave; ci < nchunk; ci += NW) {
-            const int gs = ci * chunk_groups;
-            const int sb = gs >> 4, g_lo = gs & 15;
-            int g_hi = g_lo + chunk_groups;
-            const int lim = NG - sb * 16;
-            g_hi = g_hi < lim ? g_hi : lim;
-            uint16_t* rsb = row + sb * KIVI_MF_SB_TOKENS;
-            mf_k_run1<KRING>(rk, (uint32_t)sb * sb_bytes, g_lo, g_hi, Q, [&](int tt, int, float v) { rsb[tt] = f2h_bits(v); });
-        }
+        seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
+        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], [&](int sb, int tt, float v) { row[sb * KIVI_MF_SB_TOKENS + tt] = f2h_bits(v); }, [](int, int) {});
     }
+    stamp(3);
+    // the first packed V blocks of this wave are requested now: they fly during the residual scores, the softmax and the window
+    const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
+    const int NB = (Tv + 31) >> 5;
+    const int nbw = (NB + NW - 1) / NW;
+    const int b_lo = wave * nbw;
+    const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
+    MfVStream<1, VRING> vs;
+    vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
     // ---- residual scores q . [K_full | k_new] (fp32 accumulate, one rounding: the reference's fp16 matmul, :337) + K append
     for (int idx = threadIdx.x; idx < L * 8; idx += NTH) {
         const int sub = idx & 7, t = idx >> 3;
@@ -356,7 +394,9 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         sc += __shfl_xor(sc, 4);
         if (sub == 0) row[Tq + t] = f2h_bits(sc);
     }
+    stamp(4);
     __syncthreads();
+    stamp(5);
 
     // ---- scale + mask + fp32 softmax of the row (llama_kivi.py:339, :364-375); each thread owns 4 consecutive scores per
     // chunk of 4 NTH; the probabilities of the packed prefix go back into the row as p'', the window's into pw
@@ -407,27 +447,25 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         }
     }
     __syncthreads();
+    stamp(7);
 
     // ---- fp16 window: probs[-Lw:] . V_full, V append, quantisation of the token leaving the window (:377-399)
     float ow[1][2];
     gqa_window_part<1, NTH, MF_PW>(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
     resl[wave][2 * lane] = ow[0][0];
     resl[wave][2 * lane + 1] = ow[0][1];
+    stamp(8);
 
     // ---- packed sV: contiguous block ranges per wave
     {
-        const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
-        const uint32_t sb_bytes = (uint32_t)(av.vt.sb_s * 4);
-        const int NB = (Tv + 31) >> 5;
-        const int nbw = (NB + NW - 1) / NW;
-        const int b_lo = wave * nbw;
-        const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
         MfVAcc<1> A;
         mf_v_init<1>(A);
-        mf_v_run<1, VRING>(A, rv, sb_bytes, b_lo, b_hi, row, 0, 0);
-        mf_v_finish<1>(A, zl[wave], red[wave]);
+        vs.run(A, rv, b_lo, b_hi, row, 0, 0);
+        stamp(9);
+        mf_v_finish<1, VRING>(A, zl[wave], red[wave]);
     }
     __syncthreads();
+    stamp(10);
     if (threadIdx.x < 128) {
         const int d = threadIdx.x;
         float qs = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
@@ -441,6 +479,13 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         // only the window part exists before anything is quantised (:380)
         const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
         av.out[b * av.out_sb + (int64_t)hk * av.out_sh + d] = o;
+    }
+    stamp(11);
+    if (DBG && lane == 0) {
+        unsigned long long* rec = av.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
+        rec[12] = __builtin_amdgcn_s_memrealtime();
+        rec[13] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID: wave slot, SIMD, CU, SE
+        rec[14] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // XCC_ID
     }
 }
 
@@ -464,7 +509,7 @@ int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
     const int ring = fr ? atoi(fr) : 4;
     const int R = a.ratio;
     const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
-    const size_t lds = (size_t)4 * (R * 256 + 64) * 4;
+    const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
 #define KIVI_MV(RR, RG, PB) KIVI_LAUNCH_LDS((mf_v_kernel<RR, RG, PB>), grid, dim3(256), lds, s, a)
     if (R == 1) {
         if (prob) { if (ring == 2) KIVI_MV(1, 2, true); else KIVI_MV(1, 4, true); }
@@ -489,20 +534,14 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     const int64_t n = k.Tq + k.res_len + 1;
     if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
     const int n_pad = (int)((n + 31) / 32 * 32);
-    const int NG = (int)(k.Tq / 32);
-    // whole super-blocks per wave when every wave gets at least two of them, smaller chunks for short rows
-    int cg = 16;
-    if (NG < 2 * 4 * 16) cg = 8;
-    if (NG < 2 * 4 * 8) cg = 4;
-    static const char* fc = getenv("KIVI_MF_ROW_CHUNK");          // tuning aid: groups per qK^T chunk (4, 8, 16)
-    if (fc) cg = atoi(fc);
     static const char* fr = getenv("KIVI_MF_ROW_RINGS");          // tuning aid: "<K ring><V ring>", e.g. 42
-    const int rings = fr ? atoi(fr) : 42;
+    const int rings = fr ? atoi(fr) : 43;
     const size_t lds = (size_t)n_pad * 2;
     const dim3 grid((unsigned)units);
-    if (rings == 22) KIVI_LAUNCH_LDS((mf_row_kernel<2, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
-    else if (rings == 43) KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
-    else if (rings == 23) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
-    else KIVI_LAUNCH_LDS((mf_row_kernel<4, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad, cg);
+    if (v.dbg) KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (rings == 22) KIVI_LAUNCH_LDS((mf_row_kernel<2, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (rings == 42) KIVI_LAUNCH_LDS((mf_row_kernel<4, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (rings == 23) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+    else KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");
 }

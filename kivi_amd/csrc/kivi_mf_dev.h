@@ -10,13 +10,12 @@
 //     are never read.  hi and lo (the exact fp16 split of the 22-bit product) are two chained MFMAs.  The zero-point term
 //     sum_d q * mn[d, g] comes out of 4 MFMAs per super-block in exactly the lanes / registers of the useful rows.
 //   * sV: an MFMA row is a CHANNEL GROUP (R = 1: (channel group, hi | lo); R = 4: (channel group, head) with hi and lo
-//     chained), the codes enter CENTRED: every tile first accumulates A x (-1.5) and then A x code, so the running sums
+//     chained), the code sums are CENTRED: one block in RING also accumulates A x (-1.5 RING), so the running sums
 //     through the C operand stay at the size of the output instead of growing to sum p * scale * code ~ 100x larger
 //     (the matrix pipe aligns its 32 products to the largest addend and drops what falls ~2^-26 below it: with the
 //     uncentred sums that loss, accumulated over 128 blocks, was 2e-3 of the output once code sum and zero-point sum
 //     cancelled, which is why round 2 started every MFMA from zero and added 32 registers on the VALU per block).
-//     The matching +1.5 * sum p * scale and the zero-point sum p * mn are v_dot2_f32_f16 on the operands the lane holds
-//     anyway.
+//     What was subtracted and the zero-point sum p * mn are v_dot2_f32_f16 on the operands the lane holds anyway.
 // VALU instructions per block: qK^T 106 -> ~50 (R = 1) / ~70 (R = 4), sV 115 -> ~62; matrix instructions 9-18 -> 16-24
 // on a pipe that was under 10 % busy.
 #pragma once
@@ -136,80 +135,203 @@ __device__ __forceinline__ void mf_k_build(const MfQ<R>& Q, const u32x4* sv, con
 
 // one 32-token group: 16 MFMAs (4 channel chunks x {hi, lo} x 2 token tiles), fp32 accumulate from zero.
 // acc0 / acc1: rows x tokens n / 16 + n of the group.
-template <int R>
+// DIAG (tools only, wrong results): 2 = no arithmetic at all (memory-side time), 3 = views / masks only (no MFMA),
+// 4 = MFMAs on the raw words (no views / masks), 5 = normal instead of subnormal B operands
+template <int R, int DIAG = 0>
 __device__ __forceinline__ void mf_k_group(const MfKSet<R>& S, const u32x4& w, f4& acc0, f4& acc1) {
     acc0 = f4{0.f, 0.f, 0.f, 0.f};
     acc1 = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (DIAG == 2) {
+        acc0[0] = __builtin_bit_cast(float, (w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x3FFFFFFFu);
+        acc0[1] = acc0[2] = acc0[3] = acc0[0];
+        acc1 = acc0;
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const MfB b = mf_views(w[c]);
+        MfB b;
+        if constexpr (DIAG == 4) {
+            b.b0 = as_h8(w[c], w[c], w[c], w[c]);
+            b.b1 = b.b0;
+        } else {
+            b = mf_views(w[c]);
+        }
+        if constexpr (DIAG == 5) {
+            b.b0 = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, b.b0) | 0x3C003C00u);
+            b.b1 = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, b.b1) | 0x3C003C00u);
+        }
         const h8 ah = as_h8(S.Ah[c][0], S.Ah[c][1], S.Ah[c][2], S.Ah[c][3]);
         const h8 al = as_h8(S.Al[c][0], S.Al[c][1], S.Al[c][2], S.Al[c][3]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, acc1, 0, 0, 0);
+        if constexpr (DIAG == 3) {
+            const u32x4 x0 = __builtin_bit_cast(u32x4, b.b0), x1 = __builtin_bit_cast(u32x4, b.b1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                acc0[i] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, acc0[i]) ^ x0[i] ^ S.Ah[c][i]) & 0x3FFFFFFFu);
+                acc1[i] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, acc1[i]) ^ x1[i] ^ S.Al[c][i]) & 0x3FFFFFFFu);
+            }
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, acc1, 0, 0, 0);
+            if constexpr (DIAG != 6) {           // DIAG 6: half the MFMAs (no lo part)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, acc1, 0, 0, 0);
+            }
+        }
     }
 }
 
-// Groups [g_lo, g_hi) of one super-block (g_lo a multiple of 4), R = 1: rows = the 16 groups of the super-block.
-// `rk`: buffer over the unit's K store, `sb_off`: byte offset of the super-block inside it (wave-uniform).
-// Scores: token tt of the super-block -> sink(tt, head 0, fp32 score).  RING = code blocks in flight (2 or 4).
-template <int RING, typename Sink>
-__device__ __forceinline__ void mf_k_run1(rsrc_t rk, uint32_t sb_off, int g_lo, int g_hi, const MfQ<1>& Q, Sink&& sink) {
+// ---- R = 1: rows = (8 groups) x (hi | lo).  Row m -> group (m & 7) of the current HALF super-block, m < 8: fp16(q'' scale),
+// m >= 8: the exact remainder -- one MFMA per (channel chunk, token tile) gives hi and lo sums in two rows, 8 MFMAs per group.
+// A wave walks a SEQUENCE of super-blocks (sb_first + i * sb_stride, i < n_sb; the last one may be partial) half by half:
+//   * everything the first half needs is requested before the first wait (q, scale, zero points, RING code blocks): one
+//     memory round trip, not three (the round-2 / first round-3 form paid q -> scale -> codes one after the other, per wave
+//     and super-block: ~10 us of a 46 us launch, tools/mf_ablation.sh);
+//   * the scale / zero points of half h + 1 are requested right after the A operands of half h have been built from the
+//     registers they land in; the code ring runs across halves and super-blocks.
+struct MfKSeq {
+    uint32_t sb_bytes;              // byte stride between consecutive super-blocks of the unit
+    int sb_first, sb_stride, n_sb;  // this wave's super-blocks
+    int ng_total;                   // 32-token groups in the whole sequence
+};
+
+// Scores go to sink(super-block index, token inside it, fp32 score).  RING = code blocks in flight (2 or 4).
+// done(super-block index, its number of groups) is called when the last score of a super-block has been handed to sink.
+// q_lds: 64 words of this wave's LDS (the normalised q operand is parked there: kept in registers, it and the loop-invariant
+// B operand of the zero-point product hipcc derives from it hold 32 registers across the whole loop).
+template <int RING, typename Sink, typename Done>
+__device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, Sink&& sink, Done&& done) {
     static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
-    // requests first: scale / zero points of the lane's row (group m), then the ring
+    const int gp = m & 7;
+    const uint32_t lomask = (m & 8) ? 0xFFFFFFFFu : 0u;
+    if (W.ng_total <= 0) return;
+    // ---- requests: q, scale / zero points of half 0, the ring
+    u16x8 qv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) qv[c] = *(const u16x8*)(q_row + 8 * kb + 32 * c);
+    const uint32_t row_off = (uint32_t)(kb * 128 + gp * 16);       // kt_sm_word4(gp, kb, 0) * 4: per chunk c 512 dense bytes per load
+    auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
     u32x4 sv[4], mv[4];
-    const uint32_t row_off = (uint32_t)(m * 256 + kb * 64);
+    auto request_half = [&](int hq) {
+        const uint32_t so = sb_off(hq >> 1) + (uint32_t)(hq & 1) * 2048u;      // half a super-block: 8 groups x 256 bytes
 #pragma unroll
-    for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_SCALE_WORD0 * 4 + row_off + c * 16, sb_off);
+        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_SCALE_WORD0 * 4 + row_off + c * 512, so);
 #pragma unroll
-    for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_MN_WORD0 * 4 + row_off + c * 16, sb_off);
+        for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_MN_WORD0 * 4 + row_off + c * 512, so);
+    };
+    request_half(0);
+    const int g_last = W.ng_total - 1;
     u32x4 wr[RING];
-    const int g_last = g_hi - 1;
+    auto request_group = [&](int slot, int gi) {
+        const int gc = gi < g_last ? gi : g_last;                   // clamped: no branch, no address past the sequence
+        wr[slot] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
+    };
 #pragma unroll
     for (int i = 0; i < RING; i++) {
-        const int g = (g_lo + i < g_last) ? g_lo + i : g_last;
-        wr[i] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)g * 1024u);
-        // the slots are requested in the order the loop re-requests them: hipcc merges the wait counters of the loop's two
-        // entries, and a different order here makes every wait inside the loop a vmcnt(0)
-        __builtin_amdgcn_sched_barrier(0);
+        request_group(i, i);
+        __builtin_amdgcn_sched_barrier(0);      // same request order as inside the loop: see mf_v_run
     }
-    MfKSet<1> S;
-    const float zm = __builtin_ldexpf(1.0f, -Q.sq);
-    const float zmul[4] = {zm, zm, zm, zm};
-    mf_k_build<1>(Q, sv, mv, zmul, S);
-    const float cmul = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - Q.sq);
-    float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
-        const bool mine = kb == (g0 >> 2);            // this lane's output rows 4 kb .. 4 kb + 3 are these four groups
+    // ---- q operand (kivi_mf_dev.h, MfQ): normalised to max |q| in [1, 2), times 2^aexp(i)
+    uint32_t amax = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t v = qv[c][e] & 0x7FFFu;
+            amax = v > amax ? v : amax;
+        }
+    amax = max(amax, (uint32_t)__shfl_xor((int)amax, 16));
+    amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32));
+    const int ex = (int)(amax >> 10);
+    const int sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);
+    {
+        uint32_t qq0[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sq + aexp(i));
+                const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sq + aexp(i));
+                qq0[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
+            }
+        if (m == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) *(u32x4*)(q_lds + kb * 16 + c * 4) = u32x4{qq0[c][0], qq0[c][1], qq0[c][2], qq0[c][3]};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float cmul = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sq);
+    const float zmul = __builtin_ldexpf(0.5f, -sq);                 // 0.5: the hi and the lo lane of a group each add the zero-point term
+    const int n_half = (W.ng_total + 7) >> 3;
+    for (int hq = 0; hq < n_half; hq++) {
+        // ---- A operands of this half from the registers the requests landed in; zero-point sums of its 8 groups
+        uint32_t A[4][4];
+        u32x4 qq[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) qq[c] = *(const u32x4*)(q_lds + kb * 16 + c * 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t hi = pk_mul(qq[c][i], sv[c][i]);
+                A[c][i] = pk_fms(qq[c][i], sv[c][i], hi & lomask);
+            }
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const h8 bq = as_h8(pk_mul(qq[c][0], zfac(0)), pk_mul(qq[c][1], zfac(1)), pk_mul(qq[c][2], zfac(2)), pk_mul(qq[c][3], zfac(3)));
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), bq, z, 0, 0, 0);
+        }
+        // the zero-point sums are pinned HERE: hipcc otherwise sinks their MFMAs below the group loop (where z is first
+        // read) and keeps their 32 operand registers alive across it
+        float zs[4] = {z[0] * zmul, z[1] * zmul, z[2] * zmul, z[3] * zmul};
+        asm volatile("" : "+v"(zs[0]), "+v"(zs[1]), "+v"(zs[2]), "+v"(zs[3]));
+        request_half(hq + 1 < n_half ? hq + 1 : hq);               // lands during this half's groups (the last one: a repeat)
+        __builtin_amdgcn_sched_barrier(0);
+        float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            const bool mine = (kb & 1) == u;                        // output rows 4 kb' + j: group 4 (kb' & 1) + j of the half
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int gi = hq * 8 + u * 4 + j;
+                const u32x4& w = wr[j % RING];
+                f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const MfB b = mf_views(w[c]);
+                    const h8 av = as_h8(A[c][0], A[c][1], A[c][2], A[c][3]);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b0, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, a1, 0, 0, 0);
+                }
+                o0[j] = mine ? a0[j] : o0[j];
+                o1[j] = mine ? a1[j] : o1[j];
+                request_group(j % RING, gi + RING);                 // after the last use: the load lands in the slot directly
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // lane (n, kb'), register j: the hi (kb' < 2) or lo part of group 4 (kb' & 1) + j of the half, tokens n (o0) / 16 + n (o1)
+        const int sbi = hq >> 1;
+        const int gbase = (hq & 1) * 8 + 4 * (kb & 1);
+        const int g_lim = W.ng_total - sbi * 16;                    // groups of this super-block that exist
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            f4 a0, a1;
-            mf_k_group<1>(S, wr[j % RING], a0, a1);
-            o0[j] = mine ? a0[j] : o0[j];
-            o1[j] = mine ? a1[j] : o1[j];
-            // reload AFTER the last use (the slot's register is dead here, the load lands in it directly); clamped to the
-            // chunk's last group: no branch inside the round
-            const int gn = (g0 + j + RING < g_last) ? g0 + j + RING : g_last;
-            wr[j % RING] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)gn * 1024u);
+            float v0 = __builtin_fmaf(o0[j], cmul, zs[j]), v1 = __builtin_fmaf(o1[j], cmul, zs[j]);
+            v0 += __shfl_xor(v0, 32);
+            v1 += __shfl_xor(v1, 32);
+            const int g = gbase + j;
+            if (g < g_lim) {
+                if (kb < 2) sink(W.sb_first + sbi * W.sb_stride, g * 32 + m, v0);
+                else sink(W.sb_first + sbi * W.sb_stride, g * 32 + 16 + m, v1);
+            }
         }
-    }
-    // lane (n, kb), register j: group 4 kb + j, tokens n and 16 + n
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int g = 4 * kb + j;
-        if (g >= g_lo && g < g_hi) {
-            sink(g * 32 + m, 0, __builtin_fmaf(o0[j], cmul, S.Zs[j]));
-            sink(g * 32 + 16 + m, 0, __builtin_fmaf(o1[j], cmul, S.Zs[j]));
-        }
+        if ((hq & 1) || hq + 1 == n_half) done(W.sb_first + sbi * W.sb_stride, g_lim < 16 ? g_lim : 16);
     }
 }
 
 // R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups.  `lds_s`: the super-block's scale region staged
-// in this wave's LDS (4 KiB, kt_half order, filled by the caller); `zz`: zero-point sums of the whole super-block, lane
+// in this wave's LDS (4 KiB, memory order, filled by the caller); `zz`: zero-point sums of the whole super-block, lane
 // (group, any kb), register j = head j, already in score units (mf_k_zero4).
 template <int RING, typename Sink>
 __device__ __forceinline__ void mf_k_run4(rsrc_t rk, uint32_t sb_off, int g_lo, int g_hi, const MfQ<4>& Q, const uint32_t* lds_s,
@@ -229,11 +351,10 @@ __device__ __forceinline__ void mf_k_run4(rsrc_t rk, uint32_t sb_off, int g_lo, 
     }
     for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
         // A operands of this round: row m -> group g0 + (m >> 2), head m & 3
-        const uint32_t* sp = lds_s + (g0 + (m >> 2)) * 64 + kb * 16;
         uint32_t Ah[4][4], Al[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const u32x4 s = *(const u32x4*)(sp + c * 4);
+            const u32x4 s = *(const u32x4*)(lds_s + kt_sm_word4(g0 + (m >> 2), kb, c));
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 Ah[c][i] = pk_mul(Q.qq[c][i], s[i]);
@@ -296,31 +417,46 @@ __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, con
 }
 
 // ------------------------------------------------------------------------------------------------ sV
-// Accumulators of a wave over its token blocks: acc[c][tile] = rows x channels 32 c + 16 tile + n.
+// Accumulators of a wave over its token blocks: acc[c][tile] = rows x channels 32 c + 16 tile + n, chained through the
+// C operand over all blocks.
 // R = 1: row 4 cg + j, j even = hi, j odd = lo part of p'' * scale[t, cg]; the lanes of rows j >= 2 load the ZERO POINTS
 //        instead of the scale (their rows are never read) and so accumulate sum p'' * mn while rows j < 2 accumulate
 //        sum p'' * scale -- one 16-byte load per lane brings both.
-// R = 4: row 4 cg + r = (channel group cg, head r); hi and lo are two operands; z = sum p'' * mn, hs = sum hi.
+// R = 4: row 4 cg + r = (channel group cg, head r); hi and lo are two operands.
 // p'' = the fp16 probability times 2^(Sp + aexp(i)) (exact), i = ((t & 7) >> 1): written that way into LDS by the softmax.
+// CENTRING: the codes are all >= 0 and the zero points < 0, so sum p s code grows to ~100x the output and the matrix pipe
+// (which aligns its 32 products to the largest addend, C included, and drops what falls ~2^-26 below) loses 2e-3 of the
+// output over a 4k row.  So the FIRST block of every ring round also accumulates A x (-1.5 RING) -- the expected code sum of
+// the round -- and the lanes keep the exact sum of the A they centred with (cs4 / cs6, v_dot2_f32_f16); the running sums
+// then stay within ~RING blocks' worth of the output.  (A centring MFMA for every tile of every block -- the first round-3
+// form -- doubled the matrix instructions for nothing.)
 template <int R>
 struct MfVAcc {
     f4 acc[4][2];
-    float z4, z6, h4, h6;      // dot-product sums of the registers with 2^4 / 2^6
+    float z4, z6;      // R = 1: sum p'' * (scale | mn) of every block; R = 4: sum p'' * mn        (registers with 2^4 / 2^6)
+    float c4, c6;      // sums over the centring blocks: R = 1: p'' * (scale | mn); R = 4: the hi operand
 };
 
 template <int R>
 __device__ __forceinline__ void mf_v_init(MfVAcc<R>& A) {
 #pragma unroll
     for (int c = 0; c < 4; c++) A.acc[c][0] = A.acc[c][1] = f4{0.f, 0.f, 0.f, 0.f};
-    A.z4 = A.z6 = A.h4 = A.h6 = 0.f;
+    A.z4 = A.z6 = A.c4 = A.c6 = 0.f;
 }
+
+// -1.5 * RING in the units of a masked code: registers 0, 1 hold code * 2^-16, registers 2, 3 code * 2^-18 (fp16 bits, both halves)
+template <int RING> struct MfCentre;
+template <> struct MfCentre<2> { static constexpr uint32_t a = 0x83008300u, b = 0x80C080C0u; static constexpr float f = 3.0f; };
+template <> struct MfCentre<3> { static constexpr uint32_t a = 0x84808480u, b = 0x81208120u; static constexpr float f = 4.5f; };
+template <> struct MfCentre<4> { static constexpr uint32_t a = 0x86008600u, b = 0x81808180u; static constexpr float f = 6.0f; };
 
 // one 32-token block.  w: code words; ps: the lane's 8 scaled probabilities (tokens 8 kb + e of its row's head);
 // R = 1: sm = scale (rows j < 2) or zero points (rows j >= 2), lomask = all ones in lo rows;  R = 4: sm = scale, mn = zero points.
-template <int R>
+// CENTRE: this block also accumulates A x (-1.5 RING).
+template <int R, int RING, bool CENTRE>
 __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u32x4& ps, const u32x4& sm, const u32x4& mn,
                                            uint32_t lomask) {
-    const h8 bc = as_h8(MF_C15A, MF_C15A, MF_C15B, MF_C15B);
+    const h8 bc = as_h8(MfCentre<RING>::a, MfCentre<RING>::a, MfCentre<RING>::b, MfCentre<RING>::b);
     if constexpr (R == 1) {
         uint32_t a[4];
 #pragma unroll
@@ -332,12 +468,21 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
         A.z4 = dot2_f16(ps[1], sm[1], A.z4);
         A.z6 = dot2_f16(ps[2], sm[2], A.z6);
         A.z6 = dot2_f16(ps[3], sm[3], A.z6);
+        if constexpr (CENTRE) {
+            A.c4 = dot2_f16(ps[0], sm[0], A.c4);
+            A.c4 = dot2_f16(ps[1], sm[1], A.c4);
+            A.c6 = dot2_f16(ps[2], sm[2], A.c6);
+            A.c6 = dot2_f16(ps[3], sm[3], A.c6);
+        }
         const h8 av = as_h8(a[0], a[1], a[2], a[3]);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const MfB b = mf_views(w[c]);
-            f4 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, A.acc[c][0], 0, 0, 0);
-            f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, A.acc[c][1], 0, 0, 0);
+            f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
+            if constexpr (CENTRE) {
+                x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, x1, 0, 0, 0);
+            }
             A.acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b0, x0, 0, 0, 0);
             A.acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, x1, 0, 0, 0);
         }
@@ -352,16 +497,21 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
         A.z4 = dot2_f16(ps[1], mn[1], A.z4);
         A.z6 = dot2_f16(ps[2], mn[2], A.z6);
         A.z6 = dot2_f16(ps[3], mn[3], A.z6);
-        A.h4 = dot2_f16(hi[0], MF_ONE2, A.h4);
-        A.h4 = dot2_f16(hi[1], MF_ONE2, A.h4);
-        A.h6 = dot2_f16(hi[2], MF_ONE2, A.h6);
-        A.h6 = dot2_f16(hi[3], MF_ONE2, A.h6);
+        if constexpr (CENTRE) {
+            A.c4 = dot2_f16(hi[0], MF_ONE2, A.c4);
+            A.c4 = dot2_f16(hi[1], MF_ONE2, A.c4);
+            A.c6 = dot2_f16(hi[2], MF_ONE2, A.c6);
+            A.c6 = dot2_f16(hi[3], MF_ONE2, A.c6);
+        }
         const h8 ah = as_h8(hi[0], hi[1], hi[2], hi[3]), al = as_h8(lo[0], lo[1], lo[2], lo[3]);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const MfB b = mf_views(w[c]);
-            f4 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, A.acc[c][0], 0, 0, 0);
-            f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, A.acc[c][1], 0, 0, 0);
+            f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
+            if constexpr (CENTRE) {
+                x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, x1, 0, 0, 0);
+            }
             x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, x0, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, x1, 0, 0, 0);
             A.acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, x0, 0, 0, 0);
@@ -370,69 +520,88 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
     }
 }
 
-// Token blocks [b_lo, b_hi) of one unit's V store.  `rv`: buffer over the unit's V store (all its super-blocks), sb_bytes =
-// byte stride between consecutive super-blocks; ps_lds: the R rows of scaled probabilities (halves), row pitch `pitch`
-// halves, indexed by token - tok0.
+// The stream of token blocks [b_lo, b_hi) of one unit's V store.  `rv`: buffer over the unit's V store (all its super-blocks),
+// sb_bytes = byte stride between consecutive super-blocks.  prime() requests the first RING blocks (callers do it as early
+// as they can: the fused row kernel before its softmax), run() consumes: ps_lds = the R rows of scaled probabilities
+// (halves), row pitch `pitch` halves, indexed by token - tok0.
 template <int R, int RING>
-__device__ __forceinline__ void mf_v_run(MfVAcc<R>& A, rsrc_t rv, uint32_t sb_bytes, int b_lo, int b_hi, const uint16_t* ps_lds,
-                                         int pitch, int tok0) {
-    const int lane = threadIdx.x & 63;
-    const int m = lane & 15, kb = lane >> 4;
-    // R = 1: row 4 cg + j; R = 4: row 4 cg + r
-    const int cg = m >> 2, j = m & 3;
-    const uint32_t lomask = (R == 1 && (j & 1)) ? 0xFFFFFFFFu : 0u;
-    const uint32_t sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
-    const uint32_t mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
-    const uint16_t* prow = ps_lds + (R == 1 ? 0 : j * pitch) + 8 * kb - tok0;
-    if (b_hi <= b_lo) return;
-    const int b_last = b_hi - 1;
+struct MfVStream {
     u32x4 wr[RING], sr[RING], mr[R == 1 ? 1 : RING];
-    auto request = [&](int slot, int bl) {
+    uint32_t sm_off, mn_off, sb_bytes;
+    int b_last;
+
+    __device__ __forceinline__ void request(rsrc_t rv, int slot, int bl) {
+        const int lane = threadIdx.x & 63;
         const int bc = bl < b_last ? bl : b_last;                  // clamped: no branch, no out-of-range address
         const uint32_t so = (uint32_t)(bc >> 4) * sb_bytes;
         wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16), so + (uint32_t)(bc & 15) * 1024u);
         sr[slot] = buf_load<u32x4, true>(rv, sm_off, so + (uint32_t)(bc & 15) * 256u);
         if constexpr (R != 1) mr[slot] = buf_load<u32x4, true>(rv, mn_off, so + (uint32_t)(bc & 15) * 256u);
-    };
-#pragma unroll
-    for (int i = 0; i < RING; i++) {
-        request(i, b_lo + i);
-        __builtin_amdgcn_sched_barrier(0);             // same request order as inside the loop (see mf_k_run1)
     }
-    for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
+
+    __device__ __forceinline__ void prime(rsrc_t rv, uint32_t sb_bytes_, int b_lo, int b_hi) {
+        const int lane = threadIdx.x & 63;
+        const int m = lane & 15, kb = lane >> 4;
+        const int cg = m >> 2, j = m & 3;
+        sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
+        mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
+        sb_bytes = sb_bytes_;
+        b_last = b_hi > b_lo ? b_hi - 1 : b_lo;
+        if (b_hi <= b_lo) return;
 #pragma unroll
-        for (int s = 0; s < RING; s++) {
-            const int bl = b0 + s;
-            // blocks past the range repeat the last block with zero probabilities
-            u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_last) * 32);
-            if (bl >= b_hi) ps = u32x4{0, 0, 0, 0};
-            mf_v_block<R>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
-            request(s, bl + RING);
-            // memory operations stay on their side of this point (ALU / MFMA / LDS may cross): without it hipcc moves all
-            // RING re-requests to the end of the round, i.e. a block's data is asked for one block before its use
+        for (int i = 0; i < RING; i++) {
+            request(rv, i, b_lo + i);
+            // the slots are requested in the order the loop re-requests them: hipcc merges the wait counters of the loop's
+            // two entries, and a different order here makes every wait inside the loop a vmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
+
+    __device__ __forceinline__ void run(MfVAcc<R>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0) {
+        const int lane = threadIdx.x & 63;
+        const int m = lane & 15, kb = lane >> 4;
+        const int j = m & 3;
+        const uint32_t lomask = (R == 1 && (j & 1)) ? 0xFFFFFFFFu : 0u;
+        const uint16_t* prow = ps_lds + (R == 1 ? 0 : j * pitch) + 8 * kb - tok0;
+        if (b_hi <= b_lo) return;
+        for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; s++) {
+                const int bl = b0 + s;
+                // blocks past the range repeat the last block with zero probabilities
+                u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_last) * 32);
+                if (bl >= b_hi) ps = u32x4{0, 0, 0, 0};
+                if (s == 0) mf_v_block<R, RING, true>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+                else mf_v_block<R, RING, false>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+                request(rv, s, bl + RING);
+                // nothing moves across this point: without it hipcc gathers all RING re-requests at the end of the round, i.e.
+                // a block's data is asked for one block before its use
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+};
 
 // Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]) -- 2^12 * (hi + lo sums) + zero-point
 // term + 1.5 * sum p'' s.  `zl`: 64 floats of scratch LDS of this wave.
-template <int R>
+template <int R, int RING>
 __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float* dst) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, kb = lane >> 4;
+    constexpr float CF = MfCentre<RING>::f;                       // what the centring blocks subtracted per unit of A
     // per-lane dot sums -> LDS -> every lane gathers the four kb partials of the rows it needs
     if constexpr (R == 1) {
         zl[lane] = A.z4 * 0.0625f + A.z6 * 0.015625f;
+        zl[64 + lane] = A.c4 * 0.0625f + A.c6 * 0.015625f;
         __builtin_amdgcn_wave_barrier();
-        // output lane (n, kb' = cg): bracket = sum_kb zl[row 4 cg + 2] + 1.5 * sum_kb zl[row 4 cg]
-        float zs = 0.f, zm = 0.f;
+        // output lane (n, kb' = cg): sum p'' mn (rows 4 cg + 2) + CF * sum over the centring blocks of p'' s (rows 4 cg)
+        float zc = 0.f, zm = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            zs += zl[4 * kb + 16 * k];
+            zc += zl[64 + 4 * kb + 16 * k];
             zm += zl[4 * kb + 2 + 16 * k];
         }
-        const float br = __builtin_fmaf(1.5f, zs, zm);
+        const float br = __builtin_fmaf(CF, zc, zm);
 #pragma unroll
         for (int tile = 0; tile < 2; tile++) {
             // (scalar selects: an `if (kb == c) v = acc[c]` chain over the vectors becomes a scratch array indexed by kb)
@@ -445,7 +614,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float
             dst[32 * kb + 16 * tile + n] = __builtin_fmaf(v0 + v1, (float)(1 << KIVI_MF_PROD_SHIFT), br);
         }
     } else {
-        zl[lane] = __builtin_fmaf(1.5f, A.h4 * 0.0625f + A.h6 * 0.015625f, A.z4 * 0.0625f + A.z6 * 0.015625f);
+        zl[lane] = __builtin_fmaf(CF, A.c4 * 0.0625f + A.c6 * 0.015625f, A.z4 * 0.0625f + A.z6 * 0.015625f);
         __builtin_amdgcn_wave_barrier();
         float br[4];
 #pragma unroll

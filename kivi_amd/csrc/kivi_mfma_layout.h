@@ -16,7 +16,12 @@
 //   K block, token tt (0..31), channel d (0..127):      c = d >> 5, kb = (d >> 3) & 3, e = d & 7
 //        word (n + 16 kb) * 4 + c   with n = tt & 15, tile = tt >> 4
 //        bits mf_pos(tile, e >> 1) + 16 * (e & 1)               (lo half: even channel, hi half: odd channel)
-//        scale / mn of (channel d, this group): half kb * 32 + c * 8 + e
+//        scale / mn of (channel d, group g = block index inside the super-block): half kt_sm_half(g, d) of the region =
+//        (g >> 3) * 1024 + c * 256 + kb * 64 + (g & 7) * 8 + e  -- for each 32-channel chunk c the 16 bytes (kb, g) of the
+//        8 groups of a half super-block are contiguous, i.e. the A-operand load of a wave whose MFMA rows are GROUPS (lane
+//        (row = group, kb) takes 16 bytes per chunk) reads 512 dense bytes per instruction.  (Round 2 kept the 128 halves of a
+//        group together: the same load then touched 32 cache lines for 16 bytes each, 4x the L2 requests of the whole code
+//        stream -- measured 49 us vs 35 us per BASELINE configs[1] launch, profiles/r03_kt_scale_layout.log.)
 //   V block, token tt, channel d:                        c = d >> 5 (= channel group), tile = (d >> 4) & 1, n = d & 15
 //        word (n + 16 kb) * 4 + c   with kb = tt >> 3, e = tt & 7
 //        bits mf_pos(tile, e >> 1) + 16 * (e & 1)               (lo half: even token, hi half: odd token)
@@ -50,7 +55,11 @@
 __device__ __forceinline__ int kt_word(int tt, int d) { return ((tt & 15) + 16 * ((d >> 3) & 3)) * 4 + (d >> 5); }
 __device__ __forceinline__ int mf_pos(int tile, int i) { return ((tile ? 0xEA0C : 0x2648) >> (4 * i)) & 15; }
 __device__ __forceinline__ int kt_bit(int tt, int d) { return mf_pos(tt >> 4, (d & 7) >> 1) + 16 * (d & 1); }
-__device__ __forceinline__ int kt_half(int d) { return ((d >> 3) & 3) * 32 + (d >> 5) * 8 + (d & 7); }
+__device__ __forceinline__ int kt_sm_half(int g, int d) {
+    return (g >> 3) * 1024 + (d >> 5) * 256 + ((d >> 3) & 3) * 64 + (g & 7) * 8 + (d & 7);
+}
+// word (= 2 halves) offset of the 16 bytes (channels 32 c + 8 kb .. + 7) of group g inside the scale / mn region
+__device__ __forceinline__ int kt_sm_word4(int g, int kb, int c) { return (g >> 3) * 512 + c * 128 + kb * 32 + (g & 7) * 4; }
 __device__ __forceinline__ int vt_word(int tt, int d) { return ((d & 15) + 16 * (tt >> 3)) * 4 + (d >> 5); }
 __device__ __forceinline__ int vt_bit(int tt, int d) { return mf_pos((d >> 4) & 1, (tt & 7) >> 1) + 16 * (tt & 1); }
 __device__ __forceinline__ int vt_half(int tt, int c) { return (tt >> 3) * 32 + c * 8 + (tt & 7); }

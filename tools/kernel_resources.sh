@@ -2,7 +2,7 @@
 # per-kernel register / scratch / LDS table of one .hip file (hipcc -Rpass-analysis=kernel-resource-usage), e.g.
 #   tools/kernel_resources.sh kivi_amd/csrc/kivi_mf.hip
 f=$1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -c "$f" -o /dev/null \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math $KIVI_EXTRA_FLAGS -c "$f" -o /dev/null \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re,sys,subprocess
 rows=[];cur=None
