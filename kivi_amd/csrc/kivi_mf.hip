@@ -103,21 +103,25 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
             cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
         }
         auto sink = [&](int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); };
-        for (int sb = sb0; sb < sb0 + spw && sb < a.nsb; sb++) {
+        {   // R = 4: one super-block per wave (run_mf_k passes spw = 1)
+            const int sb = sb0;
             int ng = (int)((a.Tq - (int64_t)sb * KIVI_MF_SB_TOKENS) / 32);
             ng = ng > 16 ? 16 : ng;
             const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, sb), KIVI_MF_SB_WORDS * 4);
+            // every request of the super-block before the first wait: scale (-> LDS), zero points, the first code blocks
             u32x4 sreg[4], zreg[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
 #pragma unroll
             for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(n, kb, c) * 4), 0);
+            MfKRing4<RING> ring;
+            ring.prime(rk, ng);
 #pragma unroll
             for (int j = 0; j < 4; j++) *(u32x4*)(lds_w + (j * 64 + lane) * 4) = sreg[j];
             float zz[4];
             mf_k_zero4(Q, zreg, zmul, zz);
             __builtin_amdgcn_wave_barrier();
-            mf_k_run4<RING>(rk, 0u, 0, ng, Q, lds_w, zz, cmul, sink);
+            ring.run(rk, ng, Q, lds_w, zz, cmul, sink);
             flush_sb(sb, ng);
         }
     }
@@ -133,9 +137,9 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     // a wave walks `spw` consecutive super-blocks of its unit (the next one's operands are requested while the current one is
     // multiplied): 2 when that still leaves >= 4 waves per SIMD, else 1; few super-blocks: one wave per block spreads them
     const int64_t total = (int64_t)units * a.nsb;
-    int spw = (total >= 8192 && a.nsb >= 2) ? 2 : 1;
-    static const char* fs = getenv("KIVI_MF_SPW");                 // tuning aid
-    if (fs) spw = atoi(fs) > 0 ? atoi(fs) : 1;
+    int spw = (a.ratio == 1 && total >= 8192 && a.nsb >= 2) ? 2 : 1;
+    static const char* fs = getenv("KIVI_MF_SPW");                 // tuning aid (R = 1)
+    if (fs && a.ratio == 1) spw = atoi(fs) > 0 ? atoi(fs) : 1;
     const int chunks = (a.nsb + spw - 1) / spw;                     // waves per unit
     const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
     a.sb_blocks = (chunks + W - 1) / W;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 
 // The whole decode step of one (batch row, head) in one block of NW waves.  Dynamic LDS: the score / p'' row (n_pad halves).
 // DBG (tools/mf_row_phases.py): every wave stamps the shader clock at its phase boundaries into av.dbg
-template <int KRING, int VRING, int NW, bool DBG = false>
+template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true>
 __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int NTH = NW * 64;
     extern __shared__ uint16_t row[];                              // [n_pad] fp16 scores, then p''
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     __shared__ float zl[NW][128];
     __shared__ uint32_t q_lds[NW][64];
     __shared__ uint16_t pw[1][MF_PW];
-    __shared__ float sm_lds[NW];
+    __shared__ float sm_lds[2 * NW];
     const int unit = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -366,6 +370,9 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], [&](int sb, int tt, float v) { row[sb * KIVI_MF_SB_TOKENS + tt] = f2h_bits(v); }, [](int, int) {});
     }
     stamp(3);
+    // the latency-bound middle of the step (residual scores, softmax, window: ~15 us per block when it competes with the
+    // streams of the three older blocks of its CU -- the SIMD arbiter is oldest-first) runs at raised priority
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
     // the first packed V blocks of this wave are requested now: they fly during the residual scores, the softmax and the window
     const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
     const int NB = (Tv + 31) >> 5;
@@ -405,29 +412,45 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
     float x[SMC][4];
     float mx = -__builtin_inff();
+    const int nch = (n + SCH - 1) / SCH;                           // chunks that hold scores (block-uniform)
 #pragma unroll
     for (int c = 0; c < SMC; c++) {
         const int j0 = c * SCH + (int)threadIdx.x * 4;
-        u16x4 raw = {0, 0, 0, 0};
-        if (j0 < n) raw = *(const u16x4*)(row + j0);               // n_pad >= n rounded up to 8: whole vectors stay inside the row
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float v = -__builtin_inff();
-            if (j0 + e < n) v = h2f_bits(kivi_scaled_score(raw[e], ak.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
-            x[c][e] = v;
-            mx = __builtin_fmaxf(mx, v);
+        for (int e = 0; e < 4; e++) x[c][e] = -__builtin_inff();
+        if (c < nch) {
+            u16x4 raw = {0, 0, 0, 0};
+            if (j0 < n) raw = *(const u16x4*)(row + j0);           // n_pad >= n rounded up to 8: whole vectors stay inside the row
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = -__builtin_inff();
+                if (j0 + e < n) v = h2f_bits(kivi_scaled_score(raw[e], ak.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
+                x[c][e] = v;
+                mx = __builtin_fmaxf(mx, v);
+            }
         }
     }
-    mx = kivi_block_reduce<NW>(mx, true, sm_lds);
+    // block maximum / sum: DPP inside the wave (no LDS round trips), one barrier each across the waves
+    mx = wave_max(mx);
+    if (lane == 0) sm_lds[wave] = mx;
+    __syncthreads();
+    mx = __builtin_fmaxf(__builtin_fmaxf(sm_lds[0], sm_lds[1]), __builtin_fmaxf(sm_lds[2], sm_lds[3]));
+    if constexpr (NW == 8) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(sm_lds[4], sm_lds[5]), __builtin_fmaxf(sm_lds[6], sm_lds[7])));
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < SMC; c++)
+        if (c < nch) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            x[c][e] = kivi_exp(x[c][e] - mx);                      // exp(-inf) = 0 past the row
-            sum += x[c][e];
+            for (int e = 0; e < 4; e++) {
+                x[c][e] = kivi_exp(x[c][e] - mx);                  // exp(-inf) = 0 past the row
+                sum += x[c][e];
+            }
         }
-    sum = kivi_block_reduce<NW>(sum, false, sm_lds);
+    sum = wave_sum(sum);
+    if (lane == 0) sm_lds[NW + wave] = sum;
+    __syncthreads();
+    sum = (sm_lds[NW] + sm_lds[NW + 1]) + (sm_lds[NW + 2] + sm_lds[NW + 3]);
+    if constexpr (NW == 8) sum += (sm_lds[NW + 4] + sm_lds[NW + 5]) + (sm_lds[NW + 6] + sm_lds[NW + 7]);
     const float inv = 1.0f / sum;
     const int sp = mf_sp(sum);
 #pragma unroll
@@ -438,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
             u16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const uint16_t p = f2h_bits(x[c][e] * inv);
+                const uint16_t p = (c < nch) ? f2h_bits(x[c][e] * inv) : (uint16_t)0;
                 const int j = j0 + e;
                 if (j >= Tv && j < n) pw[0][j - Tv] = p;
                 o[e] = (j < Tv) ? f2h_bits(__builtin_ldexpf(h2f_bits(p), ex)) : (uint16_t)0;
@@ -460,6 +483,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     {
         MfVAcc<1> A;
         mf_v_init<1>(A);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         vs.run(A, rv, b_lo, b_hi, row, 0, 0);
         stamp(9);
         mf_v_finish<1, VRING>(A, zl[wave], red[wave]);
@@ -535,13 +559,18 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
     const int n_pad = (int)((n + 31) / 32 * 32);
     static const char* fr = getenv("KIVI_MF_ROW_RINGS");          // tuning aid: "<K ring><V ring>", e.g. 42
-    const int rings = fr ? atoi(fr) : 43;
+    const int rings = fr ? atoi(fr) : 23;
     const size_t lds = (size_t)n_pad * 2;
     const dim3 grid((unsigned)units);
-    if (v.dbg) KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad);
+    static const char* np = getenv("KIVI_MF_ROW_NOPRIO");          // tuning aid (A/B)
+    // (K ring, V ring) = (2, 3) code blocks in flight: 76.2 us per launch at the bench shape against 77.2 (2, 2), 76.7 (2, 4),
+    // 78.4 (4, 2), 78.2 (4, 3) -- profiles/r03_row_rings.log
+    if (v.dbg && np) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, true, false>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (v.dbg) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (np) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, false>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (rings == 24) KIVI_LAUNCH_LDS((mf_row_kernel<2, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     else if (rings == 22) KIVI_LAUNCH_LDS((mf_row_kernel<2, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (rings == 42) KIVI_LAUNCH_LDS((mf_row_kernel<4, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (rings == 23) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-    else KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+    else if (rings == 43) KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+    else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");
 }

@@ -330,75 +330,85 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     }
 }
 
-// R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups.  `lds_s`: the super-block's scale region staged
-// in this wave's LDS (4 KiB, memory order, filled by the caller); `zz`: zero-point sums of the whole super-block, lane
-// (group, any kb), register j = head j, already in score units (mf_k_zero4).
-template <int RING, typename Sink>
-__device__ __forceinline__ void mf_k_run4(rsrc_t rk, uint32_t sb_off, int g_lo, int g_hi, const MfQ<4>& Q, const uint32_t* lds_s,
-                                          const float* zz, const float* cmul, Sink&& sink) {
-    static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
-    const int lane = threadIdx.x & 63;
-    const int m = lane & 15, kb = lane >> 4;
+// R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups.  The code ring of one super-block: prime()
+// requests the first RING blocks (before the caller waits for anything else), run() multiplies.
+// `lds_s`: the super-block's scale region staged in this wave's LDS (4 KiB, memory order, filled by the caller); `zz`:
+// zero-point sums of the whole super-block, lane (group, any kb), register j = head j, already in score units (mf_k_zero4).
+template <int RING>
+struct MfKRing4 {
     u32x4 wr[RING];
-    const int g_last = g_hi - 1;
-#pragma unroll
-    for (int i = 0; i < RING; i++) {
-        const int g = (g_lo + i < g_last) ? g_lo + i : g_last;
-        wr[i] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)g * 1024u);
-        // the slots are requested in the order the loop re-requests them: hipcc merges the wait counters of the loop's two
-        // entries, and a different order here makes every wait inside the loop a vmcnt(0)
-        __builtin_amdgcn_sched_barrier(0);
+    int g_last;
+
+    __device__ __forceinline__ void request(rsrc_t rk, int slot, int g) {
+        const int lane = threadIdx.x & 63;
+        const int gc = g < g_last ? g : g_last;
+        wr[slot] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), (uint32_t)gc * 1024u);
     }
-    for (int g0 = g_lo; g0 < g_hi; g0 += 4) {
-        // A operands of this round: row m -> group g0 + (m >> 2), head m & 3
-        uint32_t Ah[4][4], Al[4][4];
+    __device__ __forceinline__ void prime(rsrc_t rk, int ng) {
+        g_last = ng - 1;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const u32x4 s = *(const u32x4*)(lds_s + kt_sm_word4(g0 + (m >> 2), kb, c));
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                Ah[c][i] = pk_mul(Q.qq[c][i], s[i]);
-                Al[c][i] = pk_fms(Q.qq[c][i], s[i], Ah[c][i]);
-            }
+        for (int i = 0; i < RING; i++) {
+            request(rk, i, i);
+            __builtin_amdgcn_sched_barrier(0);     // same request order as inside the loop (see MfVStream::prime)
         }
-        // zero points of (group g0 + kb, head j) from lane (g0 + kb) of this 16-lane row
-        float zs[4];
-        const int src = ((lane & 48) + g0 + kb) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++) zs[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zz[j])));
-        float o0[4], o1[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    }
+    template <typename Sink>
+    __device__ __forceinline__ void run(rsrc_t rk, int ng, const MfQ<4>& Q, const uint32_t* lds_s, const float* zz, const float* cmul,
+                                        Sink&& sink) {
+        static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
+        const int lane = threadIdx.x & 63;
+        const int m = lane & 15, kb = lane >> 4;
+        for (int g0 = 0; g0 < ng; g0 += 4) {
+            // A operands of this round: row m -> group g0 + (m >> 2), head m & 3
+            uint32_t Ah[4][4], Al[4][4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const MfB b = mf_views(wr[j % RING][c]);
-                const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
-                const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
-            }
-            const bool mine = kb == j;                 // rows 4 kb .. 4 kb + 3 = group g0 + kb, heads 0 .. 3
+                const u32x4 s = *(const u32x4*)(lds_s + kt_sm_word4(g0 + (m >> 2), kb, c));
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                o0[r] = (j == 0 || mine) ? a0[r] : o0[r];
-                o1[r] = (j == 0 || mine) ? a1[r] : o1[r];
+                for (int i = 0; i < 4; i++) {
+                    Ah[c][i] = pk_mul(Q.qq[c][i], s[i]);
+                    Al[c][i] = pk_fms(Q.qq[c][i], s[i], Ah[c][i]);
+                }
             }
-            const int gn = (g0 + j + RING < g_last) ? g0 + j + RING : g_last;
-            wr[j % RING] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off + (uint32_t)gn * 1024u);
-        }
-        const int g = g0 + kb;
-        if (g < g_hi) {
+            // zero points of (group g0 + kb, head j) from lane (g0 + kb) of this 16-lane row
+            float zs[4];
+            const int src = ((lane & 48) + g0 + kb) * 4;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                sink(g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
-                sink(g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
+            for (int j = 0; j < 4; j++) zs[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zz[j])));
+            float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const MfB b = mf_views(wr[j % RING][c]);
+                    const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
+                    const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
+                }
+                const bool mine = kb == j;                 // rows 4 kb .. 4 kb + 3 = group g0 + kb, heads 0 .. 3
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    o0[r] = mine ? a0[r] : o0[r];
+                    o1[r] = mine ? a1[r] : o1[r];
+                }
+                request(rk, j % RING, g0 + j + RING);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int g = g0 + kb;
+            if (g < ng) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    sink(g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
+                    sink(g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
+                }
             }
         }
     }
-}
+};
 
 // Zero-point sums of a whole super-block for R = 4: zz[j] at lane (n = group, any kb) = sum_d q[head j, d] * mn[d, group n]
 // in score units.  `mv`: this lane's 4 x 16 bytes of the zero points of group n (B layout = the row layout).
@@ -414,6 +424,8 @@ __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, con
     // row 4 kb' + j carries head (4 kb' + j) % 4 = j for every kb': register j = head j in every lane
 #pragma unroll
     for (int j = 0; j < 4; j++) zz[j] = z[j] * zmul[j];
+    // pinned here: hipcc otherwise sinks the four MFMAs (and keeps their 32 operand registers alive) down to the first use
+    asm volatile("" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]));
 }
 
 // ------------------------------------------------------------------------------------------------ sV
