@@ -308,7 +308,7 @@ def main():
         if kev:
             us = [klib.kivi_event_elapsed_us(a, b) for a, b, _, _ in kev]
             timed = (klib.kivi_last_timed_kernel() or b"").decode()
-            row_fused = ("decode_row_kernel" in timed or "mf_row_kernel" in timed) and all(r is not None for _, _, _, r in kev)
+            row_fused = any(kn in timed for kn in ("decode_row_kernel", "mf_row_kernel", "mf_row4_kernel")) and all(r is not None for _, _, _, r in kev)
             kname = timed.split("<")[0].strip("( ")
             tot_bytes = sum((r if row_fused else n) for _, _, n, r in kev)
             avg_us = sum(us) / len(us)
@@ -332,6 +332,8 @@ def main():
                     "kernel": kname, "kernel_role": (
                         "one launch per layer: packed qK^T of the row on the matrix pipe -> LDS scores -> residual scores + softmax + "
                         "window + packed sV + cache update" if "mf_row_kernel" in timed else
+                        "one launch per layer: the four query heads of a kv head in one block -- packed qK^T on the matrix pipe -> LDS "
+                        "scores -> residual scores + softmax + window + packed sV + cache update" if "mf_row4_kernel" in timed else
                         "one launch per layer (VALU unpack): packed qK^T of the row -> LDS scores -> residual scores + softmax + window + "
                         "packed sV + cache update" if row_fused else
                         "packed qK^T on the matrix pipe + residual scores + softmax statistics; first of the two launches of a layer step"

@@ -1100,12 +1100,14 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.dbg = kivi_debug_stamps();
     v.counters = (int*)p->workspace;
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
-    if (newp && R == 1 && n <= 8192) {
-        // MHA rows that fit the LDS: the whole step of a (batch row, head) in one launch
+    if (newp && ((R == 1 && n <= 8192) || (R == 4 && n <= 9216))) {
+        // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
+        // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks of 8 waves per CU)
         static const char* norow = getenv("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
         const bool split = (p->flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow));
-        // fewer than 192 rows: the split two-launch form fills the chip better
-        if (!split && (units >= 192 || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, s);
+        // too few units: the split two-launch form fills the chip better
+        const int min_units = R == 1 ? 192 : 128;
+        if (!split && (units >= min_units || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, s);
     }
     int rc = skipk ? 0 : (newp ? kivi_mf_run_k(&k, units, s) : run_gqa_k(k, units, s));
     if (rc) return rc;

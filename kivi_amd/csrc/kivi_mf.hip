@@ -513,6 +513,182 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused row, R = 4
+// The whole decode step of one (batch row, kv head) with its four query heads in one block of NW waves (grouped queries,
+// rows whose four score rows fit the LDS: 4 n fp16 <= 72 KiB, two blocks per CU): no score / statistics round trip through
+// memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
+template <int KRING, int VRING, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
+    constexpr int R = 4, NTH = NW * 64;
+    extern __shared__ uint16_t rows[];                             // [R][n_pad]
+    __shared__ float zl[NW][128];
+    __shared__ uint16_t pw[R][MF_PW];
+    __shared__ float sm_lds[2 * NW];
+    __shared__ int sp_lds[R];
+    const int unit = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = unit / ak.nh_kv, hk = unit - b * ak.nh_kv;
+    const int h0 = hk * R;
+    const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
+    const int L = ak.res_len + 1;
+    const int n = Tq + L;
+    const uint16_t* q_h0 = ak.q + b * ak.q_sb + (int64_t)h0 * ak.q_sh;
+    uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
+    const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
+
+    // ---- packed qK^T: wave w walks super-blocks w, w + NW, ...
+    {
+        const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
+        MfKSeq seq;
+        seq.sb_bytes = (uint32_t)(ak.kt.sb_s * 4);
+        seq.sb_first = wave;
+        seq.sb_stride = NW;
+        seq.n_sb = ak.nsb > wave ? (ak.nsb - wave + NW - 1) / NW : 0;
+        const int last = wave + (seq.n_sb - 1) * NW;
+        const int NG = Tq >> 5;
+        seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
+        mf_k_seq4<KRING>(rk, seq, q_h0, ak.q_sh,
+                         [&](int sb, int tt, int r, float v) { rows[r * n_pad + sb * KIVI_MF_SB_TOKENS + tt] = f2h_bits(v); });
+    }
+    __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
+    const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
+    const int NB = (Tv + 31) >> 5;
+    const int nbw = (NB + NW - 1) / NW;
+    const int b_lo = wave * nbw;
+    const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
+    MfVStream<R, VRING> vs;
+    vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
+    // ---- residual scores q . [K_full | k_new] of the four heads (:337) + K append (:333-336)
+    for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
+        const int sub = idx & 7, rt = idx >> 3;
+        const int r = rt / L, t = rt - r * L;
+        const uint16_t* krow = ((t < ak.res_len) ? kres + (int64_t)t * ak.kres_st : knew) + sub * 16;
+        const uint16_t* qrow = q_h0 + (int64_t)r * ak.q_sh + sub * 16;
+        const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
+        const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
+        float sc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
+        if (t == ak.res_len && r == 0) {
+            *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = k0;
+            *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = k1;
+        }
+        sc += __shfl_xor(sc, 1);
+        sc += __shfl_xor(sc, 2);
+        sc += __shfl_xor(sc, 4);
+        if (sub == 0) rows[r * n_pad + Tq + t] = f2h_bits(sc);
+    }
+    __syncthreads();
+
+    // ---- softmax of the four rows, one after the other (scale + mask as the reference, fp32, cast to fp16: :339, :364-375):
+    // a thread owns 4 consecutive scores per chunk of 4 NTH; register resident (rows of <= SMC * 4 * NTH scores)
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    constexpr int SCH = NTH * 4, SMC = (9216 + SCH - 1) / SCH;
+    const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
+    const int nch = (n + SCH - 1) / SCH;
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        uint16_t* row = rows + r * n_pad;
+        float x[SMC][4];
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < SMC; c++) {
+            const int j0 = c * SCH + (int)threadIdx.x * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[c][e] = -__builtin_inff();
+            if (c < nch) {
+                u16x4 raw = {0, 0, 0, 0};
+                if (j0 < n) raw = *(const u16x4*)(row + j0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float v = -__builtin_inff();
+                    if (j0 + e < n) v = h2f_bits(kivi_scaled_score(raw[e], ak.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
+                    x[c][e] = v;
+                    mx = __builtin_fmaxf(mx, v);
+                }
+            }
+        }
+        mx = wave_max(mx);
+        __syncthreads();                                           // the previous row's readers of sm_lds are done
+        if (lane == 0) sm_lds[wave] = mx;
+        __syncthreads();
+        mx = sm_lds[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) mx = __builtin_fmaxf(mx, sm_lds[w]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < SMC; c++)
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    x[c][e] = kivi_exp(x[c][e] - mx);
+                    sum += x[c][e];
+                }
+            }
+        sum = wave_sum(sum);
+        if (lane == 0) sm_lds[NW + wave] = sum;
+        __syncthreads();
+        sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) sum += sm_lds[NW + w];
+        const float inv = 1.0f / sum;
+        const int sp = mf_sp(sum);
+        if (threadIdx.x == 0) sp_lds[r] = sp;
+#pragma unroll
+        for (int c = 0; c < SMC; c++) {
+            const int j0 = c * SCH + (int)threadIdx.x * 4;
+            if (j0 < n_pad) {
+                const int ex = sp + ((j0 & 4) ? 6 : 4);
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint16_t p = (c < nch) ? f2h_bits(x[c][e] * inv) : (uint16_t)0;
+                    const int j = j0 + e;
+                    if (j >= Tv && j < n) pw[r][j - Tv] = p;
+                    o[e] = (j < Tv) ? f2h_bits(__builtin_ldexpf(h2f_bits(p), ex)) : (uint16_t)0;
+                }
+                *(u16x4*)(row + j0) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fp16 window of the four heads, V append, quantisation of the token leaving the window (:377-399)
+    float ow[R][2];
+    gqa_window_part<R, NTH, MF_PW>(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+
+    // ---- packed sV
+    MfVAcc<R> A;
+    mf_v_init<R>(A);
+    __builtin_amdgcn_s_setprio(0);
+    vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0);
+    __syncthreads();                                               // every wave is done with the p'' rows: their memory is reused
+    float* red = reinterpret_cast<float*>(rows);                   // [NW][R * 128] quantised part | [NW][R * 128] window part
+    float* resl = red + NW * R * 128;
+    mf_v_finish<R, VRING>(A, zl[wave], red + wave * R * 128);
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) {
+        resl[wave * R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
+        resl[wave * R * 128 + rr * 128 + 2 * lane + 1] = ow[rr][1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * 128; i += NTH) {
+        const int rr = i >> 7, d = i & 127;
+        float qs = 0.f, ws = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            qs += red[w * R * 128 + i];
+            ws += resl[w * R * 128 + i];
+        }
+        qs = __builtin_ldexpf(qs, -sp_lds[rr]);
+        const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
+        av.out[b * av.out_sb + (int64_t)(h0 + rr) * av.out_sh + d] = o;
+    }
+}
+
 bool mf_store_ok2(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
     return base && (uintptr_t)base % 16 == 0 && sb_b % 4 == 0 && sb_h % 4 == 0 && sb_s % 4 == 0 && sb_s >= KIVI_MF_SB_WORDS;
 }
@@ -556,12 +732,34 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     const GqaKArgs& k = *(const GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = k.Tq + k.res_len + 1;
-    if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
     const int n_pad = (int)((n + 31) / 32 * 32);
+    const dim3 grid((unsigned)units);
+    if (k.ratio == 4) {
+        // four score rows in the LDS (two blocks per CU): up to 9216 keys
+        if (n > 9216) return KIVI_EUNSUPPORTED;
+        size_t lds = (size_t)4 * n_pad * 2;
+        const size_t fin = (size_t)2 * 8 * 4 * 128 * 4;           // the per-wave partial sums reuse the rows
+        if (lds < fin) lds = fin;
+        static bool attr_set = false;
+        if (!attr_set) {                                           // > 64 KiB of dynamic LDS needs the opt-in
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            attr_set = true;
+        }
+        static const char* fr4 = getenv("KIVI_MF_ROW4");          // tuning aid: "<waves><K ring><V ring>"
+        const int cfg = fr4 ? atoi(fr4) : 443;    // 4 waves with up to 256 registers: 103 us per layer at config 4 against 123 for 8 waves of 128 (spills)
+        if (cfg == 822) KIVI_LAUNCH_LDS((mf_row4_kernel<2, 2, 8>), grid, dim3(512), lds, s, k, v, n_pad);
+        else if (cfg == 444) KIVI_LAUNCH_LDS((mf_row4_kernel<4, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+        else if (cfg == 443) KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+        else KIVI_LAUNCH_LDS((mf_row4_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
+        return kivi_launch_status("mf_row4");
+    }
+    if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
     static const char* fr = getenv("KIVI_MF_ROW_RINGS");          // tuning aid: "<K ring><V ring>", e.g. 42
     const int rings = fr ? atoi(fr) : 23;
     const size_t lds = (size_t)n_pad * 2;
-    const dim3 grid((unsigned)units);
     static const char* np = getenv("KIVI_MF_ROW_NOPRIO");          // tuning aid (A/B)
     // (K ring, V ring) = (2, 3) code blocks in flight: 76.2 us per launch at the bench shape against 77.2 (2, 2), 76.7 (2, 4),
     // 78.4 (4, 2), 78.2 (4, 3) -- profiles/r03_row_rings.log

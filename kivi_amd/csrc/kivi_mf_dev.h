@@ -428,6 +428,112 @@ __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, con
     asm volatile("" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]));
 }
 
+// R = 4, the walker of the one-launch row kernel (mf_row4_kernel): the same row sets without LDS staging.  With the round-3
+// placement of the scale (kivi_mfma_layout.h) the 16 bytes (kb, chunk c) of four consecutive groups are contiguous, so the
+// A-operand load of a round touches four fully used 64-byte lines per instruction; the scale of round rq + 1 is requested
+// right after the operands of round rq have been built from the registers it lands in, the zero points of the next super-
+// block while the current one is multiplied, the code ring runs across rounds and super-blocks (cf. mf_k_seq1).
+// Scores go to sink(super-block index, token inside it, head, fp32 score).
+template <int RING, typename Sink>
+__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, Sink&& sink) {
+    static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    if (W.ng_total <= 0) return;
+    auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
+    const int g_last = W.ng_total - 1;
+    const int n_round = (W.ng_total + 3) >> 2;
+    // ---- requests: scale of round 0, zero points of super-block 0, the ring
+    u32x4 sv[4], zv[4];
+    auto request_round = [&](int rq) {
+        const int g0 = 4 * rq;
+        const uint32_t so = sb_off(g0 >> 4);
+        const int g = (g0 & 15) + (m >> 2);
+#pragma unroll
+        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4), so);
+    };
+    auto request_z = [&](int sbi) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) zv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(m, kb, c) * 4), sb_off(sbi));
+    };
+    request_round(0);
+    request_z(0);
+    u32x4 wr[RING];
+    auto request_group = [&](int slot, int gi) {
+        const int gc = gi < g_last ? gi : g_last;
+        wr[slot] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
+    };
+#pragma unroll
+    for (int i = 0; i < RING; i++) {
+        request_group(i, i);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    MfQ<4> Q;
+    mf_load_q<4>(q_h0, q_sh, Q);
+    float zmul[4], cmul[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int sqj = __shfl(Q.sq, j);                            // lane j (kb = 0, row j) holds head j's exponent
+        zmul[j] = __builtin_ldexpf(1.0f, -sqj);
+        cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
+    }
+    float zz[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rq = 0; rq < n_round; rq++) {
+        const int sbi = rq >> 2;
+        if ((rq & 3) == 0) {                                        // a new super-block: its zero-point sums, then the next one's zero points
+            mf_k_zero4(Q, zv, zmul, zz);
+            request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi);
+        }
+        uint32_t Ah[4][4], Al[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
+                Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
+            }
+        request_round(rq + 1 < n_round ? rq + 1 : rq);
+        __builtin_amdgcn_sched_barrier(0);
+        // zero points of (group 4 (rq & 3) + kb, head j) from lane (that group) of this 16-lane row
+        float zs[4];
+        const int src = ((lane & 48) + 4 * (rq & 3) + kb) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) zs[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zz[j])));
+        float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const MfB b = mf_views(wr[j % RING][c]);
+                const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
+                const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
+            }
+            const bool mine = kb == j;                             // rows 4 kb .. 4 kb + 3 = group 4 rq + kb, heads 0 .. 3
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                o0[r] = mine ? a0[r] : o0[r];
+                o1[r] = mine ? a1[r] : o1[r];
+            }
+            request_group(j % RING, 4 * rq + j + RING);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (4 * rq + kb < W.ng_total) {
+            const int sb = W.sb_first + sbi * W.sb_stride;
+            const int g = 4 * (rq & 3) + kb;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                sink(sb, g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
+                sink(sb, g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ sV
 // Accumulators of a wave over its token blocks: acc[c][tile] = rows x channels 32 c + 16 tile + n, chained through the
 // C operand over all blocks.
