@@ -14,6 +14,15 @@ typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
 #define KIVI_WAVE 64
 
+// Tuning / diagnostic environment knobs exist only in -DKIVI_TUNING builds (tools/build_variant.sh tuning -DKIVI_TUNING):
+// the product library reads no environment variable and carries no losing or result-changing instantiation.
+#include <stdlib.h>
+#ifdef KIVI_TUNING
+#define KIVI_TUNE_ENV(name) getenv(name)
+#else
+#define KIVI_TUNE_ENV(name) ((const char*)nullptr)
+#endif
+
 // ---- argument / launch error plumbing (host side) -------------------------
 void kivi_set_error(const char* fmt, ...);
 

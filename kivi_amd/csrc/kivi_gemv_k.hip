@@ -71,7 +71,7 @@ typedef void (*KLaunch)(const GemvKArgs&, dim3, hipStream_t);
 
 template <int BITS, int G, int WPL, int DSPLIT, int R, int U, int MODE, bool NT>
 void launch_k(const GemvKArgs& a, dim3 grid, hipStream_t s) {
-    static const char* xl = getenv("KIVI_K_EXTRA_LDS");   // diagnostic: cap the blocks per CU by reserving extra LDS
+    static const char* xl = KIVI_TUNE_ENV("KIVI_K_EXTRA_LDS");   // diagnostic: cap the blocks per CU by reserving extra LDS
     KIVI_LAUNCH_LDS((gemv_k_kernel<BITS, G, WPL, DSPLIT, R, U, MODE, NT>), grid, dim3(256), xl ? (size_t)atoi(xl) : 0, s, a);
 }
 
@@ -219,7 +219,7 @@ int k_run(int variant, GemvKArgs a, int B, int nh_kv, int G, int bits, hipStream
     }
     // heuristic: first fitting variant with the largest usable R; table order = preference
     int best = -1;
-    static const char* forced = getenv("KIVI_GEMV_K_VARIANT");   // tuning aid: force a variant by name if it fits
+    static const char* forced = KIVI_TUNE_ENV("KIVI_GEMV_K_VARIANT");   // tuning aid: force a variant by name if it fits
     if (forced)
         for (int i = 0; i < k_nvariants; i++)
             if (!strcmp(forced, k_variants[i].name) && k_variant_fits(k_variants[i], a, bits, G))

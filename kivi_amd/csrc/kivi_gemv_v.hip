@@ -123,10 +123,12 @@ struct VVariant {
      NT, launch_v<BITS, G, DW, WPL, R, U, MODE, (NT != 0)>}
 
 const VVariant v_variants[] = {
-    // ---- 2-bit, D=128 (DW=8), g=32, MHA: table order = dispatch preference (measured, profiles/)
+    // table order = dispatch preference (measured, profiles/); -DKIVI_TUNING builds add the losing / diagnostic shapes
+    // ---- 2-bit, D=128 (DW=8), g=32, MHA
     VV(2, 32, 8, 4, 1, 1, 2, 1),
     VV(2, 32, 8, 2, 1, 4, 2, 1),
     VV(2, 32, 8, 4, 1, 2, 2, 0),
+#ifdef KIVI_TUNING
     VV(2, 32, 8, 4, 1, 2, 2, 1),
     VV(2, 32, 8, 4, 1, 4, 2, 0),
     VV(2, 32, 8, 4, 1, 4, 2, 1),
@@ -139,6 +141,7 @@ const VVariant v_variants[] = {
     VV(2, 32, 8, 2, 1, 4, 4, 1),
     VV(2, 32, 8, 4, 1, 2, 3, 1),   // diagnostic: memory-side ceiling
     VV(2, 32, 8, 2, 1, 4, 3, 1),
+#endif
     // other group sizes / head dims
     VV(2, 64, 8, 2, 1, 4, 2, 1),
     VV(2, 128, 8, 2, 1, 4, 2, 1),
@@ -155,15 +158,12 @@ const VVariant v_variants[] = {
     VV(4, 128, 16, 4, 1, 4, 2, 1),
     VV(4, 32, 8, 4, 1, 4, 2, 1),
     VV(4, 64, 8, 4, 1, 4, 2, 1),
+#ifdef KIVI_TUNING
     VV(4, 32, 16, 4, 1, 4, 0, 0),
+#endif
     // ---- GQA (R heads share the unpack; 2 words per lane keeps R*EPL accumulators in registers)
     VV(2, 32, 8, 2, 4, 2, 4, 1),
-    VV(2, 32, 8, 1, 4, 2, 4, 1),
-    VV(2, 32, 8, 1, 4, 1, 4, 1),
-    VV(2, 32, 8, 2, 4, 1, 4, 1),
-    VV(2, 32, 8, 1, 4, 4, 4, 1),
     VV(2, 32, 8, 1, 8, 4, 4, 1),
-    VV(2, 32, 8, 1, 4, 8, 4, 1),
     VV(2, 32, 8, 2, 2, 4, 4, 1),
     VV(2, 64, 8, 2, 4, 2, 4, 1),
     VV(2, 128, 8, 2, 4, 2, 4, 1),
@@ -174,6 +174,13 @@ const VVariant v_variants[] = {
     VV(2, 128, 8, 2, 4, 2, 2, 0),
     VV(4, 32, 16, 4, 4, 2, 2, 0),
     VV(2, 32, 8, 2, 8, 1, 2, 0),
+#ifdef KIVI_TUNING
+    VV(2, 32, 8, 1, 4, 2, 4, 1),
+    VV(2, 32, 8, 1, 4, 1, 4, 1),
+    VV(2, 32, 8, 2, 4, 1, 4, 1),
+    VV(2, 32, 8, 1, 4, 4, 4, 1),
+    VV(2, 32, 8, 1, 4, 8, 4, 1),
+#endif
 };
 constexpr int v_nvariants = sizeof(v_variants) / sizeof(v_variants[0]);
 
@@ -220,7 +227,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             // R >= 4 variants hold R x EPL accumulators: 2 blocks per CU are resident, so 512 blocks = one full round
             const int64_t target = v.R >= 4 ? 512 : 768;
             S = (int)((target + units - 1) / units);
-            static const char* forced_split = getenv("KIVI_V_SPLIT");   // tuning aid
+            static const char* forced_split = KIVI_TUNE_ENV("KIVI_V_SPLIT");   // tuning aid
             if (forced_split) S = atoi(forced_split);
             if (S > nchunk / 32) S = (int)(nchunk / 32);
             if (S > 64) S = 64;
@@ -238,7 +245,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
         bool fuse_row = false;
         if (a.kside) {
             const KSide& ks = *a.kside;
-            static const char* nofuse = getenv("KIVI_NO_ROW_FUSION");   // tuning aid
+            static const char* nofuse = KIVI_TUNE_ENV("KIVI_NO_ROW_FUSION");   // tuning aid
             fuse_row = !nofuse && ks.fusable && a.softmax && S == 1 && v.R == 1 && a.n_scores <= 8192 && a.rq != nullptr &&
                        ((bits == 2 && (G == 32 || G == 64 || G == 128)) || (bits == 4 && G == 32)) && a.D == 128 &&
                        v.mode == KIVI_UNPACK_MIX;
@@ -264,7 +271,7 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             int P = (int)((2048 + rows - 1) / rows);
             if (P > a.n_scores / 2048) P = a.n_scores / 2048;
             if (P > 64) P = 64;
-            static const char* fp = getenv("KIVI_SOFTMAX_P");   // tuning aid: blocks per row of the row softmax
+            static const char* fp = KIVI_TUNE_ENV("KIVI_SOFTMAX_P");   // tuning aid: blocks per row of the row softmax
             if (fp) P = atoi(fp);
             const size_t part_bytes = ((size_t)rows * (P > 0 ? P : 1) * 2 * sizeof(float) + 255) / 256 * 256;
             if (P >= 2 && a.ws && part_bytes + (size_t)units * (S + 1) * v.R * a.D * sizeof(float) <= a.ws_bytes) {
@@ -293,64 +300,47 @@ int v_run(int variant, GemvVArgs a, int B, int G, int bits, hipStream_t s) {
             GemvKArgs ak = a.kside->args;
             ak.units_per_b = a.nh;
             ak.dbg = a.dbg;
+            ak.res_blocks = 0;
+            a.scores_lds = 1;
+            const dim3 grid((unsigned)units);
+            size_t lds = (size_t)a.n_pad * sizeof(uint16_t);
             if (bits == 4) {   // 4-bit: 8 codes per word, 4 words per lane = the same 2048-token tile; sV over 16 words per row
                 ak.tile_blocks = (int)(((ak.Tw + 255) / 256 + 1) / 2);
-                ak.res_blocks = 0;
-                a.scores_lds = 1;
-                static const char* rx4 = getenv("KIVI_ROW_X");
-                if (rx4 && !strcmp(rx4, "d2"))
-                    KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false>), dim3((unsigned)units), dim3(256),
-                                    (size_t)a.n_pad * sizeof(uint16_t), s, ak, a);
-                else
-                    KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false, false, 0, 0, 4, 3>), dim3((unsigned)units),
-                                    dim3(256), (size_t)a.n_pad * sizeof(uint16_t), s, ak, a);
+                KIVI_LAUNCH_LDS((decode_row_kernel<4, 32, 16, 4, 2, 4, 4, 2, false, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
                 return kivi_launch_status("decode_row");
             }
             const int tiles = (int)((ak.Tw + 127) / 128);
-            ak.res_blocks = 0;
-            a.scores_lds = 1;
-            static const char* xl = getenv("KIVI_ROW_EXTRA_LDS");   // diagnostic: fewer co-resident blocks per CU
-            const size_t lds = (size_t)a.n_pad * sizeof(uint16_t) + (xl ? (size_t)atoi(xl) : 0);
-            static const char* rv = getenv("KIVI_ROW_VARIANT");   // tuning aid: K-phase shape "ds<DSPLIT>u<U>"
-            static const char* rvv = getenv("KIVI_ROW_V");        // tuning aid: sV-phase shape "w<WPL>u<U>"
-            static const char* rx = getenv("KIVI_ROW_X");         // tuning aid: experimental instantiations
-            const int sel = !rv ? 1 : !strcmp(rv, "ds4u4") ? 0 : !strcmp(rv, "ds2u4") ? 1 : !strcmp(rv, "ds2u8") ? 2 : !strcmp(rv, "ds4u8") ? 3 : 1;
-            const int selv = (rvv && !strcmp(rvv, "w2u4")) ? 1 : 0;
-            ak.tile_blocks = (G != 32 || selv == 1 || sel == 1 || sel == 2) ? (tiles + 1) / 2 : tiles;   // DSPLIT = 2: two tiles per pass
-            const dim3 grid((unsigned)units);
+            ak.tile_blocks = (tiles + 1) / 2;                    // DSPLIT = 2 (four waves) / two tiles per pass (eight waves)
             // Eight waves per row (2 tiles of 2048 tokens per pass, D over 4 waves): with fewer than ~1.75 four-wave blocks per
             // CU the chip is under-occupied and the row's own waves are what hides latency -- 256 rows: 37.8 -> 32.5 us,
-            // 512 rows: equal, 768 rows: 65.9 vs 72.8 us (profiles/r02_row_nw8_small_batch.log); "d3" / "d2" force four waves
-            const bool few_rows = units < 448 && !(rx && (!strcmp(rx, "d3") || !strcmp(rx, "d2")));
-            if (G == 32 && ((rx && !strcmp(rx, "nw8ds4")) || few_rows)) {
-                ak.tile_blocks = (tiles + 1) / 2;
-                if (a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, true, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
-                else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, false, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
+            // 512 rows: equal, 768 rows: 65.9 vs 72.8 us (profiles/r02_row_nw8_small_batch.log)
+            bool few_rows = units < 448;
+#ifdef KIVI_TUNING
+            static const char* xl = KIVI_TUNE_ENV("KIVI_ROW_EXTRA_LDS");   // diagnostic: fewer co-resident blocks per CU
+            static const char* rx = KIVI_TUNE_ENV("KIVI_ROW_X");           // experimental instantiations: d2 / d3 / nw8ds4
+            lds += xl ? (size_t)atoi(xl) : 0;
+            if (rx && (!strcmp(rx, "d3") || !strcmp(rx, "d2"))) few_rows = false;
+            if (rx && !strcmp(rx, "nw8ds4")) few_rows = true;
+            if (G == 32 && !few_rows && a.dbg) {
+                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
+                return kivi_launch_status("decode_row");
             }
-            else if (G == 64 && rx && !strcmp(rx, "d2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (G == 128 && rx && !strcmp(rx, "d2")) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            if (G == 32 && !few_rows && rx && !strcmp(rx, "d2")) {    // the two-deep V ring (round 1 / first half of round 2)
+                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
+                return kivi_launch_status("decode_row");
+            }
+#endif
+            if (G == 32 && few_rows) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1, true, false, 0, 0, 8>), grid, dim3(512), lds, s, ak, a);
             else if (G == 64) KIVI_LAUNCH_LDS((decode_row_kernel<2, 64, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
             else if (G == 128) KIVI_LAUNCH_LDS((decode_row_kernel<2, 128, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
-            else if (selv == 1 && a.dbg) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4, true, true>), grid, dim3(256), lds, s, ak, a);
-            else if (selv == 1) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 2, 4>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 0) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 1 && rx && !strcmp(rx, "d2") && a.dbg)   // the two-deep V ring (round 1 / first half of round 2)
-                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 1 && rx && !strcmp(rx, "d2"))
-                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 1 && a.dbg)
-                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, true, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 1)   // default: three-deep V ring
-                KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);
-            else if (sel == 2) KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
-            else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 4, 8, 4, 1>), grid, dim3(256), lds, s, ak, a);
+            else KIVI_LAUNCH_LDS((decode_row_kernel<2, 32, 8, 2, 2, 4, 4, 1, true, false, 0, 0, 4, 3>), grid, dim3(256), lds, s, ak, a);   // three-deep V ring
             return kivi_launch_status("decode_row");
         }
         v.fn(a, dim3((unsigned)(units * S)), s);
         return kivi_launch_status(v.name);
     }
     int best = -1;
-    static const char* forced = getenv("KIVI_GEMV_V_VARIANT");   // tuning aid: force a variant by name if it fits
+    static const char* forced = KIVI_TUNE_ENV("KIVI_GEMV_V_VARIANT");   // tuning aid: force a variant by name if it fits
     if (forced)
         for (int i = 0; i < v_nvariants; i++)
             if (!strcmp(forced, v_variants[i].name) && v_variant_fits(v_variants[i], a, bits, G)) return v_run(i, a, B, G, bits, s);

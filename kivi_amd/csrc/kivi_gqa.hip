@@ -404,14 +404,15 @@ void launch_gqa_k(const GqaKArgs& a, int units, hipStream_t s) {
 
 // shared by kivi_gqa_scores and kivi_gqa_decode
 int run_gqa_k(GqaKArgs& a, int units, hipStream_t s) {
-    static const char* nohilo = getenv("KIVI_GQA_NO_HILO");      // tuning aid: fp16-rounded q * scale (no remainder rows)
-    static const char* fw = getenv("KIVI_GQA_K_WAVES");          // tuning aid: waves per block (1 or 4)
-    static const char* fr = getenv("KIVI_GQA_K_RING");           // tuning aid: code blocks in flight (2, 4 or 8)
+    static const char* nohilo = KIVI_TUNE_ENV("KIVI_GQA_NO_HILO");      // tuning aid: fp16-rounded q * scale (no remainder rows)
+    static const char* fw = KIVI_TUNE_ENV("KIVI_GQA_K_WAVES");          // tuning aid: waves per block (1 or 4)
+    static const char* fr = KIVI_TUNE_ENV("KIVI_GQA_K_RING");           // tuning aid: code blocks in flight (2, 4 or 8)
     int W = ((int64_t)units * a.nsb >= 2048) ? 4 : 1;            // few super-blocks: one wave per block spreads them over the CUs
     if (fw) W = atoi(fw) == 1 ? 1 : 4;
     const int ring = fr ? atoi(fr) : 4;
     a.sb_blocks = (a.nsb + W - 1) / W;
     if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
+#ifdef KIVI_TUNING
 #define KIVI_GK(RR, WW, HL)                                       \
     do {                                                          \
         if (ring == 2) launch_gqa_k<RR, WW, HL, 2>(a, units, s);  \
@@ -425,6 +426,14 @@ int run_gqa_k(GqaKArgs& a, int units, hipStream_t s) {
         if (nohilo) { if (W == 4) KIVI_GK(8, 4, false); else KIVI_GK(8, 1, false); }
         else { if (W == 4) KIVI_GK(8, 4, true); else KIVI_GK(8, 1, true); }
     }
+#else
+    // product build: the round-2 kernels serve nh / nh_kv = 8 only (4 and 1 run the round-3 kernels of kivi_mf.hip)
+    (void)nohilo; (void)ring;
+    KIVI_REQUIRE(a.ratio == 8, KIVI_EUNSUPPORTED, "gqa_k: nh / nh_kv = %d has no round-2 kernel in this build", a.ratio);
+    if (W == 4) launch_gqa_k<8, 4, true, 4>(a, units, s);
+    else launch_gqa_k<8, 1, true, 4>(a, units, s);
+#define KIVI_GK(RR, WW, HL)
+#endif
 #undef KIVI_GK
     return kivi_launch_status("gqa_k");
 }
@@ -885,7 +894,7 @@ int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh,
 int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream_t s);
 
 static bool mf_new_path(int ratio) {
-    static const char* old = getenv("KIVI_MF_OLD");              // tuning aid (A/B): nh / nh_kv = 4 on the round-2 kernels
+    static const char* old = KIVI_TUNE_ENV("KIVI_MF_OLD");              // tuning builds (A/B): nh / nh_kv = 4 on the round-2 kernels
     return ratio == 1 || (ratio == 4 && !(old && atoi(old)));
 }
 
@@ -919,7 +928,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
 static void gqa_v_slices(int units, int nsbv, int& S, int& spb) {
     S = 1; spb = 0;
     if (nsbv <= 0) return;
-    static const char* fs = getenv("KIVI_GQA_V_BLOCKS");         // tuning aid: target number of stream blocks
+    static const char* fs = KIVI_TUNE_ENV("KIVI_GQA_V_BLOCKS");         // tuning aid: target number of stream blocks
     const int target = fs ? atoi(fs) : 1024;
     S = (target + units - 1) / units;
     S = S < 1 ? 1 : (S > nsbv ? nsbv : S);
@@ -966,24 +975,25 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     return kivi_mf_run_v(&v, 1, s);
 }
 
+#ifdef KIVI_TUNING
 template <int R, bool HILO, int RING>
 static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
-    static const char* occ = getenv("KIVI_GQA_V_OCC");            // tuning aid: 3 = let the kernel use up to 168 registers
+    static const char* occ = KIVI_TUNE_ENV("KIVI_GQA_V_OCC");            // tuning aid: 3 = let the kernel use up to 168 registers
     if (occ && atoi(occ) == 3 && HILO && RING == 4) {
         KIVI_LAUNCH_LDS((gqa_v_kernel<R, true, 4, false, 3>), dim3((unsigned)(units * a.S + a.win_blocks)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
         return;
     }
-    static const char* v2 = getenv("KIVI_GQA_V2");                // tuning aid: 1 / 0 = row = (channel group, head) mapping on / off
+    static const char* v2 = KIVI_TUNE_ENV("KIVI_GQA_V2");                // tuning aid: 1 / 0 = row = (channel group, head) mapping on / off
     if (R == 4 && HILO && (v2 ? atoi(v2) != 0 : true)) {
         const dim3 grid((unsigned)(units * a.S + a.win_blocks));
-        static const char* occ2 = getenv("KIVI_GQA_V_OCC");
+        static const char* occ2 = KIVI_TUNE_ENV("KIVI_GQA_V_OCC");
         if (a.dbg) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, true, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
         else if (occ2 && atoi(occ2) == 3) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 3, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
         else if (RING == 2) KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 2, false, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
         else KIVI_LAUNCH_LDS((gqa_v_kernel<4, true, 4, false, 4, 0, true>), grid, dim3(256), 4 * 2048 * 4, s, a);
         return;
     }
-    static const char* dg = getenv("KIVI_GQA_V_DIAG");
+    static const char* dg = KIVI_TUNE_ENV("KIVI_GQA_V_DIAG");
     if (dg && HILO && RING == 4 && R == 4) {
         const dim3 grid((unsigned)(units * a.S + a.win_blocks));
         const size_t lds = 4 * 2048 * 4;
@@ -1008,6 +1018,7 @@ static void launch_gqa_v(const GqaVArgs& a, int units, hipStream_t s) {
     }
     KIVI_LAUNCH_LDS((gqa_v_kernel<R, HILO, RING>), dim3((unsigned)(units * a.S + a.win_blocks)), dim3(256), 4 * 2048 * 4 + (R > 4 ? 8192 : 0), s, a);
 }
+#endif
 
 extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stream) {
     KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_gqa_decode: null arguments");
@@ -1061,7 +1072,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE((int64_t)(nsbv > nsbk ? nsbv : nsbk) * (p->kt_ss > p->vt_ss ? p->kt_ss : p->vt_ss) * 4 < ((int64_t)1 << 32), KIVI_EINVAL,
                  "kivi_gqa_decode: store too large for one descriptor");
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
-    static const char* wt = getenv("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
+    static const char* wt = KIVI_TUNE_ENV("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
     const int win_blocks = (nsbv > 0 && !(wt && atoi(wt) == 0)) ? units : 0;
     const int nslot = S + (win_blocks ? 1 : 0);
     const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * nslot * 2 * R * 128 * 4;
@@ -1077,12 +1088,12 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.stats = (float*)p->stats; k.nseg = nseg; k.inv_scale = p->inv_scale;
     k.mask = (const uint16_t*)p->mask; k.mask_sb = p->mask_sb;
     k.res_blocks = units * KIVI_GQA_RES_SEGS;
-    static const char* rf = getenv("KIVI_GQA_RES_FIRST");        // tuning aid
+    static const char* rf = KIVI_TUNE_ENV("KIVI_GQA_RES_FIRST");        // tuning aid
     k.res_first = rf ? atoi(rf) : 0;
     k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
-    static const char* skipk = getenv("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
-    static const char* timev = getenv("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
+    static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
+    static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};
     if (timev) held = kivi_take_launch_events();
     const bool newp = mf_new_path(R);
@@ -1103,7 +1114,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     if (newp && ((R == 1 && n <= 8192) || (R == 4 && n <= 9216))) {
         // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
         // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks of 8 waves per CU)
-        static const char* norow = getenv("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
+        static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
         const bool split = (p->flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow));
         // too few units: the split two-launch form fills the chip better
         const int min_units = R == 1 ? 192 : 128;
@@ -1114,8 +1125,9 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     if (timev) kivi_set_launch_events(held.start, held.stop);
     if (newp) return kivi_mf_run_v(&v, 0, s);
 
-    static const char* nohilo = getenv("KIVI_GQA_NO_HILO");
-    static const char* fr = getenv("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 4 or 8)
+#ifdef KIVI_TUNING
+    static const char* nohilo = KIVI_TUNE_ENV("KIVI_GQA_NO_HILO");
+    static const char* fr = KIVI_TUNE_ENV("KIVI_GQA_V_RING");            // tuning aid: blocks in flight (2, 4 or 8)
     const int ring = fr ? atoi(fr) : (R == 4 ? 4 : 2);           // R = 8 spills at 4
 #define KIVI_GV(RR, HL)                                          \
     do {                                                         \
@@ -1126,5 +1138,9 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     if (R == 4) { if (nohilo) KIVI_GV(4, false); else KIVI_GV(4, true); }
     else { if (nohilo) KIVI_GV(8, false); else KIVI_GV(8, true); }
 #undef KIVI_GV
+#else
+    KIVI_REQUIRE(R == 8, KIVI_EUNSUPPORTED, "kivi_gqa_decode: nh / nh_kv = %d has no round-2 kernel in this build", R);
+    KIVI_LAUNCH_LDS((gqa_v_kernel<8, true, 2>), dim3((unsigned)(units * v.S + v.win_blocks)), dim3(256), 4 * 2048 * 4 + 8192, s, v);
+#endif
     return kivi_launch_status("gqa_v");
 }

@@ -138,21 +138,24 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     // multiplied): 2 when that still leaves >= 4 waves per SIMD, else 1; few super-blocks: one wave per block spreads them
     const int64_t total = (int64_t)units * a.nsb;
     int spw = (a.ratio == 1 && total >= 8192 && a.nsb >= 2) ? 2 : 1;
-    static const char* fs = getenv("KIVI_MF_SPW");                 // tuning aid (R = 1)
+    static const char* fs = KIVI_TUNE_ENV("KIVI_MF_SPW");                 // tuning aid (R = 1)
     if (fs && a.ratio == 1) spw = atoi(fs) > 0 ? atoi(fs) : 1;
     const int chunks = (a.nsb + spw - 1) / spw;                     // waves per unit
     const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
     a.sb_blocks = (chunks + W - 1) / W;
     if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
-    static const char* fr = getenv("KIVI_MF_RING");                // tuning aid: code blocks in flight (2 or 4)
-    const int ring = fr ? atoi(fr) : 4;
-    if (a.ratio == 1) {
-        if (W == 4) { if (ring == 2) launch_mf_k<1, 4, 2>(a, units, spw, s); else launch_mf_k<1, 4, 4>(a, units, spw, s); }
-        else { if (ring == 2) launch_mf_k<1, 1, 2>(a, units, spw, s); else launch_mf_k<1, 1, 4>(a, units, spw, s); }
-    } else {
-        if (W == 4) { if (ring == 2) launch_mf_k<4, 4, 2>(a, units, spw, s); else launch_mf_k<4, 4, 4>(a, units, spw, s); }
-        else { if (ring == 2) launch_mf_k<4, 1, 2>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
+    // two code blocks in flight per wave: 39.2 us per BASELINE configs[1] launch against 40.8 with four (fewer registers, the
+    // same bytes in flight per SIMD); -DKIVI_TUNING builds keep the four-deep ring for A/B
+#ifdef KIVI_TUNING
+    static const char* fr = KIVI_TUNE_ENV("KIVI_MF_RING");
+    if (fr && atoi(fr) == 4) {
+        if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 4>(a, units, spw, s); else launch_mf_k<1, 1, 4>(a, units, spw, s); }
+        else { if (W == 4) launch_mf_k<4, 4, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
+        return kivi_launch_status("mf_k");
     }
+#endif
+    if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 2>(a, units, spw, s); else launch_mf_k<1, 1, 2>(a, units, spw, s); }
+    else { if (W == 4) launch_mf_k<4, 4, 2>(a, units, spw, s); else launch_mf_k<4, 1, 2>(a, units, spw, s); }
     return kivi_launch_status("mf_k");
 }
 
@@ -705,19 +708,20 @@ int kivi_mf_run_k(void* k_args, int units, hipStream_t s) { return run_mf_k(*(Gq
 // their exponents)
 int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
     const GqaVArgs& a = *(const GqaVArgs*)v_args;
-    static const char* fr = getenv("KIVI_MF_RING");                // tuning aid
-    const int ring = fr ? atoi(fr) : 4;
     const int R = a.ratio;
     const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
     const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
 #define KIVI_MV(RR, RG, PB) KIVI_LAUNCH_LDS((mf_v_kernel<RR, RG, PB>), grid, dim3(256), lds, s, a)
-    if (R == 1) {
-        if (prob) { if (ring == 2) KIVI_MV(1, 2, true); else KIVI_MV(1, 4, true); }
-        else { if (ring == 2) KIVI_MV(1, 2, false); else KIVI_MV(1, 4, false); }
-    } else {
-        if (prob) { if (ring == 2) KIVI_MV(4, 2, true); else KIVI_MV(4, 4, true); }
-        else { if (ring == 2) KIVI_MV(4, 2, false); else KIVI_MV(4, 4, false); }
+#ifdef KIVI_TUNING
+    static const char* fr = KIVI_TUNE_ENV("KIVI_MF_RING");
+    if (fr && atoi(fr) == 4) {
+        if (R == 1) { if (prob) KIVI_MV(1, 4, true); else KIVI_MV(1, 4, false); }
+        else { if (prob) KIVI_MV(4, 4, true); else KIVI_MV(4, 4, false); }
+        return kivi_launch_status("mf_v");
     }
+#endif
+    if (R == 1) { if (prob) KIVI_MV(1, 2, true); else KIVI_MV(1, 2, false); }
+    else { if (prob) KIVI_MV(4, 2, true); else KIVI_MV(4, 2, false); }
 #undef KIVI_MV
     return kivi_launch_status("mf_v");
 }
@@ -740,35 +744,44 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
         size_t lds = (size_t)4 * n_pad * 2;
         const size_t fin = (size_t)2 * 8 * 4 * 128 * 4;           // the per-wave partial sums reuse the rows
         if (lds < fin) lds = fin;
+        // 4 waves with up to 256 registers (two blocks per CU): 103 us per layer at BASELINE config 4 against 123 for 8 waves of
+        // 128 registers (spills)
         static bool attr_set = false;
         if (!attr_set) {                                           // > 64 KiB of dynamic LDS needs the opt-in
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#ifdef KIVI_TUNING
             (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#endif
             attr_set = true;
         }
-        static const char* fr4 = getenv("KIVI_MF_ROW4");          // tuning aid: "<waves><K ring><V ring>"
-        const int cfg = fr4 ? atoi(fr4) : 443;    // 4 waves with up to 256 registers: 103 us per layer at config 4 against 123 for 8 waves of 128 (spills)
-        if (cfg == 822) KIVI_LAUNCH_LDS((mf_row4_kernel<2, 2, 8>), grid, dim3(512), lds, s, k, v, n_pad);
-        else if (cfg == 444) KIVI_LAUNCH_LDS((mf_row4_kernel<4, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-        else if (cfg == 443) KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-        else KIVI_LAUNCH_LDS((mf_row4_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
+#ifdef KIVI_TUNING
+        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<waves><K ring><V ring>"
+        const int cfg = fr4 ? atoi(fr4) : 443;
+        if (cfg == 822) { KIVI_LAUNCH_LDS((mf_row4_kernel<2, 2, 8>), grid, dim3(512), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+        if (cfg == 823) { KIVI_LAUNCH_LDS((mf_row4_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+        if (cfg == 444) { KIVI_LAUNCH_LDS((mf_row4_kernel<4, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+#endif
+        KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
         return kivi_launch_status("mf_row4");
     }
     if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
-    static const char* fr = getenv("KIVI_MF_ROW_RINGS");          // tuning aid: "<K ring><V ring>", e.g. 42
-    const int rings = fr ? atoi(fr) : 23;
     const size_t lds = (size_t)n_pad * 2;
-    static const char* np = getenv("KIVI_MF_ROW_NOPRIO");          // tuning aid (A/B)
     // (K ring, V ring) = (2, 3) code blocks in flight: 76.2 us per launch at the bench shape against 77.2 (2, 2), 76.7 (2, 4),
     // 78.4 (4, 2), 78.2 (4, 3) -- profiles/r03_row_rings.log
-    if (v.dbg && np) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, true, false>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (v.dbg) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (np) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, false>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (rings == 24) KIVI_LAUNCH_LDS((mf_row_kernel<2, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (rings == 22) KIVI_LAUNCH_LDS((mf_row_kernel<2, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-    else if (rings == 43) KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-    else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+#ifdef KIVI_TUNING
+    static const char* fr = KIVI_TUNE_ENV("KIVI_MF_ROW_RINGS");          // "<K ring><V ring>", e.g. 42
+    const int rings = fr ? atoi(fr) : 23;
+    static const char* np = KIVI_TUNE_ENV("KIVI_MF_ROW_NOPRIO");         // A/B of the raised priority
+    if (v.dbg && np) { KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, true, false>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+    if (v.dbg) { KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+    if (np) { KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, false>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+    if (rings == 24) { KIVI_LAUNCH_LDS((mf_row_kernel<2, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+    if (rings == 22) { KIVI_LAUNCH_LDS((mf_row_kernel<2, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+    if (rings == 43) { KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+    if (rings == 42) { KIVI_LAUNCH_LDS((mf_row_kernel<4, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
+#endif
+    KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");
 }

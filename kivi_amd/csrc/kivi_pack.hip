@@ -568,7 +568,7 @@ extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, v
                       ((uintptr_t)code % 8 == 0);
     if (fast) {
         const int64_t nchunk = n / 8;
-        static const char* fu = getenv("KIVI_PACK_UNROLL");   // tuning aid: chunks per thread (1, 2, 4 or 8)
+        static const char* fu = KIVI_TUNE_ENV("KIVI_PACK_UNROLL");   // tuning aid: chunks per thread (1, 2, 4 or 8)
         const int nu = fu ? atoi(fu) : (nchunk >= (int64_t)1 << 20 ? 8 : 1);
 #define KIVI_QP(BB)                                                                                                    \
     do {                                                                                                               \
@@ -581,7 +581,7 @@ extern "C" int kivi_quant_pack_lastdim(const void* x, void* code, void* scale, v
         else hipLaunchKernelGGL((quant_pack_lastdim_kernel<BB, 1>), dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s,         \
                                 (const uint16_t*)x, (uint32_t*)code, (uint16_t*)scale, (uint16_t*)mn, nchunk, lpg);                  \
     } while (0)
-        static const char* nopk = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math kernels
+        static const char* nopk = KIVI_TUNE_ENV("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math kernels
         if (bits == 2 && !nopk) {
 #define KIVI_QP2(NUU, LL, FF)                                                                                          \
     hipLaunchKernelGGL((quant_pack_lastdim2_kernel<NUU, LL, FF>), dim3((unsigned)((nchunk + 256 * NUU - 1) / (256 * NUU))), dim3(256), 0, \
@@ -658,7 +658,7 @@ extern "C" int kivi_quant_pack_k_tmajor(const void* k, int64_t k_sb, int64_t k_s
     if (fast && ngroups >= 8) {   // store-coalescing tile kernel (prefill-sized calls)
         const int64_t nchunks = (ngroups + 15) / 16;
         dim3 grid((unsigned)(nchunks * B * nh), (unsigned)((D + 127) / 128));
-        static const char* nopk_k = getenv("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math instantiation
+        static const char* nopk_k = KIVI_TUNE_ENV("KIVI_PACK_NO_PK16");   // tuning aid: the scalar-math instantiation
 #define KIVI_KT_CASE(BITS, G)                                                                                   \
     if (bits == BITS && group_size == G) {                                                                      \
         if (nopk_k) hipLaunchKernelGGL((quant_pack_k_tmajor_tiled<BITS, G, false>), grid, dim3(256), 0, s, KIVI_K_ARGS, nchunks); \

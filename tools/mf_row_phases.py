@@ -9,6 +9,10 @@ starts), 9 V stream loop done, 10 per-wave result + combine barrier, 11 end."""
 import os
 import sys
 
+_TUNING = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kivi_amd", "_variants", "libkivi_tuning.so")
+if os.path.exists(_TUNING):      # phase stamps / environment knobs exist in the -DKIVI_TUNING build only (tools/build_variant.sh)
+    os.environ.setdefault("KIVI_HIP_LIB", _TUNING)
+
 import numpy as np
 import torch
 
