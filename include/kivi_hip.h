@@ -299,6 +299,9 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  */
 #define KIVI_GQA_FORCE_SPLIT 1
 #define KIVI_GQA_FORCE_ROW 2
+/* the fp16 value window is a RING of v_window_rows rows (row of window token t = (v_win_start + t) mod v_window_rows):
+ * residual_length + 1 rows suffice and nothing is ever compacted; nh / nh_kv in {1, 4} */
+#define KIVI_GQA_WINDOW_RING 4
 typedef struct {
     int B, nh, nh_kv, D, group_size, bits;
     float inv_scale;

@@ -84,7 +84,7 @@ class GqaDecodeArgs(ctypes.Structure):
     ]
 
 
-GQA_FORCE_SPLIT, GQA_FORCE_ROW = 1, 2
+GQA_FORCE_SPLIT, GQA_FORCE_ROW, GQA_WINDOW_RING = 1, 2, 4
 
 
 class MfLayerDesc(ctypes.Structure):

@@ -334,7 +334,7 @@ def _rope_inv_freq(config, head_dim: int, theta: float) -> torch.Tensor:
     raise NotImplementedError(f"rope_scaling type {kind!r} is not implemented (default / linear / llama3 are)")
 
 
-_ROPE_CACHE = {}   # (device, dtype, head_dim, theta, past_len, q_len) -> (cos, sin) of the current step
+_ROPE_CACHE = {}   # (device, dtype, head_dim, theta, rope_scaling, past_len, q_len) -> (cos, sin) of the current step
 
 
 class LlamaAttention_KIVI(nn.Module):
@@ -388,7 +388,8 @@ class LlamaAttention_KIVI(nn.Module):
         v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         past_len = 0 if past_key_value is None else int(past_key_value[-1])
         if position_ids is None:   # consecutive positions: cos / sin are the same for every layer of this step
-            key = (hidden_states.device, q.dtype, self.head_dim, self.rope_theta, past_len, q_len)
+            key = (hidden_states.device, q.dtype, self.head_dim, self.rope_theta, repr(getattr(self.config, "rope_scaling", None)),
+                   past_len, q_len)
             cs = _ROPE_CACHE.get(key)
             if cs is None:
                 pos = torch.arange(past_len, past_len + q_len, device=hidden_states.device)[None]
@@ -426,12 +427,13 @@ class LlamaAttention_KIVI(nn.Module):
         return self.o_proj(attn_output), None, past
 
     def _capacity(self, needed: int) -> int:
-        """Initial cache capacity: the prompt plus a few residual windows (the cache doubles when it runs out, like the
-        reference's torch.cat-grown tuple, so memory follows the sequence).  `config.kivi_max_cache_len` is an opt-in
-        reservation for callers that know their final length; max_position_embeddings is never used (a 128k-context
-        config would otherwise pre-allocate GBs per sequence for a 1k-token run)."""
+        """Initial cache capacity: the prompt plus one residual window (the cache doubles when it runs out, like the
+        reference's torch.cat-grown tuple, so memory follows the sequence; the matrix-pipe stores round it up to whole
+        512-token super-blocks).  `config.kivi_max_cache_len` is an opt-in reservation for callers that know their final
+        length; max_position_embeddings is never used (a 128k-context config would otherwise pre-allocate GBs per sequence
+        for a 1k-token run)."""
         reserve = getattr(self.config, "kivi_max_cache_len", None) or 0
-        return max(needed + 4 * self.residual_length, reserve)
+        return max(needed + self.residual_length, reserve)
 
 
 class LlamaFlashAttention_KIVI(LlamaAttention_KIVI):

@@ -79,7 +79,10 @@ class KiviLayerCacheMF:
         self.kt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
         self.vt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=device)
-        self.v_res = torch.empty((batch, num_kv_heads, 2 * R + 1, head_dim), dtype=dtype, device=device)
+        # fp16 value window: a RING of R + 1 rows for the round-3 kernels (nh / nh_kv in {1, 4}: nothing is ever compacted);
+        # the round-2 kernels (nh / nh_kv = 8) keep the linear buffer of 2 R + 1 rows with a compaction every ~R steps
+        self.ring = (num_heads // num_kv_heads) in (1, 4)
+        self.v_res = torch.empty((batch, num_kv_heads, (R + 1) if self.ring else (2 * R + 1), head_dim), dtype=dtype, device=device)
         self.k_quant_len = 0
         self.k_res_len = 0
         self.v_quant_len = 0
@@ -137,7 +140,10 @@ class KiviLayerCacheMF:
         return self.k_res[:, :, : self.k_res_len] if self.k_res_len else None
 
     def v_res_view(self):
-        return self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len]
+        s, n, rows = self.v_res_start, self.v_res_len, self.v_res.shape[2]
+        if s + n <= rows:
+            return self.v_res[:, :, s: s + n]
+        return torch.cat([self.v_res[:, :, s:], self.v_res[:, :, : s + n - rows]], dim=2)      # the ring wraps (9-tuple reads only)
 
     def _tuple_members(self):
         kc, ks, km = self.k_quant_reference_layout()
@@ -232,10 +238,13 @@ class KiviLayerCacheMF:
             v_res=vr.data_ptr(), vr_sb=vr.stride(0), vr_sh=vr.stride(1), vr_st=vr.stride(2),
             scores=scores.data_ptr(), s_sb=scores.stride(0), s_sh=scores.stride(1),
             stats=stats.data_ptr(), stats_bytes=stats.numel() * 4,
-            workspace=ws.data_ptr(), workspace_bytes=ws.numel(), flags=self.flags)
+            workspace=ws.data_ptr(), workspace_bytes=ws.numel(), flags=self._flags())
         state = (ctypes.c_int64 * 6)()
         self._native = (d, state, (nh, stream), _lib.load().kivi_mf_decode_layer, (scores, stats, ws))
         return self._native
+
+    def _flags(self) -> int:
+        return self.flags | (_lib.GQA_WINDOW_RING if self.ring else 0)
 
     def decode_step(self, query_states: torch.Tensor, key_states: torch.Tensor, value_states: torch.Tensor,
                     attention_mask: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
@@ -258,7 +267,7 @@ class KiviLayerCacheMF:
         else:
             assert out.shape == (B, nh, 1, D) and out.dtype == torch.float16 and out.stride(3) == 1
         d, state, _, fn, _ = self._desc(nh, q.device)
-        d.flags = self.flags
+        d.flags = self._flags()
         state[0], state[1], state[2] = self.k_quant_len, self.k_res_len, self.v_quant_len
         state[3], state[4], state[5] = self.v_res_start, self.v_res_len, self.kv_seq_len
         hook = _launch_hook()

@@ -119,6 +119,7 @@ struct GqaVArgs {
     float* ws;                  // [units][nslot][2][R * 128] fp32 partial sums of every block: quantised part, window part
     int* counters;              // [units] arrival counters, zero between launches
     unsigned long long* dbg;    // phase time stamps or null
+    int win_rows;               // > 0: the window buffer is a RING of that many rows (row of token t = (win_start + t) % win_rows); 0: linear
     const int* sp_rows;         // kivi_gqa_output: [B][nh] exponent Sp of every probability row (mf_row_sp_kernel)
 };
 
@@ -226,10 +227,16 @@ __device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk
                                                 const uint16_t (*pw)[PW], float (*ow)[2]) {
     constexpr int NW = NTH / 64, WB = 12;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint16_t* vwin = a.vres + b * a.vres_sb + hk * a.vres_sh + (int64_t)a.win_start * a.vres_st;
+    uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
+    // row of window token t: a ring of win_rows rows (no compaction, residual_length + 1 rows suffice) or the linear buffer
+    auto wrow = [&](int t) {
+        int r = a.win_start + t;
+        if (a.win_rows) r = r >= a.win_rows ? r - a.win_rows : r;       // t <= residual_length < win_rows: one wrap at most
+        return vbuf + (int64_t)r * a.vres_st;
+    };
     const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
     uint16_t xflush = 0;
-    if (flusher && threadIdx.x < 128) xflush = vwin[threadIdx.x];      // requested early, used last
+    if (flusher && threadIdx.x < 128) xflush = wrow(0)[threadIdx.x];      // requested early, used last
 #pragma unroll
     for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
     const int nwt = w1 > w0 ? w1 - w0 : 0;
@@ -238,7 +245,7 @@ __device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk
 #pragma unroll
         for (int u = 0; u < WB; u++) {
             const int t = w0 + tb + NW * u;
-            const uint16_t* vrow = (t < a.res_len) ? vwin + (int64_t)t * a.vres_st : vnew;
+            const uint16_t* vrow = (t < a.res_len) ? wrow(t) : vnew;
             vv[u] = (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
         }
 #pragma unroll
@@ -252,7 +259,7 @@ __device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk
                     ow[rr][0] = __builtin_fmaf(p, v0, ow[rr][0]);
                     ow[rr][1] = __builtin_fmaf(p, v1, ow[rr][1]);
                 }
-                if (t == a.res_len) *(uint32_t*)(vwin + (int64_t)t * a.vres_st + 2 * lane) = vv[u];   // V append
+                if (t == a.res_len) *(uint32_t*)(wrow(t) + 2 * lane) = vv[u];   // V append
             }
         }
     }

@@ -154,7 +154,10 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
         const int rc = flush_k();
         if (rc) return rc;
     }
-    if (wstart + vres + 1 > L->v_window_rows) {
+    const bool ring = (L->flags & KIVI_GQA_WINDOW_RING) != 0;     // ring window: no compaction, R + 1 rows suffice
+    KIVI_REQUIRE(!ring || (wstart < L->v_window_rows && vres + 1 <= L->v_window_rows), KIVI_EINVAL,
+                 "kivi_mf_decode_layer: ring window of %lld rows cannot hold %lld + 1 values", (long long)L->v_window_rows, (long long)vres);
+    if (!ring && wstart + vres + 1 > L->v_window_rows) {
         KIVI_REQUIRE(L->vr_sb == (int64_t)L->nh_kv * L->vr_sh && wstart >= vres, KIVI_EUNSUPPORTED,
                      "kivi_mf_decode_layer: window buffer layout not compactable in place");
         const size_t pitch = (size_t)L->vr_sh * 2, width = (size_t)vres * L->vr_st * 2;
@@ -193,6 +196,7 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
     if (flush) {
         Tv += 1;
         wstart += 1;
+        if (ring && wstart >= L->v_window_rows) wstart -= L->v_window_rows;
         vres -= 1;
     }
     st[1] = kres; st[2] = Tv; st[3] = wstart; st[4] = vres; st[5] = kv + 1;

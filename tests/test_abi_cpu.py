@@ -224,9 +224,9 @@ def test_initial_capacity_follows_the_prompt_not_the_context_window():
     base = dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=131072,
                 rope_theta=500000.0, k_bits=2, v_bits=2, group_size=32, residual_length=128)
     a = LlamaAttention_KIVI(SimpleNamespace(**base))
-    assert a._capacity(1000) == 1000 + 4 * 128
+    assert a._capacity(1000) == 1000 + 128
     b = LlamaAttention_KIVI(SimpleNamespace(**base, kivi_max_cache_len=9000))
-    assert b._capacity(1000) == 9000 and b._capacity(20000) == 20000 + 512
+    assert b._capacity(1000) == 9000 and b._capacity(20000) == 20000 + 128
 
 
 def test_rope_scaling_matches_hf():
@@ -308,6 +308,10 @@ def _gqa_args(**over):
     (dict(vt_superblocks=0), None, b"exceed the stores"),
     (dict(Tq=1024, Tv=999, kt_superblocks=1), None, b"exceed the stores"),
     (dict(v_res_len=31, Tv=488), None, b"v_flush"),
+    # ring window (flags 4): residual_length + 1 rows are enough, the start may sit anywhere inside the buffer
+    (dict(flags=4, v_window_rows=32), None, b"window rows"),
+    (dict(flags=4, v_window_rows=33, v_win_start=33), None, b"window rows"),
+    (dict(flags=4, nh=16), -3, b"ring window"),             # nh / nh_kv = 8 runs the round-2 kernels: linear window only
 ])
 def test_gqa_decode_validates_before_launching(lib, over, rc_expected, msg):
     """kivi_gqa_decode (the grouped-query layer step, llama_kivi.py:314-399 / mistral_kivi.py:381-445) refuses bad shapes,
@@ -318,6 +322,56 @@ def test_gqa_decode_validates_before_launching(lib, over, rc_expected, msg):
     assert rc < 0 and (rc_expected is None or rc == rc_expected), rc
     assert msg in lib.kivi_last_error(), lib.kivi_last_error()
     assert lib.kivi_gqa_decode(None, None) < 0
+
+
+def _mf_layer_desc(**over):
+    """A kivi_mf_layer_desc over fake (never dereferenced) device pointers, for argument-validation tests."""
+    from kivi_amd import _lib
+    f = dict(B=2, nh_kv=2, D=128, bits=2, group_size=32, residual_length=32, inv_scale=0.088,
+             cap=512, v_window_rows=33, s_pitch=520,
+             kt=0x1000, kt_sb=2 * 6144, kt_sh=6144, kt_ss=2 * 2 * 6144, vt=0x1000, vt_sb=2 * 6144, vt_sh=6144, vt_ss=2 * 2 * 6144,
+             k_res=0x1000, kr_sb=2 * 32 * 128, kr_sh=32 * 128, kr_st=128, v_res=0x1000, vr_sb=2 * 33 * 128, vr_sh=33 * 128, vr_st=128,
+             scores=0x1000, s_sb=8 * 520, s_sh=520, stats=0x1000, stats_bytes=1 << 16, workspace=0x1000, workspace_bytes=1 << 20,
+             flags=4)
+    f.update(over)
+    return _lib.MfLayerDesc(**f)
+
+
+@pytest.mark.parametrize("over,msg", [(dict(bits=4), b"2-bit"), (dict(residual_length=48), b"inconsistent lengths"),
+                                      (dict(kt=None), b"null"), (dict(cap=64), b"capacity"), (dict(kt_ss=100), b"alignment"),
+                                      (dict(v_window_rows=32), b"ring window"), (dict(s_pitch=90), b"score rows")])
+def test_mf_decode_layer_refuses_before_anything_is_committed(lib, over, msg):
+    """kivi_mf_decode_layer (the layer step on the matrix-pipe layout: kivi_gqa_decode + bookkeeping + kivi_kt_pack flush):
+    what its K flush or its launches could reject is validated first, a refused step leaves the six lengths untouched."""
+    import ctypes
+    d = _mf_layer_desc(**over)
+    state = (ctypes.c_int64 * 6)(64, 31, 63, 5, 32, 95)      # the NEXT step would flush K (residual 31 + 1 == R)
+    before = list(state)
+    rc = lib.kivi_mf_decode_layer(ctypes.byref(d), state, 0x1000, 8 * 128, 128, 8, 0x1000, 2 * 128, 128, 0x1000, 2 * 128, 128, None, 0,
+                                  0x1000, 8 * 128, 128, None)
+    assert rc < 0 and msg in lib.kivi_last_error(), lib.kivi_last_error()
+    assert list(state) == before
+    bad = (ctypes.c_int64 * 6)(64, 31, 63, 0, 32, 96)          # inconsistent lengths
+    d = _mf_layer_desc()
+    assert lib.kivi_mf_decode_layer(ctypes.byref(d), bad, 0x1000, 8 * 128, 128, 8, 0x1000, 2 * 128, 128, 0x1000, 2 * 128, 128, None, 0,
+                                    0x1000, 8 * 128, 128, None) < 0
+    assert list(bad) == [64, 31, 63, 0, 32, 96]
+    assert lib.kivi_mf_decode_layer(None, None, None, 0, 0, 0, None, 0, 0, None, 0, 0, None, 0, None, 0, 0, None) < 0
+
+
+def test_mf_cache_ring_window_view():
+    """The fp16 value window of the matrix-pipe cache is a ring of R + 1 rows (round 3): the 9-tuple member V_full is read
+    through it in token order, also when the live rows wrap."""
+    from kivi_amd.attention import KiviConfig, make_layer_cache
+    lc = make_layer_cache(KiviConfig(2, 2, 32, 32), 1, 2, 128, 100, "cpu", num_heads=2)
+    assert lc.ring and lc.v_res.shape[2] == 33
+    lc.v_res.copy_(torch.arange(33, dtype=torch.float16)[None, None, :, None].expand(1, 2, 33, 128))
+    lc.v_res_start, lc.v_res_len = 30, 5
+    assert lc.v_res_view()[0, 0, :, 0].tolist() == [30.0, 31.0, 32.0, 0.0, 1.0]
+    lc.v_res_start, lc.v_res_len = 3, 4
+    assert lc.v_res_view()[0, 0, :, 0].tolist() == [3.0, 4.0, 5.0, 6.0]
+    old = make_layer_cache(KiviConfig(2, 2, 32, 32), 1, 1, 128, 100, "cpu", num_heads=8)      # nh / nh_kv = 8: round-2 kernels, linear window
+    assert not old.ring and old.v_res.shape[2] == 65
 
 
 def test_layer_cache_factory_picks_the_layout():
