@@ -81,7 +81,7 @@ class KiviLayerCacheMF:
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=device)
         # fp16 value window: a RING of R + 1 rows for the round-3 kernels (nh / nh_kv in {1, 4}: nothing is ever compacted);
         # the round-2 kernels (nh / nh_kv = 8) keep the linear buffer of 2 R + 1 rows with a compaction every ~R steps
-        self.ring = (num_heads // num_kv_heads) in (1, 4)
+        self.ring = (num_heads // num_kv_heads) in (1, 4) and not os.environ.get("KIVI_MF_NO_RING")   # (tuning aid: A/B)
         self.v_res = torch.empty((batch, num_kv_heads, (R + 1) if self.ring else (2 * R + 1), head_dim), dtype=dtype, device=device)
         self.k_quant_len = 0
         self.k_res_len = 0

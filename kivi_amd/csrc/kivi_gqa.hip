@@ -933,6 +933,8 @@ static void gqa_v_slices(int units, int nsbv, int& S, int& spb) {
     S = (target + units - 1) / units;
     S = S < 1 ? 1 : (S > nsbv ? nsbv : S);
     spb = (nsbv + S - 1) / S;
+    // the four waves of a block take super-blocks w, w + 4, ... of its slice: slices of fewer than 4 leave waves idle
+    if (spb < 4 && nsbv >= 4 && (int64_t)units * ((nsbv + 3) / 4) >= 256) spb = 4;
     S = (nsbv + spb - 1) / spb;
 }
 
@@ -1040,10 +1042,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
                      p->v_res_len <= p->residual_length,
                  KIVI_EINVAL, "kivi_gqa_decode: residual of %d keys / window of %d values do not fit residual_length %d",
                  p->k_res_len, p->v_res_len, p->residual_length);
-    const bool ring = (p->flags & KIVI_GQA_WINDOW_RING) != 0;
-    KIVI_REQUIRE(!ring || nh / nh_kv != 8, KIVI_EUNSUPPORTED, "kivi_gqa_decode: the ring window needs the round-3 kernels (nh / nh_kv in {1, 4})");
+    const bool win_ring = (p->flags & KIVI_GQA_WINDOW_RING) != 0;
+    KIVI_REQUIRE(!win_ring || nh / nh_kv != 8, KIVI_EUNSUPPORTED, "kivi_gqa_decode: the ring window needs the round-3 kernels (nh / nh_kv in {1, 4})");
     KIVI_REQUIRE(p->v_win_start >= 0 &&
-                     (ring ? (p->v_win_start < p->v_window_rows && p->v_res_len + 1 <= p->v_window_rows)
+                     (win_ring ? (p->v_win_start < p->v_window_rows && p->v_res_len + 1 <= p->v_window_rows)
                            : (int64_t)p->v_win_start + p->v_res_len + 1 <= p->v_window_rows),
                  KIVI_EINVAL, "kivi_gqa_decode: window rows [%d, %d] exceed the %lld rows of the buffer", p->v_win_start,
                  p->v_win_start + p->v_res_len, (long long)p->v_window_rows);
@@ -1110,7 +1112,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.units = units; v.win_blocks = win_blocks; v.nslot = nslot;
     v.vres = (uint16_t*)p->vres; v.vres_sb = p->vres_sb; v.vres_sh = p->vres_sh; v.vres_st = p->vres_st;
     v.win_start = p->v_win_start; v.res_len = p->v_res_len;
-    v.win_rows = ring ? (int)p->v_window_rows : 0;
+    v.win_rows = win_ring ? (int)p->v_window_rows : 0;
     v.vnew = (const uint16_t*)p->vnew; v.vnew_sb = p->vnew_sb; v.vnew_sh = p->vnew_sh; v.flush = p->v_flush ? 1 : 0;
     v.out = (uint16_t*)p->out; v.out_sb = p->out_sb; v.out_sh = p->out_sh;
     v.dbg = kivi_debug_stamps();

@@ -230,16 +230,25 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     mf_v_init<R>(A);
     const int sb_begin = win_role ? 0 : slice * a.spb;
     const int sb_end = win_role ? 0 : ((sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb);
-    for (int sb = sb_begin + wave; sb < sb_end; sb += 4) {
-        const int64_t tok0 = (int64_t)sb * KIVI_MF_SB_TOKENS;
-        int nb = (int)((a.Tv - tok0 + 31) / 32);
-        nb = nb > 16 ? 16 : nb;
+    // wave w streams super-blocks sb_begin + w, + 4, ... of the slice as ONE stream: the code ring runs across the super-blocks
+    // (the probabilities of the next one are made while its first blocks are already in flight)
+    static_assert(16 % RING == 0, "a super-block is a whole number of ring rounds");
+    const int sb_w0 = sb_begin + wave;
+    const int n_my = sb_end > sb_w0 ? (sb_end - sb_w0 + 3) / 4 : 0;
+    if (n_my > 0) {
+        const int last_sb = sb_w0 + 4 * (n_my - 1);
+        int nb_last = (int)((a.Tv - (int64_t)last_sb * KIVI_MF_SB_TOKENS + 31) / 32);
+        nb_last = nb_last > 16 ? 16 : nb_last;
         MfVStream<R, RING> vs;
-        vs.prime(rv, sb_bytes, sb * 16, sb * 16 + nb);              // the first code blocks fly while the probabilities are made
-        __builtin_amdgcn_wave_barrier();                           // the previous super-block's LDS reads are over
-        mf_probs_to_lds<R, PROB>(rx, (uint32_t)(a.x_sh * 2), tok0, a.Tv, M, invS, sp, lds_p);
-        __builtin_amdgcn_wave_barrier();
-        vs.run(A, rv, sb * 16, sb * 16 + nb, lds_p, 512, (int)tok0);
+        vs.prime(rv, sb_bytes, 0, 16 * (n_my - 1) + nb_last, sb_w0, 4);
+        for (int i = 0; i < n_my; i++) {
+            const int64_t tok0 = (int64_t)(sb_w0 + 4 * i) * KIVI_MF_SB_TOKENS;
+            const int nb = (i == n_my - 1) ? nb_last : 16;
+            __builtin_amdgcn_wave_barrier();                       // the previous super-block's LDS reads are over
+            mf_probs_to_lds<R, PROB>(rx, (uint32_t)(a.x_sh * 2), tok0, a.Tv, M, invS, sp, lds_p);
+            __builtin_amdgcn_wave_barrier();
+            vs.run(A, rv, 16 * i, 16 * i + nb, lds_p, 512, 16 * i * 32);
+        }
     }
 
     // ---- fp16 window (+ V append + flush): the window block of the unit (tail of the grid), or shares inside the stream blocks
@@ -782,6 +791,10 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     if (rings == 43) { KIVI_LAUNCH_LDS((mf_row_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
     if (rings == 42) { KIVI_LAUNCH_LDS((mf_row_kernel<4, 2, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row"); }
 #endif
-    KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+    // few rows (under ~2 four-wave blocks per CU): eight waves per row, the row's own waves hide the latency
+    static const char* f8 = KIVI_TUNE_ENV("KIVI_MF_ROW_NW8");            // tuning builds: 0 / 1 forces either
+    const bool nw8 = f8 ? atoi(f8) != 0 : units < 448;          // 256 rows: 31.5 -> 26.6 us, 512: equal, 768: 61.1 vs 65.4 (profiles/r03_other_shapes.log)
+    if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
+    else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");
 }

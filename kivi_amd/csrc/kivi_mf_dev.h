@@ -647,23 +647,27 @@ struct MfVStream {
     u32x4 wr[RING], sr[RING], mr[R == 1 ? 1 : RING];
     uint32_t sm_off, mn_off, sb_bytes;
     int b_last;
+    int sb_first, sb_stride;       // block q of the stream lives in super-block sb_first + (q >> 4) * sb_stride, block q & 15
 
     __device__ __forceinline__ void request(rsrc_t rv, int slot, int bl) {
         const int lane = threadIdx.x & 63;
         const int bc = bl < b_last ? bl : b_last;                  // clamped: no branch, no out-of-range address
-        const uint32_t so = (uint32_t)(bc >> 4) * sb_bytes;
+        const uint32_t so = (uint32_t)(sb_first + (bc >> 4) * sb_stride) * sb_bytes;
         wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16), so + (uint32_t)(bc & 15) * 1024u);
         sr[slot] = buf_load<u32x4, true>(rv, sm_off, so + (uint32_t)(bc & 15) * 256u);
         if constexpr (R != 1) mr[slot] = buf_load<u32x4, true>(rv, mn_off, so + (uint32_t)(bc & 15) * 256u);
     }
 
-    __device__ __forceinline__ void prime(rsrc_t rv, uint32_t sb_bytes_, int b_lo, int b_hi) {
+    // blocks [b_lo, b_hi) in stream numbering; (first, stride) = (0, 1): stream numbering = the unit's block numbering
+    __device__ __forceinline__ void prime(rsrc_t rv, uint32_t sb_bytes_, int b_lo, int b_hi, int first = 0, int stride = 1) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
         const int cg = m >> 2, j = m & 3;
         sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
         mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
         sb_bytes = sb_bytes_;
+        sb_first = first;
+        sb_stride = stride;
         b_last = b_hi > b_lo ? b_hi - 1 : b_lo;
         if (b_hi <= b_lo) return;
 #pragma unroll
@@ -675,6 +679,10 @@ struct MfVStream {
         }
     }
 
+    // Consumes blocks [b_lo, b_hi) (b_lo on a ring-round boundary relative to the primed block; b_hi <= the primed end: the
+    // ring keeps requesting up to b_last, so a caller may run() the stream piece by piece -- one super-block at a time with
+    // the probabilities of the next one made in between -- without ever draining it).  ps_lds: the R rows of scaled
+    // probabilities, row pitch `pitch` halves, indexed by (stream block * 32 + token in block) - tok0.
     __device__ __forceinline__ void run(MfVAcc<R>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
@@ -687,7 +695,7 @@ struct MfVStream {
             for (int s = 0; s < RING; s++) {
                 const int bl = b0 + s;
                 // blocks past the range repeat the last block with zero probabilities
-                u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_last) * 32);
+                u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_hi - 1) * 32);
                 if (bl >= b_hi) ps = u32x4{0, 0, 0, 0};
                 if (s == 0) mf_v_block<R, RING, true>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
                 else mf_v_block<R, RING, false>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
