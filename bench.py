@@ -348,7 +348,7 @@ def main():
         # reads a different ~200 MiB cache, L x 200 MiB >> the 256 MiB Infinity Cache), every dispatch timed -- the
         # isolated single-layer K-GEMV number, without the decode loop's kernel alternation
         single = None
-        single_hook = None
+        single_mf = None
 
         def time_kgemv(launch, ncaches, nbytes, label):
             """`launch(layer_index)` enqueues one qK^T launch with a pending event pair; 6 passes over the layer caches, the
@@ -380,39 +380,47 @@ def main():
                                                                   Tq, bits, out=scratch[..., :Tq]), L, nbytes, label + ", hook-state layout")
             else:
                 from kivi_amd.quant import mfma
-                single = time_kgemv(lambda i: mfma.gqa_scores(qs[0], layers[i].kt, Tq, scratch), L, nbytes,
-                                    label + ", matrix-pipe layout (raw fp16 scores to memory)")
+                single_mf = time_kgemv(lambda i: mfma.gqa_scores(qs[0], layers[i].kt, Tq, scratch), L, nbytes,
+                                       label + ", matrix-pipe layout (kivi_gqa_scores: raw fp16 scores to memory)")
+                single = single_mf
                 if not args.no_hook_kgemv and nh == nh_kv:
-                    # the same GEMV on the reference's hook-state layout (K_code_T (B,nh,D,T/16): kivi_gemv_k, the VALU kernel
-                    # behind quant.matmul.cuda_bmm_fA_qB_outer): 12 caches of ~200 MiB, rotating
+                    # the reference's operator for this GEMV, quant.matmul.cuda_bmm_fA_qB_outer on the hook-state layout
+                    # (K_code_T (B,nh,D,T/16): kivi_gemv_k, the VALU kernel): 12 caches of ~200 MiB, rotating.  This is the
+                    # drop-in the d2 row of SURVEY.md section 8 names, so it is the primary line; the matrix-pipe kernel on
+                    # its own layout is reported beside it.
                     from kivi_amd.quant import new_pack
                     hk = []
                     for _ in range(12):
                         kk = torch.randn((B, nh_kv, Tq, D), device=dev, dtype=torch.float16)
                         hk.append(new_pack.quantize_and_pack_k_tmajor(kk, g, bits))
                         del kk
-                    single_hook = time_kgemv(lambda i: matmul.cuda_bmm_fA_qB_outer(g, qs[0], hk[i][0], hk[i][1], hk[i][2], bits), len(hk),
-                                             nbytes, "the same GEMV on the reference's hook-state layout (kivi_gemv_k behind "
-                                             "quant.matmul.cuda_bmm_fA_qB_outer, output allocated per call), 12 rotating caches")
+                    single = time_kgemv(lambda i: matmul.cuda_bmm_fA_qB_outer(g, qs[0], hk[i][0], hk[i][1], hk[i][2], bits), len(hk),
+                                        nbytes, "BASELINE configs[1]: quant.matmul.cuda_bmm_fA_qB_outer (kivi_gemv_k) on the reference's "
+                                        "hook-state layout, output allocated per call, 12 rotating caches of "
+                                        f"{nbytes / 2**20:.0f} MiB")
                     del hk
         # cost of one K flush per layer (the launch of kivi_quant_pack_k_tmajor over the R residual tokens), timed apart
         flush_us = None
         try:
             from kivi_amd.quant import new_pack
-            if not hasattr(layers[0], "k_code"):
-                raise AttributeError("matrix-pipe layout")
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
-            scratch_page = [torch.empty_like(x[:, :, 0]) for x in (layers[0].k_code, layers[0].k_scale, layers[0].k_mn)]
+            if hasattr(layers[0], "k_code"):
+                scratch_page = [torch.empty_like(x[:, :, 0]) for x in (layers[0].k_code, layers[0].k_scale, layers[0].k_mn)]
+                flush = lambda lc: new_pack.quantize_and_pack_k_tmajor(lc.k_res, g, bits, out=tuple(scratch_page), token_offset=0)
+            else:
+                from kivi_amd.quant import mfma
+                spare = mfma.alloc_store(B, nh_kv, 1, dev)      # kivi_kt_pack of the R residual tokens into a spare super-block
+                flush = lambda lc: mfma.kt_pack(lc.k_res[:, :, :R], spare, 0, g, bits)
             for rep in range(2):
                 for i, lc in enumerate(layers):
                     ev[i][0].record()
-                    new_pack.quantize_and_pack_k_tmajor(lc.k_res, g, bits, out=tuple(scratch_page), token_offset=0)
+                    flush(lc)
                     ev[i][1].record()
             torch.cuda.synchronize()
             fl = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
             flush_us = round(fl[len(fl) // 2], 2)
         except Exception as e:    # instrumentation only
-            flush_us = f"n/a ({type(e).__name__})"
+            flush_us = f"n/a ({type(e).__name__}: {e})"[:120]
         kv_bytes = sum(lc.nbytes() for lc in layers)
         fp16_bytes = 2 * L * B * nh_kv * layers[0].kv_seq_len * D * 2
         out = {
@@ -437,7 +445,7 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / args.steps, 4),
             "roofline": roof,
             "roofline_single_layer_kgemv": single,
-            "roofline_single_layer_kgemv_hook_layout": single_hook,
+            "roofline_single_layer_kgemv_mf_layout": single_mf,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, nh, (T0 // R) * R, D, g, bits, L)   # the packed K prefix holds floor(T0 / R) * R tokens

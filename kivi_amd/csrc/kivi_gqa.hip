@@ -925,11 +925,13 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
 }
 
 // slices of the sV launch: ~1024 stream blocks (4 per CU) of 4 waves, a wave then streams 1-2 super-blocks (24 KiB each)
-static void gqa_v_slices(int units, int nsbv, int& S, int& spb) {
+static void gqa_v_slices(int units, int nsbv, int R, int& S, int& spb) {
     S = 1; spb = 0;
     if (nsbv <= 0) return;
     static const char* fs = KIVI_TUNE_ENV("KIVI_GQA_V_BLOCKS");         // tuning aid: target number of stream blocks
-    const int target = fs ? atoi(fs) : 1024;
+    // R = 4 blocks carry four heads each: 2 per CU measured best
+    // (config 4: 512 blocks 59.7 us, 1024 63.5; the 70B-like slice 63.8 vs 68.6)
+    const int target = fs ? atoi(fs) : (R == 4 ? 512 : 1024);
     S = (target + units - 1) / units;
     S = S < 1 ? 1 : (S > nsbv ? nsbv : S);
     spb = (nsbv + S - 1) / S;
@@ -956,7 +958,7 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     const int nsbv = (int)((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
     KIVI_REQUIRE((int64_t)nsbv * vt_ss * 4 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_output: store too large for one descriptor");
     int S, spb;
-    gqa_v_slices(units, nsbv, S, spb);
+    gqa_v_slices(units, nsbv, R, S, spb);
     const int64_t sp_bytes = ((int64_t)B * nh * 4 + 255) / 256 * 256;
     const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + sp_bytes + (int64_t)units * S * 2 * R * 128 * 4;
     KIVI_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && workspace_bytes >= need, KIVI_EINVAL,
@@ -1074,7 +1076,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
                  "kivi_gqa_decode: statistics buffer too small (%lld bytes for %d segments)", (long long)p->stats_bytes, nseg);
     const int nsbv = (int)((p->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
     int S, spb;
-    gqa_v_slices(units, nsbv, S, spb);
+    gqa_v_slices(units, nsbv, R, S, spb);
     KIVI_REQUIRE((int64_t)(nsbv > nsbk ? nsbv : nsbk) * (p->kt_ss > p->vt_ss ? p->kt_ss : p->vt_ss) * 4 < ((int64_t)1 << 32), KIVI_EINVAL,
                  "kivi_gqa_decode: store too large for one descriptor");
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);

@@ -222,79 +222,118 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 // quantisation of the token leaving the window into its VT slot (:386-399).  NTH threads; `pw`: R x >= 136 halves of LDS
 // that already hold the fp16 probabilities of tokens [w0, w1) (index t - w0).  A lane owns two channels, wave w takes
 // tokens w0 + w, w0 + w + NW, ...; all loads of a batch in flight.
-template <int R, int NTH, int PW>
-__device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
-                                                const uint16_t (*pw)[PW], float (*ow)[2]) {
-    constexpr int NW = NTH / 64, WB = 12;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
-    // row of window token t: a ring of win_rows rows (no compaction, residual_length + 1 rows suffice) or the linear buffer
-    auto wrow = [&](int t) {
+// Two halves, so that the loads fly while the caller does something else (the row kernels request before their softmax):
+// request() issues the loads of the first WPRE tokens of every wave (and of the token that leaves the window, and of the code
+// word it will be merged into), finish() consumes them once pw holds the probabilities and walks what is left in batches.
+template <int R, int NTH, int PW, int WPRE>
+struct GqaWindow {
+    static constexpr int NW = NTH / 64, WB = 12;
+    uint32_t vv[WPRE];
+    uint32_t wold;
+    uint16_t xflush;
+
+    __device__ __forceinline__ static uint16_t* wrow(const GqaVArgs& a, uint16_t* vbuf, int t) {
+        // row of window token t: a ring of win_rows rows (no compaction, residual_length + 1 rows suffice) or the linear buffer
         int r = a.win_start + t;
         if (a.win_rows) r = r >= a.win_rows ? r - a.win_rows : r;       // t <= residual_length < win_rows: one wrap at most
         return vbuf + (int64_t)r * a.vres_st;
-    };
-    const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
-    uint16_t xflush = 0;
-    if (flusher && threadIdx.x < 128) xflush = wrow(0)[threadIdx.x];      // requested early, used last
-#pragma unroll
-    for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
-    const int nwt = w1 > w0 ? w1 - w0 : 0;
-    for (int tb = wave; tb < nwt; tb += NW * WB) {
-        uint32_t vv[WB];
-#pragma unroll
-        for (int u = 0; u < WB; u++) {
-            const int t = w0 + tb + NW * u;
-            const uint16_t* vrow = (t < a.res_len) ? wrow(t) : vnew;
-            vv[u] = (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+    }
+    __device__ __forceinline__ static uint32_t* flush_word(const GqaVArgs& a, int b, int hk, int d) {
+        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+        const int kbq = tt >> 3, c = d >> 5, nn = d & 15;
+        return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * KIVI_MF_BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
+    }
+
+    __device__ __forceinline__ void request(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+        xflush = 0; wold = 0;
+        if (flusher && threadIdx.x < 128) {
+            xflush = wrow(a, vbuf, 0)[threadIdx.x];
+            if (((threadIdx.x >> 4) & 1) == 0) wold = *flush_word(a, b, hk, threadIdx.x);
         }
 #pragma unroll
-        for (int u = 0; u < WB; u++) {
-            const int t = w0 + tb + NW * u;
+        for (int u = 0; u < WPRE; u++) {
+            const int t = w0 + wave + NW * u;
+            const uint16_t* vrow = (t < a.res_len) ? wrow(a, vbuf, t) : vnew;
+            vv[u] = (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+        }
+    }
+
+    __device__ __forceinline__ void finish(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
+                                           const uint16_t (*pw)[PW], float (*ow)[2]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
+        const int nwt = w1 > w0 ? w1 - w0 : 0;
+        auto use = [&](int t, uint32_t v) {
             if (t < w1) {
-                const float v0 = h2f_bits((uint16_t)(vv[u] & 0xFFFFu)), v1 = h2f_bits((uint16_t)(vv[u] >> 16));
+                const float v0 = h2f_bits((uint16_t)(v & 0xFFFFu)), v1 = h2f_bits((uint16_t)(v >> 16));
 #pragma unroll
                 for (int rr = 0; rr < R; rr++) {
                     const float p = h2f_bits(pw[rr][t - w0]);
                     ow[rr][0] = __builtin_fmaf(p, v0, ow[rr][0]);
                     ow[rr][1] = __builtin_fmaf(p, v1, ow[rr][1]);
                 }
-                if (t == a.res_len) *(uint32_t*)(wrow(t) + 2 * lane) = vv[u];   // V append
+                if (t == a.res_len) *(uint32_t*)(wrow(a, vbuf, t) + 2 * lane) = v;   // V append
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < WPRE; u++) use(w0 + wave + NW * u, vv[u]);
+        for (int tb = wave + NW * WPRE; tb < nwt; tb += NW * WB) {
+            uint32_t vb[WB];
+#pragma unroll
+            for (int u = 0; u < WB; u++) {
+                const int t = w0 + tb + NW * u;
+                const uint16_t* vrow = (t < a.res_len) ? wrow(a, vbuf, t) : vnew;
+                vb[u] = (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < WB; u++) use(w0 + tb + NW * u, vb[u]);
+        }
+        if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
+            const int d = threadIdx.x;
+            const uint32_t key = h_key(xflush);
+            uint32_t kmin = key, kmax = key;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+                const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
+                kmin = o1 < kmin ? o1 : kmin;
+                kmax = o2 > kmax ? o2 : kmax;
+            }
+            const GroupQ gq = make_group(kmin, kmax, 3);
+            const uint32_t code = quant_one<2>(xflush, gq);
+            const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+            const int e = tt & 7, kbq = tt >> 3;
+            const int c = d >> 5, tile = (d >> 4) & 1;
+            const int sh = 16 * (e & 1);
+            uint32_t val = code << (mf_pos(tile, e >> 1) + sh);
+            val |= (uint32_t)__shfl_xor((int)val, 16);
+            uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+            if (tile == 0) {
+                // the two fields of this token (channel tiles 0 / 1) are cleared first: a slot may hold stale codes of an earlier,
+                // longer sequence that used the same storage
+                const uint32_t clr = (3u << (mf_pos(0, e >> 1) + sh)) | (3u << (mf_pos(1, e >> 1) + sh));
+                *flush_word(a, b, hk, d) = (wold & ~clr) | val;
+            }
+            if ((d & 31) == 0) {
+                const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
+                ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
+                ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
             }
         }
     }
-    if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
-        const int d = threadIdx.x;
-        const uint32_t key = h_key(xflush);
-        uint32_t kmin = key, kmax = key;
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
-            kmin = o1 < kmin ? o1 : kmin;
-            kmax = o2 > kmax ? o2 : kmax;
-        }
-        const GroupQ gq = make_group(kmin, kmax, 3);
-        const uint32_t code = quant_one<2>(xflush, gq);
-        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
-        const int e = tt & 7, kbq = tt >> 3;
-        const int c = d >> 5, tile = (d >> 4) & 1, nn = d & 15;
-        const int sh = 16 * (e & 1);
-        uint32_t val = code << (mf_pos(tile, e >> 1) + sh);
-        val |= (uint32_t)__shfl_xor((int)val, 16);
-        uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
-        if (tile == 0) {
-            // the two fields of this token (channel tiles 0 / 1) are cleared first: a slot may hold stale codes of an earlier,
-            // longer sequence that used the same storage
-            const uint32_t clr = (3u << (mf_pos(0, e >> 1) + sh)) | (3u << (mf_pos(1, e >> 1) + sh));
-            uint32_t* wp = sbp + blk * KIVI_MF_BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
-            *wp = (*wp & ~clr) | val;
-        }
-        if ((d & 31) == 0) {
-            const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
-            ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
-            ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
-        }
-    }
+};
+
+template <int R, int NTH, int PW>
+__device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
+                                                const uint16_t (*pw)[PW], float (*ow)[2]) {
+    GqaWindow<R, NTH, PW, 12> w;
+    w.request(a, b, hk, w0, w1, flusher);
+    w.finish(a, b, hk, w0, w1, flusher, pw, ow);
 }
 
 }  // namespace

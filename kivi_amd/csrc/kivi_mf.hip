@@ -368,7 +368,9 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
 
     // ---- packed qK^T: wave w walks super-blocks w, w + NW, ... of the row (mf_k_seq1: one memory round trip up front, the next
-    // half's operands requested while the current one is multiplied)
+    // half's operands requested while the current one is multiplied).  The row in LDS holds the SCALED scores (:339); every
+    // lane keeps the maximum of what it wrote (the softmax below starts from it: no separate pass for the maximum)
+    float mxl = -__builtin_inff();
     {
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
         MfKSeq seq;
@@ -379,7 +381,13 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         const int last = wave + (seq.n_sb - 1) * NW;                // this wave's last super-block
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], [&](int sb, int tt, float v) { row[sb * KIVI_MF_SB_TOKENS + tt] = f2h_bits(v); }, [](int, int) {});
+        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave],
+                         [&](int sb, int tt, float v) {
+                             const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
+                             row[sb * KIVI_MF_SB_TOKENS + tt] = h;
+                             mxl = __builtin_fmaxf(mxl, h2f_bits(h));
+                         },
+                         [](int, int) {});
     }
     stamp(3);
     // the latency-bound middle of the step (residual scores, softmax, window: ~15 us per block when it competes with the
@@ -411,82 +419,30 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         sc += __shfl_xor(sc, 1);
         sc += __shfl_xor(sc, 2);
         sc += __shfl_xor(sc, 4);
-        if (sub == 0) row[Tq + t] = f2h_bits(sc);
+        if (sub == 0) {
+            const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, false, 0);
+            row[Tq + t] = h;
+            mxl = __builtin_fmaxf(mxl, h2f_bits(h));
+        }
     }
+    for (int j = n + (int)threadIdx.x; j < n_pad; j += NTH) row[j] = 0xFC00u;      // -inf past the row
     stamp(4);
     __syncthreads();
     stamp(5);
 
-    // ---- scale + mask + fp32 softmax of the row (llama_kivi.py:339, :364-375); each thread owns 4 consecutive scores per
-    // chunk of 4 NTH; the probabilities of the packed prefix go back into the row as p'', the window's into pw
-    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    constexpr int SCH = NTH * 4, SMC = 8192 / SCH;
+    // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
+    GqaWindow<1, NTH, MF_PW, (NW == 8 ? 5 : 9)> win;
+    win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
+    // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
+    // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    float x[SMC][4];
-    float mx = -__builtin_inff();
-    const int nch = (n + SCH - 1) / SCH;                           // chunks that hold scores (block-uniform)
-#pragma unroll
-    for (int c = 0; c < SMC; c++) {
-        const int j0 = c * SCH + (int)threadIdx.x * 4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) x[c][e] = -__builtin_inff();
-        if (c < nch) {
-            u16x4 raw = {0, 0, 0, 0};
-            if (j0 < n) raw = *(const u16x4*)(row + j0);           // n_pad >= n rounded up to 8: whole vectors stay inside the row
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float v = -__builtin_inff();
-                if (j0 + e < n) v = h2f_bits(kivi_scaled_score(raw[e], ak.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
-                x[c][e] = v;
-                mx = __builtin_fmaxf(mx, v);
-            }
-        }
-    }
-    // block maximum / sum: DPP inside the wave (no LDS round trips), one barrier each across the waves
-    mx = wave_max(mx);
-    if (lane == 0) sm_lds[wave] = mx;
-    __syncthreads();
-    mx = __builtin_fmaxf(__builtin_fmaxf(sm_lds[0], sm_lds[1]), __builtin_fmaxf(sm_lds[2], sm_lds[3]));
-    if constexpr (NW == 8) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(sm_lds[4], sm_lds[5]), __builtin_fmaxf(sm_lds[6], sm_lds[7])));
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < SMC; c++)
-        if (c < nch) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                x[c][e] = kivi_exp(x[c][e] - mx);                  // exp(-inf) = 0 past the row
-                sum += x[c][e];
-            }
-        }
-    sum = wave_sum(sum);
-    if (lane == 0) sm_lds[NW + wave] = sum;
-    __syncthreads();
-    sum = (sm_lds[NW] + sm_lds[NW + 1]) + (sm_lds[NW + 2] + sm_lds[NW + 3]);
-    if constexpr (NW == 8) sum += (sm_lds[NW + 4] + sm_lds[NW + 5]) + (sm_lds[NW + 6] + sm_lds[NW + 7]);
-    const float inv = 1.0f / sum;
-    const int sp = mf_sp(sum);
-#pragma unroll
-    for (int c = 0; c < SMC; c++) {
-        const int j0 = c * SCH + (int)threadIdx.x * 4;
-        if (j0 < n_pad) {
-            const int ex = sp + ((j0 & 4) ? 6 : 4);
-            u16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint16_t p = (c < nch) ? f2h_bits(x[c][e] * inv) : (uint16_t)0;
-                const int j = j0 + e;
-                if (j >= Tv && j < n) pw[0][j - Tv] = p;
-                o[e] = (j < Tv) ? f2h_bits(__builtin_ldexpf(h2f_bits(p), ex)) : (uint16_t)0;
-            }
-            *(u16x4*)(row + j0) = o;
-        }
-    }
+    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4)>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds);
     __syncthreads();
     stamp(7);
 
     // ---- fp16 window: probs[-Lw:] . V_full, V append, quantisation of the token leaving the window (:377-399)
     float ow[1][2];
-    gqa_window_part<1, NTH, MF_PW>(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+    win.finish(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
     resl[wave][2 * lane] = ow[0][0];
     resl[wave][2 * lane + 1] = ow[0][1];
     stamp(8);
@@ -529,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
 // The whole decode step of one (batch row, kv head) with its four query heads in one block of NW waves (grouped queries,
 // rows whose four score rows fit the LDS: 4 n fp16 <= 72 KiB, two blocks per CU): no score / statistics round trip through
 // memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
-template <int KRING, int VRING, int NW>
+template <int KRING, int VRING, int NW, bool DBG = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     extern __shared__ uint16_t rows[];                             // [R][n_pad]
@@ -540,6 +496,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const int unit = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto stamp = [&](int i) {                                      // tools/mf_row_phases.py, slots as in mf_row_kernel
+        if constexpr (DBG) {
+            const unsigned long long tck = __builtin_amdgcn_s_memtime();
+            if (lane == 0) av.dbg[((size_t)blockIdx.x * NW + wave) * 16 + i] = tck;
+        }
+    };
+    stamp(0);
+    if (DBG && lane == 0) av.dbg[((size_t)blockIdx.x * NW + wave) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
     const int b = unit / ak.nh_kv, hk = unit - b * ak.nh_kv;
     const int h0 = hk * R;
     const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
@@ -550,6 +514,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
 
     // ---- packed qK^T: wave w walks super-blocks w, w + NW, ...
+    float mxl[R] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};   // per-lane maxima of the scores written
     {
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
         MfKSeq seq;
@@ -560,9 +525,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq4<KRING>(rk, seq, q_h0, ak.q_sh,
-                         [&](int sb, int tt, int r, float v) { rows[r * n_pad + sb * KIVI_MF_SB_TOKENS + tt] = f2h_bits(v); });
+        mf_k_seq4<KRING>(rk, seq, q_h0, ak.q_sh, [&](int sb, int tt, int r, float v) {
+            const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);     // the rows hold the SCALED scores (:339)
+            rows[r * n_pad + sb * KIVI_MF_SB_TOKENS + tt] = h;
+            mxl[r] = __builtin_fmaxf(mxl[r], h2f_bits(h));                                 // r is a constant after unrolling
+        });
     }
+    stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
     const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
     const int NB = (Tv + 31) >> 5;
@@ -591,92 +560,44 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         sc += __shfl_xor(sc, 1);
         sc += __shfl_xor(sc, 2);
         sc += __shfl_xor(sc, 4);
-        if (sub == 0) rows[r * n_pad + Tq + t] = f2h_bits(sc);
+        if (sub == 0) {
+            const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, false, 0);
+            rows[r * n_pad + Tq + t] = h;
+            const float hv = h2f_bits(h);
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) mxl[rr] = (rr == r) ? __builtin_fmaxf(mxl[rr], hv) : mxl[rr];
+        }
     }
+    for (int j = (int)threadIdx.x; j < R * (n_pad - n); j += NTH) rows[(j / (n_pad - n)) * n_pad + n + j % (n_pad - n)] = 0xFC00u;   // -inf past the rows
+    stamp(4);
     __syncthreads();
+    stamp(5);
 
-    // ---- softmax of the four rows, one after the other (scale + mask as the reference, fp32, cast to fp16: :339, :364-375):
-    // a thread owns 4 consecutive scores per chunk of 4 NTH; register resident (rows of <= SMC * 4 * NTH scores)
-    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    constexpr int SCH = NTH * 4, SMC = (9216 + SCH - 1) / SCH;
+    // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
+    GqaWindow<R, NTH, MF_PW, (128 + NW) / NW> win;
+    win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
+    // ---- [mask +] softmax of the four rows, one after the other (fp32, cast to fp16: :364-375); register resident per row
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int nch = (n + SCH - 1) / SCH;
 #pragma unroll 1
     for (int r = 0; r < R; r++) {
-        uint16_t* row = rows + r * n_pad;
-        float x[SMC][4];
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int c = 0; c < SMC; c++) {
-            const int j0 = c * SCH + (int)threadIdx.x * 4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) x[c][e] = -__builtin_inff();
-            if (c < nch) {
-                u16x4 raw = {0, 0, 0, 0};
-                if (j0 < n) raw = *(const u16x4*)(row + j0);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float v = -__builtin_inff();
-                    if (j0 + e < n) v = h2f_bits(kivi_scaled_score(raw[e], ak.inv_scale, mrow != nullptr, mrow ? mrow[j0 + e] : 0));
-                    x[c][e] = v;
-                    mx = __builtin_fmaxf(mx, v);
-                }
-            }
-        }
-        mx = wave_max(mx);
-        __syncthreads();                                           // the previous row's readers of sm_lds are done
-        if (lane == 0) sm_lds[wave] = mx;
-        __syncthreads();
-        mx = sm_lds[0];
-#pragma unroll
-        for (int w = 1; w < NW; w++) mx = __builtin_fmaxf(mx, sm_lds[w]);
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < SMC; c++)
-            if (c < nch) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    x[c][e] = kivi_exp(x[c][e] - mx);
-                    sum += x[c][e];
-                }
-            }
-        sum = wave_sum(sum);
-        if (lane == 0) sm_lds[NW + wave] = sum;
-        __syncthreads();
-        sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w++) sum += sm_lds[NW + w];
-        const float inv = 1.0f / sum;
-        const int sp = mf_sp(sum);
+        const float mxr = r == 0 ? mxl[0] : (r == 1 ? mxl[1] : (r == 2 ? mxl[2] : mxl[3]));
+        const int sp = mf_row_softmax<NTH, (9216 + NTH * 4 - 1) / (NTH * 4)>(rows + r * n_pad, n, n_pad, Tv, mxr, mrow, pw[r], sm_lds);
         if (threadIdx.x == 0) sp_lds[r] = sp;
-#pragma unroll
-        for (int c = 0; c < SMC; c++) {
-            const int j0 = c * SCH + (int)threadIdx.x * 4;
-            if (j0 < n_pad) {
-                const int ex = sp + ((j0 & 4) ? 6 : 4);
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const uint16_t p = (c < nch) ? f2h_bits(x[c][e] * inv) : (uint16_t)0;
-                    const int j = j0 + e;
-                    if (j >= Tv && j < n) pw[r][j - Tv] = p;
-                    o[e] = (j < Tv) ? f2h_bits(__builtin_ldexpf(h2f_bits(p), ex)) : (uint16_t)0;
-                }
-                *(u16x4*)(row + j0) = o;
-            }
-        }
     }
     __syncthreads();
+    stamp(7);
 
     // ---- fp16 window of the four heads, V append, quantisation of the token leaving the window (:377-399)
     float ow[R][2];
-    gqa_window_part<R, NTH, MF_PW>(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+    win.finish(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+    stamp(8);
 
     // ---- packed sV
     MfVAcc<R> A;
     mf_v_init<R>(A);
     __builtin_amdgcn_s_setprio(0);
     vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0);
+    stamp(9);
     __syncthreads();                                               // every wave is done with the p'' rows: their memory is reused
     float* red = reinterpret_cast<float*>(rows);                   // [NW][R * 128] quantised part | [NW][R * 128] window part
     float* resl = red + NW * R * 128;
@@ -698,6 +619,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         qs = __builtin_ldexpf(qs, -sp_lds[rr]);
         const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
         av.out[b * av.out_sb + (int64_t)(h0 + rr) * av.out_sh + d] = o;
+    }
+    stamp(11);
+    if (DBG && lane == 0) {
+        unsigned long long* rec = av.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
+        rec[10] = rec[9];                                          // (no separate stamp between the barrier and the final sum)
+        rec[12] = __builtin_amdgcn_s_memrealtime();
+        rec[13] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        rec[14] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
     }
 }
 
@@ -745,7 +674,7 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     const GqaKArgs& k = *(const GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = k.Tq + k.res_len + 1;
-    const int n_pad = (int)((n + 31) / 32 * 32);
+    const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
     const dim3 grid((unsigned)units);
     if (k.ratio == 4) {
         // four score rows in the LDS (two blocks per CU): up to 9216 keys
@@ -759,8 +688,10 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
         if (!attr_set) {                                           // > 64 KiB of dynamic LDS needs the opt-in
             (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 #ifdef KIVI_TUNING
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<8, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 #endif
             attr_set = true;
@@ -768,8 +699,11 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
 #ifdef KIVI_TUNING
         static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<waves><K ring><V ring>"
         const int cfg = fr4 ? atoi(fr4) : 443;
-        if (cfg == 822) { KIVI_LAUNCH_LDS((mf_row4_kernel<2, 2, 8>), grid, dim3(512), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
-        if (cfg == 823) { KIVI_LAUNCH_LDS((mf_row4_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+        // (8 waves of 128 registers spill: 123-139 us, profiles/r03_config4_row4.log)
+        if (v.dbg) { KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+        if (cfg == 423) { KIVI_LAUNCH_LDS((mf_row4_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+        if (cfg == 483) { KIVI_LAUNCH_LDS((mf_row4_kernel<8, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+        if (cfg == 484) { KIVI_LAUNCH_LDS((mf_row4_kernel<8, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
         if (cfg == 444) { KIVI_LAUNCH_LDS((mf_row4_kernel<4, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
 #endif
         KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);

@@ -434,9 +434,11 @@ __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, con
 // right after the operands of round rq have been built from the registers it lands in, the zero points of the next super-
 // block while the current one is multiplied, the code ring runs across rounds and super-blocks (cf. mf_k_seq1).
 // Scores go to sink(super-block index, token inside it, head, fp32 score).
+template <int V> struct mf_ic { static constexpr int value = V; };
+
 template <int RING, typename Sink>
 __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, Sink&& sink) {
-    static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
+    static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     if (W.ng_total <= 0) return;
@@ -478,7 +480,10 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
         cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
     }
     float zz[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rq = 0; rq < n_round; rq++) {
+    // one round = 4 groups on ring slots S0 .. S0 + 3 (mod RING); a ring of 8 alternates S0 = 0, 4 (two rounds per loop trip,
+    // so that every slot index is a constant)
+    auto do_round = [&](int rq, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;
         const int sbi = rq >> 2;
         if ((rq & 3) == 0) {                                        // a new super-block: its zero-point sums, then the next one's zero points
             mf_k_zero4(Q, zv, zmul, zz);
@@ -505,7 +510,7 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
             f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const MfB b = mf_views(wr[j % RING][c]);
+                const MfB b = mf_views(wr[(S0 + j) % RING][c]);
                 const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
                 const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
@@ -519,7 +524,7 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
                 o0[r] = mine ? a0[r] : o0[r];
                 o1[r] = mine ? a1[r] : o1[r];
             }
-            request_group(j % RING, 4 * rq + j + RING);
+            request_group((S0 + j) % RING, 4 * rq + j + RING);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (4 * rq + kb < W.ng_total) {
@@ -531,6 +536,14 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
                 sink(sb, g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
             }
         }
+    };
+    if constexpr (RING == 8) {
+        for (int rq = 0; rq < n_round; rq += 2) {
+            do_round(rq, mf_ic<0>{});
+            if (rq + 1 < n_round) do_round(rq + 1, mf_ic<4>{});
+        }
+    } else {
+        for (int rq = 0; rq < n_round; rq++) do_round(rq, mf_ic<0>{});
     }
 }
 
@@ -773,6 +786,126 @@ __device__ __forceinline__ int mf_sp(float sum) {
 __device__ __forceinline__ uint16_t mf_scale_p(uint16_t p, int sp, int t) {
     const int e = sp + ((t & 4) ? 6 : 4);
     return f2h_bits(__builtin_ldexpf(h2f_bits(p), e));
+}
+
+// ------------------------------------------------------------------------------------------------ softmax of a row held in LDS
+// The row kernels keep the SCALED fp16 scores of a row in LDS (the qK^T sinks write fp16(fp16(score) * inv_scale),
+// llama_kivi.py:339, and fold them into a per-lane running maximum `mx_lane`); halves [n, n_pad) hold fp16 -inf and
+// n_pad >= n + 4.  This turns the row into p'' in place (fp16(exp(x - M) / sum), :364-375, times 2^(Sp + 4 | 6): mf_scale_p) for
+// the packed prefix [0, Tv), zeros after it, and the fp16 probabilities of the window [Tv, n) into pw_row.  Returns Sp.
+// With a mask the row is first rewritten with the mask row added (fp16, clamped at the fp16 minimum: :366-372) and the maximum
+// taken again.  Two block barriers; sm_lds: 2 NW floats that nothing else touches between two calls.
+// A thread owns 4 consecutive scores per chunk of 4 NTH: register resident, SMC chunks.  ~8 VALU issue slots per score
+// (x - M by v_fma_mix_f32 straight from the packed halves, packed fp32 multiplies / adds, v_cvt_pk_f16_f32, two packed fp16
+// multiplies for the exact power-of-two scalings, the exponential counted as 4): this was ~25 before and, with every block of
+// the chip in its softmax at the same time (one round of blocks), 29 of the 105 us of the grouped-query row kernel.
+__device__ __forceinline__ float mf_sub_lo(uint32_t hpair, float nmx) {       // float(low half) + nmx, exact
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(nmx));
+    return d;
+}
+__device__ __forceinline__ float mf_sub_hi(uint32_t hpair, float nmx) {       // float(high half) + nmx, exact
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(nmx));
+    return d;
+}
+
+template <int NTH, int SMC>
+__device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
+                                              uint16_t* pw_row, float* sm_lds) {
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    constexpr int NW = NTH / 64, SCH = NTH * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = (n + SCH - 1) / SCH;                           // chunks that hold scores (block-uniform)
+    float mx = mx_lane;
+    if (mrow) {                                                    // masked rows: add the mask in place, take the maximum again
+        mx = -__builtin_inff();
+#pragma unroll 1
+        for (int c = 0; c < nch; c++) {
+            const int j0 = c * SCH + (int)threadIdx.x * 4;
+            if (j0 < n) {
+                u16x4 raw = *(const u16x4*)(row + j0);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (j0 + e < n) {
+                        float v = (float)(_Float16)(h2f_bits(raw[e]) + h2f_bits(mrow[j0 + e]));
+                        if (v < -65504.0f) v = -65504.0f;
+                        raw[e] = f2h_bits(v);
+                        mx = __builtin_fmaxf(mx, v);
+                    }
+                *(u16x4*)(row + j0) = raw;                         // the same thread reads it back below
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sm_lds[wave] = mx;
+    __syncthreads();
+    mx = sm_lds[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mx = __builtin_fmaxf(mx, sm_lds[w]);
+    const float nmx = -mx;
+    const f2v l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+    f2v xe[SMC][2];
+    f2v acc = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < SMC; c++) {
+        xe[c][0] = xe[c][1] = (f2v){0.f, 0.f};
+        if (c < nch) {
+            const int j0 = c * SCH + (int)threadIdx.x * 4;
+            const u32x2v raw = *(const u32x2v*)(row + (j0 < n_pad ? j0 : n_pad - 4));     // past the row: -inf -> exp = 0
+            const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;   // kivi_exp(x - M), two at a time
+            const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
+            xe[c][0] = (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
+            xe[c][1] = (f2v){__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+            acc += xe[c][0];
+            acc += xe[c][1];
+        }
+    }
+    float sum = wave_sum(acc[0] + acc[1]);
+    if (lane == 0) sm_lds[NW + wave] = sum;
+    __syncthreads();
+    sum = sm_lds[NW];
+#pragma unroll
+    for (int w = 1; w < NW; w++) sum += sm_lds[NW + w];
+    const float inv = 1.0f / sum;
+    const int sp = mf_sp(sum);
+    const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp);   // <= 2^14
+    const f2v inv2 = {inv, inv};
+#pragma unroll
+    for (int c = 0; c < SMC; c++) {
+        const int j0 = c * SCH + (int)threadIdx.x * 4;
+        if (j0 < n_pad) {
+            u32x2v o = {0u, 0u};
+            if (c < nch) {
+                // p = fp16(e / sum) first (the reference's cast, :375), then the exact power-of-two scalings
+                const h2v p01 = __builtin_convertvector(xe[c][0] * inv2, h2v);
+                const h2v p23 = __builtin_convertvector(xe[c][1] * inv2, h2v);
+                if (j0 + 4 <= Tv) {
+                    const _Float16 m_a = (j0 & 4) ? (_Float16)64.0f : (_Float16)16.0f;
+                    o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_sp, m_sp}) * (h2v){m_a, m_a});
+                    o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_sp, m_sp}) * (h2v){m_a, m_a});
+                } else {                                           // the chunk that holds the end of the packed prefix / the window
+                    // (whole-register casts: element-wise __builtin_bit_cast of the converted pair returned the low half twice)
+                    const uint32_t w01 = __builtin_bit_cast(uint32_t, p01), w23 = __builtin_bit_cast(uint32_t, p23);
+                    const uint16_t pp[4] = {(uint16_t)(w01 & 0xFFFFu), (uint16_t)(w01 >> 16), (uint16_t)(w23 & 0xFFFFu), (uint16_t)(w23 >> 16)};
+                    uint16_t q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int j = j0 + e;
+                        if (j >= Tv && j < n) pw_row[j - Tv] = pp[e];
+                        q[e] = (j < Tv) ? mf_scale_p(pp[e], sp, j) : (uint16_t)0;
+                    }
+                    o[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+                    o[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);
+                }
+            }
+            *(u32x2v*)(row + j0) = o;
+        }
+    }
+    return sp;
 }
 
 }  // namespace

@@ -23,26 +23,27 @@ from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cac
 
 lib = _lib.load()
 B, nh, D = int(os.environ.get("B", "32")), 32, 128
+nh_kv = int(os.environ.get("NHKV", "32"))      # NHKV=8: the grouped-query row kernel (mf_row4_kernel), e.g. B=64 T0=8064 R=128
 T0 = int(os.environ.get("T0", "4080"))
 STEPS = int(os.environ.get("STEPS", "4"))
 L = int(os.environ.get("LAYERS", "8"))
-cfg = KiviConfig(2, 2, 32, 32)
+cfg = KiviConfig(2, 2, 32, int(os.environ.get("R", "32")))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 layers = []
 for _ in range(L):
-    lc = make_layer_cache(cfg, B, nh, D, T0 + 64, dev, num_heads=nh)
-    lc.prefill(torch.randn((B, nh, T0, D), device=dev, dtype=torch.float16),
-               torch.randn((B, nh, T0, D), device=dev, dtype=torch.float16))
+    lc = make_layer_cache(cfg, B, nh_kv, D, T0 + 64, dev, num_heads=nh)
+    lc.prefill(torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16),
+               torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16))
     layers.append(lc)
 q = torch.randn((B, nh, 1, D), device=dev, dtype=torch.float16)
-k = torch.randn((B, nh, 1, D), device=dev, dtype=torch.float16)
-v = torch.randn((B, nh, 1, D), device=dev, dtype=torch.float16)
+k = torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16)
+v = torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16)
 for _ in range(STEPS):
     for lc in layers:
         kivi_attention_decode(q, k, v, lc)
 torch.cuda.synchronize()
-nblk = B * nh
+nblk = B * nh_kv
 NW = int(os.environ.get("NWAVES", "4"))   # waves per block of the instantiation under test (KIVI_ROW_X=nw8ds4: 8)
 stamps = torch.zeros((nblk, NW, 16), dtype=torch.int64, device=dev)
 lib.kivi_debug_set_stamps(stamps.data_ptr())
