@@ -25,9 +25,10 @@ namespace {
 
 // per-wave LDS words of mf_k_kernel: [scale of the super-block: 1024 words, R = 4 only | R x 512 fp16 scores]
 template <int R>
-constexpr int mf_k_lds_words() { return (R == 4 ? 1024 : 64) + R * 256; }   // R = 1: 64 words for the q operand
+constexpr int mf_k_lds_words() { return (R == 4 ? 0 : 64) + R * 256; }   // R = 1: 64 words for the q operand
 
-template <int R, int W, int RING>
+// DIAG (tuning builds, wrong results): 1 = nothing leaves the LDS (no flush), 2 = scores stored without the statistics
+template <int R, int W, int RING, int DIAG = 0>
 __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
     extern __shared__ uint32_t lds_all[];
     const int main_blocks = (int)gridDim.x - a.res_blocks;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_w = lds_all + wave * mf_k_lds_words<R>();
-    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 4 ? 1024 : 64));
+    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 4 ? 0 : 64));
     const int unit = bid / a.sb_blocks;
     const int sb0 = ((bid - unit * a.sb_blocks) * W + wave) * spw;  // this wave: super-blocks sb0 .. sb0 + spw - 1
     if (sb0 >= a.nsb) return;
@@ -49,25 +50,45 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     // scores of one finished super-block (R x 512 fp16 in lds_o) -> memory: one 16-byte store per lane and head; the decode
     // step scales + masks them as the reference feeds its softmax (llama_kivi.py:339, :364-372) and leaves (max, sum exp)
     auto flush_sb = [&](int sb, int ng) {
+        if constexpr (DIAG == 1) return;
         __builtin_amdgcn_wave_barrier();
         const bool valid = lane * 8 < ng * 32;
         const uint16_t* mrow = a.mask ? a.mask + b * a.mask_sb + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8 : nullptr;
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
-            u16x8 v = valid ? *(const u16x8*)(lds_o + rr * 512 + lane * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (a.stats) {
-                float x[8], m = -__builtin_inff();
+            u32x4 v = valid ? *(const u32x4*)(lds_o + rr * 512 + lane * 8) : u32x4{0, 0, 0, 0};
+            if (a.stats && DIAG != 2) {
+                float m;
+                if (mrow) {                                        // masked rows: element-wise (:366-372)
+                    m = -__builtin_inff();
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    v[e] = kivi_scaled_score(v[e], a.inv_scale, mrow != nullptr, (mrow && valid) ? mrow[e] : 0);
-                    x[e] = h2f_bits(v[e]);
-                    m = __builtin_fmaxf(m, x[e]);
+                    for (int i = 0; i < 4; i++) {
+                        const uint16_t lo = kivi_scaled_score((uint16_t)(v[i] & 0xFFFFu), a.inv_scale, true, valid ? mrow[2 * i] : 0);
+                        const uint16_t hi = kivi_scaled_score((uint16_t)(v[i] >> 16), a.inv_scale, true, valid ? mrow[2 * i + 1] : 0);
+                        v[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                        m = __builtin_fmaxf(m, __builtin_fmaxf(h2f_bits(lo), h2f_bits(hi)));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = mf_scale_pair(v[i], a.inv_scale);
+                    typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+                    // (scalar copies: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0)
+                    const uint32_t w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3];
+                    const hp2 m2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(hp2, w0), __builtin_bit_cast(hp2, w1)),
+                                                             __builtin_elementwise_max(__builtin_bit_cast(hp2, w2), __builtin_bit_cast(hp2, w3)));
+                    const uint32_t mb = __builtin_bit_cast(uint32_t, m2);
+                    m = __builtin_fmaxf(h2f_bits((uint16_t)(mb & 0xFFFFu)), h2f_bits((uint16_t)(mb >> 16)));
                 }
                 m = wave_max(valid ? m : -__builtin_inff());
-                float l = 0.f;
+                typedef float fp2 __attribute__((ext_vector_type(2)));
+                const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+                fp2 acc = {0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 8; e++) l += kivi_exp(x[e] - m);
-                l = wave_sum(valid ? l : 0.f);
+                for (int i = 0; i < 4; i++) {
+                    const fp2 d = (fp2){mf_sub_lo(v[i], -m), mf_sub_hi(v[i], -m)} * l2e;       // kivi_exp(x - m)
+                    acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                }
+                const float l = wave_sum(valid ? acc[0] + acc[1] : 0.f);
                 if (lane == 0) {
                     float* st = a.stats + (((int64_t)b * a.nh + h0 + rr) * a.nseg + sb) * 2;
                     st[0] = m;
@@ -75,71 +96,49 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
                 }
             }
             if (valid)
-                *(u16x8*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
+                *(u32x4*)(a.out + b * a.out_sb + (int64_t)(h0 + rr) * a.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
         }
         __builtin_amdgcn_wave_barrier();
     };
 
+    const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.kt.sb_s * 4));
+    MfKSeq seq;
+    seq.sb_bytes = (uint32_t)(a.kt.sb_s * 4);
+    seq.sb_first = sb0;
+    seq.sb_stride = 1;
+    seq.n_sb = (sb0 + spw <= a.nsb) ? spw : a.nsb - sb0;
+    const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
+    seq.ng_total = (int)(((a.Tq < tok_end ? a.Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
     if constexpr (R == 1) {
-        const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.kt.sb_s * 4));
-        MfKSeq seq;
-        seq.sb_bytes = (uint32_t)(a.kt.sb_s * 4);
-        seq.sb_first = sb0;
-        seq.sb_stride = 1;
-        seq.n_sb = (sb0 + spw <= a.nsb) ? spw : a.nsb - sb0;
-        const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
-        seq.ng_total = (int)(((a.Tq < tok_end ? a.Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
         mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w,
                         [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
-        const int n = lane & 15, kb = lane >> 4;
-        MfQ<4> Q;
-        mf_load_q<4>(a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, Q);
-        float zmul[4], cmul[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int sqj = __shfl(Q.sq, j);                        // lane j (kb = 0, row j) holds head j's exponent
-            zmul[j] = __builtin_ldexpf(1.0f, -sqj);
-            cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
-        }
-        auto sink = [&](int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); };
-        {   // R = 4: one super-block per wave (run_mf_k passes spw = 1)
-            const int sb = sb0;
-            int ng = (int)((a.Tq - (int64_t)sb * KIVI_MF_SB_TOKENS) / 32);
-            ng = ng > 16 ? 16 : ng;
-            const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, sb), KIVI_MF_SB_WORDS * 4);
-            // every request of the super-block before the first wait: scale (-> LDS), zero points, the first code blocks
-            u32x4 sreg[4], zreg[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) sreg[j] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + (j * 64 + lane) * 16), 0);
-#pragma unroll
-            for (int c = 0; c < 4; c++) zreg[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(n, kb, c) * 4), 0);
-            MfKRing4<RING> ring;
-            ring.prime(rk, ng);
-#pragma unroll
-            for (int j = 0; j < 4; j++) *(u32x4*)(lds_w + (j * 64 + lane) * 4) = sreg[j];
-            float zz[4];
-            mf_k_zero4(Q, zreg, zmul, zz);
-            __builtin_amdgcn_wave_barrier();
-            ring.run(rk, ng, Q, lds_w, zz, cmul, sink);
-            flush_sb(sb, ng);
-        }
+        // R = 4: the same continuous walk (mf_k_seq4: scale requested a round ahead, the code ring runs across super-blocks)
+        mf_k_seq4<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh,
+                        [&](int, int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); }, flush_sb);
     }
 }
 
-template <int R, int W, int RING>
+template <int R, int W, int RING, int DIAG = 0>
 void launch_mf_k(const GqaKArgs& a, int units, int spw, hipStream_t s) {
     const size_t lds = (size_t)W * mf_k_lds_words<R>() * 4;
-    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a, spw);
+    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING, DIAG>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a, spw);
 }
 
 int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     // a wave walks `spw` consecutive super-blocks of its unit (the next one's operands are requested while the current one is
     // multiplied): 2 when that still leaves >= 4 waves per SIMD, else 1; few super-blocks: one wave per block spreads them
     const int64_t total = (int64_t)units * a.nsb;
-    int spw = (a.ratio == 1 && total >= 8192 && a.nsb >= 2) ? 2 : 1;
-    static const char* fs = KIVI_TUNE_ENV("KIVI_MF_SPW");                 // tuning aid (R = 1)
-    if (fs && a.ratio == 1) spw = atoi(fs) > 0 ? atoi(fs) : 1;
+    int spw = (total >= 8192 && a.nsb >= 2) ? 2 : 1;
+    if (a.ratio == 4) {
+        // R = 4 holds ~190 registers (two waves per SIMD = 2048 resident waves): as many super-blocks per wave as keeps the
+        // launch in one round; the streams stay deep enough at that occupancy (cf. the qK^T phase of mf_row4_kernel)
+        spw = (int)((total + 2047) / 2048);
+        spw = spw < 1 ? 1 : (spw > 8 ? 8 : spw);
+        if (spw > a.nsb) spw = a.nsb > 0 ? a.nsb : 1;
+    }
+    static const char* fs = KIVI_TUNE_ENV("KIVI_MF_SPW");                 // tuning aid
+    if (fs) spw = atoi(fs) > 0 ? atoi(fs) : 1;
     const int chunks = (a.nsb + spw - 1) / spw;                     // waves per unit
     const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
     a.sb_blocks = (chunks + W - 1) / W;
@@ -147,43 +146,74 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     // two code blocks in flight per wave: 39.2 us per BASELINE configs[1] launch against 40.8 with four (fewer registers, the
     // same bytes in flight per SIMD); -DKIVI_TUNING builds keep the four-deep ring for A/B
 #ifdef KIVI_TUNING
+    static const char* fd = KIVI_TUNE_ENV("KIVI_MF_K_DIAG");             // 1 / 2: see mf_k_kernel (R = 4, four-wave blocks)
+    if (fd && a.ratio == 4 && W == 4) {
+        if (atoi(fd) == 1) launch_mf_k<4, 4, 4, 1>(a, units, spw, s); else launch_mf_k<4, 4, 4, 2>(a, units, spw, s);
+        return kivi_launch_status("mf_k");
+    }
     static const char* fr = KIVI_TUNE_ENV("KIVI_MF_RING");
     if (fr && atoi(fr) == 4) {
         if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 4>(a, units, spw, s); else launch_mf_k<1, 1, 4>(a, units, spw, s); }
         else { if (W == 4) launch_mf_k<4, 4, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
         return kivi_launch_status("mf_k");
     }
+    if (fr && atoi(fr) == 2 && a.ratio == 4) {
+        if (W == 4) launch_mf_k<4, 4, 2>(a, units, spw, s); else launch_mf_k<4, 1, 2>(a, units, spw, s);
+        return kivi_launch_status("mf_k");
+    }
+    if (fr && atoi(fr) == 8 && a.ratio == 4) {
+        if (W == 4) launch_mf_k<4, 4, 8>(a, units, spw, s); else launch_mf_k<4, 1, 8>(a, units, spw, s);
+        return kivi_launch_status("mf_k");
+    }
 #endif
     if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 2>(a, units, spw, s); else launch_mf_k<1, 1, 2>(a, units, spw, s); }
-    else { if (W == 4) launch_mf_k<4, 4, 2>(a, units, spw, s); else launch_mf_k<4, 1, 2>(a, units, spw, s); }
+    else { if (W == 4) launch_mf_k<4, 4, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
     return kivi_launch_status("mf_k");
 }
 
 // ------------------------------------------------------------------------------------------------ sV launch
 
 // One super-block's R x 512 scaled probabilities p'' into this wave's LDS rows (pitch 512 halves): lane l owns tokens
-// 8 l .. 8 l + 7 of every head.  PROB: the score rows already hold fp16 probabilities (kivi_gqa_output); otherwise
-// p = fp16(exp(x - M) / sum) exactly as the reference casts them (llama_kivi.py:375).  Tokens at or past Tv get 0.
-template <int R, bool PROB>
-__device__ __forceinline__ void mf_probs_to_lds(rsrc_t rx, uint32_t x_row_bytes, int64_t tok0, int64_t Tv, const float* M,
-                                                const float* invS, const int* sp, uint16_t* lds_p) {
+// 8 l .. 8 l + 7 of every head.  mf_probs_request issues the loads of the scores (or, PROB, of given fp16 probabilities:
+// kivi_gqa_output) -- one 16-byte load per lane and head, issued a super-block ahead of its use -- and mf_probs_store turns
+// them into p = fp16(exp(x - M) / sum) exactly as the reference casts them (llama_kivi.py:375) times 2^(Sp + 4 | 6)
+// (mf_scale_p), packed math as in mf_row_softmax.  Tokens at or past Tv get 0.
+template <int R>
+__device__ __forceinline__ void mf_probs_request(rsrc_t rx, uint32_t x_row_bytes, int64_t tok0, u32x4* xv) {
     const int lane = threadIdx.x & 63;
-    u16x8 xv[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) xv[r] = buf_load<u16x8, false>(rx, (uint32_t)(r * x_row_bytes + (tok0 + lane * 8) * 2), 0);
+    for (int r = 0; r < R; r++) xv[r] = buf_load<u32x4, false>(rx, (uint32_t)(r * x_row_bytes + (tok0 + lane * 8) * 2), 0);
+}
+template <int R, bool PROB>
+__device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, int64_t Tv, const float* M, const float* invS,
+                                               const int* sp, uint16_t* lds_p) {
+    typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+    typedef float fp2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
     const int64_t left = Tv - tok0 - lane * 8;                      // tokens e < left are inside the packed prefix
+    const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        u16x8 o;
+        const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp[r]);      // <= 2^14
+        u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            uint16_t p;
-            if constexpr (PROB) p = xv[r][e];
-            else p = f2h_bits(kivi_exp(h2f_bits(xv[r][e]) - M[r]) * invS[r]);
-            p = (e < left) ? p : (uint16_t)0;
-            o[e] = f2h_bits(__builtin_ldexpf(h2f_bits(p), sp[r] + ((e & 4) ? 6 : 4)));
+        for (int i = 0; i < 4; i++) {
+            hp2 pp;
+            const uint32_t xw = xv[r][i];                          // (scalar copy before the cast: see flush_sb)
+            if constexpr (PROB) pp = __builtin_bit_cast(hp2, xw);
+            else {
+                const fp2 d = (fp2){mf_sub_lo(xw, -M[r]), mf_sub_hi(xw, -M[r])} * l2e;                 // kivi_exp(x - M)
+                const fp2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                pp = __builtin_convertvector(e * (fp2){invS[r], invS[r]}, hp2);
+            }
+            const _Float16 m_a = (i >= 2) ? (_Float16)64.0f : (_Float16)16.0f;                          // tokens (e & 4): 2^6, else 2^4
+            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_sp, m_sp}) * (hp2){m_a, m_a});
         }
-        *(u16x8*)(lds_p + r * 512 + lane * 8) = o;
+        if (left < 8) {                                            // the end of the packed prefix falls into this lane's eight
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] = (2 * i >= left) ? 0u : ((2 * i + 1 >= left) ? (o[i] & 0xFFFFu) : o[i]);
+        }
+        *(u32x4*)(lds_p + r * 512 + lane * 8) = o;
     }
 }
 
@@ -239,13 +269,17 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
         const int last_sb = sb_w0 + 4 * (n_my - 1);
         int nb_last = (int)((a.Tv - (int64_t)last_sb * KIVI_MF_SB_TOKENS + 31) / 32);
         nb_last = nb_last > 16 ? 16 : nb_last;
+        u32x4 xv[R];
+        mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), (int64_t)sb_w0 * KIVI_MF_SB_TOKENS, xv);
         MfVStream<R, RING> vs;
         vs.prime(rv, sb_bytes, 0, 16 * (n_my - 1) + nb_last, sb_w0, 4);
         for (int i = 0; i < n_my; i++) {
             const int64_t tok0 = (int64_t)(sb_w0 + 4 * i) * KIVI_MF_SB_TOKENS;
             const int nb = (i == n_my - 1) ? nb_last : 16;
             __builtin_amdgcn_wave_barrier();                       // the previous super-block's LDS reads are over
-            mf_probs_to_lds<R, PROB>(rx, (uint32_t)(a.x_sh * 2), tok0, a.Tv, M, invS, sp, lds_p);
+            mf_probs_store<R, PROB>(xv, tok0, a.Tv, M, invS, sp, lds_p);
+            // the next super-block's scores fly during this one's stream
+            if (i + 1 < n_my) mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), tok0 + 4 * KIVI_MF_SB_TOKENS, xv);
             __builtin_amdgcn_wave_barrier();
             vs.run(A, rv, 16 * i, 16 * i + nb, lds_p, 512, 16 * i * 32);
         }
@@ -529,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
             const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);     // the rows hold the SCALED scores (:339)
             rows[r * n_pad + sb * KIVI_MF_SB_TOKENS + tt] = h;
             mxl[r] = __builtin_fmaxf(mxl[r], h2f_bits(h));                                 // r is a constant after unrolling
-        });
+        }, [](int, int) {});
     }
     stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
@@ -651,15 +685,22 @@ int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
     const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
 #define KIVI_MV(RR, RG, PB) KIVI_LAUNCH_LDS((mf_v_kernel<RR, RG, PB>), grid, dim3(256), lds, s, a)
 #ifdef KIVI_TUNING
-    static const char* fr = KIVI_TUNE_ENV("KIVI_MF_RING");
-    if (fr && atoi(fr) == 4) {
-        if (R == 1) { if (prob) KIVI_MV(1, 4, true); else KIVI_MV(1, 4, false); }
-        else { if (prob) KIVI_MV(4, 4, true); else KIVI_MV(4, 4, false); }
+    static const char* fr0 = KIVI_TUNE_ENV("KIVI_MF_RING");
+    static const char* fr1 = KIVI_TUNE_ENV("KIVI_MF_VRING");             // the sV ring alone
+    const char* fr = fr1 ? fr1 : fr0;
+    if (fr && atoi(fr) == 4 && R == 1) {
+        if (prob) KIVI_MV(1, 4, true); else KIVI_MV(1, 4, false);
+        return kivi_launch_status("mf_v");
+    }
+    if (fr && atoi(fr) == 2 && R == 4) {
+        if (prob) KIVI_MV(4, 2, true); else KIVI_MV(4, 2, false);
         return kivi_launch_status("mf_v");
     }
 #endif
+    // R = 4 runs two blocks per CU (gqa_v_slices): four code blocks in flight per wave, 57.4 us per launch at the 70B-like
+    // slice against 60.5 with two (profiles/r03_gqa_split_restructure.log); R = 1 keeps four waves per SIMD with two
     if (R == 1) { if (prob) KIVI_MV(1, 2, true); else KIVI_MV(1, 2, false); }
-    else { if (prob) KIVI_MV(4, 2, true); else KIVI_MV(4, 2, false); }
+    else { if (prob) KIVI_MV(4, 4, true); else KIVI_MV(4, 4, false); }
 #undef KIVI_MV
     return kivi_launch_status("mf_v");
 }

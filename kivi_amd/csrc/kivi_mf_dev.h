@@ -90,102 +90,12 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
 }
 
 // ------------------------------------------------------------------------------------------------ qK^T
-// A operands of one row set: rows m -> (group ga + m / R of the super-block, head m % R).  hi = fp16(q'' * scale), lo = its
-// exact remainder.  Zs[j] = the zero-point term of output register j in score units: lane (n, kb'), register j holds row
-// 4 kb' + j of every column n.
-template <int R>
-struct MfKSet {
-    uint32_t Ah[4][4], Al[4][4];
-    float Zs[4];
-};
-
-// `sv` / `mv`: this lane's 4 x 16 bytes of scale / zero points (channels 32 c + 8 kb + e of the row's group) -- loaded by
-// the caller (from the super-block: byte kt_row_off(m / R + ga, kb) + 16 c of the scale / mn region).
-// zmul[j] = 2^-sq of the head of output register j.
-template <int R>
-__device__ __forceinline__ void mf_k_build(const MfQ<R>& Q, const u32x4* sv, const u32x4* mv, const float* zmul, MfKSet<R>& S) {
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            S.Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
-            S.Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], S.Ah[c][i]);
-        }
-    // Z[row, col] = sum_d mn[d, group(row)] * q''[head(col), d]: A = the raw zero points (row layout = the scale's), B = q''
-    // without the 2^aexp(i) (exact power-of-two scaling of a normalised row)
-    f4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const h8 bq = as_h8(pk_mul(Q.qq[c][0], zfac(0)), pk_mul(Q.qq[c][1], zfac(1)), pk_mul(Q.qq[c][2], zfac(2)),
-                            pk_mul(Q.qq[c][3], zfac(3)));
-        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), bq, z, 0, 0, 0);
-    }
-    if constexpr (R == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) S.Zs[j] = z[j] * zmul[j];
-    } else {
-        // column n carries head n % 4; register j belongs to head j: take quad lane j (every quad of the row holds the same)
-        static_assert(R == 4, "row sets: R = 1 or 4");
-        S.Zs[0] = dpp_mov_f<0x00>(z[0]) * zmul[0];     // quad_perm [0,0,0,0]
-        S.Zs[1] = dpp_mov_f<0x55>(z[1]) * zmul[1];     // [1,1,1,1]
-        S.Zs[2] = dpp_mov_f<0xAA>(z[2]) * zmul[2];     // [2,2,2,2]
-        S.Zs[3] = dpp_mov_f<0xFF>(z[3]) * zmul[3];     // [3,3,3,3]
-    }
-}
-
-// one 32-token group: 16 MFMAs (4 channel chunks x {hi, lo} x 2 token tiles), fp32 accumulate from zero.
-// acc0 / acc1: rows x tokens n / 16 + n of the group.
-// DIAG (tools only, wrong results): 2 = no arithmetic at all (memory-side time), 3 = views / masks only (no MFMA),
-// 4 = MFMAs on the raw words (no views / masks), 5 = normal instead of subnormal B operands
-template <int R, int DIAG = 0>
-__device__ __forceinline__ void mf_k_group(const MfKSet<R>& S, const u32x4& w, f4& acc0, f4& acc1) {
-    acc0 = f4{0.f, 0.f, 0.f, 0.f};
-    acc1 = f4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (DIAG == 2) {
-        acc0[0] = __builtin_bit_cast(float, (w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x3FFFFFFFu);
-        acc0[1] = acc0[2] = acc0[3] = acc0[0];
-        acc1 = acc0;
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        MfB b;
-        if constexpr (DIAG == 4) {
-            b.b0 = as_h8(w[c], w[c], w[c], w[c]);
-            b.b1 = b.b0;
-        } else {
-            b = mf_views(w[c]);
-        }
-        if constexpr (DIAG == 5) {
-            b.b0 = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, b.b0) | 0x3C003C00u);
-            b.b1 = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, b.b1) | 0x3C003C00u);
-        }
-        const h8 ah = as_h8(S.Ah[c][0], S.Ah[c][1], S.Ah[c][2], S.Ah[c][3]);
-        const h8 al = as_h8(S.Al[c][0], S.Al[c][1], S.Al[c][2], S.Al[c][3]);
-        if constexpr (DIAG == 3) {
-            const u32x4 x0 = __builtin_bit_cast(u32x4, b.b0), x1 = __builtin_bit_cast(u32x4, b.b1);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                acc0[i] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, acc0[i]) ^ x0[i] ^ S.Ah[c][i]) & 0x3FFFFFFFu);
-                acc1[i] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, acc1[i]) ^ x1[i] ^ S.Al[c][i]) & 0x3FFFFFFFu);
-            }
-        } else {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, acc1, 0, 0, 0);
-            if constexpr (DIAG != 6) {           // DIAG 6: half the MFMAs (no lo part)
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, acc1, 0, 0, 0);
-            }
-        }
-    }
-}
-
 // ---- R = 1: rows = (8 groups) x (hi | lo).  Row m -> group (m & 7) of the current HALF super-block, m < 8: fp16(q'' scale),
 // m >= 8: the exact remainder -- one MFMA per (channel chunk, token tile) gives hi and lo sums in two rows, 8 MFMAs per group.
 // A wave walks a SEQUENCE of super-blocks (sb_first + i * sb_stride, i < n_sb; the last one may be partial) half by half:
 //   * everything the first half needs is requested before the first wait (q, scale, zero points, RING code blocks): one
 //     memory round trip, not three (the round-2 / first round-3 form paid q -> scale -> codes one after the other, per wave
-//     and super-block: ~10 us of a 46 us launch, tools/mf_ablation.sh);
+//     and super-block: ~10 us of a 46 us launch, profiles/r03_mfk_ablation.log);
 //   * the scale / zero points of half h + 1 are requested right after the A operands of half h have been built from the
 //     registers they land in; the code ring runs across halves and super-blocks.
 struct MfKSeq {
@@ -330,86 +240,6 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     }
 }
 
-// R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups.  The code ring of one super-block: prime()
-// requests the first RING blocks (before the caller waits for anything else), run() multiplies.
-// `lds_s`: the super-block's scale region staged in this wave's LDS (4 KiB, memory order, filled by the caller); `zz`:
-// zero-point sums of the whole super-block, lane (group, any kb), register j = head j, already in score units (mf_k_zero4).
-template <int RING>
-struct MfKRing4 {
-    u32x4 wr[RING];
-    int g_last;
-
-    __device__ __forceinline__ void request(rsrc_t rk, int slot, int g) {
-        const int lane = threadIdx.x & 63;
-        const int gc = g < g_last ? g : g_last;
-        wr[slot] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), (uint32_t)gc * 1024u);
-    }
-    __device__ __forceinline__ void prime(rsrc_t rk, int ng) {
-        g_last = ng - 1;
-#pragma unroll
-        for (int i = 0; i < RING; i++) {
-            request(rk, i, i);
-            __builtin_amdgcn_sched_barrier(0);     // same request order as inside the loop (see MfVStream::prime)
-        }
-    }
-    template <typename Sink>
-    __device__ __forceinline__ void run(rsrc_t rk, int ng, const MfQ<4>& Q, const uint32_t* lds_s, const float* zz, const float* cmul,
-                                        Sink&& sink) {
-        static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
-        const int lane = threadIdx.x & 63;
-        const int m = lane & 15, kb = lane >> 4;
-        for (int g0 = 0; g0 < ng; g0 += 4) {
-            // A operands of this round: row m -> group g0 + (m >> 2), head m & 3
-            uint32_t Ah[4][4], Al[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const u32x4 s = *(const u32x4*)(lds_s + kt_sm_word4(g0 + (m >> 2), kb, c));
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    Ah[c][i] = pk_mul(Q.qq[c][i], s[i]);
-                    Al[c][i] = pk_fms(Q.qq[c][i], s[i], Ah[c][i]);
-                }
-            }
-            // zero points of (group g0 + kb, head j) from lane (g0 + kb) of this 16-lane row
-            float zs[4];
-            const int src = ((lane & 48) + g0 + kb) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; j++) zs[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zz[j])));
-            float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const MfB b = mf_views(wr[j % RING][c]);
-                    const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
-                    const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
-                }
-                const bool mine = kb == j;                 // rows 4 kb .. 4 kb + 3 = group g0 + kb, heads 0 .. 3
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    o0[r] = mine ? a0[r] : o0[r];
-                    o1[r] = mine ? a1[r] : o1[r];
-                }
-                request(rk, j % RING, g0 + j + RING);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int g = g0 + kb;
-            if (g < ng) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    sink(g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
-                    sink(g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
-                }
-            }
-        }
-    }
-};
-
 // Zero-point sums of a whole super-block for R = 4: zz[j] at lane (n = group, any kb) = sum_d q[head j, d] * mn[d, group n]
 // in score units.  `mv`: this lane's 4 x 16 bytes of the zero points of group n (B layout = the row layout).
 __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, const float* zmul, float* zz) {
@@ -428,16 +258,18 @@ __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, con
     asm volatile("" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]));
 }
 
-// R = 4, the walker of the one-launch row kernel (mf_row4_kernel): the same row sets without LDS staging.  With the round-3
+// R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups, hi and lo operands chained (16 MFMAs per group).
+// The walker of mf_row4_kernel and of the two-launch qK^T (mf_k_kernel<4>).  With the round-3
 // placement of the scale (kivi_mfma_layout.h) the 16 bytes (kb, chunk c) of four consecutive groups are contiguous, so the
 // A-operand load of a round touches four fully used 64-byte lines per instruction; the scale of round rq + 1 is requested
 // right after the operands of round rq have been built from the registers it lands in, the zero points of the next super-
 // block while the current one is multiplied, the code ring runs across rounds and super-blocks (cf. mf_k_seq1).
-// Scores go to sink(super-block index, token inside it, head, fp32 score).
+// Scores go to sink(super-block index, token inside it, head, fp32 score); done(super-block index, its number of groups)
+// is called when the last score of a super-block has been handed to sink.
 template <int V> struct mf_ic { static constexpr int value = V; };
 
-template <int RING, typename Sink>
-__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, Sink&& sink) {
+template <int RING, typename Sink, typename Done>
+__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, Sink&& sink, Done&& done) {
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -535,6 +367,10 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
                 sink(sb, g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
                 sink(sb, g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
             }
+        }
+        if ((rq & 3) == 3 || rq == n_round - 1) {                  // the super-block is complete
+            const int left = W.ng_total - 16 * sbi;
+            done(W.sb_first + sbi * W.sb_stride, left < 16 ? left : 16);
         }
     };
     if constexpr (RING == 8) {
@@ -810,6 +646,15 @@ __device__ __forceinline__ float mf_sub_hi(uint32_t hpair, float nmx) {       //
     return d;
 }
 
+// fp16(float(h) * inv) of both halves of a packed pair (kivi_scaled_score without a mask: the fp32 product, then one
+// rounding to fp16 -- v_fma_mixlo / mixhi_f16 do exactly that, one instruction per score)
+__device__ __forceinline__ uint32_t mf_scale_pair(uint32_t hpair, float inv) {
+    uint32_t d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(inv));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hpair), "v"(inv));
+    return d;
+}
+
 template <int NTH, int SMC>
 __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
                                               uint16_t* pw_row, float* sm_lds) {
@@ -888,7 +733,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
                     o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_sp, m_sp}) * (h2v){m_a, m_a});
                     o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_sp, m_sp}) * (h2v){m_a, m_a});
                 } else {                                           // the chunk that holds the end of the packed prefix / the window
-                    // (whole-register casts: element-wise __builtin_bit_cast of the converted pair returned the low half twice)
+                    // (whole-register casts: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 -- hipcc 7.2)
                     const uint32_t w01 = __builtin_bit_cast(uint32_t, p01), w23 = __builtin_bit_cast(uint32_t, p23);
                     const uint16_t pp[4] = {(uint16_t)(w01 & 0xFFFFu), (uint16_t)(w01 >> 16), (uint16_t)(w23 & 0xFFFFu), (uint16_t)(w23 >> 16)};
                     uint16_t q[4];
