@@ -244,7 +244,7 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  * :381-385, :441-445) or lets the CUDA kernel map heads (quant/csrc/gemv_cuda.cu:361-365).
  *
  * kivi_kt_pack: per-channel K quantise + pack of whole 32-token blocks (T % 32 == 0) from un-transposed keys
- *   k[b, h, t, :] = k + b*k_sb + h*k_sh + t*k_st straight into the layout at token_offset (prompt pass
+ *   k[b, h, t, :] = k + b*k_sb + h*k_sh + t*k_st (16-byte aligned rows) straight into the layout at token_offset (prompt pass
  *   models/llama_kivi.py:436, residual flush :343-356); bit-identical to kivi_quant_pack_k_tmajor + relayout.
  * kivi_vt_pack: per-token V quantise + pack of tokens [0, T) of a prompt (any T; 16-byte aligned rows) into the VT
  *   layout at token 0 -- triton_quantize_and_pack_along_last_dim (new_pack.py:217-252) as llama_kivi.py:441-448 applies

@@ -35,15 +35,33 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_or(uint32_t v) {     // the value of the quad neighbour (quad_perm), for an OR across a quad
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-__global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
-                                                     int64_t blk0, int nblk, int nh_kv) {
-    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+__global__ __launch_bounds__(256) void kt_pack_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
+                                                      int64_t blk0, int nblk, int nh_kv, int64_t ntile) {
+    // four waves per block, one 32-token block each (single-wave workgroups: 131 072 of them per GiB)
+    const int wave = threadIdx.x >> 6;
+    int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const bool live_tile = tile_id < ntile;
+    if (!live_tile) tile_id = ntile - 1;                   // (keeps the barrier below uniform; its stores are skipped)
+    const int unit = (int)(tile_id / nblk), bi = (int)(tile_id - (int64_t)unit * nblk);
     const int b = unit / nh_kv, hk = unit - b * nh_kv;
-    const int lane = threadIdx.x;
-    const uint16_t* src = k + b * k_sb + hk * k_sh + (int64_t)bi * 32 * k_st + 2 * lane;
+    const int lane = threadIdx.x & 63;
+    // the 32 x 128 tile through LDS: eight 16-byte loads per lane (four whole rows per instruction) instead of 32 four-byte ones,
+    // then the lane reads its channel pair down the 32 tokens (consecutive lanes, consecutive banks)
+    constexpr int PITCH = 68;
+    __shared__ uint32_t stage[4][32 * PITCH];
+    uint32_t* stw = stage[wave];
+    {
+        const uint16_t* tb = k + b * k_sb + hk * k_sh + (int64_t)bi * 32 * k_st;
+        u32x4 in[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) in[j] = __builtin_nontemporal_load((const u32x4*)(tb + (int64_t)(4 * j + (lane >> 4)) * k_st + 8 * (lane & 15)));
+#pragma unroll
+        for (int j = 0; j < 8; j++) *(u32x4*)(stw + (4 * j + (lane >> 4)) * PITCH + 4 * (lane & 15)) = in[j];
+    }
+    __syncthreads();
     uint32_t x[32];
 #pragma unroll
-    for (int t = 0; t < 32; t++) x[t] = *(const uint32_t*)(src + (int64_t)t * k_st);
+    for (int t = 0; t < 32; t++) x[t] = stw[t * PITCH + lane];
     // both channels of the lane at once on packed 16-bit math (kivi_quant.h): cq[t] = code(2l) | code(2l + 1) << 16
     uint32_t cq[32], scale2, mn2;
     pk16_pair_quant2<32>(x, cq, scale2, mn2);
@@ -61,9 +79,16 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
     const int64_t blk = blk0 + bi;
     uint32_t* sb = mf_sb(st, b, hk, blk >> 4);
     uint32_t* cw = sb + (blk & 15) * KIVI_MF_BLOCK_WORDS;
+    // the 256 code words of the block meet in LDS and leave as ONE 1 KiB store (16 bytes per lane): written straight from the
+    // quads they were 16 four-byte stores per lane group, 64 partial-line transactions per block
+    __shared__ uint32_t tiles[4][256];
+    uint32_t* tile = tiles[wave];
 #pragma unroll
     for (int n = 0; n < 16; n++)
-        if ((n >> 2) == i) cw[(n + 16 * kb) * 4 + c] = pw[n];
+        if ((n >> 2) == i) tile[(n + 16 * kb) * 4 + c] = pw[n];
+    __syncthreads();
+    if (!live_tile) return;
+    *(u32x4*)(cw + lane * 4) = *(const u32x4*)(tile + lane * 4);
     const int hidx = kt_sm_half((int)(blk & 15), 2 * lane);    // channel 2l (even): the pair (2l, 2l+1) is one word
     (sb + KIVI_MF_SB_SCALE_WORD0)[hidx >> 1] = scale2;
     (sb + KIVI_MF_SB_MN_WORD0)[hidx >> 1] = mn2;
@@ -77,19 +102,42 @@ __global__ __launch_bounds__(64) void kt_pack_kernel(const uint16_t* k, int64_t 
 // the VT word's halves -- so the pair quantiser (kivi_quant.h) gives both groups at once, the 4 lanes of a quad (ee)
 // complete a word with two DPP ORs, and the lane index is the index of the pair's scale / zero-point word.  Tokens at
 // or past T read as zeros (constant group: scale 0, zero point 0, codes 0 = never-written storage).
-__global__ __launch_bounds__(64) void vt_pack_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
-                                                     int64_t T, int nblk, int nh_kv) {
-    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+__global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
+                                                      int64_t T, int nblk, int nh_kv, int64_t ntile) {
+    const int wave = threadIdx.x >> 6;                     // four waves per block, one 32-token block each (cf. kt_pack_kernel)
+    int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const bool live_tile = tile_id < ntile;
+    if (!live_tile) tile_id = ntile - 1;
+    const int unit = (int)(tile_id / nblk), bi = (int)(tile_id - (int64_t)unit * nblk);
     const int b = unit / nh_kv, hk = unit - b * nh_kv;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int kb = lane >> 4, c = (lane >> 2) & 3, ee = lane & 3;
-    const int64_t t0 = (int64_t)bi * 32 + 8 * kb + 2 * ee;
-    const uint16_t* src = v + b * v_sb + hk * v_sh + t0 * v_st + 32 * c;
-    u32x4 ra[4], rb[4];                                   // 32 channels of the even / odd token
+    // the 32 x 128 tile comes in through LDS: eight loads of 16 bytes per lane that each cover four whole rows (lane l of load j:
+    // row 4 j + l / 16, bytes 16 (l % 16) ...), then every lane picks the 2 x 64 bytes of its token pair and channel group.
+    // Read straight from memory the lanes of one instruction took 16-byte pieces out of 32 different cache lines.
+    constexpr int PITCH = 68;                              // words per staged row (256 bytes + 16: rows start 4 banks apart)
+    __shared__ uint32_t stage[4][32 * PITCH];
+    uint32_t* stw = stage[wave];
+    {
+        const uint16_t* tb = v + b * v_sb + hk * v_sh + (int64_t)bi * 32 * v_st;
+        u32x4 in[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        ra[i] = (t0 < T) ? *(const u32x4*)(src + 8 * i) : u32x4{0, 0, 0, 0};
-        rb[i] = (t0 + 1 < T) ? *(const u32x4*)(src + v_st + 8 * i) : u32x4{0, 0, 0, 0};
+        for (int j = 0; j < 8; j++) {
+            const int r = 4 * j + (lane >> 4);
+            in[j] = ((int64_t)bi * 32 + r < T) ? __builtin_nontemporal_load((const u32x4*)(tb + (int64_t)r * v_st + 8 * (lane & 15))) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) *(u32x4*)(stw + (4 * j + (lane >> 4)) * PITCH + 4 * (lane & 15)) = in[j];
+    }
+    __syncthreads();
+    u32x4 ra[4], rb[4];                                   // 32 channels of the even / odd token
+    {
+        const uint32_t* pa = stw + (8 * kb + 2 * ee) * PITCH + 16 * c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ra[i] = *(const u32x4*)(pa + 4 * i);
+            rb[i] = *(const u32x4*)(pa + PITCH + 4 * i);
+        }
     }
     uint32_t x[32];
 #pragma unroll
@@ -105,13 +153,18 @@ __global__ __launch_bounds__(64) void vt_pack_kernel(const uint16_t* v, int64_t 
     const int p0 = mf_pos(0, ee), p1 = mf_pos(1, ee);
     uint32_t* sb = mf_sb(st, b, hk, bi >> 4);
     uint32_t* cw = sb + (bi & 15) * KIVI_MF_BLOCK_WORDS;
+    __shared__ uint32_t tiles[4][256];                     // as in kt_pack_kernel: one 1 KiB store for the block's code words
+    uint32_t* tile = tiles[wave];
 #pragma unroll
     for (int n = 0; n < 16; n++) {
         uint32_t w = (cq[n] << p0) | (cq[n + 16] << p1);   // channels n (tile 0) and 16 + n (tile 1) of the group
         w |= dpp_or<0xB1>(w);
         w |= dpp_or<0x4E>(w);
-        if ((n >> 2) == ee) cw[(n + 16 * kb) * 4 + c] = w;
+        if ((n >> 2) == ee) tile[(n + 16 * kb) * 4 + c] = w;
     }
+    __syncthreads();
+    if (!live_tile) return;
+    *(u32x4*)(cw + lane * 4) = *(const u32x4*)(tile + lane * 4);
     (sb + KIVI_MF_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;    // vt_half(8 kb + 2 ee, c) / 2 == lane
     (sb + KIVI_MF_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
 }
@@ -822,13 +875,14 @@ extern "C" int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
                  "kivi_kt_pack: T=%lld and token_offset=%lld must be multiples of the 32-token block", (long long)T,
                  (long long)token_offset);
     KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss), KIVI_EALIGN, "kivi_kt_pack: cache storage must be 16-byte aligned super-blocks");
-    KIVI_REQUIRE(k && (uintptr_t)k % 4 == 0 && k_sb % 2 == 0 && k_sh % 2 == 0 && k_st % 2 == 0, KIVI_EALIGN,
-                 "kivi_kt_pack: key rows must be 4-byte aligned");
+    KIVI_REQUIRE(k && (uintptr_t)k % 16 == 0 && k_sb % 8 == 0 && k_sh % 8 == 0 && k_st % 8 == 0, KIVI_EALIGN,
+                 "kivi_kt_pack: key rows must be 16-byte aligned");
     if (T == 0) return 0;
     const int nblk = (int)(T / 32);
     const MfStore st = {(uint32_t*)kt, kt_sb, kt_sh, kt_ss};
-    hipLaunchKernelGGL(kt_pack_kernel, dim3((unsigned)((int64_t)B * nh_kv * nblk)), dim3(64), 0, (hipStream_t)stream,
-                       (const uint16_t*)k, k_sb, k_sh, k_st, st, token_offset / 32, nblk, nh_kv);
+    const int64_t ntile = (int64_t)B * nh_kv * nblk;
+    hipLaunchKernelGGL(kt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)k, k_sb, k_sh, k_st, st, token_offset / 32, nblk, nh_kv, ntile);
     return kivi_launch_status("kt_pack");
 }
 
@@ -842,8 +896,9 @@ extern "C" int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v
     if (T == 0) return 0;
     const int nblk = (int)((T + 31) / 32);
     const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
-    hipLaunchKernelGGL(vt_pack_kernel, dim3((unsigned)((int64_t)B * nh_kv * nblk)), dim3(64), 0, (hipStream_t)stream,
-                       (const uint16_t*)v, v_sb, v_sh, v_st, st, T, nblk, nh_kv);
+    const int64_t ntile = (int64_t)B * nh_kv * nblk;
+    hipLaunchKernelGGL(vt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)v, v_sb, v_sh, v_st, st, T, nblk, nh_kv, ntile);
     return kivi_launch_status("vt_pack");
 }
 

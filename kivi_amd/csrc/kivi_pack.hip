@@ -98,31 +98,27 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-// Front end shared by the packed-math kernels: order-preserving keys of the 8 halves of a chunk (-0 < +0), their min / max,
-// then the lpg lanes of a group (aligned, power of two) meet through DPP inside a 16-lane row and shuffles beyond.
-__device__ __forceinline__ void pk16_group_minmax(const u32x4& v, int lpg, uint32_t& kmin, uint32_t& kmax) {
-    uint32_t key[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t sgn;                                                                  // 0xFFFF for negative halves
-        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[k]));    // shift count in BOTH halves (an inline 15 reaches only the low one)
-        key[k] = v[k] ^ (sgn | 0x80008000u);
-    }
-    us16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
-                                           __builtin_elementwise_min(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
-    us16x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us16x2, key[0]), __builtin_bit_cast(us16x2, key[1])),
-                                           __builtin_elementwise_max(__builtin_bit_cast(us16x2, key[2]), __builtin_bit_cast(us16x2, key[3])));
-    kmin = mn2[0] < mn2[1] ? mn2[0] : mn2[1];
-    kmax = mx2[0] > mx2[1] ? mx2[0] : mx2[1];
-    if (lpg > 1) { const uint32_t a = dpp_u<0xB1>(kmin), b = dpp_u<0xB1>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-    if (lpg > 2) { const uint32_t a = dpp_u<0x4E>(kmin), b = dpp_u<0x4E>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-    if (lpg > 4) { const uint32_t a = dpp_u<0x141>(kmin), b = dpp_u<0x141>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
-    if (lpg > 8) { const uint32_t a = dpp_u<0x140>(kmin), b = dpp_u<0x140>(kmax); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+// Front end shared by the packed-math kernels: min / max of the 8 halves of a chunk, then the lpg lanes of a group (aligned,
+// power of two) meet through DPP inside a 16-lane row and shuffles beyond.  All in the fp16 domain with the NaN-propagating
+// three-operand minimum / maximum of gfx950 (kivi_quant.h): the maximum travels NEGATED in the high half next to the minimum
+// in the low half, so one packed minimum per step reduces both (-max = min of the negated values; negation is exact and keeps
+// -0 < +0 in order).  Returns the fp16 bit patterns.
+__device__ __forceinline__ void pk16_group_minmax(const u32x4& v, int lpg, uint32_t& gmn, uint32_t& gmx) {
+    const uint32_t v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    const uint32_t a = pk_min3_f16(pk_min3_f16(v0, v1, v2), v3, v3), b = pk_max3_f16(pk_max3_f16(v0, v1, v2), v3, v3);
+    // (min lo | -max lo << 16) and (min hi | -max hi << 16)
+    const uint32_t c = __builtin_amdgcn_perm(b, a, 0x05040100u) ^ 0x80000000u, d = __builtin_amdgcn_perm(b, a, 0x07060302u) ^ 0x80000000u;
+    uint32_t r = pk_min3_f16(c, d, d);
+    if (lpg > 1) { const uint32_t o = dpp_u<0xB1>(r); r = pk_min3_f16(r, o, o); }
+    if (lpg > 2) { const uint32_t o = dpp_u<0x4E>(r); r = pk_min3_f16(r, o, o); }
+    if (lpg > 4) { const uint32_t o = dpp_u<0x141>(r); r = pk_min3_f16(r, o, o); }
+    if (lpg > 8) { const uint32_t o = dpp_u<0x140>(r); r = pk_min3_f16(r, o, o); }
     for (int m = 16; m < lpg; m <<= 1) {
-        const uint32_t a = __shfl_xor(kmin, m), b = __shfl_xor(kmax, m);
-        kmin = a < kmin ? a : kmin;
-        kmax = b > kmax ? b : kmax;
+        const uint32_t o = (uint32_t)__shfl_xor((int)r, m);
+        r = pk_min3_f16(r, o, o);
     }
+    gmn = r & 0xFFFFu;
+    gmx = (r >> 16) ^ 0x8000u;
 }
 
 // LPG = lanes per group when known at compile time (4 / 8 / 16 for group 32 / 64 / 128), 0 = the runtime value;
@@ -146,9 +142,9 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t
         const int64_t c = c0 + 256 * u;
         const bool valid = FULL || c < nchunk;
         const u32x4 v = vv[u];
-        uint32_t kmin, kmax;
-        pk16_group_minmax(v, lpg, kmin, kmax);
-        const Group2 g = make_group2(kmin, kmax);
+        uint32_t gmn_b, gmx_b;
+        pk16_group_minmax(v, lpg, gmn_b, gmx_b);
+        const Group2 g = make_group2_bits((uint16_t)gmn_b, (uint16_t)gmx_b);
         const us16x2 t02 = __builtin_bit_cast(us16x2, g.t02);
         const us16x2 t0 = {t02[0], t02[0]}, t1 = __builtin_bit_cast(us16x2, g.t11), t2 = {t02[1], t02[1]};
         const _Float16 hmn = __builtin_bit_cast(_Float16, g.mn);
@@ -160,8 +156,7 @@ __global__ __launch_bounds__(256) void quant_pack_lastdim2_kernel(const uint16_t
             const hf2 d = __builtin_bit_cast(hf2, xk) - mnv;                              // new_pack.py:239
             const us16x2 db = __builtin_bit_cast(us16x2, d);
             // 1 where bits(d) > T: the sign of T - bits(d) (both < 0x8000), per half
-            cq[k] = pk_lshr15(__builtin_bit_cast(uint32_t, t0 - db)) + pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db)) +
-                    pk_lshr15(__builtin_bit_cast(uint32_t, t2 - db));
+            cq[k] = pk_code2(db, t0, t1, t2 - t0);
         }
         // lo halves: codes 0, 2, 4, 6; hi halves: codes 1, 3, 5, 7
         const uint32_t t = cq[0] | (cq[1] << 4) | (cq[2] << 8) | (cq[3] << 12);
@@ -208,9 +203,9 @@ __global__ __launch_bounds__(256) void quant_pack_lastdimN_kernel(const uint16_t
         const int64_t c = c0 + 256 * u;
         const bool valid = FULL || c < nchunk;
         const u32x4 v = vv[u];
-        uint32_t kmin, kmax;
-        pk16_group_minmax(v, lpg, kmin, kmax);
-        const uint16_t gmn = (uint16_t)h_unkey(kmin), gmx = (uint16_t)h_unkey(kmax);
+        uint32_t gmn_b, gmx_b;
+        pk16_group_minmax(v, lpg, gmn_b, gmx_b);
+        const uint16_t gmn = (uint16_t)gmn_b, gmx = (uint16_t)gmx_b;
         const uint16_t range = f2h_bits(h2f_bits(gmx) - h2f_bits(gmn));                       // new_pack.py:238 (mx - mn)
         const uint16_t gscale = f2h_bits(h2f_bits(range) * (1.0f / (float)MAXQ));             //   / max_int (equal to the division for every fp16 range)
         const float r = 1.0f / h2f_bits(gscale);                                              // IEEE; inf for scale 0, 0 for scale inf
@@ -371,18 +366,11 @@ __global__ __launch_bounds__(256) void quant_pack_k_tmajor_tiled(const uint16_t*
                     for (int t = 0; t < G; t++) W[t / TPR] |= cq[t] << (BITS * (t % TPR));
                 } else {
                     constexpr int MAXQ = (1 << BITS) - 1;
-                    uint32_t kmin2 = 0xFFFFFFFFu, kmax2 = 0u;
-#pragma unroll
-                    for (int t = 0; t < G; t++) {
-                        uint32_t sgn;
-                        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(v[t]));
-                        const uint32_t key = v[t] ^ (sgn | 0x80008000u);
-                        kmin2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, kmin2), __builtin_bit_cast(us16x2, key)));
-                        kmax2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us16x2, kmax2), __builtin_bit_cast(us16x2, key)));
-                    }
-                    const uint16_t mn0 = (uint16_t)h_unkey(kmin2 & 0xFFFFu), mn1 = (uint16_t)h_unkey(kmin2 >> 16);
-                    const uint16_t r0 = f2h_bits(h2f_bits((uint16_t)h_unkey(kmax2 & 0xFFFFu)) - h2f_bits(mn0));
-                    const uint16_t r1 = f2h_bits(h2f_bits((uint16_t)h_unkey(kmax2 >> 16)) - h2f_bits(mn1));
+                    uint32_t mnb, mxb;
+                    pk16_pair_minmax<G>(v, mnb, mxb);
+                    const uint16_t mn0 = (uint16_t)(mnb & 0xFFFFu), mn1 = (uint16_t)(mnb >> 16);
+                    const uint16_t r0 = f2h_bits(h2f_bits((uint16_t)(mxb & 0xFFFFu)) - h2f_bits(mn0));
+                    const uint16_t r1 = f2h_bits(h2f_bits((uint16_t)(mxb >> 16)) - h2f_bits(mn1));
                     const uint16_t sc0 = f2h_bits(h2f_bits(r0) * (1.0f / (float)MAXQ)), sc1 = f2h_bits(h2f_bits(r1) * (1.0f / (float)MAXQ));
                     scale2 = (uint32_t)sc0 | ((uint32_t)sc1 << 16);
                     mn2 = (uint32_t)mn0 | ((uint32_t)mn1 << 16);

@@ -78,15 +78,33 @@ __device__ __forceinline__ uint32_t pk_lshr15(uint32_t v) {
 //     boundary, the product is within 2^-23 of the quotient;
 //   * tau_k * scale (a 12-bit odd factor times an 11-bit mantissa) is never an fp16 value, so "d > th" and "d >= th"
 //     are both  bits(d) > bits(RTZ(th))  for d >= +0: v_cvt_pkrtz_f16_f32 makes two thresholds per instruction.
+// min / max of three packed fp16 pairs, IEEE 754-2019 minimum / maximum: a NaN in any operand gives NaN (torch.min / max
+// propagate it: new_pack.py:236-237), -0 < +0.  gfx950 instructions; two new elements per instruction where the
+// order-preserving integer key costs five per element pair.
+__device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 struct Group2 {
     uint32_t t02, t11;   // (T0 | T2 << 16), (T1 | T1 << 16)
     uint16_t mn, scale;
     bool live;           // false: scale inf / NaN -> every code 0
 };
+__device__ __forceinline__ Group2 make_group2_bits(uint16_t mn, uint16_t mx);
 __device__ __forceinline__ Group2 make_group2(uint32_t kmin, uint32_t kmax) {
+    return make_group2_bits((uint16_t)h_unkey(kmin), (uint16_t)h_unkey(kmax));
+}
+// the same from the fp16 bit patterns of the group's minimum and maximum
+__device__ __forceinline__ Group2 make_group2_bits(uint16_t mn, uint16_t mx) {
     Group2 g;
-    g.mn = (uint16_t)h_unkey(kmin);
-    const uint16_t mx = (uint16_t)h_unkey(kmax);
+    g.mn = mn;
     const uint16_t range = f2h_bits(h2f_bits(mx) - h2f_bits(g.mn));          // new_pack.py:238 (mx - mn)
     g.scale = f2h_bits(h2f_bits(range) * 0.3333333432674408f);               //                 / max_int
     const float fs0 = h2f_bits(g.scale);
@@ -98,20 +116,37 @@ __device__ __forceinline__ Group2 make_group2(uint32_t kmin, uint32_t kmax) {
 }
 
 
+// 2-bit codes of both halves from the thresholds T0 <= T1 <= T2 of their groups (dt = T2 - T0): [bits(d) > T1] picks the
+// second threshold to compare with (T2 or T0) -- the same three comparisons as [d > T0] + [d > T1] + [d > T2], evaluated as
+// a tree: 6 packed instructions per pair instead of 8.  "bits(d) > T" is the sign of T - bits(d) (both < 0x8000).
+__device__ __forceinline__ uint32_t pk_code2(us16x2 db, us16x2 t0, us16x2 t1, us16x2 dt) {
+    const uint32_t b1 = pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db));
+    const us16x2 ts = __builtin_bit_cast(us16x2, b1) * dt + t0;                   // v_pk_mad_u16: b1 ? T2 : T0
+    const uint32_t b0 = pk_lshr15(__builtin_bit_cast(uint32_t, ts - db));
+    return (b1 << 1) + b0;                                                        // v_lshl_add_u32 (no carry between the halves)
+}
+
+// min / max of the two channels (or rows) a lane holds in the halves of x[0..N): (mn lo | mn hi << 16), (mx lo | mx hi << 16)
+template <int N>
+__device__ __forceinline__ void pk16_pair_minmax(const uint32_t* x, uint32_t& mnb, uint32_t& mxb) {
+    static_assert(N >= 2 && N % 2 == 0, "an even number of elements");
+    mnb = pk_min3_f16(x[0], x[1], x[1]);
+    mxb = pk_max3_f16(x[0], x[1], x[1]);
+#pragma unroll
+    for (int t = 2; t < N; t += 2) {
+        mnb = pk_min3_f16(mnb, x[t], x[t + 1]);
+        mxb = pk_max3_f16(mxb, x[t], x[t + 1]);
+    }
+}
+
 // The 2-bit codes of the TWO channels (or rows) a lane holds in the halves of x[0..N): min / max, groups and threshold
 // compares on both halves at once.  cq[t] = code of the low half | code of the high half << 16; scale2 / mn2 likewise.
 template <int N>
 __device__ __forceinline__ void pk16_pair_quant2(const uint32_t* x, uint32_t* cq, uint32_t& scale2, uint32_t& mn2) {
-    uint32_t kmin2 = 0xFFFFFFFFu, kmax2 = 0u;
-#pragma unroll
-    for (int t = 0; t < N; t++) {
-        uint32_t sgn;
-        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(sgn) : "s"(0x000F000Fu), "v"(x[t]));   // shift count in BOTH halves
-        const uint32_t key = x[t] ^ (sgn | 0x80008000u);                                  // order-preserving, -0 < +0
-        kmin2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, kmin2), __builtin_bit_cast(us16x2, key)));
-        kmax2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us16x2, kmax2), __builtin_bit_cast(us16x2, key)));
-    }
-    const Group2 g0 = make_group2(kmin2 & 0xFFFFu, kmax2 & 0xFFFFu), g1 = make_group2(kmin2 >> 16, kmax2 >> 16);
+    uint32_t mnb, mxb;
+    pk16_pair_minmax<N>(x, mnb, mxb);
+    const Group2 g0 = make_group2_bits((uint16_t)(mnb & 0xFFFFu), (uint16_t)(mxb & 0xFFFFu)),
+                 g1 = make_group2_bits((uint16_t)(mnb >> 16), (uint16_t)(mxb >> 16));
     scale2 = (uint32_t)g0.scale | ((uint32_t)g1.scale << 16);
     mn2 = (uint32_t)g0.mn | ((uint32_t)g1.mn << 16);
     const uint32_t live = (g0.live ? 0x00000003u : 0u) | (g1.live ? 0x00030000u : 0u);   // scale inf / NaN: code 0
@@ -119,11 +154,11 @@ __device__ __forceinline__ void pk16_pair_quant2(const uint32_t* x, uint32_t* cq
     const us16x2 t2 = __builtin_bit_cast(us16x2, (g0.t02 >> 16) | (g1.t02 & 0xFFFF0000u));
     const us16x2 t1 = __builtin_bit_cast(us16x2, (g0.t11 & 0xFFFFu) | (g1.t11 & 0xFFFF0000u));
     const hf2 mnv = __builtin_bit_cast(hf2, mn2);
+    const us16x2 dt = t2 - t0;
 #pragma unroll
     for (int t = 0; t < N; t++) {
         const uint32_t xt = x[t];
         const us16x2 db = __builtin_bit_cast(us16x2, __builtin_bit_cast(hf2, xt) - mnv);
-        cq[t] = (pk_lshr15(__builtin_bit_cast(uint32_t, t0 - db)) + pk_lshr15(__builtin_bit_cast(uint32_t, t1 - db)) +
-                 pk_lshr15(__builtin_bit_cast(uint32_t, t2 - db))) & live;
+        cq[t] = pk_code2(db, t0, t1, dt) & live;
     }
 }
