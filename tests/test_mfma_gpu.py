@@ -38,6 +38,35 @@ def test_kt_pack_equals_reference_pack(mods, oracle, B, nh_kv, T, off, kind):
     assert torch.equal(store2, store)
 
 
+def test_kt_vt_pack_nan_inputs_follow_torch_min_max(mods):
+    """As tests/test_pack_gpu.py::test_nan_inputs_follow_torch_min_max for the packers of the matrix-pipe layout (seen through
+    the relayout kernels): a NaN makes its group's scale and zero point NaN and its codes 0, nothing else moves."""
+    mfma, _, _ = mods
+    k = make_kv(31, 1, 2, 64, 128, "randn")
+    v = make_kv(32, 1, 2, 64, 128, "randn")
+    k2, v2 = k.clone(), v.clone()
+    k2[0, 1, 40, 9] = float("nan")                      # K: channel 9, token group 1 (per-channel groups along the tokens)
+    v2[0, 0, 5, 100] = -float("nan")                    # V: token 5, channel group 3 (per-token groups along the channels)
+    outs = []
+    for kk, vv in ((k, v), (k2, v2)):
+        kt, vt = mfma.alloc_store(1, 2, 1, "cuda"), mfma.alloc_store(1, 2, 1, "cuda")
+        mfma.kt_pack(kk.cuda(), kt)
+        mfma.vt_pack(vv.cuda(), vt)
+        outs.append([t.cpu() for t in mfma.kt_to_ref(kt, 64)] + [t.cpu() for t in mfma.vt_to_ref(vt, 64)])
+    (kc0, ks0, km0, vc0, vs0, vm0), (kc1, ks1, km1, vc1, vs1, vm1) = outs
+    khit = torch.zeros_like(ks0, dtype=torch.bool)
+    khit[0, 1, 9, 1] = True                              # K_scale_T (B, nh_kv, D, T / 32)
+    vhit = torch.zeros_like(vs0, dtype=torch.bool)
+    vhit[0, 0, 5, 3] = True                              # V_scale (B, nh_kv, T, D / 32)
+    for s0, s1, m0, m1, hit in ((ks0, ks1, km0, km1, khit), (vs0, vs1, vm0, vm1, vhit)):
+        assert torch.isnan(s1[hit]).all() and torch.isnan(m1[hit]).all()
+        assert same_bits(s1[~hit], s0[~hit]) and same_bits(m1[~hit], m0[~hit])
+    kw0, kw1 = kc0.reshape(1, 2, 128, 2, 2), kc1.reshape(1, 2, 128, 2, 2)      # 2 words per (channel, token group)
+    vw0, vw1 = vc0.reshape(1, 2, 64, 4, 2), vc1.reshape(1, 2, 64, 4, 2)        # 2 words per (token, channel group)
+    assert (kw1[khit] == 0).all() and torch.equal(kw1[~khit], kw0[~khit])
+    assert (vw1[vhit] == 0).all() and torch.equal(vw1[~vhit], vw0[~vhit])
+
+
 @pytest.mark.parametrize("B,nh_kv,T,kind", [(1, 1, 1, "randn"), (2, 2, 33, "outlier"), (1, 3, 512, "randn"), (2, 1, 1000, "outlier"),
                                              (1, 2, 75, "tiny_rows"), (3, 8, 2049, "randn")])
 def test_vt_pack_equals_reference_pack(mods, oracle, B, nh_kv, T, kind):

@@ -134,6 +134,40 @@ def test_lastdim_every_exponent(np_mod, oracle, g, bits):
                                      f"kernel {a.reshape(ngrp, -1)[gi].tolist()} oracle {b.reshape(ngrp, -1)[gi].tolist()}")
 
 
+@pytest.mark.parametrize("bits", [2, 4])
+def test_nan_inputs_follow_torch_min_max(np_mod, bits):
+    """torch.min / max propagate NaN (new_pack.py:236-237): a group that contains a NaN -- of either sign -- gets scale = mn =
+    NaN and (the reference's CUDA float->int of NaN) codes 0; every other group is untouched.  The packed-math kernels get
+    this from v_pk_minimum3_f16 / v_pk_maximum3_f16; checked for the last-dim pack and the per-channel K pack."""
+    fpi = 32 // bits
+    x = make_kv(23, 1, 2, 8, 128, "randn")
+    c0, s0, m0 = [t.cpu() for t in np_mod.triton_quantize_and_pack_along_last_dim(x.cuda(), 32, bits)]
+    y = x.clone()
+    y[0, 0, 0, 40] = float("nan")                       # row 0, group 1
+    y[0, 1, 3, 70] = -float("nan")                      # row 3 of head 1, group 2
+    c1, s1, m1 = [t.cpu() for t in np_mod.triton_quantize_and_pack_along_last_dim(y.cuda(), 32, bits)]
+    hit = torch.zeros_like(s0, dtype=torch.bool)
+    hit[0, 0, 0, 1] = hit[0, 1, 3, 2] = True
+    assert torch.isnan(s1[hit]).all() and torch.isnan(m1[hit]).all()
+    assert same_bits(s1[~hit], s0[~hit]) and same_bits(m1[~hit], m0[~hit])
+    wpg = 32 // fpi                                      # code words per group
+    cw0, cw1 = c0.reshape(1, 2, 8, 4, wpg), c1.reshape(1, 2, 8, 4, wpg)
+    assert (cw1[hit] == 0).all() and torch.equal(cw1[~hit], cw0[~hit])
+    # per-channel K (groups along the token axis; the tiled kernel needs >= 8 groups)
+    k = make_kv(24, 1, 1, 256, 128, "randn")
+    kc0, ks0, km0 = [t.cpu() for t in np_mod.quantize_and_pack_k_tmajor(k.cuda(), 32, bits)]
+    k2 = k.clone()
+    k2[0, 0, 70, 5] = float("nan")                      # channel 5, token group 2
+    k2[0, 0, 255, 127] = -float("nan")                  # channel 127, token group 7
+    kc1, ks1, km1 = [t.cpu() for t in np_mod.quantize_and_pack_k_tmajor(k2.cuda(), 32, bits)]
+    khit = torch.zeros_like(ks0, dtype=torch.bool)
+    khit[0, 0, 5, 2] = khit[0, 0, 127, 7] = True
+    assert torch.isnan(ks1[khit]).all() and torch.isnan(km1[khit]).all()
+    assert same_bits(ks1[~khit], ks0[~khit]) and same_bits(km1[~khit], km0[~khit])
+    kw0, kw1 = kc0.reshape(1, 1, 128, 8, wpg), kc1.reshape(1, 1, 128, 8, wpg)
+    assert (kw1[khit] == 0).all() and torch.equal(kw1[~khit], kw0[~khit])
+
+
 @pytest.mark.parametrize("B,nh,T,D,g,bits,kind", [
     (2, 2, 64, 128, 32, 2, "randn"), (1, 3, 128, 64, 64, 2, "outlier"), (1, 2, 256, 128, 128, 4, "randn"),
     (1, 2, 64, 128, 32, 2, "tiny"), (1, 2, 64, 128, 32, 4, "tiny"),
