@@ -768,7 +768,7 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
 #endif
     // few rows (under ~2 four-wave blocks per CU): eight waves per row, the row's own waves hide the latency
     static const char* f8 = KIVI_TUNE_ENV("KIVI_MF_ROW_NW8");            // tuning builds: 0 / 1 forces either
-    const bool nw8 = f8 ? atoi(f8) != 0 : units < 448;          // 256 rows: 31.5 -> 26.6 us, 512: equal, 768: 61.1 vs 65.4 (profiles/r03_other_shapes.log)
+    const bool nw8 = f8 ? atoi(f8) != 0 : units <= 512;         // 256 rows: 30.3 -> 26.8 us, 384: 39.7 -> 37.0, 512: 45.8 -> 44.0, 768: 61.1 vs 65.4 (profiles/r03_other_shapes.log)
     if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
     else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");
