@@ -250,11 +250,7 @@ class KiviLayerCacheMF:
                     attention_mask: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
         B, nh, _, D = query_states.shape
         assert nh == self.nh and B == self.B and D == self.D
-
-        def rows16(x):   # 16-byte loads of whole rows: unit inner stride, 16-byte aligned rows
-            ok = x.stride(3) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0
-            return x if ok else x.contiguous()
-        q, k, v = rows16(query_states), rows16(key_states), rows16(value_states)
+        q, k, v = _rows16(query_states), _rows16(key_states), _rows16(value_states)
         kv_seq_len = self.kv_seq_len + 1
         mask_ptr, mask_sb = None, 0
         if attention_mask is not None:
@@ -266,7 +262,7 @@ class KiviLayerCacheMF:
             out = torch.empty((B, nh, 1, D), dtype=torch.float16, device=q.device)
         else:
             assert out.shape == (B, nh, 1, D) and out.dtype == torch.float16 and out.stride(3) == 1
-        d, state, _, fn, _ = self._desc(nh, q.device)
+        d, state, key, fn, _ = self._desc(nh, q.device)     # key = (nh, stream handle the descriptor was built for = the current one)
         d.flags = self._flags()
         state[0], state[1], state[2] = self.k_quant_len, self.k_res_len, self.v_quant_len
         state[3], state[4], state[5] = self.v_res_start, self.v_res_len, self.kv_seq_len
@@ -276,8 +272,7 @@ class KiviLayerCacheMF:
                                   group_size=self.cfg.group_size, v_bits=self.cfg.v_bits, Tv=self.v_quant_len,
                                   k_res=self.k_res_len + 1, v_res=self.v_res_len + 1))
         rc = fn(ctypes.byref(d), state, q.data_ptr(), q.stride(0), q.stride(1), nh, k.data_ptr(), k.stride(0), k.stride(1),
-                v.data_ptr(), v.stride(0), v.stride(1), mask_ptr, mask_sb, out.data_ptr(), out.stride(0), out.stride(1),
-                torch.cuda.current_stream(q.device).cuda_stream)
+                v.data_ptr(), v.stride(0), v.stride(1), mask_ptr, mask_sb, out.data_ptr(), out.stride(0), out.stride(1), key[1])
         # the library writes `state` after every phase it has enqueued: read the lengths back whether or not the call succeeded
         self.k_quant_len, self.k_res_len, self.v_quant_len = state[0], state[1], state[2]
         self.v_res_start, self.v_res_len, self.kv_seq_len = state[3], state[4], state[5]
@@ -286,9 +281,21 @@ class KiviLayerCacheMF:
         return out
 
 
+def _rows16(x):
+    """16-byte loads of whole rows: unit inner stride, 16-byte aligned rows (a copy otherwise)."""
+    ok = x.stride(3) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0
+    return x if ok else x.contiguous()
+
+
+_MATMUL = None
+
+
 def _launch_hook():
-    from .quant import matmul
-    return matmul.launch_hook
+    global _MATMUL
+    if _MATMUL is None:           # (imported lazily: quant.matmul imports this package)
+        from .quant import matmul
+        _MATMUL = matmul
+    return _MATMUL.launch_hook
 
 
 def make_layer_cache(cfg: KiviConfig, batch: int, num_kv_heads: int, head_dim: int, max_len: int, device,
