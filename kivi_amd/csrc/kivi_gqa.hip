@@ -1180,9 +1180,12 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
         // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks of 8 waves per CU)
         static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
         const bool split = (p->flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow));
-        // too few units: the split two-launch form fills the chip better
+        // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
+        // of a row block to take one super-block each (nh == nh_kv, <= 4096 packed keys): then one launch beats two whatever
+        // the batch (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79,
+        // profiles/r03_other_shapes.log)
         const int min_units = R == 1 ? 192 : 128;
-        if (!split && (units >= min_units || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, s);
+        if (!split && (units >= min_units || (R == 1 && nsbk <= 8) || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, s);
     }
     int rc = skipk ? 0 : (newp ? kivi_mf_run_k(&k, units, s) : run_gqa_k(k, units, s));
     if (rc) return rc;

@@ -116,11 +116,14 @@ def test_bench_shape_mf_row_kernel_vs_oracle(oracle, T0, masked):
     print("worst ratio vs the 3e-3 hook bar:", worst)
 
 
-@pytest.mark.parametrize("B,T0", [(1, 32768 + 13), (4, 4080), (16, 4080)])
-def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0):
-    """Few (batch row, head) rows (B = 1 x 32k keys, B = 4 / 16 x 4k): rows longer than the LDS row or fewer than 192 rows
-    run the two-launch form with the rows cut into slices."""
-    run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=6, samples=[(0, 0), (B - 1, 31)], seed=15, layout="auto")
+@pytest.mark.parametrize("B,T0,kernel", [(1, 32768 + 13, "mf_k_kernel"), (4, 4080, "mf_row_kernel"), (4, 6000, "mf_k_kernel"),
+                                         (16, 4080, "mf_row_kernel")])
+def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0, kernel):
+    """Few (batch row, head) rows: rows longer than the LDS row (B = 1 x 32k keys) and fewer than 192 rows of more than 8
+    super-blocks (B = 4 x 6000) run the two-launch form with the rows cut into slices; rows of at most 8 super-blocks take
+    the eight-wave row kernel whatever the batch (B = 4 / 16 x 4k)."""
+    run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=6, samples=[(0, 0), (B - 1, 31)], seed=15, layout="auto",
+                expect_kernel=kernel)
 
 
 def test_bench_shape_prompt_4080_k_flush_mid_page(oracle):
