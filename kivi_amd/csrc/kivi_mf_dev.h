@@ -98,6 +98,8 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
 //     and super-block: ~10 us of a 46 us launch, profiles/r03_mfk_ablation.log);
 //   * the scale / zero points of half h + 1 are requested right after the A operands of half h have been built from the
 //     registers they land in; the code ring runs across halves and super-blocks.
+constexpr uint32_t MF_DEAD_OFF = 0xFFFE0000u;    // + any in-super-block offset (< 25 KiB) stays below 2^32 and past every descriptor (a store within 128 KiB of 4 GiB would merely fetch)
+
 struct MfKSeq {
     uint32_t sb_bytes;              // byte stride between consecutive super-blocks of the unit
     int sb_first, sb_stride, n_sb;  // this wave's super-blocks
@@ -123,19 +125,24 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     const uint32_t row_off = (uint32_t)(kb * 128 + gp * 16);       // kt_sm_word4(gp, kb, 0) * 4: per chunk c 512 dense bytes per load
     auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
     u32x4 sv[4], mv[4];
-    auto request_half = [&](int hq) {
+    // Requests past the end of the sequence keep the loop branch-free but must not cost traffic: their per-lane offset is
+    // pushed past the descriptor's range (MF_DEAD_OFF: a buffer load out of range returns zeros without touching memory; the
+    // scalar offset stays a valid one).  Repeating the last block instead cost 5 % of the launch's HBM reads.
+    auto request_half = [&](int hq, bool live) {
         const uint32_t so = sb_off(hq >> 1) + (uint32_t)(hq & 1) * 2048u;      // half a super-block: 8 groups x 256 bytes
+        const uint32_t ro = live ? row_off : MF_DEAD_OFF;
 #pragma unroll
-        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_SCALE_WORD0 * 4 + row_off + c * 512, so);
+        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_SCALE_WORD0 * 4 + ro + c * 512, so);
 #pragma unroll
-        for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_MN_WORD0 * 4 + row_off + c * 512, so);
+        for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_MN_WORD0 * 4 + ro + c * 512, so);
     };
-    request_half(0);
+    request_half(0, true);
     const int g_last = W.ng_total - 1;
     u32x4 wr[RING];
     auto request_group = [&](int slot, int gi) {
-        const int gc = gi < g_last ? gi : g_last;                   // clamped: no branch, no address past the sequence
-        wr[slot] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
+        const bool live = gi <= g_last;
+        const int gc = live ? gi : g_last;                          // (a valid scalar offset either way)
+        wr[slot] = buf_load<u32x4, true>(rk, live ? (uint32_t)(lane * 16) : MF_DEAD_OFF, sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
     };
 #pragma unroll
     for (int i = 0; i < RING; i++) {
@@ -197,7 +204,7 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
         // read) and keeps their 32 operand registers alive across it
         float zs[4] = {z[0] * zmul, z[1] * zmul, z[2] * zmul, z[3] * zmul};
         asm volatile("" : "+v"(zs[0]), "+v"(zs[1]), "+v"(zs[2]), "+v"(zs[3]));
-        request_half(hq + 1 < n_half ? hq + 1 : hq);               // lands during this half's groups (the last one: a repeat)
+        request_half(hq + 1 < n_half ? hq + 1 : hq, hq + 1 < n_half);   // lands during this half's groups (after the last one: nothing)
         __builtin_amdgcn_sched_barrier(0);
         float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -279,23 +286,27 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
     const int n_round = (W.ng_total + 3) >> 2;
     // ---- requests: scale of round 0, zero points of super-block 0, the ring
     u32x4 sv[4], zv[4];
-    auto request_round = [&](int rq) {
+    // (requests past the end: out-of-range per-lane offsets, no traffic -- see mf_k_seq1)
+    auto request_round = [&](int rq, bool live) {
         const int g0 = 4 * rq;
         const uint32_t so = sb_off(g0 >> 4);
         const int g = (g0 & 15) + (m >> 2);
+        const uint32_t dead = live ? 0u : MF_DEAD_OFF;
 #pragma unroll
-        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4), so);
+        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4) + dead, so);
     };
-    auto request_z = [&](int sbi) {
+    auto request_z = [&](int sbi, bool live) {
+        const uint32_t dead = live ? 0u : MF_DEAD_OFF;
 #pragma unroll
-        for (int c = 0; c < 4; c++) zv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(m, kb, c) * 4), sb_off(sbi));
+        for (int c = 0; c < 4; c++) zv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(m, kb, c) * 4) + dead, sb_off(sbi));
     };
-    request_round(0);
-    request_z(0);
+    request_round(0, true);
+    request_z(0, true);
     u32x4 wr[RING];
     auto request_group = [&](int slot, int gi) {
-        const int gc = gi < g_last ? gi : g_last;
-        wr[slot] = buf_load<u32x4, true>(rk, (uint32_t)(lane * 16), sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
+        const bool live = gi <= g_last;
+        const int gc = live ? gi : g_last;
+        wr[slot] = buf_load<u32x4, true>(rk, live ? (uint32_t)(lane * 16) : MF_DEAD_OFF, sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
     };
 #pragma unroll
     for (int i = 0; i < RING; i++) {
@@ -319,7 +330,7 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
         const int sbi = rq >> 2;
         if ((rq & 3) == 0) {                                        // a new super-block: its zero-point sums, then the next one's zero points
             mf_k_zero4(Q, zv, zmul, zz);
-            request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi);
+            request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
         uint32_t Ah[4][4], Al[4][4];
 #pragma unroll
@@ -329,7 +340,7 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
                 Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
                 Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
             }
-        request_round(rq + 1 < n_round ? rq + 1 : rq);
+        request_round(rq + 1 < n_round ? rq + 1 : rq, rq + 1 < n_round);
         __builtin_amdgcn_sched_barrier(0);
         // zero points of (group 4 (rq & 3) + kb, head j) from lane (that group) of this 16-lane row
         float zs[4];
@@ -500,11 +511,13 @@ struct MfVStream {
 
     __device__ __forceinline__ void request(rsrc_t rv, int slot, int bl) {
         const int lane = threadIdx.x & 63;
-        const int bc = bl < b_last ? bl : b_last;                  // clamped: no branch, no out-of-range address
+        const bool live = bl <= b_last;                            // past the stream: out-of-range per-lane offsets (zeros, no traffic)
+        const int bc = live ? bl : b_last;
+        const uint32_t dead = live ? 0u : MF_DEAD_OFF;
         const uint32_t so = (uint32_t)(sb_first + (bc >> 4) * sb_stride) * sb_bytes;
-        wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16), so + (uint32_t)(bc & 15) * 1024u);
-        sr[slot] = buf_load<u32x4, true>(rv, sm_off, so + (uint32_t)(bc & 15) * 256u);
-        if constexpr (R != 1) mr[slot] = buf_load<u32x4, true>(rv, mn_off, so + (uint32_t)(bc & 15) * 256u);
+        wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16) + dead, so + (uint32_t)(bc & 15) * 1024u);
+        sr[slot] = buf_load<u32x4, true>(rv, sm_off + dead, so + (uint32_t)(bc & 15) * 256u);
+        if constexpr (R != 1) mr[slot] = buf_load<u32x4, true>(rv, mn_off + dead, so + (uint32_t)(bc & 15) * 256u);
     }
 
     // blocks [b_lo, b_hi) in stream numbering; (first, stride) = (0, 1): stream numbering = the unit's block numbering
