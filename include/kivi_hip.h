@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KIVI_ABI_VERSION 1
+#define KIVI_ABI_VERSION 2
 
 #define KIVI_EINVAL (-1)       /* unsupported bits / group size / shape */
 #define KIVI_EALIGN (-2)       /* pointer or stride alignment the kernels rely on is violated */
@@ -240,6 +240,13 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  * (kivi_amd/csrc/kivi_mfma_layout.h): per (batch row, kv head) a sequence of super-blocks of 512 tokens,
  *   [ codes 16 x 256 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 6144 int32 words each,
  * addressed as base + b*sb_b + hk*sb_h + (t / 512)*sb_s (strides in words).  Never-written slots must be ZERO.
+ * RANGE FLAGS: every store comes with `range`, B * nh_kv int32 (index b * nh_kv + hk), zeroed by the caller together with
+ *   the store.  The matrix pipe takes q * scale (qK^T) and p * scale (sV) as fp16 hi / lo pairs; with the default placement of
+ *   q and p a group scale >= 512 would overflow them where the reference's fp32 `scale * code + zero`
+ *   (quant/csrc/gemv_cuda.cu:407-413) stays finite.  So every entry point that WRITES scales (kivi_kt_pack, kivi_vt_pack, the
+ *   relayouts towards the layout, the V flush inside kivi_gqa_decode) sets range[b * nh_kv + hk] = 1 when it writes a scale
+ *   >= 256 (inf / NaN included), and the consumers place q / p 2^10 lower for such a unit: finite for every finite fp16 scale.
+ *   Sticky (never cleared by the library); units that never saw such a scale compute exactly what they did without the flag.
  * The reference has no counterpart: it expands codes / scale / mn nh / nh_kv times (models/mistral_kivi.py:58-67,
  * :381-385, :441-445) or lets the CUDA kernel map heads (quant/csrc/gemv_cuda.cu:361-365).
  *
@@ -260,27 +267,32 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  *   (nh / nh_kv) * 128 floats, slices <= max(1, ceil(T / 512)).
  */
 int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* kt, int64_t kt_sb, int64_t kt_sh,
-                 int64_t kt_ss, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
-                 kivi_stream_t stream);
+                 int64_t kt_ss, void* kt_range, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size,
+                 int bits, kivi_stream_t stream);
 int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v_st, void* vt, int64_t vt_sb, int64_t vt_sh,
-                 int64_t vt_ss, int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
-int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* code, int64_t code_sb,
-                     int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
-                     int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
-int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss, void* code, int64_t code_sb,
-                     int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh, int64_t sm_sr,
-                     int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
+                 int64_t vt_ss, void* vt_range, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
+                 kivi_stream_t stream);
+/* (kt_range / vt_range may be null when to_ref != 0: reading a store does not touch its flags) */
+int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* kt_range, void* code,
+                     int64_t code_sb, int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh,
+                     int64_t sm_sr, int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
+int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss, void* vt_range, void* code,
+                     int64_t code_sb, int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb, int64_t sm_sh,
+                     int64_t sm_sr, int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream);
 int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss,
-                    void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
-                    int bits, kivi_stream_t stream);
+                    const void* kt_range, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T,
+                    int group_size, int bits, kivi_stream_t stream);
 int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss,
-                    void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T, int group_size,
-                    int bits, void* workspace, int64_t workspace_bytes, kivi_stream_t stream);
+                    const void* vt_range, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D, int64_t T,
+                    int group_size, int bits, void* workspace, int64_t workspace_bytes, kivi_stream_t stream);
 
 /*
- * kivi_gqa_decode: the whole decode step of one layer over the KT / VT layouts.  nh == nh_kv, rows of <= 8192 keys and
- * >= 192 (batch row, head) rows: ONE launch (mf_row_kernel: packed qK^T -> LDS scores -> residual scores -> softmax ->
- * window -> packed sV; `scores` / `stats` / `workspace` are not touched).  Otherwise two launches:
+ * kivi_gqa_decode: the whole decode step of one layer over the KT / VT layouts.  ONE launch (packed qK^T -> LDS scores ->
+ * residual scores -> softmax -> window -> packed sV; `scores` / `stats` / `workspace` are validated but not touched) when the
+ * score rows of a (batch row, kv head) unit fit the LDS and the units fill the chip:
+ *   nh == nh_kv      rows of <= 8192 keys and (>= 192 units, or <= 4096 packed keys at any batch)      -> mf_row_kernel
+ *   nh / nh_kv == 4  rows of <= 9216 keys and >= 128 units                                            -> mf_row4_kernel
+ * Otherwise two launches:
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies
  *      1/sqrt(D) and the mask (:339, :364-372), writes the scaled scores to `scores` and (max, sum exp) of every
  *      512-token segment to `stats`;
@@ -295,10 +307,14 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * kres), v_window_rows (v_win_start + v_res_len + 1 <= v_window_rows: the V append), vt_superblocks (Tv + 1 <= 512 *
  * vt_superblocks when v_flush), kt_superblocks (Tq <= 512 * kt_superblocks).
  * flags: KIVI_GQA_FORCE_SPLIT = the two-launch form even where the one-launch form applies, KIVI_GQA_FORCE_ROW = the
- * one-launch form for any number of rows (nh == nh_kv, <= 8192 keys) -- tests and tuning.
+ * one-launch form for any number of units (rows that fit the LDS as above) -- tests and tuning.  KIVI_GQA_DUMP_SCORES
+ * (tests): the one-launch form also writes the fp16 rows its softmax consumes (scaled, mask added: what the two-launch form
+ * leaves in `scores`) to `scores`, through separate instantiations of the kernels.
+ * kt_range / vt_range: the range flags of the two stores (see above); the V flush may set vt_range.
  */
 #define KIVI_GQA_FORCE_SPLIT 1
 #define KIVI_GQA_FORCE_ROW 2
+#define KIVI_GQA_DUMP_SCORES 8
 /* the fp16 value window is a RING of v_window_rows rows (row of window token t = (v_win_start + t) mod v_window_rows):
  * residual_length + 1 rows suffice and nothing is ever compacted; nh / nh_kv in {1, 4} */
 #define KIVI_GQA_WINDOW_RING 4
@@ -318,6 +334,7 @@ typedef struct {
     void* out; int64_t out_sb, out_sh;
     int residual_length; int64_t v_window_rows, kt_superblocks, vt_superblocks;
     int flags;
+    void* kt_range; void* vt_range;                    /* B * nh_kv int32 each */
 } kivi_gqa_decode_args;
 int kivi_gqa_decode(const kivi_gqa_decode_args* args, kivi_stream_t stream);
 
@@ -368,7 +385,8 @@ typedef struct {
     void* scores; int64_t s_sb, s_sh;                  /* (B, nh, s_pitch) fp16 scratch rows */
     void* stats; int64_t stats_bytes;
     void* workspace; int64_t workspace_bytes;
-    int flags;                                         /* KIVI_GQA_FORCE_* */
+    int flags;                                         /* KIVI_GQA_* */
+    void* kt_range; void* vt_range;                    /* range flags of the two stores: B * nh_kv int32 each */
 } kivi_mf_layer_desc;
 int kivi_mf_decode_layer(const kivi_mf_layer_desc* layer, int64_t* state, const void* q, int64_t q_sb, int64_t q_sh, int nh,
                          const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb, int64_t vn_sh,

@@ -13,8 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkivi_hip.so")
-# tuning aid (A/B of two builds inside one GPU session): KIVI_HIP_LIB=/path/to/other/libkivi_hip.so
-LIB_PATH = os.environ.get("KIVI_HIP_LIB", LIB_PATH)
+# tuning sessions (KIVI_TUNING=1; A/B of two builds inside one GPU session): KIVI_HIP_LIB=/path/to/other/libkivi_hip.so
+from . import _tuning  # noqa: E402
+
+LIB_PATH = _tuning.knob("KIVI_HIP_LIB", LIB_PATH)
 
 _i64, _i32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 
@@ -81,10 +83,11 @@ class GqaDecodeArgs(ctypes.Structure):
         ("out", _vp), ("out_sb", _i64), ("out_sh", _i64),
         ("residual_length", _i32), ("v_window_rows", _i64), ("kt_superblocks", _i64), ("vt_superblocks", _i64),
         ("flags", _i32),
+        ("kt_range", _vp), ("vt_range", _vp),
     ]
 
 
-GQA_FORCE_SPLIT, GQA_FORCE_ROW, GQA_WINDOW_RING = 1, 2, 4
+GQA_FORCE_SPLIT, GQA_FORCE_ROW, GQA_WINDOW_RING, GQA_DUMP_SCORES = 1, 2, 4, 8
 
 
 class MfLayerDesc(ctypes.Structure):
@@ -101,6 +104,7 @@ class MfLayerDesc(ctypes.Structure):
         ("stats", _vp), ("stats_bytes", _i64),
         ("workspace", _vp), ("workspace_bytes", _i64),
         ("flags", _i32),
+        ("kt_range", _vp), ("vt_range", _vp),
     ]
 
 
@@ -131,15 +135,16 @@ SIGNATURES = {
     "kivi_decode_attend": (_i32, [ctypes.POINTER(DecodeAttendArgs), _vp]),
     "kivi_decode_layer": (_i32, [ctypes.POINTER(LayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
                                  _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
-    "kivi_kt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
-    "kivi_vt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
-    "kivi_kt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+    # (a KT / VT store = pointer + 3 word strides + the pointer to its range flags)
+    "kivi_kt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_vt_pack": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "kivi_kt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                 _i64, _i32, _i32, _i32, _vp]),
-    "kivi_vt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+    "kivi_vt_relayout": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                 _i64, _i32, _i32, _i32, _vp]),
-    "kivi_gqa_scores": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
+    "kivi_gqa_scores": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
                                _i32, _vp]),
-    "kivi_gqa_output": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
+    "kivi_gqa_output": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
                                _i32, _vp, _i64, _vp]),
     "kivi_gqa_decode": (_i32, [ctypes.POINTER(GqaDecodeArgs), _vp]),
     "kivi_mf_decode_layer": (_i32, [ctypes.POINTER(MfLayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
@@ -184,8 +189,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.kivi_abi_version() != 1:
-        raise KiviHipError(f"ABI version mismatch: library reports {lib.kivi_abi_version()}, binding expects 1")
+    if lib.kivi_abi_version() != 2:
+        raise KiviHipError(f"ABI version mismatch: library reports {lib.kivi_abi_version()}, binding expects 2")
     _lib = lib
     return lib
 

@@ -13,13 +13,13 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _tuning
 from ._lib import KiviUnsupported
 from .cache import KiviCacheTuple, KiviConfig, KiviLayerCache
 from .cache_mf import KiviLayerCacheMF, make_layer_cache, supported as _mf_supported
@@ -65,8 +65,8 @@ def _composed_output(attn_weights: torch.Tensor, value_states: torch.Tensor, lay
     return attn_output
 
 
-_NATIVE_STEP = os.environ.get("KIVI_NATIVE_STEP", "1") != "0"   # tuning aid: 0 = the Python bookkeeping path
-_FUSION_ENV = os.environ.get("KIVI_DECODE_FUSION")   # tuning aid: "attend" (2 launches), "softmax" (3), "separate" (4)
+_NATIVE_STEP = _tuning.knob("KIVI_NATIVE_STEP", "1") != "0"   # tuning sessions: 0 = the Python bookkeeping path
+_FUSION_ENV = _tuning.knob("KIVI_DECODE_FUSION")   # tuning sessions: "attend" (2 launches), "softmax" (3), "separate" (4)
 
 
 def _fusion_level(layer, nh: int, kv_len: int) -> int:

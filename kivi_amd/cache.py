@@ -23,13 +23,13 @@ Cache policy (llama_kivi.py:343-356, 386-399, 425-452):
 """
 from __future__ import annotations
 
-import os
 
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
 
+from . import _tuning
 from .quant import new_pack
 
 PAGE_TOKENS = 2048   # = the tile of the default qK^T kernels (64 lanes x 2 words x 16 codes; 4-bit: 4 words x 8)
@@ -113,7 +113,7 @@ class KiviLayerCache:
     @staticmethod
     def _paged(shape, dtype, device) -> torch.Tensor:
         B, h, P, D, W = shape
-        if os.environ.get("KIVI_K_HEAD_MAJOR"):   # tuning aid: the plain (B, nh_kv, P, ...) memory order
+        if _tuning.flag("KIVI_K_HEAD_MAJOR"):   # tuning sessions: the plain (B, nh_kv, P, ...) memory order
             return torch.empty(shape, dtype=dtype, device=device)
         return torch.empty((B, P, h, D, W), dtype=dtype, device=device).permute(0, 2, 1, 3, 4)
 

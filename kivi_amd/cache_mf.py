@@ -16,11 +16,10 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 
 import torch
 
-from . import _lib
+from . import _lib, _tuning
 from .cache import KiviCacheTuple, KiviConfig
 from .quant import mfma, new_pack
 
@@ -31,9 +30,9 @@ _WS_COUNTER_BYTES = 65536
 
 
 def supported(cfg: KiviConfig, head_dim: int, num_heads: int, num_kv_heads: int) -> bool:
-    if os.environ.get("KIVI_NO_MFMA_LAYOUT"):     # tuning aid: keep every model on the hook-state layout
+    if _tuning.flag("KIVI_NO_MFMA_LAYOUT"):     # tuning sessions: keep every model on the hook-state layout
         return False
-    if num_heads == num_kv_heads and os.environ.get("KIVI_NO_MFMA_MHA"):   # tuning aid (A/B): multi-head models on the hook-state layout
+    if num_heads == num_kv_heads and _tuning.flag("KIVI_NO_MFMA_MHA"):   # tuning sessions (A/B): multi-head models on the hook-state layout
         return False
     return num_heads % num_kv_heads == 0 and mfma.supported(cfg.k_bits, cfg.v_bits, cfg.group_size, head_dim,
                                                             cfg.residual_length, num_heads // num_kv_heads) \
@@ -81,7 +80,7 @@ class KiviLayerCacheMF:
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=device)
         # fp16 value window: a RING of R + 1 rows for the round-3 kernels (nh / nh_kv in {1, 4}: nothing is ever compacted);
         # the round-2 kernels (nh / nh_kv = 8) keep the linear buffer of 2 R + 1 rows with a compaction every ~R steps
-        self.ring = (num_heads // num_kv_heads) in (1, 4) and not os.environ.get("KIVI_MF_NO_RING")   # (tuning aid: A/B)
+        self.ring = (num_heads // num_kv_heads) in (1, 4) and not _tuning.flag("KIVI_MF_NO_RING")   # (tuning sessions: A/B)
         self.v_res = torch.empty((batch, num_kv_heads, (R + 1) if self.ring else (2 * R + 1), head_dim), dtype=dtype, device=device)
         self.k_quant_len = 0
         self.k_res_len = 0
@@ -103,7 +102,7 @@ class KiviLayerCacheMF:
             for name in ("kt", "vt"):
                 old = getattr(self, name)
                 new = mfma.alloc_store(self.B, self.nh_kv, n_sb, old.device)
-                new[:, :, : self.n_sb].copy_(old)
+                mfma.copy_store(new, old)                      # super-blocks in use + the store's range flags
                 setattr(self, name, new)
             self.n_sb = n_sb
         self.cap = cap
@@ -117,7 +116,12 @@ class KiviLayerCacheMF:
     def clone(self) -> "KiviLayerCacheMF":
         import copy
         other = copy.copy(self)
-        for name in ("kt", "vt", "k_res", "v_res"):
+        for name in ("kt", "vt"):
+            src = getattr(self, name)
+            dst = mfma.alloc_store(self.B, self.nh_kv, self.n_sb, src.device)
+            mfma.copy_store(dst, src)
+            setattr(other, name, dst)
+        for name in ("k_res", "v_res"):
             src = getattr(self, name)
             dst = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device)
             dst.copy_(src)
@@ -170,8 +174,9 @@ class KiviLayerCacheMF:
         T = key_states.shape[2]
         self.reserve(T)
         if self.kv_seq_len:        # reuse of the object: the V slots are filled token by token later, start from clean storage
-            self.kt.zero_()
-            self.vt.zero_()
+            for st in (self.kt, self.vt):
+                st.zero_()
+                mfma.range_flags(st).zero_()
         nq = (T // R) * R
         if nq:
             mfma.kt_pack(key_states[:, :, :nq], self.kt, 0, g, cfg.k_bits)
@@ -192,11 +197,6 @@ class KiviLayerCacheMF:
         self.v_res_len = T - nv
         self.v_res[:, :, : self.v_res_len].copy_(value_states[:, :, nv:])
         self.kv_seq_len = T
-
-    def compact_v_window(self) -> None:
-        live = self.v_res[:, :, self.v_res_start: self.v_res_start + self.v_res_len].clone()
-        self.v_res[:, :, : self.v_res_len].copy_(live)
-        self.v_res_start = 0
 
     @classmethod
     def from_tuple(cls, cfg: KiviConfig, past, max_len: int, num_heads: int) -> "KiviLayerCacheMF":
@@ -238,7 +238,8 @@ class KiviLayerCacheMF:
             v_res=vr.data_ptr(), vr_sb=vr.stride(0), vr_sh=vr.stride(1), vr_st=vr.stride(2),
             scores=scores.data_ptr(), s_sb=scores.stride(0), s_sh=scores.stride(1),
             stats=stats.data_ptr(), stats_bytes=stats.numel() * 4,
-            workspace=ws.data_ptr(), workspace_bytes=ws.numel(), flags=self._flags())
+            workspace=ws.data_ptr(), workspace_bytes=ws.numel(), flags=self._flags(),
+            kt_range=mfma.range_flags(kt).data_ptr(), vt_range=mfma.range_flags(vt).data_ptr())
         state = (ctypes.c_int64 * 6)()
         self._native = (d, state, (nh, stream), _lib.load().kivi_mf_decode_layer, (scores, stats, ws))
         return self._native

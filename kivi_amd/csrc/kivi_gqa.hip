@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t dpp_or(uint32_t v) {     // the value of the
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 __global__ __launch_bounds__(256) void kt_pack_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
-                                                      int64_t blk0, int nblk, int nh_kv, int64_t ntile) {
+                                                      int* range, int64_t blk0, int nblk, int nh_kv, int64_t ntile) {
     // four waves per block, one 32-token block each (single-wave workgroups: 131 072 of them per GiB)
     const int wave = threadIdx.x >> 6;
     int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256) void kt_pack_kernel(const uint16_t* k, int64_t
     const int hidx = kt_sm_half((int)(blk & 15), 2 * lane);    // channel 2l (even): the pair (2l, 2l+1) is one word
     (sb + KIVI_MF_SB_SCALE_WORD0)[hidx >> 1] = scale2;
     (sb + KIVI_MF_SB_MN_WORD0)[hidx >> 1] = mn2;
+    // range flag of the unit (kivi_mfma_layout.h): sticky, every writer stores the same value
+    if ((scale2 & 0xFFFFu) >= KIVI_MF_BIG_SCALE_BITS || (scale2 >> 16) >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
 }
 
 // Per-token V quantise + pack of a prompt straight into the VT layout (prompt pass, models/llama_kivi.py:441-448: the
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void kt_pack_kernel(const uint16_t* k, int64_t
 // complete a word with two DPP ORs, and the lane index is the index of the pair's scale / zero-point word.  Tokens at
 // or past T read as zeros (constant group: scale 0, zero point 0, codes 0 = never-written storage).
 __global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
-                                                      int64_t T, int nblk, int nh_kv, int64_t ntile) {
+                                                      int* range, int64_t T, int nblk, int nh_kv, int64_t ntile) {
     const int wave = threadIdx.x >> 6;                     // four waves per block, one 32-token block each (cf. kt_pack_kernel)
     int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
     const bool live_tile = tile_id < ntile;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* v, int64_t
     *(u32x4*)(cw + lane * 4) = *(const u32x4*)(tile + lane * 4);
     (sb + KIVI_MF_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;    // vt_half(8 kb + 2 ee, c) / 2 == lane
     (sb + KIVI_MF_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
+    if ((scale2 & 0xFFFFu) >= KIVI_MF_BIG_SCALE_BITS || (scale2 >> 16) >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;   // range flag (kt_pack_kernel)
 }
 
 // KT <-> reference layout K_code_T (B, nh_kv, D, T/16), K_scale_T / K_mn_T (B, nh_kv, D, T/32) (llama_kivi.py:454-455).
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* v, int64_t
 template <bool TO_REF>
 __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* code, int64_t code_sb, int64_t code_sh,
                                                           int64_t code_sr, uint16_t* scale, uint16_t* mn, int64_t sm_sb,
-                                                          int64_t sm_sh, int64_t sm_sr, int nblk, int nh_kv) {
+                                                          int64_t sm_sh, int64_t sm_sr, int nblk, int nh_kv, int* range) {
     __shared__ uint32_t lds[256];
     const int unit = blockIdx.x / nblk, blk = blockIdx.x - unit * nblk;
     const int b = unit / nh_kv, hk = unit - b * nh_kv;
@@ -216,8 +219,10 @@ __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* 
                 }
             cw[wi] = w;
         }
-        ks[kt_sm_half(gsb, d)] = scale[sidx];
+        const uint16_t sc = scale[sidx];
+        ks[kt_sm_half(gsb, d)] = sc;
         km[kt_sm_half(gsb, d)] = mn[sidx];
+        if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;      // range flag of the unit (kivi_mfma_layout.h)
     }
 }
 
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* 
 template <bool TO_REF>
 __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* code, int64_t code_sb, int64_t code_sh,
                                                           int64_t code_sr, uint16_t* scale, uint16_t* mn, int64_t sm_sb,
-                                                          int64_t sm_sh, int64_t sm_sr, int64_t T, int nblk, int nh_kv) {
+                                                          int64_t sm_sh, int64_t sm_sr, int64_t T, int nblk, int nh_kv, int* range) {
     __shared__ uint32_t lds[256];
     const int unit = blockIdx.x / nblk, blk = blockIdx.x - unit * nblk;
     const int b = unit / nh_kv, hk = unit - b * nh_kv;
@@ -265,7 +270,9 @@ __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* 
             }
         cw[tid] = w;
         if (wi < 4) {
-            vs[vt_half(tt, wi)] = (t < T) ? scale[b * sm_sb + hk * sm_sh + t * sm_sr + wi] : (uint16_t)0;
+            const uint16_t sc = (t < T) ? scale[b * sm_sb + hk * sm_sh + t * sm_sr + wi] : (uint16_t)0;
+            vs[vt_half(tt, wi)] = sc;
+            if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;  // range flag of the unit (kivi_mfma_layout.h)
             vm[vt_half(tt, wi)] = (t < T) ? mn[b * sm_sb + hk * sm_sh + t * sm_sr + wi] : (uint16_t)0;
         }
     }
@@ -852,6 +859,10 @@ __global__ __launch_bounds__(256, OCC) void gqa_v_kernel(const GqaVArgs a) {
     if (DBG && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 }
 
+// Largest byte extent a buffer descriptor over a unit's store may have: requests past the end of a wave's stream carry the
+// per-lane offset MF_DEAD_OFF (kivi_mf_dev.h) and must fall OUTSIDE the descriptor's range (zeros, no memory access)
+constexpr uint32_t MF_DESC_LIMIT = 0xFFFE0000u;
+
 bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
     return base && (uintptr_t)base % 16 == 0 && sb_b % 4 == 0 && sb_h % 4 == 0 && sb_s % 4 == 0 && sb_s >= KIVI_MF_SB_WORDS;
 }
@@ -868,9 +879,10 @@ bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
     KIVI_REQUIRE((int64_t)B * nh_kv * ((T + 31) / 32) < ((int64_t)1 << 31), KIVI_EINVAL, who ": grid too large")
 
 extern "C" int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_st, void* kt, int64_t kt_sb, int64_t kt_sh,
-                            int64_t kt_ss, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
-                            kivi_stream_t stream) {
+                            int64_t kt_ss, void* kt_range, int64_t token_offset, int B, int nh_kv, int64_t T, int D, int group_size,
+                            int bits, kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_kt_pack");
+    KIVI_REQUIRE(kt_range && (uintptr_t)kt_range % 4 == 0, KIVI_EINVAL, "kivi_kt_pack: null / misaligned range flags");
     KIVI_REQUIRE(T >= 0 && T % 32 == 0 && token_offset >= 0 && token_offset % 32 == 0, KIVI_EINVAL,
                  "kivi_kt_pack: T=%lld and token_offset=%lld must be multiples of the 32-token block", (long long)T,
                  (long long)token_offset);
@@ -882,13 +894,15 @@ extern "C" int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     const MfStore st = {(uint32_t*)kt, kt_sb, kt_sh, kt_ss};
     const int64_t ntile = (int64_t)B * nh_kv * nblk;
     hipLaunchKernelGGL(kt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)k, k_sb, k_sh, k_st, st, token_offset / 32, nblk, nh_kv, ntile);
+                       (const uint16_t*)k, k_sb, k_sh, k_st, st, (int*)kt_range, token_offset / 32, nblk, nh_kv, ntile);
     return kivi_launch_status("kt_pack");
 }
 
 extern "C" int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v_st, void* vt, int64_t vt_sb, int64_t vt_sh,
-                            int64_t vt_ss, int B, int nh_kv, int64_t T, int D, int group_size, int bits, kivi_stream_t stream) {
+                            int64_t vt_ss, void* vt_range, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
+                            kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_vt_pack");
+    KIVI_REQUIRE(vt_range && (uintptr_t)vt_range % 4 == 0, KIVI_EINVAL, "kivi_vt_pack: null / misaligned range flags");
     KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_vt_pack: negative length");
     KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss), KIVI_EALIGN, "kivi_vt_pack: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(v && (uintptr_t)v % 16 == 0 && v_sb % 8 == 0 && v_sh % 8 == 0 && v_st % 8 == 0, KIVI_EALIGN,
@@ -898,55 +912,58 @@ extern "C" int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v
     const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
     const int64_t ntile = (int64_t)B * nh_kv * nblk;
     hipLaunchKernelGGL(vt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)v, v_sb, v_sh, v_st, st, T, nblk, nh_kv, ntile);
+                       (const uint16_t*)v, v_sb, v_sh, v_st, st, (int*)vt_range, T, nblk, nh_kv, ntile);
     return kivi_launch_status("vt_pack");
 }
 
-extern "C" int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* code,
+extern "C" int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_sh, int64_t kt_ss, void* kt_range, void* code,
                                 int64_t code_sb, int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb,
                                 int64_t sm_sh, int64_t sm_sr, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
                                 kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_kt_relayout");
     KIVI_REQUIRE(T >= 0 && T % 32 == 0, KIVI_EINVAL, "kivi_kt_relayout: T=%lld must be a multiple of 32", (long long)T);
     KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss) && code && scale && mn, KIVI_EALIGN, "kivi_kt_relayout: bad buffers");
+    KIVI_REQUIRE(to_ref || (kt_range && (uintptr_t)kt_range % 4 == 0), KIVI_EINVAL, "kivi_kt_relayout: writing a store needs its range flags");
     if (T == 0) return 0;
     const int nblk = (int)(T / 32);
     const MfStore st = {(uint32_t*)kt, kt_sb, kt_sh, kt_ss};
     const dim3 grid((unsigned)((int64_t)B * nh_kv * nblk));
     if (to_ref)
         hipLaunchKernelGGL(kt_relayout_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
-                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv);
+                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv, (int*)kt_range);
     else
         hipLaunchKernelGGL(kt_relayout_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
-                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv);
+                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv, (int*)kt_range);
     return kivi_launch_status("kt_relayout");
 }
 
-extern "C" int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss, void* code,
+extern "C" int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_sh, int64_t vt_ss, void* vt_range, void* code,
                                 int64_t code_sb, int64_t code_sh, int64_t code_sr, void* scale, void* mn, int64_t sm_sb,
                                 int64_t sm_sh, int64_t sm_sr, int B, int nh_kv, int64_t T, int D, int group_size, int bits,
                                 kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_vt_relayout");
     KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_vt_relayout: negative length");
     KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss) && code && scale && mn, KIVI_EALIGN, "kivi_vt_relayout: bad buffers");
+    KIVI_REQUIRE(to_ref || (vt_range && (uintptr_t)vt_range % 4 == 0), KIVI_EINVAL, "kivi_vt_relayout: writing a store needs its range flags");
     if (T == 0) return 0;
     const int nblk = (int)((T + 31) / 32);
     const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
     const dim3 grid((unsigned)((int64_t)B * nh_kv * nblk));
     if (to_ref)
         hipLaunchKernelGGL(vt_relayout_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
-                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv);
+                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv, (int*)vt_range);
     else
         hipLaunchKernelGGL(vt_relayout_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
-                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv);
+                           code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv, (int*)vt_range);
     return kivi_launch_status("vt_relayout");
 }
 
 // round-3 kernels for nh / nh_kv in {1, 4} (kivi_mf.hip); the argument blocks cross the translation-unit boundary as void*
 int kivi_mf_run_k(void* k_args, int units, hipStream_t s);
 int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s);
-int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int64_t T, int* sp, hipStream_t s);
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream_t s);
+int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int nh_kv, int64_t T, const int* range, int* sp,
+                       hipStream_t s);
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump, hipStream_t s);
 
 static bool mf_new_path(int ratio) {
     static const char* old = KIVI_TUNE_ENV("KIVI_MF_OLD");              // tuning builds (A/B): nh / nh_kv = 4 on the round-2 kernels
@@ -954,13 +971,16 @@ static bool mf_new_path(int ratio) {
 }
 
 extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh,
-                               int64_t kt_ss, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D,
-                               int64_t T, int group_size, int bits, kivi_stream_t stream) {
+                               int64_t kt_ss, const void* kt_range, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                               int nh_kv, int D, int64_t T, int group_size, int bits, kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_gqa_scores");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_scores: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
     KIVI_REQUIRE(T >= 0 && T % 32 == 0, KIVI_EINVAL, "kivi_gqa_scores: T=%lld must be a multiple of 32", (long long)T);
     KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss), KIVI_EALIGN, "kivi_gqa_scores: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(kt_range && (uintptr_t)kt_range % 4 == 0, KIVI_EINVAL, "kivi_gqa_scores: null / misaligned range flags");
+    KIVI_REQUIRE(((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS) * kt_ss * 4 <= (int64_t)MF_DESC_LIMIT, KIVI_EINVAL,
+                 "kivi_gqa_scores: store too large for one descriptor");
     KIVI_REQUIRE(q && (uintptr_t)q % 16 == 0 && q_sb % 8 == 0 && q_sh % 8 == 0, KIVI_EALIGN, "kivi_gqa_scores: q rows must be 16-byte aligned");
     KIVI_REQUIRE(out && (uintptr_t)out % 16 == 0 && out_sb % 8 == 0 && out_sh % 8 == 0, KIVI_EALIGN,
                  "kivi_gqa_scores: score rows must be 16-byte aligned");
@@ -975,6 +995,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.stats = nullptr; a.nseg = 0; a.inv_scale = 1.0f; a.mask = nullptr; a.mask_sb = 0;
     a.res_blocks = 0; a.res_first = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
+    a.range = (const int*)kt_range;
     if (mf_new_path(a.ratio)) return kivi_mf_run_k(&a, B * nh_kv, (hipStream_t)stream);
     return run_gqa_k(a, B * nh_kv, (hipStream_t)stream);
 }
@@ -996,8 +1017,8 @@ static void gqa_v_slices(int units, int nsbv, int R, int& S, int& spb) {
 }
 
 extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* vt, int64_t vt_sb, int64_t vt_sh,
-                               int64_t vt_ss, void* out, int64_t out_sb, int64_t out_sh, int B, int nh, int nh_kv, int D,
-                               int64_t T, int group_size, int bits, void* workspace, int64_t workspace_bytes,
+                               int64_t vt_ss, const void* vt_range, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
+                               int nh_kv, int D, int64_t T, int group_size, int bits, void* workspace, int64_t workspace_bytes,
                                kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_gqa_output");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4), KIVI_EUNSUPPORTED,
@@ -1011,7 +1032,8 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     KIVI_REQUIRE((int64_t)(R - 1) * p_sh * 2 + T * 2 + 16 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_output: rows too long");
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_output: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
     const int nsbv = (int)((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
-    KIVI_REQUIRE((int64_t)nsbv * vt_ss * 4 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_output: store too large for one descriptor");
+    KIVI_REQUIRE((int64_t)nsbv * vt_ss * 4 <= (int64_t)MF_DESC_LIMIT, KIVI_EINVAL, "kivi_gqa_output: store too large for one descriptor");
+    KIVI_REQUIRE(vt_range && (uintptr_t)vt_range % 4 == 0, KIVI_EINVAL, "kivi_gqa_output: null / misaligned range flags");
     int S, spb;
     gqa_v_slices(units, nsbv, R, S, spb);
     const int64_t sp_bytes = ((int64_t)B * nh * 4 + 255) / 256 * 256;
@@ -1029,7 +1051,8 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     v.counters = (int*)workspace;
     v.sp_rows = (const int*)((char*)workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
     v.ws = (float*)((char*)workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4 + sp_bytes);
-    int rc = kivi_mf_run_row_sp(probs, p_sb, p_sh, B, nh, T, (int*)v.sp_rows, s);
+    v.range = (int*)vt_range;        // (read only here: no V flush in this launch)
+    int rc = kivi_mf_run_row_sp(probs, p_sb, p_sh, B, nh, nh_kv, T, (const int*)vt_range, (int*)v.sp_rows, s);
     if (rc) return rc;
     return kivi_mf_run_v(&v, 1, s);
 }
@@ -1132,8 +1155,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     const int nsbv = (int)((p->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
     int S, spb;
     gqa_v_slices(units, nsbv, R, S, spb);
-    KIVI_REQUIRE((int64_t)(nsbv > nsbk ? nsbv : nsbk) * (p->kt_ss > p->vt_ss ? p->kt_ss : p->vt_ss) * 4 < ((int64_t)1 << 32), KIVI_EINVAL,
+    KIVI_REQUIRE((int64_t)(nsbv > nsbk ? nsbv : nsbk) * (p->kt_ss > p->vt_ss ? p->kt_ss : p->vt_ss) * 4 <= (int64_t)MF_DESC_LIMIT, KIVI_EINVAL,
                  "kivi_gqa_decode: store too large for one descriptor");
+    KIVI_REQUIRE(p->kt_range && p->vt_range && (uintptr_t)p->kt_range % 4 == 0 && (uintptr_t)p->vt_range % 4 == 0, KIVI_EINVAL,
+                 "kivi_gqa_decode: null / misaligned range flags");
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
     static const char* wt = KIVI_TUNE_ENV("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
     const int win_blocks = (nsbv > 0 && !(wt && atoi(wt) == 0)) ? units : 0;
@@ -1155,6 +1180,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.res_first = rf ? atoi(rf) : 0;
     k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
+    k.range = (const int*)p->kt_range;
     static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
     static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};
@@ -1175,6 +1201,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.dbg = kivi_debug_stamps();
     v.counters = (int*)p->workspace;
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
+    v.range = (int*)p->vt_range;
     if (newp && ((R == 1 && n <= 8192) || (R == 4 && n <= 9216))) {
         // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
         // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks of 8 waves per CU)
@@ -1185,7 +1212,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
         // the batch (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79,
         // profiles/r03_other_shapes.log)
         const int min_units = R == 1 ? 192 : 128;
-        if (!split && (units >= min_units || (R == 1 && nsbk <= 8) || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, s);
+        if (!split && (units >= min_units || (R == 1 && nsbk <= 8) || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, s);
     }
     int rc = skipk ? 0 : (newp ? kivi_mf_run_k(&k, units, s) : run_gqa_k(k, units, s));
     if (rc) return rc;

@@ -34,6 +34,7 @@ struct GqaKArgs {
     const uint16_t* knew;
     int64_t knew_sb, knew_sh;
     int res_len;                // keys already in the residual; the new one becomes index res_len
+    const int* range;           // [B * nh_kv] range flags of the K store (kivi_mfma_layout.h: a scale >= 256 was written)
 };
 
 // Residual role of the decode step: block (unit, j) scores keys [j c, (j + 1) c) of the residual (c = ceil(L / 4), L =
@@ -121,6 +122,7 @@ struct GqaVArgs {
     unsigned long long* dbg;    // phase time stamps or null
     int win_rows;               // > 0: the window buffer is a RING of that many rows (row of token t = (win_start + t) % win_rows); 0: linear
     const int* sp_rows;         // kivi_gqa_output: [B][nh] exponent Sp of every probability row (mf_row_sp_kernel)
+    int* range;                 // [B * nh_kv] range flags of the V store: read by every block, set by the V flush
 };
 
 // phase time stamps (kivi_debug_set_stamps; tools/gqa_phases.py): 16 slots per wave, DBG instantiations only
@@ -323,6 +325,8 @@ struct GqaWindow {
                 const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
                 ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
                 ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
+                // range flag of the unit (kivi_mfma_layout.h): the token becomes part of the packed prefix with the NEXT step
+                if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) a.range[b * a.nh_kv + hk] = 1;
             }
         }
     }

@@ -131,8 +131,9 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
                  L->bits, L->group_size, L->D);
     KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL, "kivi_mf_decode_layer: bad shape (B=%d nh=%d nh_kv=%d)",
                  L->B, nh, L->nh_kv);
-    KIVI_REQUIRE(L->kt && L->vt && L->k_res && L->v_res && L->scores && L->stats && L->workspace, KIVI_EINVAL,
+    KIVI_REQUIRE(L->kt && L->vt && L->k_res && L->v_res && L->scores && L->stats && L->workspace && L->kt_range && L->vt_range, KIVI_EINVAL,
                  "kivi_mf_decode_layer: null cache buffer in the descriptor");
+    KIVI_REQUIRE((uintptr_t)L->kt_range % 4 == 0 && (uintptr_t)L->vt_range % 4 == 0, KIVI_EALIGN, "kivi_mf_decode_layer: range flags alignment");
     KIVI_REQUIRE(L->cap % 512 == 0 && kv + 1 <= L->cap, KIVI_EINVAL, "kivi_mf_decode_layer: cache capacity %lld exceeded", (long long)L->cap);
     KIVI_REQUIRE((uintptr_t)L->kt % 16 == 0 && L->kt_sb % 4 == 0 && L->kt_sh % 4 == 0 && L->kt_ss % 4 == 0 && L->kt_ss >= 6144 &&
                      (uintptr_t)L->k_res % 4 == 0 && L->kr_sb % 2 == 0 && L->kr_sh % 2 == 0 && L->kr_st % 2 == 0,
@@ -142,8 +143,8 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
     hipStream_t s = (hipStream_t)stream;
 
     auto flush_k = [&]() -> int {
-        const int rc = kivi_kt_pack(L->k_res, L->kr_sb, L->kr_sh, L->kr_st, L->kt, L->kt_sb, L->kt_sh, L->kt_ss, Tq, L->B, L->nh_kv,
-                                    R, L->D, L->group_size, L->bits, stream);
+        const int rc = kivi_kt_pack(L->k_res, L->kr_sb, L->kr_sh, L->kr_st, L->kt, L->kt_sb, L->kt_sh, L->kt_ss, L->kt_range, Tq, L->B,
+                                    L->nh_kv, R, L->D, L->group_size, L->bits, stream);
         if (rc) return rc;
         Tq += R;
         kres = 0;
@@ -189,6 +190,7 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
     a.residual_length = R; a.v_window_rows = L->v_window_rows;
     a.kt_superblocks = L->cap / 512; a.vt_superblocks = L->cap / 512;
     a.flags = L->flags;
+    a.kt_range = L->kt_range; a.vt_range = L->vt_range;
     int rc = kivi_gqa_decode(&a, stream);
     if (rc) return rc;            // nothing of the step has been committed
     kres += 1;

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     };
 
     const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.kt.sb_s * 4));
+    const int big = __builtin_amdgcn_readfirstlane(a.range[unit]);  // range flag of the unit's K store (kivi_mfma_layout.h)
     MfKSeq seq;
     seq.sb_bytes = (uint32_t)(a.kt.sb_s * 4);
     seq.sb_first = sb0;
@@ -110,11 +111,11 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
     seq.ng_total = (int)(((a.Tq < tok_end ? a.Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
     if constexpr (R == 1) {
-        mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w,
+        mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, big,
                         [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
         // R = 4: the same continuous walk (mf_k_seq4: scale requested a round ahead, the code ring runs across super-blocks)
-        mf_k_seq4<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh,
+        mf_k_seq4<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
                         [&](int, int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); }, flush_sb);
     }
 }
@@ -194,7 +195,7 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
     const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp[r]);      // <= 2^14
+        const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp[r]);      // 2^-10 .. 2^14
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -207,7 +208,7 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
                 pp = __builtin_convertvector(e * (fp2){invS[r], invS[r]}, hp2);
             }
             const _Float16 m_a = (i >= 2) ? (_Float16)64.0f : (_Float16)16.0f;                          // tokens (e & 4): 2^6, else 2^4
-            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_sp, m_sp}) * (hp2){m_a, m_a});
+            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});   // (order: see mf_row_softmax)
         }
         if (left < 8) {                                            // the end of the packed prefix falls into this lane's eight
 #pragma unroll
@@ -244,12 +245,15 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
         for (int rr = 0; rr < R; rr++) {
             M[rr] = 0.f;
             invS[rr] = 1.f;
-            sp[rr] = a.sp_rows[(int64_t)b * a.nh + h0 + rr];
+            sp[rr] = a.sp_rows[(int64_t)b * a.nh + h0 + rr];          // (mf_row_sp_kernel has applied the range flag)
         }
     } else {
+        // range flag of the unit's V store: the blocks of a unit may read different values in the step whose V flush sets it
+        // (the token it is set for is not part of this step's packed prefix); every block undoes its own 2^Sp before the hand-off
+        const int big = __builtin_amdgcn_readfirstlane(a.range[unit]);
         gqa_row_consts<R>(a, b, h0, M, invS);
 #pragma unroll
-        for (int rr = 0; rr < R; rr++) sp[rr] = mf_sp(1.0f / invS[rr]);
+        for (int rr = 0; rr < R; rr++) sp[rr] = mf_sp(1.0f / invS[rr], big);
     }
 
     const rsrc_t rx = make_rsrc(a.x + b * a.x_sb + (int64_t)h0 * a.x_sh, (uint32_t)((R - 1) * a.x_sh * 2 + ((a.Tv + 7) & ~(int64_t)7) * 2));
@@ -353,7 +357,8 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
 }
 
 // row maximum of given fp16 probabilities -> Sp of the row (kivi_gqa_output): 2^Sp * max p in [1, 2) (clamped to [0, 14])
-__global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64_t p_sb, int64_t p_sh, int nh, int64_t T, int* sp) {
+__global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64_t p_sb, int64_t p_sh, int nh, int nh_kv, int64_t T,
+                                                        const int* range, int* sp) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const int b = row / nh, h = row - b * nh;
@@ -364,7 +369,8 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
     if (threadIdx.x == 0) {
         int e = 0;
         if (m > 0.f && m < __builtin_inff()) e = -((int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u) - 127);
-        sp[row] = e < 0 ? 0 : (e > 14 ? 14 : e);
+        // range flag of the (batch row, kv head) the row reads (mf_sp)
+        sp[row] = (e < 0 ? 0 : (e > 14 ? 14 : e)) - (range[b * nh_kv + h / (nh / nh_kv)] ? KIVI_MF_BIG_SHIFT : 0);
     }
 }
 
@@ -372,7 +378,8 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 
 // The whole decode step of one (batch row, head) in one block of NW waves.  Dynamic LDS: the score / p'' row (n_pad halves).
 // DBG (tools/mf_row_phases.py): every wave stamps the shader clock at its phase boundaries into av.dbg
-template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true>
+// DUMP (KIVI_GQA_DUMP_SCORES, tests): the fp16 row the softmax consumes (scaled, mask added) also goes to ak.out
+template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, bool DUMP = false>
 __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int NTH = NW * 64;
     extern __shared__ uint16_t row[];                              // [n_pad] fp16 scores, then p''
@@ -396,6 +403,8 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
     const int L = ak.res_len + 1;                                  // residual keys incl. the new one
     const int n = Tq + L;                                          // row length
+    // range flags of the unit's stores (kivi_mfma_layout.h): where q'' / p'' are placed; read before this step's V flush can set one
+    const int kbig = __builtin_amdgcn_readfirstlane(ak.range[unit]), vbig = __builtin_amdgcn_readfirstlane(av.range[unit]);
 
     const uint16_t* qrow = ak.q + b * ak.q_sb + (int64_t)hk * ak.q_sh;
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
         const int last = wave + (seq.n_sb - 1) * NW;                // this wave's last super-block
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave],
+        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], kbig,
                          [&](int sb, int tt, float v) {
                              const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
                              row[sb * KIVI_MF_SB_TOKENS + tt] = h;
@@ -470,7 +479,8 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4)>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds);
+    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4), DUMP>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vbig,
+                                                              DUMP ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
     __syncthreads();
     stamp(7);
 
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
 // The whole decode step of one (batch row, kv head) with its four query heads in one block of NW waves (grouped queries,
 // rows whose four score rows fit the LDS: 4 n fp16 <= 72 KiB, two blocks per CU): no score / statistics round trip through
 // memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
-template <int KRING, int VRING, int NW, bool DBG = false>
+template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     extern __shared__ uint16_t rows[];                             // [R][n_pad]
@@ -543,6 +553,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
     const int L = ak.res_len + 1;
     const int n = Tq + L;
+    const int kbig = __builtin_amdgcn_readfirstlane(ak.range[unit]), vbig = __builtin_amdgcn_readfirstlane(av.range[unit]);   // see mf_row_kernel
     const uint16_t* q_h0 = ak.q + b * ak.q_sb + (int64_t)h0 * ak.q_sh;
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq4<KRING>(rk, seq, q_h0, ak.q_sh, [&](int sb, int tt, int r, float v) {
+        mf_k_seq4<KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v) {
             const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);     // the rows hold the SCALED scores (:339)
             rows[r * n_pad + sb * KIVI_MF_SB_TOKENS + tt] = h;
             mxl[r] = __builtin_fmaxf(mxl[r], h2f_bits(h));                                 // r is a constant after unrolling
@@ -615,7 +626,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
 #pragma unroll 1
     for (int r = 0; r < R; r++) {
         const float mxr = r == 0 ? mxl[0] : (r == 1 ? mxl[1] : (r == 2 ? mxl[2] : mxl[3]));
-        const int sp = mf_row_softmax<NTH, (9216 + NTH * 4 - 1) / (NTH * 4)>(rows + r * n_pad, n, n_pad, Tv, mxr, mrow, pw[r], sm_lds);
+        const int sp = mf_row_softmax<NTH, (9216 + NTH * 4 - 1) / (NTH * 4), DUMP>(
+            rows + r * n_pad, n, n_pad, Tv, mxr, mrow, pw[r], sm_lds, vbig, DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
         if (threadIdx.x == 0) sp_lds[r] = sp;
     }
     __syncthreads();
@@ -705,13 +717,35 @@ int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
     return kivi_launch_status("mf_v");
 }
 
-int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int64_t T, int* sp, hipStream_t s) {
-    hipLaunchKernelGGL(mf_row_sp_kernel, dim3((unsigned)(B * nh)), dim3(256), 0, s, (const uint16_t*)p, p_sb, p_sh, nh, T, sp);
+int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int nh_kv, int64_t T, const int* range, int* sp,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(mf_row_sp_kernel, dim3((unsigned)(B * nh)), dim3(256), 0, s, (const uint16_t*)p, p_sb, p_sh, nh, nh_kv, T, range, sp);
     return kivi_launch_status("mf_row_sp");
 }
 
-// the whole step in one launch (R = 1, rows <= 8192 keys); returns KIVI_EUNSUPPORTED when the shape does not qualify
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream_t s) {
+// > 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (the attribute belongs to the function object of the
+// device that is current): tracked per device ordinal, return code checked.
+template <typename K>
+static int mf_lds_opt_in(K kernel, unsigned long long* done_mask, const char* what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { kivi_set_error("%s: hipGetDevice: %s", what, hipGetErrorString(e)); return (int)e; }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return 0;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) {
+        kivi_set_error("%s: opting in to 80 KiB of dynamic LDS failed on device %d: %s", what, dev, hipGetErrorString(e));
+        return (int)e;
+    }
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return 0;
+}
+
+// The whole step in one launch: nh == nh_kv (rows <= 8192 keys: mf_row_kernel, 4 blocks of 4 waves per CU, 8 waves per row
+// for <= 512 rows) or nh / nh_kv == 4 (rows <= 9216 keys: mf_row4_kernel, the four score rows of a unit in one block of 4
+// waves, 2 blocks per CU).  KIVI_EUNSUPPORTED (with a message) when the shape does not qualify.  dump != 0: the test
+// instantiations that also write the softmax input rows to the score buffer (KIVI_GQA_DUMP_SCORES).
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump, hipStream_t s) {
     const GqaKArgs& k = *(const GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = k.Tq + k.res_len + 1;
@@ -719,38 +753,45 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     const dim3 grid((unsigned)units);
     if (k.ratio == 4) {
         // four score rows in the LDS (two blocks per CU): up to 9216 keys
-        if (n > 9216) return KIVI_EUNSUPPORTED;
+        KIVI_REQUIRE(n <= 9216, KIVI_EUNSUPPORTED, "mf_row4: rows of %lld keys do not fit the LDS (<= 9216)", (long long)n);
         size_t lds = (size_t)4 * n_pad * 2;
         const size_t fin = (size_t)2 * 8 * 4 * 128 * 4;           // the per-wave partial sums reuse the rows
         if (lds < fin) lds = fin;
         // 4 waves with up to 256 registers (two blocks per CU): 103 us per layer at BASELINE config 4 against 123 for 8 waves of
         // 128 registers (spills)
-        static bool attr_set = false;
-        if (!attr_set) {                                           // > 64 KiB of dynamic LDS needs the opt-in
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-#ifdef KIVI_TUNING
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<8, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)mf_row4_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-#endif
-            attr_set = true;
+        static unsigned long long opt_main = 0, opt_dump = 0;
+        if (dump) {
+            const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, true>, &opt_dump, "mf_row4");
+            if (rc) return rc;
+            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, true>), grid, dim3(256), lds, s, k, v, n_pad);
+            return kivi_launch_status("mf_row4");
         }
 #ifdef KIVI_TUNING
+        static unsigned long long opt_t[5] = {0, 0, 0, 0, 0};
         static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<waves><K ring><V ring>"
         const int cfg = fr4 ? atoi(fr4) : 443;
         // (8 waves of 128 registers spill: 123-139 us, profiles/r03_config4_row4.log)
-        if (v.dbg) { KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, true>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
-        if (cfg == 423) { KIVI_LAUNCH_LDS((mf_row4_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
-        if (cfg == 483) { KIVI_LAUNCH_LDS((mf_row4_kernel<8, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
-        if (cfg == 484) { KIVI_LAUNCH_LDS((mf_row4_kernel<8, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
-        if (cfg == 444) { KIVI_LAUNCH_LDS((mf_row4_kernel<4, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad); return kivi_launch_status("mf_row4"); }
+#define KIVI_ROW4_VARIANT(IDX, ...)                                                                \
+    do {                                                                                           \
+        const int rc = mf_lds_opt_in(mf_row4_kernel<__VA_ARGS__>, &opt_t[IDX], "mf_row4");         \
+        if (rc) return rc;                                                                         \
+        KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad);      \
+        return kivi_launch_status("mf_row4");                                                      \
+    } while (0)
+        if (v.dbg) KIVI_ROW4_VARIANT(0, 4, 3, 4, true);
+        if (cfg == 423) KIVI_ROW4_VARIANT(1, 2, 3, 4);
+        if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
+        if (cfg == 484) KIVI_ROW4_VARIANT(3, 8, 4, 4);
+        if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
+#undef KIVI_ROW4_VARIANT
 #endif
+        const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");
+        if (rc) return rc;
         KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
         return kivi_launch_status("mf_row4");
     }
-    if (k.ratio != 1 || n > 8192) return KIVI_EUNSUPPORTED;
+    KIVI_REQUIRE(k.ratio == 1 && n <= 8192, KIVI_EUNSUPPORTED, "mf_row: nh / nh_kv = %d with rows of %lld keys has no one-launch kernel",
+                 k.ratio, (long long)n);
     const size_t lds = (size_t)n_pad * 2;
     // (K ring, V ring) = (2, 3) code blocks in flight: 76.2 us per launch at the bench shape against 77.2 (2, 2), 76.7 (2, 4),
     // 78.4 (4, 2), 78.2 (4, 3) -- profiles/r03_row_rings.log
@@ -769,6 +810,11 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, hipStream
     // few rows (under ~2 four-wave blocks per CU): eight waves per row, the row's own waves hide the latency
     static const char* f8 = KIVI_TUNE_ENV("KIVI_MF_ROW_NW8");            // tuning builds: 0 / 1 forces either
     const bool nw8 = f8 ? atoi(f8) != 0 : units <= 512;         // 256 rows: 30.3 -> 26.8 us, 384: 39.7 -> 37.0, 512: 45.8 -> 44.0, 768: 61.1 vs 65.4 (profiles/r03_other_shapes.log)
+    if (dump) {
+        if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8, false, true, true>), grid, dim3(512), lds, s, k, v, n_pad);
+        else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, true, true>), grid, dim3(256), lds, s, k, v, n_pad);
+        return kivi_launch_status("mf_row");
+    }
     if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
     else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");

@@ -50,17 +50,24 @@ __device__ __forceinline__ MfB mf_views(uint32_t w) {
 
 // ------------------------------------------------------------------------------------------------ q operand
 // Lane (m, kb) of a wave, m = lane & 15: the query of head r = m % R, channels 32 c + 8 kb + 2 i (+ 1) as fp16 pairs,
-// normalised to max |q| in [1, 2) (exponent sq, so A = q'' * scale stays a normal fp16 for any realistic scale) and
-// pre-multiplied by 2^aexp(i).  The same registers are the A operand's q factor (row m) and, because a lane's A row and
-// B column have the same index, the B operand of the zero-point product (column m -> head m % R).
+// normalised to max |q| in [1, 2) (exponent sq) -- or, when the unit's store holds a scale >= 256 (`big`: the range flag of
+// kivi_mfma_layout.h), to [2^-10, 2^-9) (exponent sa = sq - 10), so that A = q'' * scale * 2^(4 | 6) is a finite fp16 for EVERY
+// finite scale -- and pre-multiplied by 2^aexp(i).  The same registers are the A operand's q factor (row m) and, because a
+// lane's A row and B column have the same index, the B operand of the zero-point product (column m -> head m % R): that
+// product takes them back to [1, 2) first (mf_zfac), so the zero-point sums do not depend on the placement.
 template <int R>
 struct MfQ {
     uint32_t qq[4][4];
-    int sq;
+    int sq, sa;        // exponent of the zero-point operand, exponent of the A operand
 };
 
+// packed factor that takes a q'' register (times 2^aexp(i), placed at sa) to q * 2^sq: 2^-aexp(i), or 2^(10 - aexp(i))
+__device__ __forceinline__ uint32_t mf_zfac(int i, int big) {
+    return i < 2 ? (big ? 0x54005400u : 0x2C002C00u) : (big ? 0x4C004C00u : 0x24002400u);
+}
+
 template <int R>
-__device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, MfQ<R>& Q) {
+__device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, MfQ<R>& Q, int big) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     const uint16_t* qrow = q_h0 + (int64_t)(m % R) * q_sh + 8 * kb;
@@ -79,12 +86,13 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
     amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32));
     const int ex = (int)(amax >> 10);                              // biased exponent of the row maximum (0: zero / subnormal)
     Q.sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);               // inf / nan rows: no scaling (they poison the row anyway)
+    Q.sa = Q.sq - (big ? KIVI_MF_BIG_SHIFT : 0);
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), Q.sq + aexp(i));
-            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), Q.sq + aexp(i));
+            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), Q.sa + aexp(i));
+            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), Q.sa + aexp(i));
             Q.qq[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
         }
 }
@@ -110,8 +118,9 @@ struct MfKSeq {
 // done(super-block index, its number of groups) is called when the last score of a super-block has been handed to sink.
 // q_lds: 64 words of this wave's LDS (the normalised q operand is parked there: kept in registers, it and the loop-invariant
 // B operand of the zero-point product hipcc derives from it hold 32 registers across the whole loop).
+// big: the unit's range flag (wave-uniform; mf_load_q).
 template <int RING, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, Sink&& sink, Done&& done) {
+__device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, int big, Sink&& sink, Done&& done) {
     static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -162,14 +171,16 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32));
     const int ex = (int)(amax >> 10);
     const int sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);
+    const int sa = sq - (big ? KIVI_MF_BIG_SHIFT : 0);               // placement of the A operand (mf_load_q)
+    const uint32_t zf01 = mf_zfac(0, big), zf23 = mf_zfac(2, big);
     {
         uint32_t qq0[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sq + aexp(i));
-                const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sq + aexp(i));
+                const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sa + aexp(i));
+                const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sa + aexp(i));
                 qq0[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
             }
         if (m == 0) {
@@ -178,7 +189,7 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const float cmul = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sq);
+    const float cmul = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sa);
     const float zmul = __builtin_ldexpf(0.5f, -sq);                 // 0.5: the hi and the lo lane of a group each add the zero-point term
     const int n_half = (W.ng_total + 7) >> 3;
     for (int hq = 0; hq < n_half; hq++) {
@@ -197,7 +208,7 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
         f4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const h8 bq = as_h8(pk_mul(qq[c][0], zfac(0)), pk_mul(qq[c][1], zfac(1)), pk_mul(qq[c][2], zfac(2)), pk_mul(qq[c][3], zfac(3)));
+            const h8 bq = as_h8(pk_mul(qq[c][0], zf01), pk_mul(qq[c][1], zf01), pk_mul(qq[c][2], zf23), pk_mul(qq[c][3], zf23));
             z = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), bq, z, 0, 0, 0);
         }
         // the zero-point sums are pinned HERE: hipcc otherwise sinks their MFMAs below the group loop (where z is first
@@ -249,13 +260,14 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
 
 // Zero-point sums of a whole super-block for R = 4: zz[j] at lane (n = group, any kb) = sum_d q[head j, d] * mn[d, group n]
 // in score units.  `mv`: this lane's 4 x 16 bytes of the zero points of group n (B layout = the row layout).
-__device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, const float* zmul, float* zz) {
+__device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, const float* zmul, float* zz, int big) {
     f4 z = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t zf01 = mf_zfac(0, big), zf23 = mf_zfac(2, big);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        // rows = heads (A = q'' without the 2^aexp), columns = groups
-        const h8 aq = as_h8(pk_mul(Q.qq[c][0], zfac(0)), pk_mul(Q.qq[c][1], zfac(1)), pk_mul(Q.qq[c][2], zfac(2)),
-                            pk_mul(Q.qq[c][3], zfac(3)));
+        // rows = heads (A = q * 2^sq: q'' without the 2^aexp and the placement), columns = groups
+        const h8 aq = as_h8(pk_mul(Q.qq[c][0], zf01), pk_mul(Q.qq[c][1], zf01), pk_mul(Q.qq[c][2], zf23),
+                            pk_mul(Q.qq[c][3], zf23));
         z = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq, as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), z, 0, 0, 0);
     }
     // row 4 kb' + j carries head (4 kb' + j) % 4 = j for every kb': register j = head j in every lane
@@ -276,7 +288,7 @@ __device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, con
 template <int V> struct mf_ic { static constexpr int value = V; };
 
 template <int RING, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, Sink&& sink, Done&& done) {
+__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -314,13 +326,13 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
         __builtin_amdgcn_sched_barrier(0);
     }
     MfQ<4> Q;
-    mf_load_q<4>(q_h0, q_sh, Q);
+    mf_load_q<4>(q_h0, q_sh, Q, big);
     float zmul[4], cmul[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int sqj = __shfl(Q.sq, j);                            // lane j (kb = 0, row j) holds head j's exponent
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
-        cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - sqj);
+        cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT + (big ? KIVI_MF_BIG_SHIFT : 0) - sqj);
     }
     float zz[4] = {0.f, 0.f, 0.f, 0.f};
     // one round = 4 groups on ring slots S0 .. S0 + 3 (mod RING); a ring of 8 alternates S0 = 0, 4 (two rounds per loop trip,
@@ -329,7 +341,7 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
         constexpr int S0 = decltype(slot0)::value;
         const int sbi = rq >> 2;
         if ((rq & 3) == 0) {                                        // a new super-block: its zero-point sums, then the next one's zero points
-            mf_k_zero4(Q, zv, zmul, zz);
+            mf_k_zero4(Q, zv, zmul, zz, big);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
         uint32_t Ah[4][4], Al[4][4];
@@ -626,10 +638,11 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float
 }
 
 // Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = clamp(floor(log2 sum), 0, 14),
-// so that p'' * scale stays a normal fp16 whatever the row length
-__device__ __forceinline__ int mf_sp(float sum) {
+// so that p'' * scale stays a normal fp16 whatever the row length; `big` (the range flag of the unit's V store,
+// kivi_mfma_layout.h): 2^KIVI_MF_BIG_SHIFT lower, so that p'' * scale <= 2^-4 * scale is finite for every finite scale.
+__device__ __forceinline__ int mf_sp(float sum, int big) {
     const int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
-    return e < 0 ? 0 : (e > 14 ? 14 : e);
+    return (e < 0 ? 0 : (e > 14 ? 14 : e)) - (big ? KIVI_MF_BIG_SHIFT : 0);
 }
 // fp16 p -> p'' for token t: 2^(Sp + 4) for (t & 7) < 4, 2^(Sp + 6) otherwise (the register i = (t & 7) >> 1 of the operand)
 __device__ __forceinline__ uint16_t mf_scale_p(uint16_t p, int sp, int t) {
@@ -668,9 +681,11 @@ __device__ __forceinline__ uint32_t mf_scale_pair(uint32_t hpair, float inv) {
     return d;
 }
 
-template <int NTH, int SMC>
+// big: the range flag of the unit's V store (mf_sp).  dump (test instantiations: KIVI_GQA_DUMP_SCORES): the fp16 row as the
+// softmax consumes it (scaled, mask added) also goes to this row of the caller's score buffer.
+template <int NTH, int SMC, bool DUMP = false>
 __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
-                                              uint16_t* pw_row, float* sm_lds) {
+                                              uint16_t* pw_row, float* sm_lds, int big, uint16_t* dump = nullptr) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -714,6 +729,9 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
         if (c < nch) {
             const int j0 = c * SCH + (int)threadIdx.x * 4;
             const u32x2v raw = *(const u32x2v*)(row + (j0 < n_pad ? j0 : n_pad - 4));     // past the row: -inf -> exp = 0
+            if constexpr (DUMP) {
+                if (dump && j0 < n) *(u32x2v*)(dump + j0) = raw;    // (rows are padded to a multiple of 8 scores)
+            }
             const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;   // kivi_exp(x - M), two at a time
             const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
             xe[c][0] = (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
@@ -729,8 +747,8 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
 #pragma unroll
     for (int w = 1; w < NW; w++) sum += sm_lds[NW + w];
     const float inv = 1.0f / sum;
-    const int sp = mf_sp(sum);
-    const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp);   // <= 2^14
+    const int sp = mf_sp(sum, big);
+    const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp);   // 2^-10 .. 2^14
     const f2v inv2 = {inv, inv};
 #pragma unroll
     for (int c = 0; c < SMC; c++) {
@@ -738,13 +756,15 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
         if (j0 < n_pad) {
             u32x2v o = {0u, 0u};
             if (c < nch) {
-                // p = fp16(e / sum) first (the reference's cast, :375), then the exact power-of-two scalings
+                // p = fp16(e / sum) first (the reference's cast, :375), then the power-of-two scalings: 2^(4 | 6) first (p <= 1:
+                // exact), then 2^Sp (exact for Sp >= 0; with the range flag Sp may be negative and the smallest probabilities
+                // of a row round once, 2^-19 of the row's largest p'' at worst)
                 const h2v p01 = __builtin_convertvector(xe[c][0] * inv2, h2v);
                 const h2v p23 = __builtin_convertvector(xe[c][1] * inv2, h2v);
                 if (j0 + 4 <= Tv) {
                     const _Float16 m_a = (j0 & 4) ? (_Float16)64.0f : (_Float16)16.0f;
-                    o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_sp, m_sp}) * (h2v){m_a, m_a});
-                    o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_sp, m_sp}) * (h2v){m_a, m_a});
+                    o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
+                    o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
                 } else {                                           // the chunk that holds the end of the packed prefix / the window
                     // (whole-register casts: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 -- hipcc 7.2)
                     const uint32_t w01 = __builtin_bit_cast(uint32_t, p01), w23 = __builtin_bit_cast(uint32_t, p23);

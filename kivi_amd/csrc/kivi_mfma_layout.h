@@ -50,6 +50,15 @@
 #define KIVI_MF_SB_WORDS 6144
 #define KIVI_MF_SHIFT 4                // A operands carry 2^(4 + 2 (i >> 1))
 #define KIVI_MF_PROD_SHIFT 12          // accumulated products = a * code * 2^-12
+// Range of the fp16 A operands (q * scale, p * scale).  With q normalised to [1, 2) (times up to 2^6) and the probabilities
+// of a row to <= 2^6, a group scale >= 512 would overflow the fp16 hi part where the reference's fp32 scale * code + zero
+// (quant/csrc/gemv_cuda.cu:407-413) stays finite.  Every kernel that WRITES scales into a store (kivi_kt_pack, kivi_vt_pack,
+// the relayouts, the V flush of the decode step) records a sticky per-(batch row, kv head) flag when it sees a scale whose
+// fp16 bits are >= KIVI_MF_BIG_SCALE_BITS (256.0; NaN / inf included); the consumers then place q (or the probabilities)
+// 2^KIVI_MF_BIG_SHIFT lower for that unit: 128 * 65504 * 2^-10 < 2^13, so every finite fp16 scale is safe, and units
+// that never saw such a scale compute bit for bit what they did before the flag existed.
+#define KIVI_MF_BIG_SCALE_BITS 0x5C00u
+#define KIVI_MF_BIG_SHIFT 10
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int kt_word(int tt, int d) { return ((tt & 15) + 16 * ((d >> 3) & 3)) * 4 + (d >> 5); }

@@ -21,15 +21,40 @@ def supported(k_bits: int, v_bits: int, group_size: int, head_dim: int, residual
             and ratio in (1, 4, 8))
 
 
+def _flag_words(B: int, nh_kv: int) -> int:
+    return (B * nh_kv + 63) // 64 * 64          # the flags take whole 256-byte lines behind the super-blocks
+
+
 def alloc_store(B: int, nh_kv: int, n_sb: int, device) -> torch.Tensor:
     """Zero-initialised storage of n_sb super-blocks per (batch row, kv head): logical shape (B, nh_kv, n_sb, 6144) int32,
-    in memory the super-block index sits outside the head index (the super-blocks in use form one dense region)."""
-    return torch.zeros((B, n_sb, nh_kv, SB_WORDS), dtype=torch.int32, device=device).permute(0, 2, 1, 3)
+    in memory the super-block index sits outside the head index (the super-blocks in use form one dense region).
+    The store's RANGE FLAGS (include/kivi_hip.h: B * nh_kv int32, set by whatever writes a scale >= 256 into the store)
+    live in the same allocation, right behind the super-blocks: `range_flags(store)` is the (B, nh_kv) view, and every
+    wrapper below passes it along with the store."""
+    main = B * n_sb * nh_kv * SB_WORDS
+    flat = torch.zeros(main + _flag_words(B, nh_kv), dtype=torch.int32, device=device)
+    return flat[:main].view(B, n_sb, nh_kv, SB_WORDS).permute(0, 2, 1, 3)
+
+
+def range_flags(store: torch.Tensor) -> torch.Tensor:
+    """(B, nh_kv) int32 view of a store's range flags (the store must come from alloc_store)."""
+    B, nh_kv, n_sb = store.shape[0], store.shape[1], store.shape[2]
+    main = B * n_sb * nh_kv * SB_WORDS
+    stg = store.untyped_storage()
+    if store.storage_offset() != 0 or stg.nbytes() != (main + _flag_words(B, nh_kv)) * 4:
+        raise ValueError("not a store of kivi_amd.quant.mfma.alloc_store (its range flags live behind the super-blocks)")
+    return torch.empty(0, dtype=torch.int32, device=store.device).set_(stg, main, (B, nh_kv), (nh_kv, 1))
+
+
+def copy_store(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """The first src.shape[2] super-blocks of `dst` and its range flags <- `src` (cache growth, clone)."""
+    dst[:, :, : src.shape[2]].copy_(src)
+    range_flags(dst).copy_(range_flags(src))
 
 
 def _st(store: torch.Tensor):
     assert store.dtype == torch.int32 and store.dim() == 4 and store.shape[3] == SB_WORDS and store.stride(3) == 1
-    return _lib.ptr(store), store.stride(0), store.stride(1), store.stride(2)
+    return _lib.ptr(store), store.stride(0), store.stride(1), store.stride(2), _lib.ptr(range_flags(store))
 
 
 def kt_pack(k: torch.Tensor, store: torch.Tensor, token_offset: int = 0, group_size: int = 32, bits: int = 2) -> None:

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/kivi_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in kivi_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.kivi_abi_version() == 1
+    assert lib.kivi_abi_version() == 2
 
 
 def test_variant_tables(lib):
@@ -284,7 +284,7 @@ def _gqa_args(**over):
              vnew=0x1000, vnew_sb=2 * 128, vnew_sh=128, v_flush=1,
              scores=0x1000, s_sb=8 * 528, s_sh=528, stats=0x1000, stats_bytes=2 * 8 * 5 * 2 * 4,
              workspace=0x1000, workspace_bytes=65536 + 4 * (1 + 1) * 2 * 4 * 128 * 4, out=0x1000, out_sb=8 * 128, out_sh=128,
-             residual_length=32, v_window_rows=65, kt_superblocks=2, vt_superblocks=2, flags=0)
+             residual_length=32, v_window_rows=65, kt_superblocks=2, vt_superblocks=2, flags=0, kt_range=0x1000, vt_range=0x1000)
     f.update(over)
     return _lib.GqaDecodeArgs(**f)
 
@@ -299,6 +299,8 @@ def _gqa_args(**over):
     (dict(workspace_bytes=65536), None, b"workspace"),
     (dict(workspace_bytes=65536 + 4 * 1 * 2 * 4 * 128 * 4), None, b"workspace"),   # one slot per slice is not enough: + the window block's
     (dict(vnew=0x1004), None, b"value rows"),
+    (dict(kt_range=None), None, b"range flags"),              # every store comes with its range flags (include/kivi_hip.h)
+    (dict(vt_range=0x1002), None, b"range flags"),
     # what the step writes must lie inside the caller's buffers: K append row, V append row, the VT slot of the
     # token leaving the window, the packed prefix
     (dict(k_res_len=32, Tq=480, Tv=480), None, b"residual_length"),
@@ -332,13 +334,13 @@ def _mf_layer_desc(**over):
              kt=0x1000, kt_sb=2 * 6144, kt_sh=6144, kt_ss=2 * 2 * 6144, vt=0x1000, vt_sb=2 * 6144, vt_sh=6144, vt_ss=2 * 2 * 6144,
              k_res=0x1000, kr_sb=2 * 32 * 128, kr_sh=32 * 128, kr_st=128, v_res=0x1000, vr_sb=2 * 33 * 128, vr_sh=33 * 128, vr_st=128,
              scores=0x1000, s_sb=8 * 520, s_sh=520, stats=0x1000, stats_bytes=1 << 16, workspace=0x1000, workspace_bytes=1 << 20,
-             flags=4)
+             flags=4, kt_range=0x1000, vt_range=0x1000)
     f.update(over)
     return _lib.MfLayerDesc(**f)
 
 
 @pytest.mark.parametrize("over,msg", [(dict(bits=4), b"2-bit"), (dict(residual_length=48), b"inconsistent lengths"),
-                                      (dict(kt=None), b"null"), (dict(cap=64), b"capacity"), (dict(kt_ss=100), b"alignment"),
+                                      (dict(kt=None), b"null"), (dict(vt_range=None), b"null"), (dict(cap=64), b"capacity"), (dict(kt_ss=100), b"alignment"),
                                       (dict(v_window_rows=32), b"ring window"), (dict(s_pitch=90), b"score rows")])
 def test_mf_decode_layer_refuses_before_anything_is_committed(lib, over, msg):
     """kivi_mf_decode_layer (the layer step on the matrix-pipe layout: kivi_gqa_decode + bookkeeping + kivi_kt_pack flush):
@@ -389,6 +391,75 @@ def test_layer_cache_factory_picks_the_layout():
     assert isinstance(make_layer_cache(KiviConfig(2, 2, 64, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
     mf.reserve(3000)
     assert mf.n_sb == 6 and mf.cap >= 3000
+
+
+def test_store_wrappers_refuse_without_range_flags(lib):
+    """kivi_kt_pack / kivi_vt_pack / kivi_gqa_scores / kivi_gqa_output / the relayouts towards the layout refuse a store without
+    its range flags before touching a device (include/kivi_hip.h, RANGE FLAGS); reading a store (to_ref) does not need them."""
+    st = (0x1000, 2 * 6144, 6144, 2 * 2 * 6144)
+    assert lib.kivi_kt_pack(0x1000, 8192, 4096, 128, *st, None, 0, 1, 2, 32, 128, 32, 2, None) < 0 and b"range flags" in lib.kivi_last_error()
+    assert lib.kivi_vt_pack(0x1000, 8192, 4096, 128, *st, None, 1, 2, 32, 128, 32, 2, None) < 0 and b"range flags" in lib.kivi_last_error()
+    assert lib.kivi_gqa_scores(0x1000, 1024, 128, *st, None, 0x1000, 1024, 128, 1, 8, 2, 128, 32, 32, 2, None) < 0
+    assert b"range flags" in lib.kivi_last_error()
+    assert lib.kivi_gqa_output(0x1000, 1024, 128, *st, None, 0x1000, 1024, 128, 1, 8, 2, 128, 32, 32, 2, 0x1000, 1 << 20, None) < 0
+    assert b"range flags" in lib.kivi_last_error()
+    rel = (0x1000, 4096, 2048, 16, 0x1000, 0x1000, 1024, 512, 4)
+    assert lib.kivi_kt_relayout(0, *st, None, *rel, 1, 2, 32, 128, 32, 2, None) < 0 and b"range flags" in lib.kivi_last_error()
+    assert lib.kivi_vt_relayout(0, *st, None, *rel, 1, 2, 32, 128, 32, 2, None) < 0 and b"range flags" in lib.kivi_last_error()
+    assert lib.kivi_kt_relayout(1, *st, None, *rel, 1, 2, 0, 128, 32, 2, None) == 0        # (T = 0: nothing to launch)
+
+
+def test_store_range_flags_travel_with_the_store():
+    """kivi_amd.quant.mfma keeps a store's range flags in the same allocation (behind the super-blocks): growth and clone carry
+    them along, prefill of a reused cache clears them, foreign tensors are refused."""
+    from kivi_amd.attention import KiviConfig, make_layer_cache
+    from kivi_amd.quant import mfma
+    st = mfma.alloc_store(2, 3, 2, "cpu")
+    fl = mfma.range_flags(st)
+    assert fl.shape == (2, 3) and not fl.any() and fl.data_ptr() == st.data_ptr() + 2 * 2 * 3 * 6144 * 4
+    fl[1, 2] = 1
+    st.fill_(-1)                                         # the view covers the super-blocks only
+    assert mfma.range_flags(st).tolist() == [[0, 0, 0], [0, 0, 1]]
+    with pytest.raises(ValueError):
+        mfma.range_flags(torch.zeros((2, 2, 3, 6144), dtype=torch.int32).permute(0, 2, 1, 3))
+    lc = make_layer_cache(KiviConfig(2, 2, 32, 32), 2, 3, 128, 600, "cpu", num_heads=3)
+    mfma.range_flags(lc.vt)[0, 1] = 1
+    lc.reserve(3000)
+    assert lc.n_sb == 6 and mfma.range_flags(lc.vt).tolist() == [[0, 1, 0], [0, 0, 0]] and not mfma.range_flags(lc.kt).any()
+    c = lc.clone()
+    assert mfma.range_flags(c.vt).tolist() == [[0, 1, 0], [0, 0, 0]] and c.vt.data_ptr() != lc.vt.data_ptr()
+
+
+def test_product_python_reads_the_environment_only_through_the_tuning_module():
+    """the product reads no tuning knob unless the process was started with KIVI_TUNING=1.  The only module
+    of the package that touches os.environ is kivi_amd/_tuning.py (build.py: the HIPCC path of the build script)."""
+    import glob
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "kivi_amd", "**", "*.py"), recursive=True)):
+        rel = os.path.relpath(path, ROOT)
+        if rel in ("kivi_amd/_tuning.py", "kivi_amd/build.py"):
+            continue
+        if re.search(r"\bos\.environ\b|\bgetenv\b", open(path).read()):
+            offenders.append(rel)
+    assert not offenders, offenders
+    import importlib
+    from kivi_amd import _tuning
+    saved = {k: os.environ.get(k) for k in ("KIVI_TUNING", "KIVI_NO_MFMA_LAYOUT")}
+    try:
+        os.environ["KIVI_NO_MFMA_LAYOUT"] = "1"
+        os.environ.pop("KIVI_TUNING", None)
+        importlib.reload(_tuning)
+        assert not _tuning.ENABLED and not _tuning.flag("KIVI_NO_MFMA_LAYOUT") and _tuning.knob("KIVI_NO_MFMA_LAYOUT", "d") == "d"
+        os.environ["KIVI_TUNING"] = "1"
+        importlib.reload(_tuning)
+        assert _tuning.ENABLED and _tuning.flag("KIVI_NO_MFMA_LAYOUT")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        importlib.reload(_tuning)
 
 
 def test_tuning_build_still_compiles():
