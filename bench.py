@@ -176,7 +176,6 @@ def dry_run(args, rank, world, dist):
         time.sleep(0.002 * (rank + 1))            # rank r is (r + 1) x slower: the slowest rank sets the job's time
     barrier(dist)
     own = time.perf_counter() - t0
-    peak_timed = torch.cuda.max_memory_allocated(dev)     # caches + per-step scratch: before this script's own measurement harness allocates
     elapsed = max_over_ranks(own, dist, dev)
     per_rank = gather_over_ranks(own, dist, dev)
     if rank == 0:

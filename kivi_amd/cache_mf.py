@@ -7,10 +7,11 @@ the relayout kernels.  What differs is where the packed codes live: super-blocks
 of v_mfma_f32_16x16x32_f16, so that the nh / nh_kv query heads of a kv head share every code on the matrix pipe instead of
 costing one FMA each (the shared-unpack VALU kernels run at ~0.35 of the HBM roofline for nh / nh_kv = 4).
 
-A decode step is ONE library call (kivi_mf_decode_layer: lengths, window compaction, the launches, the K flush through
-kivi_kt_pack every R steps).  Launches: multi-head rows of <= 8192 keys -> one (mf_row_kernel); otherwise two (packed
-qK^T + residual scores + K append + softmax statistics, then softmax-on-the-fly + packed sV + fp16 window + V append /
-quantise).
+A decode step is ONE library call (kivi_mf_decode_layer: lengths, the launches, the K flush through kivi_kt_pack every R
+steps).  Launches: rows whose scores fit the LDS (nh = nh_kv: <= 8192 keys, nh / nh_kv = 4: <= 9216) and enough of them ->
+one (mf_row_kernel / mf_row4_kernel); otherwise two (packed qK^T + residual scores + K append + softmax statistics, then
+softmax-on-the-fly + packed sV + fp16 window + V append / quantise).  Every store carries range flags (quant/mfma.py) that
+keep the fp16 operands of the matrix pipe finite for any finite scale.
 """
 from __future__ import annotations
 
@@ -78,10 +79,9 @@ class KiviLayerCacheMF:
         self.kt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
         self.vt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=device)
-        # fp16 value window: a RING of R + 1 rows for the round-3 kernels (nh / nh_kv in {1, 4}: nothing is ever compacted);
-        # the round-2 kernels (nh / nh_kv = 8) keep the linear buffer of 2 R + 1 rows with a compaction every ~R steps
-        self.ring = (num_heads // num_kv_heads) in (1, 4) and not _tuning.flag("KIVI_MF_NO_RING")   # (tuning sessions: A/B)
-        self.v_res = torch.empty((batch, num_kv_heads, (R + 1) if self.ring else (2 * R + 1), head_dim), dtype=dtype, device=device)
+        # fp16 value window: a RING of R + 1 rows (row of window token t = (v_res_start + t) mod rows): nothing is ever compacted
+        self.ring = True
+        self.v_res = torch.empty((batch, num_kv_heads, R + 1, head_dim), dtype=dtype, device=device)
         self.k_quant_len = 0
         self.k_res_len = 0
         self.v_quant_len = 0

@@ -1,5 +1,4 @@
-// Roles shared by the matrix-pipe decode kernels (kivi_gqa.hip: round-2 bodies, kept for nh / nh_kv = 8; kivi_mf.hip:
-// round-3 bodies for nh / nh_kv in {1, 4}): argument blocks, the fp16 K-residual role of the qK^T launch, the softmax
+// Roles shared by the matrix-pipe decode kernels (kivi_mf.hip, nh / nh_kv in {1, 4, 8}): argument blocks, the fp16 K-residual role of the qK^T launch, the softmax
 // constants of a row from its segment statistics, the hand-off of partial sums between the blocks of a unit.
 #pragma once
 #include "kivi_common.h"
@@ -28,7 +27,6 @@ struct GqaKArgs {
     int64_t mask_sb;
     // residual role (the FIRST res_blocks blocks of the grid): q . [fp16 K residual | new key] (:333-337) + the K append
     int res_blocks;             // units * KIVI_GQA_RES_SEGS or 0
-    int res_first;              // residual blocks at the head (1) or at the tail (0) of the grid
     uint16_t* kres;
     int64_t kres_sb, kres_sh, kres_st;
     const uint16_t* knew;
@@ -124,18 +122,6 @@ struct GqaVArgs {
     const int* sp_rows;         // kivi_gqa_output: [B][nh] exponent Sp of every probability row (mf_row_sp_kernel)
     int* range;                 // [B * nh_kv] range flags of the V store: read by every block, set by the V flush
 };
-
-// phase time stamps (kivi_debug_set_stamps; tools/gqa_phases.py): 16 slots per wave, DBG instantiations only
-template <bool DBG>
-__device__ __forceinline__ void gstamp(unsigned long long* dbg, int i) {
-    if constexpr (DBG) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i] = t;
-    }
-}
-
-template <int PAT>
-__device__ __forceinline__ uint32_t swz(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, PAT); }
 
 // softmax constants of the R rows of a unit from the segment statistics: M = max, 1 / sum exp(x - M).  Every lane of the
 // calling wave ends up with the same values.

@@ -25,7 +25,7 @@ namespace {
 
 // per-wave LDS words of mf_k_kernel: [scale of the super-block: 1024 words, R = 4 only | R x 512 fp16 scores]
 template <int R>
-constexpr int mf_k_lds_words() { return (R == 4 ? 0 : 64) + R * 256; }   // R = 1: 64 words for the q operand
+constexpr int mf_k_lds_words() { return (R == 1 ? 64 : 0) + R * 256; }   // R = 1: 64 words for the q operand
 
 // DIAG (tuning builds, wrong results): 1 = nothing leaves the LDS (no flush), 2 = scores stored without the statistics
 template <int R, int W, int RING, int DIAG = 0>
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_w = lds_all + wave * mf_k_lds_words<R>();
-    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 4 ? 0 : 64));
+    uint16_t* lds_o = (uint16_t*)(lds_w + (R == 1 ? 64 : 0));
     const int unit = bid / a.sb_blocks;
     const int sb0 = ((bid - unit * a.sb_blocks) * W + wave) * spw;  // this wave: super-blocks sb0 .. sb0 + spw - 1
     if (sb0 >= a.nsb) return;
@@ -114,9 +114,10 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
         mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, big,
                         [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
-        // R = 4: the same continuous walk (mf_k_seq4: scale requested a round ahead, the code ring runs across super-blocks)
-        mf_k_seq4<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
-                        [&](int, int tt, int r, float v) { lds_o[r * 512 + tt] = f2h_bits(v); }, flush_sb);
+        // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
+        const int hb = (4 * (lane >> 4)) % R;                       // heads hb .. hb + 3 sit in this lane's result registers
+        mf_k_seqR<R, RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
+                           [&](int, int tt, int r, float v) { lds_o[(hb + r) * 512 + tt] = f2h_bits(v); }, flush_sb);
     }
 }
 
@@ -131,8 +132,8 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     // multiplied): 2 when that still leaves >= 4 waves per SIMD, else 1; few super-blocks: one wave per block spreads them
     const int64_t total = (int64_t)units * a.nsb;
     int spw = (total >= 8192 && a.nsb >= 2) ? 2 : 1;
-    if (a.ratio == 4) {
-        // R = 4 holds ~190 registers (two waves per SIMD = 2048 resident waves): as many super-blocks per wave as keeps the
+    if (a.ratio >= 4) {
+        // R = 4 / 8 hold ~190 registers (two waves per SIMD = 2048 resident waves): as many super-blocks per wave as keeps the
         // launch in one round; the streams stay deep enough at that occupancy (cf. the qK^T phase of mf_row4_kernel)
         spw = (int)((total + 2047) / 2048);
         spw = spw < 1 ? 1 : (spw > 8 ? 8 : spw);
@@ -153,7 +154,7 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
         return kivi_launch_status("mf_k");
     }
     static const char* fr = KIVI_TUNE_ENV("KIVI_MF_RING");
-    if (fr && atoi(fr) == 4) {
+    if (fr && atoi(fr) == 4 && a.ratio != 8) {
         if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 4>(a, units, spw, s); else launch_mf_k<1, 1, 4>(a, units, spw, s); }
         else { if (W == 4) launch_mf_k<4, 4, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
         return kivi_launch_status("mf_k");
@@ -168,7 +169,8 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     }
 #endif
     if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 2>(a, units, spw, s); else launch_mf_k<1, 1, 2>(a, units, spw, s); }
-    else { if (W == 4) launch_mf_k<4, 4, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
+    else if (a.ratio == 4) { if (W == 4) launch_mf_k<4, 4, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4>(a, units, spw, s); }
+    else { if (W == 4) launch_mf_k<8, 4, 4>(a, units, spw, s); else launch_mf_k<8, 1, 4>(a, units, spw, s); }
     return kivi_launch_status("mf_k");
 }
 
@@ -711,8 +713,10 @@ int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
 #endif
     // R = 4 runs two blocks per CU (gqa_v_slices): four code blocks in flight per wave, 57.4 us per launch at the 70B-like
     // slice against 60.5 with two (profiles/r03_gqa_split_restructure.log); R = 1 keeps four waves per SIMD with two
+    // R = 8: two row sets of scale / zero points per block in flight (20 registers per ring slot): two blocks
     if (R == 1) { if (prob) KIVI_MV(1, 2, true); else KIVI_MV(1, 2, false); }
-    else { if (prob) KIVI_MV(4, 4, true); else KIVI_MV(4, 4, false); }
+    else if (R == 4) { if (prob) KIVI_MV(4, 4, true); else KIVI_MV(4, 4, false); }
+    else { if (prob) KIVI_MV(8, 2, true); else KIVI_MV(8, 2, false); }
 #undef KIVI_MV
     return kivi_launch_status("mf_v");
 }

@@ -258,51 +258,59 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     }
 }
 
-// Zero-point sums of a whole super-block for R = 4: zz[j] at lane (n = group, any kb) = sum_d q[head j, d] * mn[d, group n]
-// in score units.  `mv`: this lane's 4 x 16 bytes of the zero points of group n (B layout = the row layout).
-__device__ __forceinline__ void mf_k_zero4(const MfQ<4>& Q, const u32x4* mv, const float* zmul, float* zz, int big) {
+// Zero-point sums of a whole super-block for R = 4 / 8: rows = heads (row m -> head m % R), columns = groups.  zz[j] at lane
+// (n = group, kb') = sum_d q[head (4 kb' + j) % R, d] * mn[d, group n] in score units (R = 4: register j = head j in every lane;
+// R = 8: heads 4 (kb' & 1) + j); `zmul`: 2^-sq of those heads.  `mv`: this lane's 4 x 16 bytes of the zero points of group n
+// (B layout = the row layout).
+template <int R>
+__device__ __forceinline__ void mf_k_zero(const MfQ<R>& Q, const u32x4* mv, const float* zmul, float* zz, int big) {
     f4 z = {0.f, 0.f, 0.f, 0.f};
     const uint32_t zf01 = mf_zfac(0, big), zf23 = mf_zfac(2, big);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        // rows = heads (A = q * 2^sq: q'' without the 2^aexp and the placement), columns = groups
+        // A = q * 2^sq: q'' without the 2^aexp and the placement
         const h8 aq = as_h8(pk_mul(Q.qq[c][0], zf01), pk_mul(Q.qq[c][1], zf01), pk_mul(Q.qq[c][2], zf23),
                             pk_mul(Q.qq[c][3], zf23));
         z = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq, as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), z, 0, 0, 0);
     }
-    // row 4 kb' + j carries head (4 kb' + j) % 4 = j for every kb': register j = head j in every lane
 #pragma unroll
     for (int j = 0; j < 4; j++) zz[j] = z[j] * zmul[j];
     // pinned here: hipcc otherwise sinks the four MFMAs (and keeps their 32 operand registers alive) down to the first use
     asm volatile("" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]));
 }
 
-// R = 4: rows = (4 groups) x (4 heads); one row set per round of four groups, hi and lo operands chained (16 MFMAs per group).
-// The walker of mf_row4_kernel and of the two-launch qK^T (mf_k_kernel<4>).  With the round-3
-// placement of the scale (kivi_mfma_layout.h) the 16 bytes (kb, chunk c) of four consecutive groups are contiguous, so the
-// A-operand load of a round touches four fully used 64-byte lines per instruction; the scale of round rq + 1 is requested
-// right after the operands of round rq have been built from the registers it lands in, the zero points of the next super-
-// block while the current one is multiplied, the code ring runs across rounds and super-blocks (cf. mf_k_seq1).
-// Scores go to sink(super-block index, token inside it, head, fp32 score); done(super-block index, its number of groups)
-// is called when the last score of a super-block has been handed to sink.
+// R = 4 / 8: rows = (16 / R groups) x (R heads) -- row m -> group m / R of the round, head m % R; one row set per round of
+// 16 / R groups, hi and lo operands chained (16 MFMAs per group).  The walker of mf_row4_kernel and of the two-launch qK^T
+// (mf_k_kernel<4 | 8>).  With the round-3 placement of the scale (kivi_mfma_layout.h) the 16 bytes (kb, chunk c) of consecutive
+// groups are contiguous, so the A-operand load of a round touches fully used 64-byte lines (four per instruction for R = 4);
+// the scale of round rq + 1 is requested right after the operands of round rq have been built from the registers it lands in,
+// the zero points of the next super-block while the current one is multiplied, the code ring runs across rounds and super-
+// blocks (cf. mf_k_seq1).
+// Scores go to sink(super-block index, token inside it, register r, fp32 score): the head is (4 kb) % R + r, i.e. r itself
+// for R = 4 and 4 (kb & 1) + r for R = 8; done(super-block index, its number of groups) is called when the last score of a
+// super-block has been handed to sink.  RING code blocks in flight, a multiple of the 16 / R groups of a round.
 template <int V> struct mf_ic { static constexpr int value = V; };
 
-template <int RING, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
-    static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
+template <int R, int RING, typename Sink, typename Done>
+__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
+    static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
+    constexpr int GPR = 16 / R;                                      // groups per round
+    static_assert((RING >= GPR ? RING % GPR == 0 : GPR % RING == 0) && RING <= 8, "whole rounds per ring, or whole rings per round");
+    constexpr int RPT = RING > GPR ? RING / GPR : 1;               // rounds per trip of the loop below
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
+    const int gl = (4 * kb) / R;                                    // the group of the round whose scores this lane's registers hold
     if (W.ng_total <= 0) return;
     auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
     const int g_last = W.ng_total - 1;
-    const int n_round = (W.ng_total + 3) >> 2;
+    const int n_round = (W.ng_total + GPR - 1) / GPR;
     // ---- requests: scale of round 0, zero points of super-block 0, the ring
     u32x4 sv[4], zv[4];
     // (requests past the end: out-of-range per-lane offsets, no traffic -- see mf_k_seq1)
     auto request_round = [&](int rq, bool live) {
-        const int g0 = 4 * rq;
+        const int g0 = GPR * rq;
         const uint32_t so = sb_off(g0 >> 4);
-        const int g = (g0 & 15) + (m >> 2);
+        const int g = (g0 & 15) + m / R;
         const uint32_t dead = live ? 0u : MF_DEAD_OFF;
 #pragma unroll
         for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4) + dead, so);
@@ -325,23 +333,24 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
         request_group(i, i);
         __builtin_amdgcn_sched_barrier(0);
     }
-    MfQ<4> Q;
-    mf_load_q<4>(q_h0, q_sh, Q, big);
+    MfQ<R> Q;
+    mf_load_q<R>(q_h0, q_sh, Q, big);
     float zmul[4], cmul[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int sqj = __shfl(Q.sq, j);                            // lane j (kb = 0, row j) holds head j's exponent
+        const int sqj = __shfl(Q.sq, (4 * kb) % R + j);             // lane h (kb = 0, row h) holds head h's exponent
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
         cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT + (big ? KIVI_MF_BIG_SHIFT : 0) - sqj);
     }
     float zz[4] = {0.f, 0.f, 0.f, 0.f};
-    // one round = 4 groups on ring slots S0 .. S0 + 3 (mod RING); a ring of 8 alternates S0 = 0, 4 (two rounds per loop trip,
-    // so that every slot index is a constant)
+    // one round = GPR groups on ring slots S0 .. S0 + GPR - 1; a ring of several rounds walks S0 = 0, GPR, ... inside one loop
+    // trip (so that every slot index is a constant)
     auto do_round = [&](int rq, auto slot0) {
         constexpr int S0 = decltype(slot0)::value;
-        const int sbi = rq >> 2;
-        if ((rq & 3) == 0) {                                        // a new super-block: its zero-point sums, then the next one's zero points
-            mf_k_zero4(Q, zv, zmul, zz, big);
+        const int sbi = rq / R;                                     // R rounds per super-block
+        const int rs = rq - sbi * R;
+        if (rs == 0) {                                              // a new super-block: its zero-point sums, then the next one's zero points
+            mf_k_zero<R>(Q, zv, zmul, zz, big);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
         uint32_t Ah[4][4], Al[4][4];
@@ -354,14 +363,14 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
             }
         request_round(rq + 1 < n_round ? rq + 1 : rq, rq + 1 < n_round);
         __builtin_amdgcn_sched_barrier(0);
-        // zero points of (group 4 (rq & 3) + kb, head j) from lane (that group) of this 16-lane row
+        // zero points of (group GPR rs + gl, heads (4 kb) % R + j) from the lane of that group in this 16-lane row
         float zs[4];
-        const int src = ((lane & 48) + 4 * (rq & 3) + kb) * 4;
+        const int src = ((lane & 48) + GPR * rs + gl) * 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) zs[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zz[j])));
         float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < GPR; j++) {
             f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -373,37 +382,45 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
             }
-            const bool mine = kb == j;                             // rows 4 kb .. 4 kb + 3 = group 4 rq + kb, heads 0 .. 3
+            const bool mine = gl == j;                              // rows 4 kb .. 4 kb + 3 = group GPR rq + gl, heads (4 kb) % R + 0 .. 3
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 o0[r] = mine ? a0[r] : o0[r];
                 o1[r] = mine ? a1[r] : o1[r];
             }
-            request_group((S0 + j) % RING, 4 * rq + j + RING);
+            request_group((S0 + j) % RING, GPR * rq + j + RING);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (4 * rq + kb < W.ng_total) {
+        if (GPR * rq + gl < W.ng_total) {
             const int sb = W.sb_first + sbi * W.sb_stride;
-            const int g = 4 * (rq & 3) + kb;
+            const int g = GPR * rs + gl;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 sink(sb, g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
                 sink(sb, g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
             }
         }
-        if ((rq & 3) == 3 || rq == n_round - 1) {                  // the super-block is complete
+        if (rs == R - 1 || rq == n_round - 1) {                    // the super-block is complete
             const int left = W.ng_total - 16 * sbi;
             done(W.sb_first + sbi * W.sb_stride, left < 16 ? left : 16);
         }
     };
-    if constexpr (RING == 8) {
-        for (int rq = 0; rq < n_round; rq += 2) {
-            do_round(rq, mf_ic<0>{});
-            if (rq + 1 < n_round) do_round(rq + 1, mf_ic<4>{});
+    static_assert(RPT == 1 || RPT == 2 || RPT == 4, "1, 2 or 4 rounds per trip");
+    for (int rq = 0; rq < n_round; rq += RPT) {
+        do_round(rq, mf_ic<0>{});
+        if constexpr (RPT >= 2) {
+            if (rq + 1 < n_round) do_round(rq + 1, mf_ic<GPR>{});
         }
-    } else {
-        for (int rq = 0; rq < n_round; rq++) do_round(rq, mf_ic<0>{});
+        if constexpr (RPT == 4) {
+            if (rq + 2 < n_round) do_round(rq + 2, mf_ic<2 * GPR>{});
+            if (rq + 3 < n_round) do_round(rq + 3, mf_ic<3 * GPR>{});
+        }
     }
+}
+
+template <int RING, typename Sink, typename Done>
+__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
+    mf_k_seqR<4, RING>(rk, W, q_h0, q_sh, big, sink, done);
 }
 
 // ------------------------------------------------------------------------------------------------ sV
@@ -422,16 +439,18 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
 // form -- doubled the matrix instructions for nothing.)
 template <int R>
 struct MfVAcc {
+    static constexpr int NS = R == 8 ? 2 : 1;      // row sets (R = 8: channel groups {0, 1} and {2, 3})
     f4 acc[4][2];
-    float z4, z6;      // R = 1: sum p'' * (scale | mn) of every block; R = 4: sum p'' * mn        (registers with 2^4 / 2^6)
-    float c4, c6;      // sums over the centring blocks: R = 1: p'' * (scale | mn); R = 4: the hi operand
+    float z4[NS], z6[NS];      // R = 1: sum p'' * (scale | mn) of every block; R = 4 / 8: sum p'' * mn        (registers with 2^4 / 2^6)
+    float c4[NS], c6[NS];      // sums over the centring blocks: R = 1: p'' * (scale | mn); R = 4 / 8: the hi operand
 };
 
 template <int R>
 __device__ __forceinline__ void mf_v_init(MfVAcc<R>& A) {
 #pragma unroll
     for (int c = 0; c < 4; c++) A.acc[c][0] = A.acc[c][1] = f4{0.f, 0.f, 0.f, 0.f};
-    A.z4 = A.z6 = A.c4 = A.c6 = 0.f;
+#pragma unroll
+    for (int s = 0; s < MfVAcc<R>::NS; s++) A.z4[s] = A.z6[s] = A.c4[s] = A.c6[s] = 0.f;
 }
 
 // -1.5 * RING in the units of a masked code: registers 0, 1 hold code * 2^-16, registers 2, 3 code * 2^-18 (fp16 bits, both halves)
@@ -441,28 +460,31 @@ template <> struct MfCentre<3> { static constexpr uint32_t a = 0x84808480u, b = 
 template <> struct MfCentre<4> { static constexpr uint32_t a = 0x86008600u, b = 0x81808180u; static constexpr float f = 6.0f; };
 
 // one 32-token block.  w: code words; ps: the lane's 8 scaled probabilities (tokens 8 kb + e of its row's head);
-// R = 1: sm = scale (rows j < 2) or zero points (rows j >= 2), lomask = all ones in lo rows;  R = 4: sm = scale, mn = zero points.
+// R = 1: sm[0] = scale (rows j < 2) or zero points (rows j >= 2), lomask = all ones in lo rows;
+// R = 4: row (channel group m >> 2, head m & 3): sm[0] = scale, mn[0] = zero points of that channel group;
+// R = 8: row (channel group 2 s + (m >> 3), head m & 7) for the row sets s = 0, 1: sm[s], mn[s]; channel chunk c multiplies with
+//        row set c >> 1 (its rows for channel group c are the useful ones).
 // CENTRE: this block also accumulates A x (-1.5 RING).
 template <int R, int RING, bool CENTRE>
-__device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u32x4& ps, const u32x4& sm, const u32x4& mn,
+__device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u32x4& ps, const u32x4* sm, const u32x4* mn,
                                            uint32_t lomask) {
     const h8 bc = as_h8(MfCentre<RING>::a, MfCentre<RING>::a, MfCentre<RING>::b, MfCentre<RING>::b);
     if constexpr (R == 1) {
         uint32_t a[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t hi = pk_mul(ps[i], sm[i]);
-            a[i] = pk_fms(ps[i], sm[i], hi & lomask);          // hi rows: fp16(p'' s); lo rows: the exact remainder
+            const uint32_t hi = pk_mul(ps[i], sm[0][i]);
+            a[i] = pk_fms(ps[i], sm[0][i], hi & lomask);          // hi rows: fp16(p'' s); lo rows: the exact remainder
         }
-        A.z4 = dot2_f16(ps[0], sm[0], A.z4);
-        A.z4 = dot2_f16(ps[1], sm[1], A.z4);
-        A.z6 = dot2_f16(ps[2], sm[2], A.z6);
-        A.z6 = dot2_f16(ps[3], sm[3], A.z6);
+        A.z4[0] = dot2_f16(ps[0], sm[0][0], A.z4[0]);
+        A.z4[0] = dot2_f16(ps[1], sm[0][1], A.z4[0]);
+        A.z6[0] = dot2_f16(ps[2], sm[0][2], A.z6[0]);
+        A.z6[0] = dot2_f16(ps[3], sm[0][3], A.z6[0]);
         if constexpr (CENTRE) {
-            A.c4 = dot2_f16(ps[0], sm[0], A.c4);
-            A.c4 = dot2_f16(ps[1], sm[1], A.c4);
-            A.c6 = dot2_f16(ps[2], sm[2], A.c6);
-            A.c6 = dot2_f16(ps[3], sm[3], A.c6);
+            A.c4[0] = dot2_f16(ps[0], sm[0][0], A.c4[0]);
+            A.c4[0] = dot2_f16(ps[1], sm[0][1], A.c4[0]);
+            A.c6[0] = dot2_f16(ps[2], sm[0][2], A.c6[0]);
+            A.c6[0] = dot2_f16(ps[3], sm[0][3], A.c6[0]);
         }
         const h8 av = as_h8(a[0], a[1], a[2], a[3]);
 #pragma unroll
@@ -477,25 +499,30 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
             A.acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, x1, 0, 0, 0);
         }
     } else {
-        uint32_t hi[4], lo[4];
+        constexpr int NS = MfVAcc<R>::NS;
+        uint32_t hi[NS][4], lo[NS][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            hi[i] = pk_mul(ps[i], sm[i]);
-            lo[i] = pk_fms(ps[i], sm[i], hi[i]);
+        for (int s = 0; s < NS; s++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                hi[s][i] = pk_mul(ps[i], sm[s][i]);
+                lo[s][i] = pk_fms(ps[i], sm[s][i], hi[s][i]);
+            }
+            A.z4[s] = dot2_f16(ps[0], mn[s][0], A.z4[s]);
+            A.z4[s] = dot2_f16(ps[1], mn[s][1], A.z4[s]);
+            A.z6[s] = dot2_f16(ps[2], mn[s][2], A.z6[s]);
+            A.z6[s] = dot2_f16(ps[3], mn[s][3], A.z6[s]);
+            if constexpr (CENTRE) {
+                A.c4[s] = dot2_f16(hi[s][0], MF_ONE2, A.c4[s]);
+                A.c4[s] = dot2_f16(hi[s][1], MF_ONE2, A.c4[s]);
+                A.c6[s] = dot2_f16(hi[s][2], MF_ONE2, A.c6[s]);
+                A.c6[s] = dot2_f16(hi[s][3], MF_ONE2, A.c6[s]);
+            }
         }
-        A.z4 = dot2_f16(ps[0], mn[0], A.z4);
-        A.z4 = dot2_f16(ps[1], mn[1], A.z4);
-        A.z6 = dot2_f16(ps[2], mn[2], A.z6);
-        A.z6 = dot2_f16(ps[3], mn[3], A.z6);
-        if constexpr (CENTRE) {
-            A.c4 = dot2_f16(hi[0], MF_ONE2, A.c4);
-            A.c4 = dot2_f16(hi[1], MF_ONE2, A.c4);
-            A.c6 = dot2_f16(hi[2], MF_ONE2, A.c6);
-            A.c6 = dot2_f16(hi[3], MF_ONE2, A.c6);
-        }
-        const h8 ah = as_h8(hi[0], hi[1], hi[2], hi[3]), al = as_h8(lo[0], lo[1], lo[2], lo[3]);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
+            const int s = (NS == 2) ? (c >> 1) : 0;               // (a constant after unrolling)
+            const h8 ah = as_h8(hi[s][0], hi[s][1], hi[s][2], hi[s][3]), al = as_h8(lo[s][0], lo[s][1], lo[s][2], lo[s][3]);
             const MfB b = mf_views(w[c]);
             f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
             if constexpr (CENTRE) {
@@ -516,7 +543,8 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
 // (halves), row pitch `pitch` halves, indexed by token - tok0.
 template <int R, int RING>
 struct MfVStream {
-    u32x4 wr[RING], sr[RING], mr[R == 1 ? 1 : RING];
+    static constexpr int NS = MfVAcc<R>::NS;
+    u32x4 wr[RING], sr[RING][NS], mr[R == 1 ? 1 : RING][NS];
     uint32_t sm_off, mn_off, sb_bytes;
     int b_last;
     int sb_first, sb_stride;       // block q of the stream lives in super-block sb_first + (q >> 4) * sb_stride, block q & 15
@@ -528,15 +556,18 @@ struct MfVStream {
         const uint32_t dead = live ? 0u : MF_DEAD_OFF;
         const uint32_t so = (uint32_t)(sb_first + (bc >> 4) * sb_stride) * sb_bytes;
         wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16) + dead, so + (uint32_t)(bc & 15) * 1024u);
-        sr[slot] = buf_load<u32x4, true>(rv, sm_off + dead, so + (uint32_t)(bc & 15) * 256u);
-        if constexpr (R != 1) mr[slot] = buf_load<u32x4, true>(rv, mn_off + dead, so + (uint32_t)(bc & 15) * 256u);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {                             // (row set s: two channel groups = 32 bytes further)
+            sr[slot][s] = buf_load<u32x4, true>(rv, sm_off + 32u * s + dead, so + (uint32_t)(bc & 15) * 256u);
+            if constexpr (R != 1) mr[slot][s] = buf_load<u32x4, true>(rv, mn_off + 32u * s + dead, so + (uint32_t)(bc & 15) * 256u);
+        }
     }
 
     // blocks [b_lo, b_hi) in stream numbering; (first, stride) = (0, 1): stream numbering = the unit's block numbering
     __device__ __forceinline__ void prime(rsrc_t rv, uint32_t sb_bytes_, int b_lo, int b_hi, int first = 0, int stride = 1) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
-        const int cg = m >> 2, j = m & 3;
+        const int cg = R == 8 ? (m >> 3) : (m >> 2), j = m & 3;   // channel group of the lane's row (row set 0)
         sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
         mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
         sb_bytes = sb_bytes_;
@@ -562,7 +593,7 @@ struct MfVStream {
         const int m = lane & 15, kb = lane >> 4;
         const int j = m & 3;
         const uint32_t lomask = (R == 1 && (j & 1)) ? 0xFFFFFFFFu : 0u;
-        const uint16_t* prow = ps_lds + (R == 1 ? 0 : j * pitch) + 8 * kb - tok0;
+        const uint16_t* prow = ps_lds + (R == 1 ? 0 : (m % R) * pitch) + 8 * kb - tok0;      // the head of the lane's row
         if (b_hi <= b_lo) return;
         for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
 #pragma unroll
@@ -583,7 +614,7 @@ struct MfVStream {
 };
 
 // Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]) -- 2^12 * (hi + lo sums) + zero-point
-// term + 1.5 * sum p'' s.  `zl`: 64 floats of scratch LDS of this wave.
+// term + 1.5 * sum p'' s.  `zl`: 128 floats of scratch LDS of this wave.
 template <int R, int RING>
 __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float* dst) {
     const int lane = threadIdx.x & 63;
@@ -591,8 +622,8 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float
     constexpr float CF = MfCentre<RING>::f;                       // what the centring blocks subtracted per unit of A
     // per-lane dot sums -> LDS -> every lane gathers the four kb partials of the rows it needs
     if constexpr (R == 1) {
-        zl[lane] = A.z4 * 0.0625f + A.z6 * 0.015625f;
-        zl[64 + lane] = A.c4 * 0.0625f + A.c6 * 0.015625f;
+        zl[lane] = A.z4[0] * 0.0625f + A.z6[0] * 0.015625f;
+        zl[64 + lane] = A.c4[0] * 0.0625f + A.c6[0] * 0.015625f;
         __builtin_amdgcn_wave_barrier();
         // output lane (n, kb' = cg): sum p'' mn (rows 4 cg + 2) + CF * sum over the centring blocks of p'' s (rows 4 cg)
         float zc = 0.f, zm = 0.f;
@@ -613,8 +644,8 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float
             }
             dst[32 * kb + 16 * tile + n] = __builtin_fmaf(v0 + v1, (float)(1 << KIVI_MF_PROD_SHIFT), br);
         }
-    } else {
-        zl[lane] = __builtin_fmaf(CF, A.c4 * 0.0625f + A.c6 * 0.015625f, A.z4 * 0.0625f + A.z6 * 0.015625f);
+    } else if constexpr (R == 4) {
+        zl[lane] = __builtin_fmaf(CF, A.c4[0] * 0.0625f + A.c6[0] * 0.015625f, A.z4[0] * 0.0625f + A.z6[0] * 0.015625f);
         __builtin_amdgcn_wave_barrier();
         float br[4];
 #pragma unroll
@@ -631,6 +662,33 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float
 #pragma unroll
                 for (int c = 1; c < 4; c++) v = (kb == c) ? A.acc[c][tile][r] : v;
                 dst[r * 128 + 32 * kb + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+            }
+        }
+    } else {
+        // R = 8: this lane's accumulator rows 4 kb + j = (channel group kb >> 1 of the row set, head 4 (kb & 1) + j); they are the
+        // useful rows of the channel chunks c = (kb >> 1) + 2 s, s = 0, 1
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            zl[64 * s + lane] = __builtin_fmaf(CF, A.c4[s] * 0.0625f + A.c6[s] * 0.015625f, A.z4[s] * 0.0625f + A.z6[s] * 0.015625f);
+        __builtin_amdgcn_wave_barrier();
+        const int hb = 4 * (kb & 1);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            float br[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                br[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) br[r] += zl[64 * s + 4 * kb + r + 16 * k];
+            }
+            const int c = (kb >> 1) + 2 * s;
+#pragma unroll
+            for (int tile = 0; tile < 2; tile++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float v = (kb >> 1) ? A.acc[2 * s + 1][tile][r] : A.acc[2 * s][tile][r];
+                    dst[(hb + r) * 128 + 32 * c + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+                }
             }
         }
     }

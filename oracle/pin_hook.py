@@ -134,6 +134,12 @@ CASES = [
     # Mistral-7B head ratio (4 query heads per kv head), R = 128, across a K flush
     ("mistral_flash_gqa4_r128", "mistral_flash", 1, 8, 2, 128, 2, 32, 128, 300, 90, False),
     ("mistral_eager_gqa4_r32_mask", "mistral_eager", 2, 4, 1, 128, 2, 32, 32, 40, 36, True),
+    # round 4: eight query heads per kv head (the Llama-3-70B ratio; the kernel's own head mapping, gemv_cuda.cu:361-365) ...
+    ("flash_gqa8_b2_r32_mask", "flash", 2, 8, 1, 128, 2, 32, 32, 45, 40, True),
+    # ... and keys with a few large-magnitude channels (every 17th output row of k_proj x 12: what per-channel K quantisation
+    # is for), multi-head and grouped
+    ("flash_mha_outlier_b2_r32", "flash", 2, 4, 4, 128, 2, 32, 32, 90, 40, False),
+    ("mistral_flash_gqa4_outlier_r32", "mistral_flash", 2, 8, 2, 128, 2, 32, 32, 70, 40, False),
 ]
 
 
@@ -173,6 +179,8 @@ def run_case(classes, check, name, kind, B, nh, nh_kv, D, bits, g, R, T0, steps,
         mod.o_proj.weight.copy_(torch.eye(hidden))
         for lin in (mod.q_proj, mod.k_proj, mod.v_proj):
             lin.weight.copy_(torch.randn_like(lin.weight.float()) * hidden ** -0.5)
+        if "outlier" in name:
+            mod.k_proj.weight[::17] *= 12.0
     if kind.endswith("flash"):   # the prompt pass goes through flash-attn in the reference; its output is not cache state
         mod._flash_attention_forward = lambda q, k, v, m, ql, dropout=0.0, softmax_scale=None: torch.zeros_like(q)
 

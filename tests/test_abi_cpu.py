@@ -313,7 +313,6 @@ def _gqa_args(**over):
     # ring window (flags 4): residual_length + 1 rows are enough, the start may sit anywhere inside the buffer
     (dict(flags=4, v_window_rows=32), None, b"window rows"),
     (dict(flags=4, v_window_rows=33, v_win_start=33), None, b"window rows"),
-    (dict(flags=4, nh=16), -3, b"ring window"),             # nh / nh_kv = 8 runs the round-2 kernels: linear window only
 ])
 def test_gqa_decode_validates_before_launching(lib, over, rc_expected, msg):
     """kivi_gqa_decode (the grouped-query layer step, llama_kivi.py:314-399 / mistral_kivi.py:381-445) refuses bad shapes,
@@ -372,8 +371,8 @@ def test_mf_cache_ring_window_view():
     assert lc.v_res_view()[0, 0, :, 0].tolist() == [30.0, 31.0, 32.0, 0.0, 1.0]
     lc.v_res_start, lc.v_res_len = 3, 4
     assert lc.v_res_view()[0, 0, :, 0].tolist() == [3.0, 4.0, 5.0, 6.0]
-    old = make_layer_cache(KiviConfig(2, 2, 32, 32), 1, 1, 128, 100, "cpu", num_heads=8)      # nh / nh_kv = 8: round-2 kernels, linear window
-    assert not old.ring and old.v_res.shape[2] == 65
+    r8 = make_layer_cache(KiviConfig(2, 2, 32, 32), 1, 1, 128, 100, "cpu", num_heads=8)       # nh / nh_kv = 8: the same kernels since round 4
+    assert r8.ring and r8.v_res.shape[2] == 33
 
 
 def test_layer_cache_factory_picks_the_layout():

@@ -36,23 +36,38 @@ class LaunchProbe:
         return (self.lib.kivi_last_timed_kernel() or b"").decode()
 
 
-def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False, expect_kernel=None, D=128, layout="hook"):
+def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False, expect_kernel=None, D=128, layout="hook",
+                stage_ab=False, outlier=False):
     """Full-size decode steps on the GPU; hook_ref on the sampled (b, kv head) slices.  Returns the kernels seen.
     layout "hook": the hook-state layout (KiviLayerCache, VALU kernels); "auto": what make_layer_cache picks for the shape
-    (the matrix-pipe layout for 2-bit / g=32 / D=128 with nh / nh_kv in {1, 4, 8})."""
+    (the matrix-pipe layout for 2-bit / g=32 / D=128 with nh / nh_kv in {1, 4, 8}).
+    outlier: every 17th key channel x 12 (what per-channel K quantisation exists for).  With such keys the fp16 scores reach
+    |s| ~ 100, where ONE ulp of a dominant score (0.0625 / sqrt(D)) moves its probability by 0.5 %, so the end-to-end bar is
+    replaced by the stage check of tests/test_mfma_gpu.py (stage_ab, matrix-pipe layout only): A. the fp16 rows the softmax
+    consumed (KIVI_GQA_DUMP_SCORES makes the one-launch kernels write them) within the GEMV bar of the reference's rows;
+    B. the output within 2e-3 of the reference's attend half run on the rows the GPU produced."""
+    from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode, make_layer_cache
     from oracle import hook_ref as H
     ratio = nh // nh_kv
     cfg = KiviConfig(bits, bits, g, R)
     gen = torch.Generator(device="cuda").manual_seed(seed)
-    k0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+
+    def keys(T):
+        k = torch.randn((B, nh_kv, T, D), device="cuda", dtype=torch.float32, generator=gen)
+        if outlier:
+            k[..., ::17] *= 12.0
+        return k.half()
+
+    k0 = keys(T0)
     v0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
-    # plain randn: with large-magnitude K channels the fp16 scores reach |s| ~ 100, where ONE ulp of a dominant score
-    # (0.0625 / sqrt(D)) moves its probability by 0.5 % -- summation-order flips would then exceed any output bar
     if layout == "hook":
         layer = KiviLayerCache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda")
     else:
         layer = make_layer_cache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda", num_heads=nh)
+    if stage_ab:
+        assert layer.layout == "mfma"
+        layer.flags |= _lib.GQA_DUMP_SCORES
     layer.prefill(k0, v0)
     pasts = {}
     for (b, hk) in samples:
@@ -63,7 +78,7 @@ def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False
     worst = 0.0
     for s in range(steps):
         q = torch.randn((B, nh, 1, D), device="cuda", dtype=torch.float16, generator=gen)
-        kn = torch.randn((B, nh_kv, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        kn = keys(1)
         vn = torch.randn((B, nh_kv, 1, D), device="cuda", dtype=torch.float16, generator=gen)
         mask = None
         if masked:
@@ -76,10 +91,22 @@ def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False
         seen.add(probe.kernel().split("<")[0].strip("( "))
         for (b, hk) in samples:
             hs = slice(hk * ratio, (hk + 1) * ratio)
-            ref, pasts[(b, hk)] = H.decode_step(q[b:b + 1, hs].cpu(), kn[b:b + 1, hk:hk + 1].cpu(), vn[b:b + 1, hk:hk + 1].cpu(),
-                                                pasts[(b, hk)], bits, bits, g, R,
-                                                attention_mask=None if mask is None else mask[b:b + 1].cpu())
-            ok, ratio_err = gemv_close(out[b:b + 1, hs], ref, rtol=3e-3)      # the hook bar (tests/test_hook_gpu.py)
+            args = (q[b:b + 1, hs].cpu(), kn[b:b + 1, hk:hk + 1].cpu(), vn[b:b + 1, hk:hk + 1].cpu(), pasts[(b, hk)], bits, bits, g, R)
+            m_cpu = None if mask is None else mask[b:b + 1].cpu()
+            if stage_ab:
+                n = T0 + s + 1
+                x_gpu = layer._native[4][0][b:b + 1, hs, :, :n].cpu()
+                ref, new_past, x_ref = H.decode_step(*args, attention_mask=m_cpu, return_scores=True)
+                live = x_ref.float() > -60000
+                ok, ra = gemv_close(torch.where(live, x_gpu.float(), 0.0), torch.where(live, x_ref.float(), 0.0), rtol=1e-3)
+                assert ok, ("scores", s, b, hk, ra)
+                assert torch.equal(x_gpu[~live], x_ref[~live])
+                ref_b, _ = H.decode_step(*args, attention_mask=m_cpu, scores_override=x_gpu)
+                ok, ratio_err = gemv_close(out[b:b + 1, hs], ref_b, rtol=2e-3)
+                pasts[(b, hk)] = new_past
+            else:
+                ref, pasts[(b, hk)] = H.decode_step(*args, attention_mask=m_cpu)
+                ok, ratio_err = gemv_close(out[b:b + 1, hs], ref, rtol=3e-3)      # the hook bar (tests/test_hook_gpu.py)
             worst = max(worst, ratio_err)
             assert ok, (s, b, hk, ratio_err)
     t = layer.as_tuple()
@@ -114,6 +141,23 @@ def test_bench_shape_mf_row_kernel_vs_oracle(oracle, T0, masked):
     seen, worst = run_sampled(B=32, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=40, samples=[(0, 0), (13, 7), (31, 31)],
                               seed=11, masked=masked, expect_kernel="mf_row_kernel", layout="auto")
     print("worst ratio vs the 3e-3 hook bar:", worst)
+
+
+@pytest.mark.parametrize("T0,masked", [(4096, False), (4080, True)])
+def test_bench_shape_mf_row_kernel_stages_on_outlier_keys(oracle, T0, masked):
+    """The same shape and kernel with large-magnitude key channels, checked stage by stage on the sampled rows (the scores of
+    mf_row_kernel never leave the LDS: its test instantiation writes the rows its softmax consumes), 40 steps through the K
+    flush.  VERDICT r3 "what's weak" #2."""
+    seen, worst = run_sampled(B=32, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=40, samples=[(0, 0), (13, 7), (31, 31)],
+                              seed=21, masked=masked, expect_kernel="mf_row_kernel", layout="auto", stage_ab=True, outlier=True)
+    print("worst ratio vs the 2e-3 attend bar:", worst)
+
+
+def test_config4_shape_mf_row4_kernel_stages_on_outlier_keys(oracle):
+    """BASELINE config 4 (32 / 8 heads, 8k keys, R = 128, B = 64: one mf_row4_kernel launch per layer) likewise."""
+    seen, worst = run_sampled(B=64, nh=32, nh_kv=8, T0=8192 - 4, R=128, bits=2, g=32, steps=8, samples=[(0, 0), (63, 7), (32, 3)],
+                              seed=22, expect_kernel="mf_row4_kernel", layout="auto", stage_ab=True, outlier=True)
+    print("worst ratio vs the 2e-3 attend bar:", worst)
 
 
 @pytest.mark.parametrize("B,T0,kernel", [(1, 32768 + 13, "mf_k_kernel"), (4, 4080, "mf_row_kernel"), (4, 6000, "mf_k_kernel"),

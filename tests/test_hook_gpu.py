@@ -57,19 +57,47 @@ def _golden_hook_cases():
     return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hook_*.npz")))
 
 
+@pytest.mark.parametrize("layout", ["hook", "auto", "row", "split"])
 @pytest.mark.parametrize("path", _golden_hook_cases(), ids=lambda p: p.split("hook_")[-1][:-4])
-def test_hook_matches_reference_class_fixtures(path):
+def test_hook_matches_reference_class_fixtures(path, layout):
     """The HIP hook replays the inputs of fixtures recorded from the REFERENCE's own attention classes
-    (oracle/pin_hook.py): step outputs within the hook bar, final 9-tuple bit-identical to the reference's."""
+    (oracle/pin_hook.py): step outputs within the hook bar, final 9-tuple bit-identical to the reference's.
+    layout "hook": the hook-state layout (VALU kernels); "auto": what make_layer_cache gives a model of that shape -- the
+    matrix-pipe layout for 2-bit / g = 32 / D = 128 with nh / nh_kv in {1, 4, 8}, i.e. what every real model and the bench
+    run; "row" / "split": the matrix-pipe layout with the one-launch (mf_row_kernel / mf_row4_kernel) and the two-launch
+    (mf_k_kernel + mf_v_kernel) form forced, a launch probe naming the kernel that ran."""
     from test_hook_golden_cpu import NAMES, load_case
-    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    from kivi_amd import _lib
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, KiviLayerCacheMF, kivi_attention_decode, make_layer_cache
     c = load_case(path)
     cfg = KiviConfig(c["bits"], c["bits"], c["g"], c["R"])
-    layer = KiviLayerCache(cfg, c["B"], c["nh_kv"], c["D"], c["T0"] + c["steps"] + 4, "cuda")
+    cap = c["T0"] + c["steps"] + 4
+    expect = None
+    if layout == "hook":
+        layer = KiviLayerCache(cfg, c["B"], c["nh_kv"], c["D"], cap, "cuda")
+    else:
+        layer = make_layer_cache(cfg, c["B"], c["nh_kv"], c["D"], cap, "cuda", num_heads=c["nh"])
+        ratio = c["nh"] // c["nh_kv"]
+        if layout != "auto":
+            if not isinstance(layer, KiviLayerCacheMF):
+                pytest.skip("shape outside the matrix-pipe layout: covered by layout=auto")
+            if layout == "row":
+                if ratio not in (1, 4):
+                    pytest.skip("no one-launch kernel for this head ratio")
+                layer.flags, expect = _lib.GQA_FORCE_ROW, (b"mf_row_kernel" if ratio == 1 else b"mf_row4_kernel")
+            else:
+                layer.flags, expect = _lib.GQA_FORCE_SPLIT, b"mf_k_kernel"
     layer.prefill(c["k0"].cuda(), c["v0"].cuda())
+    lib = _lib.load()
     for s in range(c["steps"]):
         m = c["masks"][s].cuda() if c["masks"][s] is not None else None
+        if expect is not None and s in (0, c["steps"] - 1):
+            e0, e1 = lib.kivi_event_create(), lib.kivi_event_create()
+            lib.kivi_set_launch_events(e0, e1)
         out = kivi_attention_decode(c["q"][s].cuda(), c["k"][s].cuda(), c["v"][s].cuda(), layer, attention_mask=m)
+        if expect is not None and s in (0, c["steps"] - 1):
+            torch.cuda.synchronize()
+            assert expect in (lib.kivi_last_timed_kernel() or b""), lib.kivi_last_timed_kernel()
         # the fixture outputs come from the reference classes' CPU fp16 matmuls (their own rounding noise ~1e-3 on top of
         # the two fp16 partial sums): hook bar 3e-3 + that
         ok, ratio = gemv_close(out, c["out"][s], rtol=4e-3)

@@ -174,9 +174,10 @@ def _probs(kind, B, nh, T, seed):
 
 @pytest.mark.parametrize("kind", ["softmax", "uniform", "sparse"])
 @pytest.mark.parametrize("B,nh,nh_kv,T", [(2, 4, 1, 33), (1, 8, 2, 544), (2, 32, 8, 8192), (1, 32, 8, 32768),
-                                          (2, 2, 2, 33), (1, 3, 3, 544), (4, 32, 32, 4064), (1, 4, 4, 32768)])
+                                          (2, 2, 2, 33), (1, 3, 3, 544), (4, 32, 32, 4064), (1, 4, 4, 32768),
+                                          (2, 8, 1, 33), (1, 16, 2, 544), (2, 64, 8, 8192), (1, 8, 1, 32768)])
 def test_gqa_output_vs_oracle(mods, oracle, B, nh, nh_kv, T, kind):
-    """out = probs @ dequant(V) on the VT layout (ratio 1 and 4; ragged last block; one to 64 super-blocks; rows cut into
+    """out = probs @ dequant(V) on the VT layout (ratio 1, 4 and 8; ragged last block; one to 64 super-blocks; rows cut into
     slices) against the oracle's restatement of the reference kernel (gemv_cuda.cu:348-427 at llama_kivi.py:382) on
     sampled kv heads with gemv_close(rtol=1e-3), and against the VALU kernel of the hook-state layout everywhere."""
     mfma, new_pack, matmul = mods
@@ -207,7 +208,7 @@ def test_gqa_output_exact_arithmetic(mods):
     centring of the codes (A x (code - 1.5) + 1.5 sum A) and the hi / lo split must reproduce the dequantised matmul
     exactly."""
     mfma, new_pack, _ = mods
-    for nh, nh_kv in ((4, 1), (2, 2)):
+    for nh, nh_kv in ((4, 1), (2, 2), (8, 1)):
         B, T = 2, 700
         g = torch.Generator().manual_seed(0)
         v = torch.randint(0, 4, (B, nh_kv, T, 128), generator=g).half()
@@ -237,13 +238,19 @@ def _cmp_cache(t_gpu, t_ref):
     assert t_gpu[8] == t_ref[8]
 
 
-@pytest.mark.parametrize("nh,nh_kv,T0,R,masked", [(4, 1, 5, 32, False), (8, 2, 70, 32, True), (8, 1, 33, 32, False),
-                                                    (16, 2, 600, 64, False), (8, 2, 1100, 128, True), (32, 8, 300, 128, False),
-                                                    (2, 2, 5, 32, False), (3, 3, 70, 32, True), (4, 4, 600, 64, False),
-                                                    (2, 2, 1100, 128, True)])
-def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked):
-    """Every step of R + 9 (one K flush, V flushes, a window compaction, cache growth, a partial last super-block), stage by
-    stage against the reference logic (oracle/hook_ref.py), no step-level escape:
+@pytest.mark.parametrize("form", ["split", "row"])
+@pytest.mark.parametrize("nh,nh_kv,T0,R,masked,kind", [(4, 1, 5, 32, False, "randn"), (8, 2, 70, 32, True, "outlier"), (8, 1, 33, 32, False, "outlier"),
+                                                         (16, 2, 600, 64, False, "randn"), (8, 2, 1100, 128, True, "outlier"),
+                                                         (32, 8, 300, 128, False, "outlier"), (2, 2, 5, 32, False, "randn"),
+                                                         (3, 3, 70, 32, True, "outlier"), (4, 4, 600, 64, False, "outlier"),
+                                                         (2, 2, 1100, 128, True, "randn"), (16, 2, 1100, 128, True, "outlier")])
+def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked, kind, form):
+    """Every step of R + 9 (one K flush, V flushes, the window ring wrapping, cache growth, a partial last super-block), stage by
+    stage against the reference logic (oracle/hook_ref.py), no step-level escape -- for keys with large-magnitude channels
+    (kind "outlier": what per-channel K quantisation exists for; scores reach |s| ~ 100) as well as plain normal ones, and for
+    BOTH forms of the step: "split" (mf_k_kernel -> score rows in memory -> mf_v_kernel) and "row" (mf_row_kernel /
+    mf_row4_kernel: the scores never leave the LDS; KIVI_GQA_DUMP_SCORES makes the test instantiations of those kernels also
+    write the rows their softmax consumes):
       A. the fp16 row fed to the softmax (packed qK^T | residual scores, / sqrt(D), + mask; llama_kivi.py:324-372) within
          the north_star GEMV bar (1e-3 of max(|ref|, rms) + 1 ulp) of the reference's row;
       B. the output within 2e-3 of the reference's attend half (:375-399) run ON THE ROW THE GPU PRODUCED: the GEMV bar
@@ -251,35 +258,46 @@ def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked)
          different order) + the roundings of the two partial sums.
     A and B bound the end-to-end difference by the triangle inequality; what they leave out -- how a one-ulp difference in
     a dominant score moves its probability -- is the reference softmax itself, run on the CPU in stage B.
-    After R + 9 steps the 9-tuple is bit-identical to the reference logic's.  nh == nh_kv: the two-launch form is forced
-    (the one-launch row kernel keeps its scores in LDS; test_mf_row_kernel_matches_two_launch_form ties it to this)."""
+    After R + 9 steps the 9-tuple is bit-identical to the reference logic's."""
+    mk = lambda seed, h, T: make_kv(seed, 2, h, T, 128, kind)        # noqa: E731
+    mo = lambda seed, h, T: make_kv(seed, 2, h, T, 128)              # noqa: E731
+    _stage_ab_steps(nh, nh_kv, T0, R, masked, form, R + 9, k_prompt=mk, k_step=mk, v_prompt=mo, v_step=mo, q_step=mo)
+
+
+def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_prompt, v_step, q_step, check_at=None):
+    """The stage A / B loop of test_mf_decode_steps_match_reference_logic over caller-made inputs (f(seed, heads, T))."""
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, KiviLayerCacheMF, kivi_attention_decode, make_layer_cache
     from oracle import hook_ref as H
+    if form == "row" and nh // nh_kv == 8:
+        pytest.skip("nh / nh_kv = 8: eight score rows of a unit do not fit the LDS at useful lengths, two-launch form only")
     B, D, g = 2, 128, 32
-    steps = R + 9
     cfg = KiviConfig(2, 2, g, R)
-    k0, v0 = make_kv(1, B, nh_kv, T0, D), make_kv(2, B, nh_kv, T0, D)
+    k0, v0 = k_prompt(1, nh_kv, T0), v_prompt(2, nh_kv, T0)
     layer = make_layer_cache(cfg, B, nh_kv, D, T0 + 8, "cuda", num_heads=nh)    # small capacity: the cache must grow
     assert isinstance(layer, KiviLayerCacheMF)
-    layer.flags = _lib.GQA_FORCE_SPLIT
+    layer.flags = _lib.GQA_FORCE_SPLIT if form == "split" else (_lib.GQA_FORCE_ROW | _lib.GQA_DUMP_SCORES)
     layer.prefill(k0.cuda(), v0.cuda())
     past = H.prefill_cache(k0, v0, 2, 2, g, R)
     _cmp_cache(layer.as_tuple(), past)
     gen = torch.Generator().manual_seed(5)
     worst_a = worst_b = 0.0
     for s in range(steps):
-        q = make_kv(100 + s, B, nh, 1, D)
-        kn, vn = make_kv(200 + s, B, nh_kv, 1, D), make_kv(300 + s, B, nh_kv, 1, D)
+        q = q_step(100 + s, nh, 1)
+        kn, vn = k_step(200 + s, nh_kv, 1), v_step(300 + s, nh_kv, 1)
         mask = None
         n = T0 + s + 1
         if masked:
             mask = torch.zeros((B, 1, 1, n), dtype=torch.float16)
             mask[0, ..., : min(7, n - 1)] = torch.finfo(torch.float16).min          # left padding of batch row 0
             mask[1, ..., torch.randint(0, n - 1, (3,), generator=gen)] = -3.0
+        if layer._native:
+            layer._native[4][0].fill_(float("nan"))                                  # (a stale row must not pass for this step's)
         out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer, attention_mask=None if mask is None else mask.cuda())
-        x_gpu = layer._native[4][0][:B, :nh, :, :n].cpu()                            # the row the sV launch consumed
+        assert torch.isfinite(out).all(), s
+        x_gpu = layer._native[4][0][:B, :nh, :, :n].cpu()                            # the row the softmax / the sV launch consumed
         ref, past_ref, x_ref = H.decode_step(q, kn, vn, past, 2, 2, g, R, attention_mask=mask, return_scores=True)
+        assert torch.isfinite(x_ref.float()).all() and torch.isfinite(ref.float()).all(), "test inputs must keep the reference finite"
         live = x_ref.float() > -60000                                                # fully masked keys: both sides at the fp16 minimum
         ok, ra = gemv_close(torch.where(live, x_gpu.float(), 0.0), torch.where(live, x_ref.float(), 0.0), rtol=1e-3)
         assert ok, ("scores", s, ra)
@@ -289,9 +307,108 @@ def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked)
         assert ok, ("attend", s, rb)
         worst_a, worst_b = max(worst_a, ra), max(worst_b, rb)
         past = past_ref
-        if s in (0, R - 1, R, steps - 1):
+        if s in (check_at or (0, R - 1, R, steps - 1)):
             _cmp_cache(layer.as_tuple(), past)
     print(f"worst ratio: scores {worst_a:.3f} of the 1e-3 bar, attend {worst_b:.3f} of the 2e-3 bar")
+    return layer
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dynamic range of the matrix-pipe operands: the fp16 A operands q * scale / p * scale must stay finite and
+# accurate from subnormal scales to the largest finite ones, as the reference's fp32 scale * code + zero does
+# (quant/csrc/gemv_cuda.cu:407-413).  Values are uniform in +-mag with a per-channel spread, so a unit mixes small and large
+# scales; q (or nothing, for sV) is scaled so that the REFERENCE's fp16 result stays finite.
+
+def _ranged(seed, B, h, T, mag, spread_dim):
+    """Uniform in +-mag, times a factor per index of `spread_dim` (3: channel, 2: token) drawn from three decades below 1."""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand((B, h, T, 128), generator=g) * 2 - 1) * mag
+    n = x.shape[spread_dim]
+    shape = [1, 1, 1, 1]
+    shape[spread_dim] = n
+    return (x * torch.logspace(0, -3, n)[torch.randperm(n, generator=g)].reshape(shape)).half()
+
+
+MAGS = [1e-4, 1.0, 1e3, 3e4]
+
+
+@pytest.mark.parametrize("mag", MAGS)
+@pytest.mark.parametrize("B,nh,nh_kv,T", [(2, 2, 2, 1056), (2, 8, 2, 1056), (1, 8, 1, 1056), (32, 32, 32, 4096)])
+def test_gqa_scores_dynamic_range(mods, oracle, B, nh, nh_kv, T, mag):
+    """Matrix-pipe qK^T over keys of magnitude 1e-4 .. 3e4 (K scales from the fp16 subnormals to ~2e4; channels spread over three
+    decades): finite, within the GEMV bar of the oracle on sampled units and of the VALU kernel (fp32 scale * code + zero)
+    everywhere; the store's range flags are set exactly for the units that hold a scale >= 256."""
+    mfma, new_pack, matmul = mods
+    k = _ranged(3, B, nh_kv, T, mag, 3).cuda()                      # per-channel magnitudes: K groups run along the tokens
+    q = (make_kv(4, B, nh, 1, 128) * min(1.0, 300.0 / mag)).half().cuda()
+    store = mfma.alloc_store(B, nh_kv, (T + 511) // 512, "cuda")
+    mfma.kt_pack(k, store, 0)
+    code, scale, mn = new_pack.quantize_and_pack_k_tmajor(k, 32, 2)
+    big = (scale.float() >= 256).flatten(2).any(-1)
+    assert torch.equal(mfma.range_flags(store).bool(), big) and bool(big.any()) == (mag >= 1e3)
+    out = torch.full((B, nh, 1, T + 8), 7.0, dtype=torch.float16, device="cuda")
+    mfma.gqa_scores(q, store, T, out)
+    assert torch.isfinite(out).all()
+    ref_gpu = matmul.cuda_bmm_fA_qB_outer(32, q, code, scale, mn, 2)
+    assert torch.isfinite(ref_gpu).all(), "test inputs must keep the reference finite"
+    ok, ratio = gemv_close(out[..., :T], ref_gpu.cpu(), rtol=1.5e-3)
+    assert ok, ratio
+    rh = nh // nh_kv
+    for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
+        hs = slice(hk * rh, (hk + 1) * rh)
+        ref = oracle.bmm_fA_qB_outer(32, q[b:b + 1, hs].cpu(), code[b:b + 1, hk:hk + 1].cpu(), scale[b:b + 1, hk:hk + 1].cpu(),
+                                     mn[b:b + 1, hk:hk + 1].cpu(), 2)
+        ok, ratio = gemv_close(out[b:b + 1, hs, :, :T], ref)
+        assert ok, (b, hk, ratio)
+
+
+@pytest.mark.parametrize("mag", MAGS)
+@pytest.mark.parametrize("B,nh,nh_kv,T", [(2, 2, 2, 1000), (2, 8, 2, 1000), (1, 8, 1, 1000), (4, 32, 32, 4064)])
+def test_gqa_output_dynamic_range(mods, oracle, B, nh, nh_kv, T, mag):
+    """Matrix-pipe sV over values of magnitude 1e-4 .. 3e4 (token magnitudes spread over three decades): as above."""
+    mfma, new_pack, matmul = mods
+    v = _ranged(21, B, nh_kv, T, mag, 2).cuda()                     # per-token magnitudes: V groups run along the channels
+    store = mfma.alloc_store(B, nh_kv, (T + 511) // 512, "cuda")
+    mfma.vt_pack(v, store)
+    code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(v, 32, 2)
+    big = (scale.float() >= 256).flatten(2).any(-1)
+    assert torch.equal(mfma.range_flags(store).bool(), big) and bool(big.any()) == (mag >= 1e3)
+    pitch = (T + 7) // 8 * 8 + 8
+    probs = torch.zeros((B, nh, 1, pitch), dtype=torch.float16, device="cuda")
+    probs[..., :T] = _probs("softmax", B, nh, T, 5).cuda()
+    out = mfma.gqa_output(probs, store, T)
+    assert torch.isfinite(out).all()
+    ref_gpu = matmul.cuda_bmm_fA_qB_outer(32, probs[..., :T], code, scale, mn, 2)
+    assert torch.isfinite(ref_gpu).all(), "test inputs must keep the reference finite"
+    ok, ratio = gemv_close(out, ref_gpu.cpu(), rtol=1.5e-3)
+    assert ok, ratio
+    rh = nh // nh_kv
+    for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
+        hs = slice(hk * rh, (hk + 1) * rh)
+        ref = oracle.bmm_fA_qB_outer(32, probs[b:b + 1, hs, :, :T].cpu().contiguous(), code[b:b + 1, hk:hk + 1].cpu(),
+                                     scale[b:b + 1, hk:hk + 1].cpu(), mn[b:b + 1, hk:hk + 1].cpu(), 2)
+        ok, ratio = gemv_close(out[b:b + 1, hs], ref, rtol=1e-3)
+        assert ok, (b, hk, ratio)
+
+
+@pytest.mark.parametrize("form", ["split", "row"])
+@pytest.mark.parametrize("m0,m1", [(1e-4, 1e-4), (1.0, 1e3), (1e3, 1.0), (1e3, 1e3), (3e4, 3e4)])
+@pytest.mark.parametrize("nh,nh_kv", [(2, 2), (8, 2), (8, 1)])
+def test_mf_decode_steps_dynamic_range(oracle, nh, nh_kv, m0, m1, form):
+    """The whole step, stage by stage as above, with a prompt of magnitude m0 and new tokens of magnitude m1 (K and V both):
+    (1, 1e3) sets the range flags of both stores in the middle of the run -- the K flag by the K flush (kivi_kt_pack), the V
+    flag by the V flush inside the step's own launch -- (1e3, 1) keeps them set while the new groups are small, (3e4, 3e4)
+    runs scales ~2e4 through every path.  R + 3 steps: one K flush, V flushes from the first step on."""
+    R, T0 = 32, 600
+    qmag = min(1.0, 300.0 / max(m0, m1))
+    layer = _stage_ab_steps(
+        nh, nh_kv, T0, R, False, form, R + 3,
+        k_prompt=lambda seed, h, T: _ranged(seed, 2, h, T, m0, 3), k_step=lambda seed, h, T: _ranged(seed, 2, h, T, m1, 3),
+        v_prompt=lambda seed, h, T: _ranged(seed, 2, h, T, m0, 2), v_step=lambda seed, h, T: _ranged(seed, 2, h, T, m1, 3),
+        q_step=lambda seed, h, T: (make_kv(seed, 2, h, T, 128) * qmag).half(), check_at=(0, 5, R - 1, R, R + 2))
+    from kivi_amd.quant import mfma
+    expect = max(m0, m1) >= 1e3
+    assert bool(mfma.range_flags(layer.kt).any()) == expect and bool(mfma.range_flags(layer.vt).any()) == expect
 
 
 @pytest.mark.parametrize("B,nh,nh_kv,T0,R,masked", [(2, 4, 4, 5, 32, False), (8, 32, 32, 1500, 32, True), (2, 2, 2, 8100, 32, False),

@@ -1,0 +1,112 @@
+#!/bin/bash
+# ONE parameterised GPU session script (replaces the per-experiment session_*.sh of rounds 1-3).  Run through gpurun from the
+# repo root, e.g.   gpurun --timeout 900 -- 'bash tools/session.sh tests bench shapes'
+# Every stage writes under gpurun_out/<tag>/ (tag = $SESSION_TAG, default "s"); copy what is to be judged into profiles/.
+#
+#   tests            pytest -m gpu (+ smoke)                                  -> pytest_gpu.log
+#   bench            the driver's command (default workload)                  -> bench.json
+#   shapes           the other shapes of DESIGN section 5 through bench.py    -> shape_*.json + a one-line summary each
+#   trace            rocprofv3 --kernel-trace --stats of the bench command + per-kernel medians (tools/trace_median.py)
+#   trace_gqa        the same for BASELINE config 4, the config-5 per-GPU slice and the 70B-like (64 / 8 heads) slice
+#   pmc              FETCH_SIZE / WRITE_SIZE passes (separate, kernel trace only) of the bench command + calibration
+#   pmc_c4           the same at BASELINE config 4
+#   e2e              examples/mem_spd_test.py --recipe and the configs[2] decode loop
+#   ab <lib.so>...   same-box A/B of bench.py (headline + config 4) between the in-tree library and the given builds
+#                    (tools/build_variant.sh; KIVI_TUNING=1 KIVI_HIP_LIB=...)
+#   phases           per-wave phase timeline of mf_row_kernel / mf_row4_kernel (tuning build, tools/mf_row_phases.py)
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
+TAG=${SESSION_TAG:-s}
+O=$R/gpurun_out/$TAG; mkdir -p $O
+export PYTHONUNBUFFERED=1
+BN="python $R/bench.py --no-cpu-baseline --no-hook-kgemv"
+C4="--batch 64 --heads 32 --kv-heads 8 --prompt 8064 --residual 128"
+C5="--batch 16 --heads 32 --kv-heads 8 --prompt 32640 --residual 128"
+C70="--batch 16 --heads 64 --kv-heads 8 --prompt 8064 --residual 128"
+
+line() {  # one-line summary of a bench JSON line
+python - "$1" <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j.get("roofline") or {}
+    print(sys.argv[1].split("/")[-1], j["value"], "tok/s", j["ms_per_step"], "ms", r.get("kernel"), r.get("median_launch_us"), "us frac", r.get("frac"), "host", j.get("host_enqueue_ms_per_step"))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+}
+
+trace_one() {  # <name> <skip> <bench args...>
+    local name=$1 skip=$2; shift 2
+    cd /tmp && export TMPDIR=/tmp
+    rm -rf $O/trace_$name
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -o b -- $BN "$@" > $O/trace_${name}_bench.json 2> $O/trace_$name.err
+    cd $R
+    python tools/trace_median.py $(find $O/trace_$name -name "*kernel_trace.csv" | head -1) --skip $skip --match mf_ decode_row gemv_ kt_pack vt_pack quant_pack \
+        --json $O/trace_median_$name.json > $O/trace_median_$name.log 2>&1
+    cp $(find $O/trace_$name -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$name.csv 2>/dev/null
+    rm -rf $O/trace_$name
+    head -12 $O/trace_median_$name.log; line $O/trace_${name}_bench.json
+}
+
+pmc_one() {  # <name> <config json> <bench args...>
+    local name=$1 cfg=$2; shift 2
+    cd /tmp && export TMPDIR=/tmp
+    rm -rf $O/pmc_f_$name $O/pmc_w_$name $O/pmc_calib
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$name -o b -- $BN --steps 3 --warmup 1 --no-kernel-events "$@" > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$name -o b -- $BN --steps 3 --warmup 1 --no-kernel-events "$@" > /dev/null 2>&1
+    [ -f $O/pmc_calib_done ] || { timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -o c -- $R/tools/hbm_read_bw.bin 2 > $O/hbm_bw.log 2>&1; touch $O/pmc_calib_done; }
+    cd $R
+    python tools/pmc_traffic.py $(find $O/pmc_f_$name -name "*counter_collection.csv" | head -1) $(find $O/pmc_w_$name -name "*counter_collection.csv" | head -1) \
+        $(find $O/pmc_calib -name "*counter_collection.csv" | head -1) --skip 32 --config "$cfg" --out $O/pmc_traffic_$name.json > $O/pmc_traffic_$name.log 2>&1
+    find $O/pmc_f_$name $O/pmc_w_$name -name "*.csv" -size +4M -delete
+    cat $O/pmc_traffic_$name.log
+}
+
+cd $R
+while [ $# -gt 0 ]; do
+    stage=$1; shift
+    case $stage in
+    tests)
+        timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/status.log
+        tail -15 $O/pytest_gpu.log
+        timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" >> $O/pytest_gpu.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.log ;;
+    bench)
+        timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/status.log
+        head -c 2500 $O/bench.json; echo; line $O/bench.json ;;
+    shapes)
+        for b in 16 8 64 128; do timeout 300 $BN --batch $b --steps 10 --warmup 3 > $O/shape_b$b.json 2>> $O/shapes.err; line $O/shape_b$b.json; done
+        timeout 300 $BN --batch 1 --prompt 32752 --steps 10 --warmup 3 > $O/shape_b1_32k.json 2>> $O/shapes.err; line $O/shape_b1_32k.json
+        timeout 300 $BN --batch 4 --steps 10 --warmup 3 > $O/shape_b4.json 2>> $O/shapes.err; line $O/shape_b4.json
+        timeout 300 $BN --bits 4 --steps 10 --warmup 3 > $O/shape_4bit.json 2>> $O/shapes.err; line $O/shape_4bit.json
+        timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/shape_config4.json 2>> $O/shapes.err; line $O/shape_config4.json
+        timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/shape_config4_4bit.json 2>> $O/shapes.err; line $O/shape_config4_4bit.json
+        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/shape_config5_slice.json 2>> $O/shapes.err; line $O/shape_config5_slice.json
+        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/shape_70b_slice.json 2>> $O/shapes.err; line $O/shape_70b_slice.json
+        KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN > $O/shape_headline_hook_layout.json 2>> $O/shapes.err; line $O/shape_headline_hook_layout.json ;;
+    trace) trace_one bench 160 ;;
+    trace_gqa)
+        trace_one config4 96 $C4 --steps 10 --warmup 3
+        trace_one config5slice 64 $C5 --steps 6 --warmup 2
+        trace_one slice70b 96 $C70 --steps 10 --warmup 3 ;;
+    pmc) pmc_one bench '{"B": 32, "nh": 32, "nh_kv": 32, "prompt": 4080, "bits": 2, "group": 32, "residual": 32}' ;;
+    pmc_c4) pmc_one config4 '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 2, "group": 32, "residual": 128}' $C4 ;;
+    e2e)
+        timeout 900 python examples/mem_spd_test.py --recipe > $O/e2e_mem_spd_recipe.log 2>&1; echo "recipe rc=$?" | tee -a $O/status.log; tail -12 $O/e2e_mem_spd_recipe.log
+        timeout 900 python examples/mem_spd_test.py --graphs > $O/e2e_llama7b_shape.log 2>&1; echo "e2e rc=$?" | tee -a $O/status.log; tail -8 $O/e2e_llama7b_shape.log ;;
+    ab)
+        libs=("")
+        while [ $# -gt 0 ] && [[ $1 == *.so ]]; do libs+=("$1"); shift; done
+        for i in 1 2; do
+            for l in "${libs[@]}"; do
+                n=$(basename "${l:-intree}" .so)
+                KIVI_TUNING=1 KIVI_HIP_LIB=${l:-$R/kivi_amd/libkivi_hip.so} timeout 300 $BN > $O/ab_${n}_hl_$i.json 2>> $O/ab.err; line $O/ab_${n}_hl_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=${l:-$R/kivi_amd/libkivi_hip.so} timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/ab_${n}_c4_$i.json 2>> $O/ab.err; line $O/ab_${n}_c4_$i.json
+            done
+        done ;;
+    phases)
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T timeout 300 python tools/mf_row_phases.py > $O/row_phases.log 2>&1; tail -30 $O/row_phases.log
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/row4_phases.log 2>&1; tail -30 $O/row4_phases.log ;;
+    *) echo "unknown stage $stage" ;;
+    esac
+done
+cat $O/status.log 2>/dev/null
