@@ -117,7 +117,11 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
         // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
         const int hb = (4 * (lane >> 4)) % R;                       // heads hb .. hb + 3 sit in this lane's result registers
         mf_k_seqR<R, RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
-                           [&](int, int tt, int r, float v) { lds_o[(hb + r) * 512 + tt] = f2h_bits(v); }, flush_sb);
+                           [&](int, int tt, int r, float v0, float v1) {
+                               const uint32_t hp = mf_cvt_pair(v0, v1);
+                               lds_o[(hb + r) * 512 + tt] = (uint16_t)(hp & 0xFFFFu);
+                               lds_o[(hb + r) * 512 + tt + 16] = (uint16_t)(hp >> 16);
+                           }, flush_sb);
     }
 }
 
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     const uint32_t sb_bytes = (uint32_t)(a.vt.sb_s * 4);
 
     MfVAcc<R> A;
-    mf_v_init<R>(A);
+    mf_v_init(A);
     const int sb_begin = win_role ? 0 : slice * a.spb;
     const int sb_end = win_role ? 0 : ((sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb);
     // wave w streams super-blocks sb_begin + w, + 4, ... of the slice as ONE stream: the code ring runs across the super-blocks
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R, RING>(A, zl, Lf);                               // Lf[r * 128 + d], before 2^-Sp
+    mf_v_finish<R, RING, false>(A, zl, Lf);                               // Lf[r * 128 + d], before 2^-Sp
     // the p'' region of a wave holds R x 256 words = R x 128 floats twice: quantised part first, window part second
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
@@ -496,11 +500,11 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
     // ---- packed sV: contiguous block ranges per wave
     {
         MfVAcc<1> A;
-        mf_v_init<1>(A);
+        mf_v_init(A);
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         vs.run(A, rv, b_lo, b_hi, row, 0, 0);
         stamp(9);
-        mf_v_finish<1, VRING>(A, zl[wave], red[wave]);
+        mf_v_finish<1, VRING, false>(A, zl[wave], red[wave]);
     }
     __syncthreads();
     stamp(10);
@@ -531,7 +535,9 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
 // The whole decode step of one (batch row, kv head) with its four query heads in one block of NW waves (grouped queries,
 // rows whose four score rows fit the LDS: 4 n fp16 <= 72 KiB, two blocks per CU): no score / statistics round trip through
 // memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
-template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false>
+// KHL / VHL: hi / lo of q'' * scale (p'' * scale) in MFMA rows (mf_k_seqR<4, ., true> / MfVStream<4, ., true>: 8 instead of 16
+// matrix instructions per group / block)
+template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool KHL = false, bool VHL = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     extern __shared__ uint16_t rows[];                             // [R][n_pad]
@@ -556,12 +562,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const int L = ak.res_len + 1;
     const int n = Tq + L;
     const int kbig = __builtin_amdgcn_readfirstlane(ak.range[unit]), vbig = __builtin_amdgcn_readfirstlane(av.range[unit]);   // see mf_row_kernel
+    if (ak.stagger > 0 && ((unit / ak.stagger_cus) & 1)) {
+        // the second block of a CU starts late, so that its latency-bound middle (softmax, window) falls into the other block's
+        // streams and vice versa (the two blocks of a CU otherwise run in lock-step: section 3.7)
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ak.stagger) __builtin_amdgcn_s_sleep(32);
+    }
     const uint16_t* q_h0 = ak.q + b * ak.q_sb + (int64_t)h0 * ak.q_sh;
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
 
     // ---- packed qK^T: wave w walks super-blocks w, w + NW, ...
-    float mxl[R] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};   // per-lane maxima of the scores written
+    // per-lane maxima of the scores written: a packed pair per head while the K stream runs (one v_pk_max_f16 per two scores)
+    typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+    uint32_t mxp[R] = {0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u};
     {
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
         MfKSeq seq;
@@ -572,11 +586,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq4<KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v) {
-            const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);     // the rows hold the SCALED scores (:339)
-            rows[r * n_pad + sb * KIVI_MF_SB_TOKENS + tt] = h;
-            mxl[r] = __builtin_fmaxf(mxl[r], h2f_bits(h));                                 // r is a constant after unrolling
+        mf_k_seqR<4, KRING, KHL>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
+            // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
+            // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
+            const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
+            uint16_t* dst = rows + r * n_pad + sb * KIVI_MF_SB_TOKENS + tt;
+            dst[0] = (uint16_t)(hs & 0xFFFFu);
+            if constexpr (KHL) {                                   // heads r, r + 1 at token tt
+                dst[n_pad] = (uint16_t)(hs >> 16);
+                mxp[r >> 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r >> 1]), __builtin_bit_cast(hp2, hs)));
+            } else {                                               // head r at tokens tt, tt + 16
+                dst[16] = (uint16_t)(hs >> 16);
+                mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
+            }
         }, [](int, int) {});
+    }
+    float mxl[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if constexpr (KHL) mxl[r] = h2f_bits((uint16_t)((r & 1) ? mxp[r >> 1] >> 16 : mxp[r >> 1] & 0xFFFFu));       // mxp[0]: heads 0 | 1, mxp[1]: heads 2 | 3
+        else mxl[r] = __builtin_fmaxf(h2f_bits((uint16_t)(mxp[r] & 0xFFFFu)), h2f_bits((uint16_t)(mxp[r] >> 16)));
     }
     stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
@@ -585,7 +614,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const int nbw = (NB + NW - 1) / NW;
     const int b_lo = wave * nbw;
     const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
-    MfVStream<R, VRING> vs;
+    MfVStream<R, VRING, VHL> vs;
     vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
     // ---- residual scores q . [K_full | k_new] of the four heads (:337) + K append (:333-336)
     for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
@@ -641,15 +670,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     stamp(8);
 
     // ---- packed sV
-    MfVAcc<R> A;
-    mf_v_init<R>(A);
+    MfVAcc<R, VHL> A;
+    mf_v_init(A);
     __builtin_amdgcn_s_setprio(0);
     vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0);
     stamp(9);
     __syncthreads();                                               // every wave is done with the p'' rows: their memory is reused
-    float* red = reinterpret_cast<float*>(rows);                   // [NW][R * 128] quantised part | [NW][R * 128] window part
-    float* resl = red + NW * R * 128;
-    mf_v_finish<R, VRING>(A, zl[wave], red + wave * R * 128);
+    constexpr int NP = VHL ? 2 * NW : NW;                          // partial results of the quantised part (VHL: hi and lo of every wave)
+    float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part
+    float* resl = red + NP * R * 128;
+    mf_v_finish<R, VRING, VHL>(A, zl[wave], red + wave * (NP / NW) * R * 128);
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
         resl[wave * R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
@@ -660,10 +690,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int rr = i >> 7, d = i & 127;
         float qs = 0.f, ws = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            qs += red[w * R * 128 + i];
-            ws += resl[w * R * 128 + i];
-        }
+        for (int w = 0; w < NP; w++) qs += red[w * R * 128 + i];
+#pragma unroll
+        for (int w = 0; w < NW; w++) ws += resl[w * R * 128 + i];
         qs = __builtin_ldexpf(qs, -sp_lds[rr]);
         const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
         av.out[b * av.out_sb + (int64_t)(h0 + rr) * av.out_sh + d] = o;
@@ -771,7 +800,15 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump,
             return kivi_launch_status("mf_row4");
         }
 #ifdef KIVI_TUNING
-        static unsigned long long opt_t[5] = {0, 0, 0, 0, 0};
+        static const char* stg = KIVI_TUNE_ENV("KIVI_MF_STAG_US");       // A/B: the second block of every CU starts that many us late
+        if (stg) {
+            GqaKArgs& km = const_cast<GqaKArgs&>(k);
+            km.stagger = (int)(atof(stg) * 100.0);
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+            km.stagger_cus = cus > 0 ? cus : 256;
+        }
+        static unsigned long long opt_t[16] = {0};
         static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<waves><K ring><V ring>"
         const int cfg = fr4 ? atoi(fr4) : 443;
         // (8 waves of 128 registers spill: 123-139 us, profiles/r03_config4_row4.log)
@@ -782,11 +819,19 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump,
         KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad);      \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
+        // <K ring><V ring><waves> + 1000: hi / lo rows in the qK^T phase, + 2000: in the sV phase (mf_row4_kernel KHL / VHL)
+        if (v.dbg && cfg >= 3000) KIVI_ROW4_VARIANT(5, 4, 3, 4, true, false, true, true);
         if (v.dbg) KIVI_ROW4_VARIANT(0, 4, 3, 4, true);
         if (cfg == 423) KIVI_ROW4_VARIANT(1, 2, 3, 4);
         if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
-        if (cfg == 484) KIVI_ROW4_VARIANT(3, 8, 4, 4);
         if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
+        if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, true, false);
+        if (cfg == 2443) KIVI_ROW4_VARIANT(7, 4, 3, 4, false, false, false, true);
+        if (cfg == 3443) KIVI_ROW4_VARIANT(8, 4, 3, 4, false, false, true, true);
+        if (cfg == 3843) KIVI_ROW4_VARIANT(9, 8, 3, 4, false, false, true, true);
+        if (cfg == 3844) KIVI_ROW4_VARIANT(10, 8, 4, 4, false, false, true, true);
+        if (cfg == 3444) KIVI_ROW4_VARIANT(11, 4, 4, 4, false, false, true, true);
+        if (cfg == 3243) KIVI_ROW4_VARIANT(12, 2, 3, 4, false, false, true, true);
 #undef KIVI_ROW4_VARIANT
 #endif
         const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");

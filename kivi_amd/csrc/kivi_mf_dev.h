@@ -286,20 +286,32 @@ __device__ __forceinline__ void mf_k_zero(const MfQ<R>& Q, const u32x4* mv, cons
 // the scale of round rq + 1 is requested right after the operands of round rq have been built from the registers it lands in,
 // the zero points of the next super-block while the current one is multiplied, the code ring runs across rounds and super-
 // blocks (cf. mf_k_seq1).
-// Scores go to sink(super-block index, token inside it, register r, fp32 score): the head is (4 kb) % R + r, i.e. r itself
-// for R = 4 and 4 (kb & 1) + r for R = 8; done(super-block index, its number of groups) is called when the last score of a
-// super-block has been handed to sink.  RING code blocks in flight, a multiple of the 16 / R groups of a round.
+// Scores go to sink(super-block index, token tt inside it, register r, fp32 scores of tokens tt and tt + 16): the head is
+// (4 kb) % R + r, i.e. r itself for R = 4 and 4 (kb & 1) + r for R = 8 (the two scores of a call share everything but the token
+// tile, so a sink can convert / scale / compare them as a packed pair); done(super-block index, its number of groups) is called
+// when the last score of a super-block has been handed to sink.  RING code blocks in flight, a multiple of the 16 / R groups of a round.
 template <int V> struct mf_ic { static constexpr int value = V; };
 
-template <int R, int RING, typename Sink, typename Done>
+//
+// HL (R = 4 only): hi and lo parts of q'' * scale sit in ROWS instead of two chained operands -- row m -> group m / 8, hi (m & 4
+// == 0) | lo, head m & 3: two groups per round, ONE MFMA per (channel chunk, token tile) = 8 per group instead of 16, the hi and
+// lo sums of a score meet with one v_permlane16_swap + add per register.  Why: with 16 MFMAs (256 matrix-pipe cycles) per KiB of
+// codes and two waves per SIMD the R = 4 kernels keep the matrix pipe ~80 % busy at 5.7 TB/s -- it, not the VALU or the memory,
+// paces them; this form halves the matrix work for ~12 more VALU instructions per group.  The sink then
+// receives pairs of HEADS: sink(sb, token, r in {0, 2}, score of head r, score of head r + 1).
+template <int R, int RING, bool HL = false, typename Sink, typename Done>
 __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
-    constexpr int GPR = 16 / R;                                      // groups per round
+    static_assert(!HL || R == 4, "hi / lo rows: 2 groups x (hi | lo) x 4 heads");
+    constexpr int RR = HL ? 2 * R : R;                              // rows per group
+    constexpr int GPR = 16 / RR;                                     // groups per round
     static_assert((RING >= GPR ? RING % GPR == 0 : GPR % RING == 0) && RING <= 8, "whole rounds per ring, or whole rings per round");
     constexpr int RPT = RING > GPR ? RING / GPR : 1;               // rounds per trip of the loop below
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
-    const int gl = (4 * kb) / R;                                    // the group of the round whose scores this lane's registers hold
+    const int gl = (4 * kb) / RR;                                   // the group of the round whose scores this lane's registers hold
+    const int hb = HL ? 0 : (4 * kb) % R;                           // ... for the heads hb .. hb + 3
+    const uint32_t lom = (HL && (m & R)) ? 0xFFFFFFFFu : 0u;        // all ones in the lanes of a lo row
     if (W.ng_total <= 0) return;
     auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
     const int g_last = W.ng_total - 1;
@@ -310,7 +322,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
     auto request_round = [&](int rq, bool live) {
         const int g0 = GPR * rq;
         const uint32_t so = sb_off(g0 >> 4);
-        const int g = (g0 & 15) + m / R;
+        const int g = (g0 & 15) + m / RR;
         const uint32_t dead = live ? 0u : MF_DEAD_OFF;
 #pragma unroll
         for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4) + dead, so);
@@ -338,7 +350,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
     float zmul[4], cmul[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int sqj = __shfl(Q.sq, (4 * kb) % R + j);             // lane h (kb = 0, row h) holds head h's exponent
+        const int sqj = __shfl(Q.sq, hb + j);                       // lane h (kb = 0, row h) holds head h's exponent
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
         cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT + (big ? KIVI_MF_BIG_SHIFT : 0) - sqj);
     }
@@ -347,19 +359,24 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
     // trip (so that every slot index is a constant)
     auto do_round = [&](int rq, auto slot0) {
         constexpr int S0 = decltype(slot0)::value;
-        const int sbi = rq / R;                                     // R rounds per super-block
-        const int rs = rq - sbi * R;
+        const int sbi = rq / RR;                                    // 16 / GPR = RR rounds per super-block
+        const int rs = rq - sbi * RR;
         if (rs == 0) {                                              // a new super-block: its zero-point sums, then the next one's zero points
             mf_k_zero<R>(Q, zv, zmul, zz, big);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
-        uint32_t Ah[4][4], Al[4][4];
+        uint32_t Ah[4][4], Al[HL ? 1 : 4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
-                Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
+                if constexpr (HL) {
+                    // hi rows: fp16(q'' s) (the subtrahend is 0); lo rows: the exact remainder q'' s - fp16(q'' s)
+                    Ah[c][i] = pk_fms(Q.qq[c][i], sv[c][i], pk_mul(Q.qq[c][i], sv[c][i]) & lom);
+                } else {
+                    Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
+                    Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
+                }
             }
         request_round(rq + 1 < n_round ? rq + 1 : rq, rq + 1 < n_round);
         __builtin_amdgcn_sched_barrier(0);
@@ -376,13 +393,15 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
             for (int c = 0; c < 4; c++) {
                 const MfB b = mf_views(wr[(S0 + j) % RING][c]);
                 const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
-                const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
+                if constexpr (!HL) {
+                    const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
+                }
             }
-            const bool mine = gl == j;                              // rows 4 kb .. 4 kb + 3 = group GPR rq + gl, heads (4 kb) % R + 0 .. 3
+            const bool mine = gl == j;                              // rows 4 kb .. 4 kb + 3 = group GPR rq + gl, heads hb + 0 .. 3 (HL: hi | lo of them)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 o0[r] = mine ? a0[r] : o0[r];
@@ -391,16 +410,28 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
             request_group((S0 + j) % RING, GPR * rq + j + RING);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (GPR * rq + gl < W.ng_total) {
+        if constexpr (HL) {
+            // rows (kb = 2 g + hl): tile 0 in o0, tile 1 in o1.  v_permlane16_swap exchanges the odd 16-lane rows of the first with
+            // the even rows of the second operand: afterwards o0 holds the hi sums (row 2 g: tile 0, row 2 g + 1: tile 1) and o1
+            // the lo sums in the same places -- one add, and lane (n, kb) holds token 16 (kb & 1) + n of group kb >> 1, heads 0..3
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(o0[r]), "+v"(o1[r]));
+                o0[r] += o1[r];
+            }
+            if (GPR * rq + gl < W.ng_total) {
+                const int sb = W.sb_first + sbi * W.sb_stride;
+                const int tok = (GPR * rs + gl) * 32 + 16 * (kb & 1) + m;
+                sink(sb, tok, 0, __builtin_fmaf(o0[0], cmul[0], zs[0]), __builtin_fmaf(o0[1], cmul[1], zs[1]));
+                sink(sb, tok, 2, __builtin_fmaf(o0[2], cmul[2], zs[2]), __builtin_fmaf(o0[3], cmul[3], zs[3]));
+            }
+        } else if (GPR * rq + gl < W.ng_total) {
             const int sb = W.sb_first + sbi * W.sb_stride;
             const int g = GPR * rs + gl;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                sink(sb, g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]));
-                sink(sb, g * 32 + 16 + m, r, __builtin_fmaf(o1[r], cmul[r], zs[r]));
-            }
+            for (int r = 0; r < 4; r++) sink(sb, g * 32 + m, r, __builtin_fmaf(o0[r], cmul[r], zs[r]), __builtin_fmaf(o1[r], cmul[r], zs[r]));
         }
-        if (rs == R - 1 || rq == n_round - 1) {                    // the super-block is complete
+        if (rs == RR - 1 || rq == n_round - 1) {                   // the super-block is complete
             const int left = W.ng_total - 16 * sbi;
             done(W.sb_first + sbi * W.sb_stride, left < 16 ? left : 16);
         }
@@ -418,11 +449,6 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
     }
 }
 
-template <int RING, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
-    mf_k_seqR<4, RING>(rk, W, q_h0, q_sh, big, sink, done);
-}
-
 // ------------------------------------------------------------------------------------------------ sV
 // Accumulators of a wave over its token blocks: acc[c][tile] = rows x channels 32 c + 16 tile + n, chained through the
 // C operand over all blocks.
@@ -437,20 +463,24 @@ __device__ __forceinline__ void mf_k_seq4(rsrc_t rk, const MfKSeq& W, const uint
 // the round -- and the lanes keep the exact sum of the A they centred with (cs4 / cs6, v_dot2_f32_f16); the running sums
 // then stay within ~RING blocks' worth of the output.  (A centring MFMA for every tile of every block -- the first round-3
 // form -- doubled the matrix instructions for nothing.)
-template <int R>
+// HL (R = 4 only): hi and lo parts of p'' * scale in ROWS -- row m -> channel group m >> 3 of the row set, hi (m & 4 == 0) | lo,
+// head m & 3; two row sets as for R = 8, ONE MFMA per (channel chunk, tile): 8 (+ the centring ones) per block instead of 16.
+// The hi and lo sums of an output meet in the caller's final reduction (mf_v_finish writes them to separate slots).
+template <int R, bool HL = false>
 struct MfVAcc {
-    static constexpr int NS = R == 8 ? 2 : 1;      // row sets (R = 8: channel groups {0, 1} and {2, 3})
+    static_assert(!HL || R == 4, "hi / lo rows: 2 channel groups x (hi | lo) x 4 heads");
+    static constexpr int NS = (R == 8 || HL) ? 2 : 1;      // row sets (channel groups {0, 1} and {2, 3})
     f4 acc[4][2];
     float z4[NS], z6[NS];      // R = 1: sum p'' * (scale | mn) of every block; R = 4 / 8: sum p'' * mn        (registers with 2^4 / 2^6)
     float c4[NS], c6[NS];      // sums over the centring blocks: R = 1: p'' * (scale | mn); R = 4 / 8: the hi operand
 };
 
-template <int R>
-__device__ __forceinline__ void mf_v_init(MfVAcc<R>& A) {
+template <int R, bool HL>
+__device__ __forceinline__ void mf_v_init(MfVAcc<R, HL>& A) {
 #pragma unroll
     for (int c = 0; c < 4; c++) A.acc[c][0] = A.acc[c][1] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < MfVAcc<R>::NS; s++) A.z4[s] = A.z6[s] = A.c4[s] = A.c6[s] = 0.f;
+    for (int s = 0; s < MfVAcc<R, HL>::NS; s++) A.z4[s] = A.z6[s] = A.c4[s] = A.c6[s] = 0.f;
 }
 
 // -1.5 * RING in the units of a masked code: registers 0, 1 hold code * 2^-16, registers 2, 3 code * 2^-18 (fp16 bits, both halves)
@@ -465,11 +495,43 @@ template <> struct MfCentre<4> { static constexpr uint32_t a = 0x86008600u, b = 
 // R = 8: row (channel group 2 s + (m >> 3), head m & 7) for the row sets s = 0, 1: sm[s], mn[s]; channel chunk c multiplies with
 //        row set c >> 1 (its rows for channel group c are the useful ones).
 // CENTRE: this block also accumulates A x (-1.5 RING).
-template <int R, int RING, bool CENTRE>
-__device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u32x4& ps, const u32x4* sm, const u32x4* mn,
+template <int R, int RING, bool CENTRE, bool HL>
+__device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const u32x4& w, const u32x4& ps, const u32x4* sm, const u32x4* mn,
                                            uint32_t lomask) {
     const h8 bc = as_h8(MfCentre<RING>::a, MfCentre<RING>::a, MfCentre<RING>::b, MfCentre<RING>::b);
-    if constexpr (R == 1) {
+    if constexpr (HL) {
+        // lomask: all ones in the lanes of a lo row.  hi rows: fp16(p'' s); lo rows: the exact remainder (cf. mf_k_seqR)
+        uint32_t psm[4], a[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) psm[i] = ps[i] & lomask;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[s][i] = pk_fms(ps[i], sm[s][i], pk_mul(psm[i], sm[s][i]));
+            A.z4[s] = dot2_f16(ps[0], mn[s][0], A.z4[s]);            // (hi and lo lanes both: halved in mf_v_finish)
+            A.z4[s] = dot2_f16(ps[1], mn[s][1], A.z4[s]);
+            A.z6[s] = dot2_f16(ps[2], mn[s][2], A.z6[s]);
+            A.z6[s] = dot2_f16(ps[3], mn[s][3], A.z6[s]);
+            if constexpr (CENTRE) {                                // what this lane's own row (hi or lo) is centred with
+                A.c4[s] = dot2_f16(a[s][0], MF_ONE2, A.c4[s]);
+                A.c4[s] = dot2_f16(a[s][1], MF_ONE2, A.c4[s]);
+                A.c6[s] = dot2_f16(a[s][2], MF_ONE2, A.c6[s]);
+                A.c6[s] = dot2_f16(a[s][3], MF_ONE2, A.c6[s]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const h8 av = as_h8(a[c >> 1][0], a[c >> 1][1], a[c >> 1][2], a[c >> 1][3]);
+            const MfB b = mf_views(w[c]);
+            f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
+            if constexpr (CENTRE) {
+                x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, x1, 0, 0, 0);
+            }
+            A.acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b0, x0, 0, 0, 0);
+            A.acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, x1, 0, 0, 0);
+        }
+    } else if constexpr (R == 1) {
         uint32_t a[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -499,7 +561,7 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
             A.acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, x1, 0, 0, 0);
         }
     } else {
-        constexpr int NS = MfVAcc<R>::NS;
+        constexpr int NS = MfVAcc<R, HL>::NS;
         uint32_t hi[NS][4], lo[NS][4];
 #pragma unroll
         for (int s = 0; s < NS; s++) {
@@ -541,9 +603,9 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R>& A, const u32x4& w, const u
 // sb_bytes = byte stride between consecutive super-blocks.  prime() requests the first RING blocks (callers do it as early
 // as they can: the fused row kernel before its softmax), run() consumes: ps_lds = the R rows of scaled probabilities
 // (halves), row pitch `pitch` halves, indexed by token - tok0.
-template <int R, int RING>
+template <int R, int RING, bool HL = false>
 struct MfVStream {
-    static constexpr int NS = MfVAcc<R>::NS;
+    static constexpr int NS = MfVAcc<R, HL>::NS;
     u32x4 wr[RING], sr[RING][NS], mr[R == 1 ? 1 : RING][NS];
     uint32_t sm_off, mn_off, sb_bytes;
     int b_last;
@@ -567,7 +629,7 @@ struct MfVStream {
     __device__ __forceinline__ void prime(rsrc_t rv, uint32_t sb_bytes_, int b_lo, int b_hi, int first = 0, int stride = 1) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
-        const int cg = R == 8 ? (m >> 3) : (m >> 2), j = m & 3;   // channel group of the lane's row (row set 0)
+        const int cg = (R == 8 || HL) ? (m >> 3) : (m >> 2), j = m & 3;   // channel group of the lane's row (row set 0)
         sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
         mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
         sb_bytes = sb_bytes_;
@@ -588,11 +650,11 @@ struct MfVStream {
     // ring keeps requesting up to b_last, so a caller may run() the stream piece by piece -- one super-block at a time with
     // the probabilities of the next one made in between -- without ever draining it).  ps_lds: the R rows of scaled
     // probabilities, row pitch `pitch` halves, indexed by (stream block * 32 + token in block) - tok0.
-    __device__ __forceinline__ void run(MfVAcc<R>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0) {
+    __device__ __forceinline__ void run(MfVAcc<R, HL>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
         const int j = m & 3;
-        const uint32_t lomask = (R == 1 && (j & 1)) ? 0xFFFFFFFFu : 0u;
+        const uint32_t lomask = (HL ? (m & 4) != 0 : (R == 1 && (j & 1))) ? 0xFFFFFFFFu : 0u;
         const uint16_t* prow = ps_lds + (R == 1 ? 0 : (m % R) * pitch) + 8 * kb - tok0;      // the head of the lane's row
         if (b_hi <= b_lo) return;
         for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
@@ -602,8 +664,8 @@ struct MfVStream {
                 // blocks past the range repeat the last block with zero probabilities
                 u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_hi - 1) * 32);
                 if (bl >= b_hi) ps = u32x4{0, 0, 0, 0};
-                if (s == 0) mf_v_block<R, RING, true>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
-                else mf_v_block<R, RING, false>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+                if (s == 0) mf_v_block<R, RING, true, HL>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+                else mf_v_block<R, RING, false, HL>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
                 request(rv, s, bl + RING);
                 // nothing moves across this point: without it hipcc gathers all RING re-requests at the end of the round, i.e.
                 // a block's data is asked for one block before its use
@@ -613,15 +675,43 @@ struct MfVStream {
     }
 };
 
-// Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]) -- 2^12 * (hi + lo sums) + zero-point
-// term + 1.5 * sum p'' s.  `zl`: 128 floats of scratch LDS of this wave.
-template <int R, int RING>
-__device__ __forceinline__ void mf_v_finish(const MfVAcc<R>& A, float* zl, float* dst) {
+// Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]; HL: [2][R][128], the hi and the lo
+// part of every output, to be added by the caller) -- 2^12 * (hi + lo sums) + zero-point term + 1.5 * sum p'' s.
+// `zl`: 128 floats of scratch LDS of this wave.
+template <int R, int RING, bool HL>
+__device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, float* dst) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, kb = lane >> 4;
     constexpr float CF = MfCentre<RING>::f;                       // what the centring blocks subtracted per unit of A
     // per-lane dot sums -> LDS -> every lane gathers the four kb partials of the rows it needs
-    if constexpr (R == 1) {
+    if constexpr (HL) {
+        // this lane's accumulator rows 4 kb + j = (channel group kb >> 1 of the row set, hi | lo = kb & 1, head j): the useful rows
+        // of the channel chunks c = (kb >> 1) + 2 s.  The zero-point term was summed by the hi AND the lo lanes: half each.
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            zl[64 * s + lane] = __builtin_fmaf(CF, A.c4[s] * 0.0625f + A.c6[s] * 0.015625f, A.z4[s] * 0.03125f + A.z6[s] * 0.0078125f);
+        __builtin_amdgcn_wave_barrier();
+        float* dhl = dst + (kb & 1) * R * 128;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            float br[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                br[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) br[r] += zl[64 * s + 4 * kb + r + 16 * k];
+            }
+            const int c = (kb >> 1) + 2 * s;
+#pragma unroll
+            for (int tile = 0; tile < 2; tile++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float v = (kb >> 1) ? A.acc[2 * s + 1][tile][r] : A.acc[2 * s][tile][r];
+                    dhl[r * 128 + 32 * c + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+                }
+            }
+        }
+    } else if constexpr (R == 1) {
         zl[lane] = A.z4[0] * 0.0625f + A.z6[0] * 0.015625f;
         zl[64 + lane] = A.c4[0] * 0.0625f + A.c6[0] * 0.015625f;
         __builtin_amdgcn_wave_barrier();
@@ -728,6 +818,13 @@ __device__ __forceinline__ float mf_sub_hi(uint32_t hpair, float nmx) {       //
     float d;
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(nmx));
     return d;
+}
+
+// two fp32 values -> packed fp16 pair, round to nearest even (v_cvt_pk_f16_f32): lo = fp16(a), hi = fp16(b)
+__device__ __forceinline__ uint32_t mf_cvt_pair(float a, float b) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2v){a, b}, h2v));
 }
 
 // fp16(float(h) * inv) of both halves of a packed pair (kivi_scaled_score without a mask: the fp32 product, then one

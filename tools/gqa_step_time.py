@@ -2,6 +2,7 @@
 """Per-dispatch medians of the two launches of the matrix-pipe decode step (kivi_gqa_decode) at a given shape, rotating
 over several layer caches.  KIVI_GQA_TIME_V=1 (set by this script for the second pass) moves the event pair to the sV launch."""
 import argparse, os, subprocess, sys
+os.environ.setdefault("KIVI_TUNING", "1")   # the knobs below are honoured in tuning sessions only (kivi_amd/_tuning.py)
 _TUNING = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kivi_amd", "_variants", "libkivi_tuning.so")
 if os.path.exists(_TUNING):      # environment knobs exist in the -DKIVI_TUNING build only (tools/build_variant.sh)
     os.environ.setdefault("KIVI_HIP_LIB", _TUNING)

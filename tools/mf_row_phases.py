@@ -7,6 +7,7 @@ stamp slots: 0 entry, 1 realtime(100 MHz), 3 packed qK^T of the wave's super-blo
 4 residual scores done, 5 after the barrier, 7 softmax done (2 block reductions + barrier), 8 window / flush done (V stream
 starts), 9 V stream loop done, 10 per-wave result + combine barrier, 11 end."""
 import os
+os.environ.setdefault("KIVI_TUNING", "1")   # the knobs below are honoured in tuning sessions only (kivi_amd/_tuning.py)
 import sys
 
 _TUNING = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kivi_amd", "_variants", "libkivi_tuning.so")

@@ -7,6 +7,7 @@ stamp slots: 0 entry, 1 realtime(100 MHz), 2 small operands requested, 3 K strea
 scores in LDS), 5 after the tile barrier(s), 6 residual scores done + first V batch requested, 7 softmax done,
 8 window / flush done (V stream starts), 9 V stream loop done, 10 butterfly + LDS combine barrier, 11 end."""
 import os
+os.environ.setdefault("KIVI_TUNING", "1")   # the knobs below are honoured in tuning sessions only (kivi_amd/_tuning.py)
 import sys
 
 _TUNING = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kivi_amd", "_variants", "libkivi_tuning.so")

@@ -14,6 +14,10 @@
 #   ab <lib.so>...   same-box A/B of bench.py (headline + config 4) between the in-tree library and the given builds
 #                    (tools/build_variant.sh; KIVI_TUNING=1 KIVI_HIP_LIB=...)
 #   phases           per-wave phase timeline of mf_row_kernel / mf_row4_kernel (tuning build, tools/mf_row_phases.py)
+#   row4ab           mf_row4_kernel variants at BASELINE config 4 (tuning build: KIVI_MF_ROW4 = <K ring><V ring><waves>
+#                    + 1000 / 2000 for hi / lo rows in the qK^T / sV phase, KIVI_MF_STAG_US): parity of the variants through the
+#                    row-form tests, then same-box bench lines
+#   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
 O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -106,6 +110,33 @@ while [ $# -gt 0 ]; do
         T=$R/kivi_amd/_variants/libkivi_tuning.so
         KIVI_TUNING=1 KIVI_HIP_LIB=$T timeout 300 python tools/mf_row_phases.py > $O/row_phases.log 2>&1; tail -30 $O/row_phases.log
         KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/row4_phases.log 2>&1; tail -30 $O/row4_phases.log ;;
+    row4ab)
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        for cfg in 1443 2443 3443; do
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg timeout 600 python -m pytest tests/test_mfma_gpu.py tests/test_hook_gpu.py -m gpu -x -q \
+                -k "(row and fixtures) or matches_two_launch" > $O/row4_parity_$cfg.log 2>&1; echo "parity $cfg rc=$?" | tee -a $O/status.log; tail -3 $O/row4_parity_$cfg.log
+        done
+        for i in 1 2; do
+            for cfg in 443 1443 2443 3443 3843 3444 3844 3243; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/c4_${cfg}_$i.json 2>> $O/row4ab.err; line $O/c4_${cfg}_$i.json
+            done
+        done
+        for cfg in 443 3443 3843; do
+            for us in 8 14 20 28; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg KIVI_MF_STAG_US=$us timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/c4_${cfg}_stag$us.json 2>> $O/row4ab.err; line $O/c4_${cfg}_stag$us.json
+            done
+        done ;;
+    sq)
+        name=$1; shift
+        extra=()
+        while [ $# -gt 0 ] && [[ $1 == --* || $1 =~ ^[0-9]+$ ]]; do extra+=("$1"); shift; done
+        cd /tmp && export TMPDIR=/tmp
+        rm -rf $O/sq_$name
+        timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv \
+            -d $O/sq_$name -o p -- $BN --steps 2 --warmup 1 --no-kernel-events "${extra[@]}" > $O/sq_$name.run.log 2>&1
+        cd $R
+        python tools/sq_counters.py $(find $O/sq_$name -name "*counter_collection.csv" | head -1) > $O/sq_$name.log 2>&1; cat $O/sq_$name.log
+        rm -rf $O/sq_$name ;;
     *) echo "unknown stage $stage" ;;
     esac
 done
