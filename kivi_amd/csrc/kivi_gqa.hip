@@ -401,7 +401,6 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     a.range = (const int*)kt_range;
-    a.stagger = 0; a.stagger_cus = 1;
     return kivi_mf_run_k(&a, B * nh_kv, (hipStream_t)stream);
 }
 
@@ -538,7 +537,6 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
     k.range = (const int*)p->kt_range;
-    k.stagger = 0; k.stagger_cus = 1;
     static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
     static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};

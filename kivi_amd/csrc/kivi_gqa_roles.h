@@ -33,7 +33,6 @@ struct GqaKArgs {
     int64_t knew_sb, knew_sh;
     int res_len;                // keys already in the residual; the new one becomes index res_len
     const int* range;           // [B * nh_kv] range flags of the K store (kivi_mfma_layout.h: a scale >= 256 was written)
-    int stagger, stagger_cus;   // one-launch kernels: blocks with (blockIdx / stagger_cus) odd start `stagger` x 10 ns late (0: off)
 };
 
 // Residual role of the decode step: block (unit, j) scores keys [j c, (j + 1) c) of the residual (c = ceil(L / 4), L =

@@ -227,7 +227,8 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
 // PW: window probabilities per head kept in LDS
 constexpr int MF_PW = 136;
 
-template <int R, int RING, bool PROB>
+// HL (R = 4): hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>), as in mf_row4_kernel
+template <int R, int RING, bool PROB, bool HL = false>
 __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
     __shared__ uint16_t pw[R][MF_PW];
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     const rsrc_t rv = make_rsrc(mf_sb(a.vt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.vt.sb_s * 4));
     const uint32_t sb_bytes = (uint32_t)(a.vt.sb_s * 4);
 
-    MfVAcc<R> A;
+    MfVAcc<R, HL> A;
     mf_v_init(A);
     const int sb_begin = win_role ? 0 : slice * a.spb;
     const int sb_end = win_role ? 0 : ((sb_begin + a.spb < a.nsb) ? sb_begin + a.spb : a.nsb);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
         nb_last = nb_last > 16 ? 16 : nb_last;
         u32x4 xv[R];
         mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), (int64_t)sb_w0 * KIVI_MF_SB_TOKENS, xv);
-        MfVStream<R, RING> vs;
+        MfVStream<R, RING, HL> vs;
         vs.prime(rv, sb_bytes, 0, 16 * (n_my - 1) + nb_last, sb_w0, 4);
         for (int i = 0; i < n_my; i++) {
             const int64_t tok0 = (int64_t)(sb_w0 + 4 * i) * KIVI_MF_SB_TOKENS;
@@ -325,7 +326,11 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R, RING, false>(A, zl, Lf);                               // Lf[r * 128 + d], before 2^-Sp
+    mf_v_finish<R, RING, HL>(A, zl, Lf);                           // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
+    if constexpr (HL) {
+        for (int i = lane; i < R * 128; i += 64) Lf[i] += Lf[R * 128 + i];
+        __builtin_amdgcn_wave_barrier();
+    }
     // the p'' region of a wave holds R x 256 words = R x 128 floats twice: quantised part first, window part second
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
@@ -535,9 +540,9 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
 // The whole decode step of one (batch row, kv head) with its four query heads in one block of NW waves (grouped queries,
 // rows whose four score rows fit the LDS: 4 n fp16 <= 72 KiB, two blocks per CU): no score / statistics round trip through
 // memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
-// KHL / VHL: hi / lo of q'' * scale (p'' * scale) in MFMA rows (mf_k_seqR<4, ., true> / MfVStream<4, ., true>: 8 instead of 16
-// matrix instructions per group / block)
-template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool KHL = false, bool VHL = false>
+// VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block; -3 % per launch
+// at BASELINE config 4, profiles/r04_row4_levers.log)
+template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     extern __shared__ uint16_t rows[];                             // [R][n_pad]
@@ -562,12 +567,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const int L = ak.res_len + 1;
     const int n = Tq + L;
     const int kbig = __builtin_amdgcn_readfirstlane(ak.range[unit]), vbig = __builtin_amdgcn_readfirstlane(av.range[unit]);   // see mf_row_kernel
-    if (ak.stagger > 0 && ((unit / ak.stagger_cus) & 1)) {
-        // the second block of a CU starts late, so that its latency-bound middle (softmax, window) falls into the other block's
-        // streams and vice versa (the two blocks of a CU otherwise run in lock-step: section 3.7)
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ak.stagger) __builtin_amdgcn_s_sleep(32);
-    }
     const uint16_t* q_h0 = ak.q + b * ak.q_sb + (int64_t)h0 * ak.q_sh;
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
@@ -586,27 +585,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seqR<4, KRING, KHL>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
+        mf_k_seqR<4, KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
             // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
             // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
             const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
             uint16_t* dst = rows + r * n_pad + sb * KIVI_MF_SB_TOKENS + tt;
-            dst[0] = (uint16_t)(hs & 0xFFFFu);
-            if constexpr (KHL) {                                   // heads r, r + 1 at token tt
-                dst[n_pad] = (uint16_t)(hs >> 16);
-                mxp[r >> 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r >> 1]), __builtin_bit_cast(hp2, hs)));
-            } else {                                               // head r at tokens tt, tt + 16
-                dst[16] = (uint16_t)(hs >> 16);
-                mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
-            }
+            dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head r at tokens tt, tt + 16
+            dst[16] = (uint16_t)(hs >> 16);
+            mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
         }, [](int, int) {});
     }
     float mxl[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        if constexpr (KHL) mxl[r] = h2f_bits((uint16_t)((r & 1) ? mxp[r >> 1] >> 16 : mxp[r >> 1] & 0xFFFFu));       // mxp[0]: heads 0 | 1, mxp[1]: heads 2 | 3
-        else mxl[r] = __builtin_fmaxf(h2f_bits((uint16_t)(mxp[r] & 0xFFFFu)), h2f_bits((uint16_t)(mxp[r] >> 16)));
-    }
+    for (int r = 0; r < R; r++) mxl[r] = __builtin_fmaxf(h2f_bits((uint16_t)(mxp[r] & 0xFFFFu)), h2f_bits((uint16_t)(mxp[r] >> 16)));
     stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
     const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
@@ -743,9 +734,21 @@ int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
     // R = 4 runs two blocks per CU (gqa_v_slices): four code blocks in flight per wave, 57.4 us per launch at the 70B-like
     // slice against 60.5 with two (profiles/r03_gqa_split_restructure.log); R = 1 keeps four waves per SIMD with two
     // R = 8: two row sets of scale / zero points per block in flight (20 registers per ring slot): two blocks
+#ifdef KIVI_TUNING
+    static const char* hl = KIVI_TUNE_ENV("KIVI_MF_VHL");                // A/B: hi / lo rows in the two-launch sV (R = 4), ring 4 or 2
+    if (hl && R == 4 && !prob) {
+        if (atoi(hl) == 4) KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, false, true>), grid, dim3(256), lds, s, a);
+        else KIVI_LAUNCH_LDS((mf_v_kernel<4, 2, false, true>), grid, dim3(256), lds, s, a);
+        return kivi_launch_status("mf_v");
+    }
+    if (fr && atoi(fr) == 2 && R == 8) {
+        if (prob) KIVI_MV(8, 2, true); else KIVI_MV(8, 2, false);
+        return kivi_launch_status("mf_v");
+    }
+#endif
     if (R == 1) { if (prob) KIVI_MV(1, 2, true); else KIVI_MV(1, 2, false); }
     else if (R == 4) { if (prob) KIVI_MV(4, 4, true); else KIVI_MV(4, 4, false); }
-    else { if (prob) KIVI_MV(8, 2, true); else KIVI_MV(8, 2, false); }
+    else { if (prob) KIVI_MV(8, 4, true); else KIVI_MV(8, 4, false); }
 #undef KIVI_MV
     return kivi_launch_status("mf_v");
 }
@@ -796,18 +799,10 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump,
         if (dump) {
             const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, true>, &opt_dump, "mf_row4");
             if (rc) return rc;
-            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, true>), grid, dim3(256), lds, s, k, v, n_pad);
+            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, true>), grid, dim3(256), lds, s, k, v, n_pad);   // (VHL as the product kernel)
             return kivi_launch_status("mf_row4");
         }
 #ifdef KIVI_TUNING
-        static const char* stg = KIVI_TUNE_ENV("KIVI_MF_STAG_US");       // A/B: the second block of every CU starts that many us late
-        if (stg) {
-            GqaKArgs& km = const_cast<GqaKArgs&>(k);
-            km.stagger = (int)(atof(stg) * 100.0);
-            int cus = 256;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-            km.stagger_cus = cus > 0 ? cus : 256;
-        }
         static unsigned long long opt_t[16] = {0};
         static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<waves><K ring><V ring>"
         const int cfg = fr4 ? atoi(fr4) : 443;
@@ -819,19 +814,12 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump,
         KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad);      \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
-        // <K ring><V ring><waves> + 1000: hi / lo rows in the qK^T phase, + 2000: in the sV phase (mf_row4_kernel KHL / VHL)
-        if (v.dbg && cfg >= 3000) KIVI_ROW4_VARIANT(5, 4, 3, 4, true, false, true, true);
+        // <K ring><V ring><waves>; + 1000: the sV phase with hi and lo as two chained operands (the round-3 form)
         if (v.dbg) KIVI_ROW4_VARIANT(0, 4, 3, 4, true);
         if (cfg == 423) KIVI_ROW4_VARIANT(1, 2, 3, 4);
         if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
         if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
-        if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, true, false);
-        if (cfg == 2443) KIVI_ROW4_VARIANT(7, 4, 3, 4, false, false, false, true);
-        if (cfg == 3443) KIVI_ROW4_VARIANT(8, 4, 3, 4, false, false, true, true);
-        if (cfg == 3843) KIVI_ROW4_VARIANT(9, 8, 3, 4, false, false, true, true);
-        if (cfg == 3844) KIVI_ROW4_VARIANT(10, 8, 4, 4, false, false, true, true);
-        if (cfg == 3444) KIVI_ROW4_VARIANT(11, 4, 4, 4, false, false, true, true);
-        if (cfg == 3243) KIVI_ROW4_VARIANT(12, 2, 3, 4, false, false, true, true);
+        if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, false);
 #undef KIVI_ROW4_VARIANT
 #endif
         const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");

@@ -292,26 +292,21 @@ __device__ __forceinline__ void mf_k_zero(const MfQ<R>& Q, const u32x4* mv, cons
 // when the last score of a super-block has been handed to sink.  RING code blocks in flight, a multiple of the 16 / R groups of a round.
 template <int V> struct mf_ic { static constexpr int value = V; };
 
-//
-// HL (R = 4 only): hi and lo parts of q'' * scale sit in ROWS instead of two chained operands -- row m -> group m / 8, hi (m & 4
-// == 0) | lo, head m & 3: two groups per round, ONE MFMA per (channel chunk, token tile) = 8 per group instead of 16, the hi and
-// lo sums of a score meet with one v_permlane16_swap + add per register.  Why: with 16 MFMAs (256 matrix-pipe cycles) per KiB of
-// codes and two waves per SIMD the R = 4 kernels keep the matrix pipe ~80 % busy at 5.7 TB/s -- it, not the VALU or the memory,
-// paces them; this form halves the matrix work for ~12 more VALU instructions per group.  The sink then
-// receives pairs of HEADS: sink(sb, token, r in {0, 2}, score of head r, score of head r + 1).
-template <int R, int RING, bool HL = false, typename Sink, typename Done>
+// (Round 4 also built the walker with hi and lo of q'' * scale in ROWS -- 2 groups x (hi | lo) x 4 heads, 8 instead of 16 matrix
+// instructions per group, the sums meeting through v_permlane16_swap -- : SQ_VALU_MFMA_BUSY_CYCLES fell from 0.74 to 0.40 of the
+// wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
+// profiles/r04_row4_levers.log.)
+template <int R, int RING, typename Sink, typename Done>
 __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
-    static_assert(!HL || R == 4, "hi / lo rows: 2 groups x (hi | lo) x 4 heads");
-    constexpr int RR = HL ? 2 * R : R;                              // rows per group
+    constexpr int RR = R;                                           // rows per group
     constexpr int GPR = 16 / RR;                                     // groups per round
     static_assert((RING >= GPR ? RING % GPR == 0 : GPR % RING == 0) && RING <= 8, "whole rounds per ring, or whole rings per round");
     constexpr int RPT = RING > GPR ? RING / GPR : 1;               // rounds per trip of the loop below
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     const int gl = (4 * kb) / RR;                                   // the group of the round whose scores this lane's registers hold
-    const int hb = HL ? 0 : (4 * kb) % R;                           // ... for the heads hb .. hb + 3
-    const uint32_t lom = (HL && (m & R)) ? 0xFFFFFFFFu : 0u;        // all ones in the lanes of a lo row
+    const int hb = (4 * kb) % R;                                    // ... for the heads hb .. hb + 3
     if (W.ng_total <= 0) return;
     auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
     const int g_last = W.ng_total - 1;
@@ -365,18 +360,13 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
             mf_k_zero<R>(Q, zv, zmul, zz, big);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
-        uint32_t Ah[4][4], Al[HL ? 1 : 4][4];
+        uint32_t Ah[4][4], Al[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if constexpr (HL) {
-                    // hi rows: fp16(q'' s) (the subtrahend is 0); lo rows: the exact remainder q'' s - fp16(q'' s)
-                    Ah[c][i] = pk_fms(Q.qq[c][i], sv[c][i], pk_mul(Q.qq[c][i], sv[c][i]) & lom);
-                } else {
-                    Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
-                    Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
-                }
+                Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
+                Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
             }
         request_round(rq + 1 < n_round ? rq + 1 : rq, rq + 1 < n_round);
         __builtin_amdgcn_sched_barrier(0);
@@ -393,15 +383,13 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
             for (int c = 0; c < 4; c++) {
                 const MfB b = mf_views(wr[(S0 + j) % RING][c]);
                 const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
+                const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b1, a1, 0, 0, 0);
-                if constexpr (!HL) {
-                    const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
-                }
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.b1, a1, 0, 0, 0);
             }
-            const bool mine = gl == j;                              // rows 4 kb .. 4 kb + 3 = group GPR rq + gl, heads hb + 0 .. 3 (HL: hi | lo of them)
+            const bool mine = gl == j;                              // rows 4 kb .. 4 kb + 3 = group GPR rq + gl, heads hb + 0 .. 3
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 o0[r] = mine ? a0[r] : o0[r];
@@ -410,22 +398,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
             request_group((S0 + j) % RING, GPR * rq + j + RING);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (HL) {
-            // rows (kb = 2 g + hl): tile 0 in o0, tile 1 in o1.  v_permlane16_swap exchanges the odd 16-lane rows of the first with
-            // the even rows of the second operand: afterwards o0 holds the hi sums (row 2 g: tile 0, row 2 g + 1: tile 1) and o1
-            // the lo sums in the same places -- one add, and lane (n, kb) holds token 16 (kb & 1) + n of group kb >> 1, heads 0..3
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(o0[r]), "+v"(o1[r]));
-                o0[r] += o1[r];
-            }
-            if (GPR * rq + gl < W.ng_total) {
-                const int sb = W.sb_first + sbi * W.sb_stride;
-                const int tok = (GPR * rs + gl) * 32 + 16 * (kb & 1) + m;
-                sink(sb, tok, 0, __builtin_fmaf(o0[0], cmul[0], zs[0]), __builtin_fmaf(o0[1], cmul[1], zs[1]));
-                sink(sb, tok, 2, __builtin_fmaf(o0[2], cmul[2], zs[2]), __builtin_fmaf(o0[3], cmul[3], zs[3]));
-            }
-        } else if (GPR * rq + gl < W.ng_total) {
+        if (GPR * rq + gl < W.ng_total) {
             const int sb = W.sb_first + sbi * W.sb_stride;
             const int g = GPR * rs + gl;
 #pragma unroll
