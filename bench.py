@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the K-GEMV launches with HIP events")
     ap.add_argument("--event-every", type=int, default=9, help="bracket the dominant kernel of every n-th layer step of the timed region")
     ap.add_argument("--no-hook-kgemv", action="store_true", help="skip the hook-state-layout K-GEMV comparison line")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step's launches from ONE hipGraph (device-resident lengths: kivi_amd/graph.py); matrix-pipe layout only")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: a sleep per step (launcher / reduction / JSON plumbing on CPU, gloo)")
     args = ap.parse_args()
 
@@ -250,6 +252,22 @@ def main():
     def step():
         for i in range(L):
             kivi_attention_decode(qs[i], ks[i], vs[i], layers[i], fused_kernels=not args.unfused)
+
+    graphed = None
+    if args.graph:
+        # the whole step = ONE graph launch (+ a one-thread kernel that uploads the six lengths, + the K flushes every R steps)
+        from kivi_amd.graph import GraphedDecode, MfStepDriver
+        assert all(getattr(lc, "layout", "hook") == "mfma" for lc in layers), "--graph needs the matrix-pipe cache layout"
+        outs = [torch.empty((B, nh, 1, D), device=dev, dtype=torch.float16) for _ in range(L)]
+        drv = MfStepDriver(layers)
+
+        def graph_body():
+            for i in range(L):
+                drv.enqueue(i, qs[i], ks[i], vs[i], outs[i])
+
+        graphed = GraphedDecode(drv, graph_body)
+        step = graphed.step          # noqa: F811
+        args.no_kernel_events = True   # (event pairs cannot be captured)
 
     for _ in range(args.warmup):
         step()
@@ -445,6 +463,8 @@ def main():
             "allocator_peak_bytes": peak_timed,
             "allocator_peak_bytes_incl_bench_harness": torch.cuda.max_memory_allocated(dev),   # + the rotating K-GEMV caches etc. of the lines below
             "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / args.steps, 4),
+            "hipgraph": None if graphed is None else {"eager_steps": graphed.eager, "captures": graphed.captures, "replays": graphed.replays,
+                                                      "note": "whole step replayed from one hipGraph; lengths device-resident (kivi_mf_decode_layer_dyn)"},
             "roofline": roof,
             "roofline_single_layer_kgemv": single,
             "roofline_single_layer_kgemv_mf_layout": single_mf,

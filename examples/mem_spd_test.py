@@ -109,9 +109,7 @@ def main():
         tok = logits.argmax(-1)
         if args.graphs:
             assert not args.baseline, "--graphs drives the KIVI hook (the fp16 baseline cache grows in shape every step)"
-            if rep == 0:
-                model.prepare_graphs(args.batch, dev)
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()    # (the graphs are built by the first graphed step: whole-step graphs for matrix-pipe caches)
         t1 = time.time()
         if args.graphs:
             model.decode_graphed(tok, pasts, args.prompt, args.gen)
@@ -130,7 +128,8 @@ def main():
         kv = sum(p.layer.nbytes() for p in pasts)                 # what the reference's 9-tuples would hold
         kv_alloc = sum(p.layer.allocated_bytes() for p in pasts)  # incl. page / window slack of the in-place cache
     print(json.dumps({
-        "mode": "fp16 KV + SDPA" if args.baseline else f"KIVI {args.bits}-bit g={args.group} R={args.residual}" + (" + hipGraph dense" if args.graphs else ""),
+        "mode": "fp16 KV + SDPA" if args.baseline else f"KIVI {args.bits}-bit g={args.group} R={args.residual}" + (" + hipGraph" if args.graphs else ""),
+        "hipgraph_eager_captures_replays": getattr(model, "_last_graph_stats", None),
         "model": f"llama-shaped random weights: L={args.layers} h={args.hidden} nh={args.heads}/{args.kv_heads} ffn={args.intermediate}",
         "batch": args.batch, "prompt": args.prompt, "gen": args.gen,
         "repeats": args.repeats, "generate_ms": round(1e3 * t_generate, 1),     # what the reference prints as "used time"

@@ -318,6 +318,20 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
 /* the fp16 value window is a RING of v_window_rows rows (row of window token t = (v_win_start + t) mod v_window_rows):
  * residual_length + 1 rows suffice and nothing is ever compacted; nh / nh_kv in {1, 4} */
 #define KIVI_GQA_WINDOW_RING 4
+/*
+ * Device-resident step lengths (hipGraph capture).  A decode step's launches depend on six lengths that change every step;
+ * with `dyn_step` = a DEVICE pointer to a kivi_mf_step the kernels read them from there, and the launch geometry (grids, LDS,
+ * slices) is sized for the step's whole geometry class: every step with the same kivi_mf_step_key -- the same number of
+ * 512-token super-blocks of packed keys and values and the same one- / two-launch decision -- can REPLAY the captured
+ * launches after the caller has updated the six numbers in device memory.  The host-side lengths passed with the call are the
+ * ones of the step being captured (validated as usual); keeping later steps inside the caller's buffers is the caller's job
+ * (kivi_mf_step_advance is the same bookkeeping kivi_mf_decode_layer does).  Buffers named by the arguments (q, new key /
+ * value, mask with a fixed row pitch, out, scratch) must stay where they are across replays.
+ */
+typedef struct {
+    int64_t Tq, Tv;                                    /* packed keys (multiple of 32), packed values */
+    int32_t k_res_len, v_res_len, v_win_start, v_flush;
+} kivi_mf_step;
 typedef struct {
     int B, nh, nh_kv, D, group_size, bits;
     float inv_scale;
@@ -335,6 +349,7 @@ typedef struct {
     int residual_length; int64_t v_window_rows, kt_superblocks, vt_superblocks;
     int flags;
     void* kt_range; void* vt_range;                    /* B * nh_kv int32 each */
+    const void* dyn_step;                              /* device kivi_mf_step or null (lengths from the fields above) */
 } kivi_gqa_decode_args;
 int kivi_gqa_decode(const kivi_gqa_decode_args* args, kivi_stream_t stream);
 
@@ -391,6 +406,27 @@ typedef struct {
 int kivi_mf_decode_layer(const kivi_mf_layer_desc* layer, int64_t* state, const void* q, int64_t q_sb, int64_t q_sh, int nh,
                          const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew, int64_t vn_sb, int64_t vn_sh,
                          const void* mask, int64_t mask_sb, void* out, int64_t out_sb, int64_t out_sh, kivi_stream_t stream);
+
+/*
+ * The attend phase of the same step with device-resident lengths, for hipGraph capture (see kivi_mf_step above): launches
+ * kivi_gqa_decode with dyn_step = `dev_step` and NOTHING else -- no bookkeeping, no K flush.  `host_step` = the lengths of the
+ * step being enqueued (what *dev_step will hold when the launches run).  The caller, per step: writes the lengths to
+ * *dev_step, replays (or calls this), kivi_mf_step_advance(host_step, ...), and when that returns 1 packs the full K residual
+ * with kivi_kt_pack at token offset Tq and sets Tq += residual_length, k_res_len = 0.  A captured step may be replayed while
+ * kivi_mf_step_key of the current lengths equals the key at capture time (and the cache buffers have not been reallocated).
+ */
+int kivi_mf_decode_layer_dyn(const kivi_mf_layer_desc* layer, const kivi_mf_step* host_step, const void* dev_step, const void* q,
+                             int64_t q_sb, int64_t q_sh, int nh, const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew,
+                             int64_t vn_sb, int64_t vn_sh, const void* mask, int64_t mask_sb, void* out, int64_t out_sb,
+                             int64_t out_sh, kivi_stream_t stream);
+/* geometry class of a step (-1: bad arguments); flags = the descriptor's KIVI_GQA_* flags */
+int64_t kivi_mf_step_key(const kivi_mf_step* step, int B, int nh, int nh_kv, int residual_length, int flags);
+/* lengths after the attend phase of one step (llama_kivi.py:333-336, :377, :386-399); returns 1 when the K residual is full
+ * (the K flush of :343-356 is due), 0 otherwise, < 0 on inconsistent lengths.  window_rows: rows of the ring window buffer. */
+int kivi_mf_step_advance(kivi_mf_step* step, int residual_length, int64_t window_rows);
+/* *dev_step <- *host_step by a one-thread kernel on `stream` (the values travel as kernel arguments: the host struct may be
+ * reused as soon as the call returns, nothing synchronises) */
+int kivi_mf_step_upload(const kivi_mf_step* host_step, void* dev_step, kivi_stream_t stream);
 
 /* ------------------------------------------------- tuning / bench hooks --- */
 

@@ -84,7 +84,13 @@ class GqaDecodeArgs(ctypes.Structure):
         ("residual_length", _i32), ("v_window_rows", _i64), ("kt_superblocks", _i64), ("vt_superblocks", _i64),
         ("flags", _i32),
         ("kt_range", _vp), ("vt_range", _vp),
+        ("dyn_step", _vp),
     ]
+
+
+class MfStep(ctypes.Structure):
+    """kivi_mf_step (include/kivi_hip.h): the six lengths of a decode step, host copy of the device-resident struct."""
+    _fields_ = [("Tq", _i64), ("Tv", _i64), ("k_res_len", _i32), ("v_res_len", _i32), ("v_win_start", _i32), ("v_flush", _i32)]
 
 
 GQA_FORCE_SPLIT, GQA_FORCE_ROW, GQA_WINDOW_RING, GQA_DUMP_SCORES = 1, 2, 4, 8
@@ -149,6 +155,11 @@ SIGNATURES = {
     "kivi_gqa_decode": (_i32, [ctypes.POINTER(GqaDecodeArgs), _vp]),
     "kivi_mf_decode_layer": (_i32, [ctypes.POINTER(MfLayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
                                     _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "kivi_mf_decode_layer_dyn": (_i32, [ctypes.POINTER(MfLayerDesc), ctypes.POINTER(MfStep), _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64,
+                                        _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "kivi_mf_step_key": (_i64, [ctypes.POINTER(MfStep), _i32, _i32, _i32, _i32, _i32]),
+    "kivi_mf_step_advance": (_i32, [ctypes.POINTER(MfStep), _i32, _i64]),
+    "kivi_mf_step_upload": (_i32, [ctypes.POINTER(MfStep), _vp, _vp]),
     "kivi_gemv_awq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
     "kivi_gemv_k_num_variants": (_i32, []),
     "kivi_gemv_k_variant_name": (ctypes.c_char_p, [_i32]),

@@ -225,7 +225,7 @@ class KiviLayerCacheMF:
         nat = self._native
         if nat is not None and nat[2] == (nh, stream):
             return nat
-        pitch = ((self.cap + 1 + 7) // 8) * 8
+        pitch = ((self.n_sb * SB + self.cfg.residual_length + 1 + 7) // 8) * 8     # the longest row of any step the stores can hold
         scores, stats, ws = _scratch(device, self.B, nh, self.nh_kv, pitch, self.n_sb + 4, self.n_sb)
         kt, vt, kr, vr = self.kt, self.vt, self.k_res, self.v_res
         d = _lib.MfLayerDesc(
@@ -280,6 +280,51 @@ class KiviLayerCacheMF:
         if rc:
             _lib.check(rc, "kivi_mf_decode_layer")
         return out
+
+
+    # ------------------------------------------------------------------ device-resident lengths (hipGraph capture; kivi_amd/graph.py)
+    def host_step(self) -> "_lib.MfStep":
+        """The six lengths of the NEXT decode step as a kivi_mf_step (include/kivi_hip.h)."""
+        R = self.cfg.residual_length
+        return _lib.MfStep(Tq=self.k_quant_len, Tv=self.v_quant_len, k_res_len=self.k_res_len, v_res_len=self.v_res_len,
+                           v_win_start=self.v_res_start, v_flush=int(self.v_res_len + 1 > R))
+
+    def apply_step(self, hs: "_lib.MfStep") -> None:
+        """Take the lengths a driver advanced (kivi_mf_step_advance / the K flush) back into this cache."""
+        self.k_quant_len, self.k_res_len, self.v_quant_len = int(hs.Tq), int(hs.k_res_len), int(hs.Tv)
+        self.v_res_start, self.v_res_len = int(hs.v_win_start), int(hs.v_res_len)
+        self.kv_seq_len = self.k_quant_len + self.k_res_len
+
+    def decode_step_dyn(self, query_states, key_states, value_states, hs: "_lib.MfStep", dev_step: torch.Tensor, out: torch.Tensor,
+                        attention_mask: torch.Tensor = None) -> torch.Tensor:
+        """The attend phase of one step with the lengths read from `dev_step` on the device (kivi_mf_decode_layer_dyn): what a
+        hipGraph captures.  No bookkeeping happens here -- the caller advances `hs` (kivi_mf_step_advance), flushes K when due
+        (flush_k) and applies the lengths (apply_step); buffers must be static across replays."""
+        B, nh, _, D = query_states.shape
+        assert nh == self.nh and B == self.B and D == self.D
+        for t in (query_states, key_states, value_states):
+            assert t.stride(3) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0, "static 16-byte rows"
+        mask_ptr, mask_sb = None, 0
+        if attention_mask is not None:          # a static (B, 1, 1, pitch >= capacity) buffer the caller refills every step
+            assert attention_mask.dtype == torch.float16 and attention_mask.stride(3) == 1 and attention_mask.shape[3] >= self.kv_seq_len + 1
+            mask_ptr, mask_sb = attention_mask.data_ptr(), attention_mask.stride(0)
+        assert out.shape == (B, nh, 1, D) and out.dtype == torch.float16 and out.stride(3) == 1
+        d, _, key, _, _ = self._desc(nh, query_states.device)
+        d.flags = self._flags()
+        q, k, v = query_states, key_states, value_states
+        rc = _lib.load().kivi_mf_decode_layer_dyn(ctypes.byref(d), ctypes.byref(hs), dev_step.data_ptr(), q.data_ptr(), q.stride(0), q.stride(1),
+                                                  nh, k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
+                                                  mask_ptr, mask_sb, out.data_ptr(), out.stride(0), out.stride(1), key[1])
+        _lib.check(rc, "kivi_mf_decode_layer_dyn")
+        return out
+
+    def flush_k(self) -> None:
+        """The K flush of llama_kivi.py:343-356 for a full residual: R tokens quantised per channel into the layout at token Tq."""
+        R = self.cfg.residual_length
+        assert self.k_res_len == R
+        mfma.kt_pack(self.k_res, self.kt, self.k_quant_len, self.cfg.group_size, self.cfg.k_bits)
+        self.k_quant_len += R
+        self.k_res_len = 0
 
 
 def _rows16(x):

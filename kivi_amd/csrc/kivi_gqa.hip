@@ -4,6 +4,7 @@
 // (cuda_bmm_fA_qB_outer at :324), kivi_gqa_output (:382), kivi_gqa_decode (:314-399; models/mistral_kivi.py:381-445; head
 // mapping quant/csrc/gemv_cuda.cu:361-365) for nh / nh_kv in {1, 4, 8}.  The kernels behind them live in kivi_mf.hip /
 // kivi_mf_dev.h (round 3; the round-2 kernels that used to be here served nh / nh_kv = 8 until round 4 and are gone).
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -373,7 +374,34 @@ int kivi_mf_run_k(void* k_args, int units, hipStream_t s);
 int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s);
 int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int nh_kv, int64_t T, const int* range, int* sp,
                        hipStream_t s);
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump, hipStream_t s);
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, hipStream_t s);
+
+// One launch (true) or two for a step whose LONGEST row has n_rows keys (kivi_gqa_decode's rule; also part of kivi_mf_step_key)
+static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags) {
+    if (!((R == 1 && n_rows <= 8192) || (R == 4 && n_rows <= 9216))) return false;
+    static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
+    if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return false;
+    // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
+    // of a row block to take one super-block each (nh == nh_kv, <= 4096 packed keys): then one launch beats two whatever
+    // the batch (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79,
+    // profiles/r03_other_shapes.log)
+    const int min_units = R == 1 ? 192 : 128;
+    return units >= min_units || (R == 1 && nsbk <= 8) || (flags & KIVI_GQA_FORCE_ROW);
+}
+
+static_assert(sizeof(MfStep) == sizeof(kivi_mf_step) && offsetof(MfStep, Tv) == offsetof(kivi_mf_step, Tv) &&
+                  offsetof(MfStep, k_res_len) == offsetof(kivi_mf_step, k_res_len) && offsetof(MfStep, v_flush) == offsetof(kivi_mf_step, v_flush),
+              "the kernels read a kivi_mf_step through MfStep");
+
+// Geometry class of a decode step (include/kivi_hip.h): launches captured for one step may be replayed for every later step
+// with the same key.
+extern "C" int64_t kivi_mf_step_key(const kivi_mf_step* st, int B, int nh, int nh_kv, int residual_length, int flags) {
+    if (!st || nh_kv <= 0 || nh <= 0 || nh % nh_kv) return -1;
+    const int R = nh / nh_kv;
+    const int64_t nsbk = (st->Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS, nsbv = (st->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS;
+    const int64_t n_rows = nsbk * KIVI_MF_SB_TOKENS + residual_length;
+    return (nsbk << 40) | (nsbv << 16) | ((int64_t)(st->v_flush != 0) << 1) | (int64_t)mf_one_launch(R, B * nh_kv, n_rows, (int)nsbk, flags);
+}
 
 extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh,
                                int64_t kt_ss, const void* kt_range, void* out, int64_t out_sb, int64_t out_sh, int B, int nh,
@@ -401,6 +429,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.res_blocks = 0; a.kres = nullptr; a.knew = nullptr; a.res_len = 0;
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     a.range = (const int*)kt_range;
+    a.dyn = nullptr;
     return kivi_mf_run_k(&a, B * nh_kv, (hipStream_t)stream);
 }
 
@@ -475,6 +504,11 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
                  KIVI_EINVAL, "kivi_gqa_decode: inconsistent lengths (Tq=%lld k_res=%d Tv=%lld v_res=%d)", (long long)p->Tq,
                  p->k_res_len, (long long)p->Tv, p->v_res_len);
     const int64_t n = p->Tq + p->k_res_len + 1;
+    // device-resident lengths (dyn_step): the launch geometry is sized for EVERY step with the same super-block counts
+    // (kivi_mf_step_key), whose longest row has ceil(Tq / 512) * 512 + residual_length keys
+    const bool dyn = p->dyn_step != nullptr;
+    KIVI_REQUIRE(!dyn || (uintptr_t)p->dyn_step % 8 == 0, KIVI_EALIGN, "kivi_gqa_decode: dyn_step must be 8-byte aligned");
+    const int64_t n_rows = dyn ? (p->Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS * KIVI_MF_SB_TOKENS + p->residual_length : n;
     // what the step WRITES: the K append (row k_res_len of kres), the V append (row v_win_start + v_res_len of vres), the
     // slot of the token leaving the window (token Tv of the VT store)
     KIVI_REQUIRE(p->residual_length > 0 && p->residual_length <= 128 && p->k_res_len < p->residual_length &&
@@ -502,9 +536,9 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE(p->vres && p->vnew && (uintptr_t)p->vres % 16 == 0 && (uintptr_t)p->vnew % 16 == 0 && p->vres_sb % 8 == 0 &&
                      p->vres_sh % 8 == 0 && p->vres_st % 8 == 0 && p->vnew_sb % 8 == 0 && p->vnew_sh % 8 == 0,
                  KIVI_EALIGN, "kivi_gqa_decode: value rows must be 16-byte aligned");
-    KIVI_REQUIRE(p->scores && (uintptr_t)p->scores % 16 == 0 && p->s_sb % 8 == 0 && p->s_sh % 8 == 0 && p->s_sh >= ((n + 7) & ~(int64_t)7),
-                 KIVI_EALIGN, "kivi_gqa_decode: score rows must be 16-byte aligned and hold %lld scores", (long long)n);
-    KIVI_REQUIRE((int64_t)(R - 1) * p->s_sh * 2 + n * 2 + 16 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_decode: score rows too long");
+    KIVI_REQUIRE(p->scores && (uintptr_t)p->scores % 16 == 0 && p->s_sb % 8 == 0 && p->s_sh % 8 == 0 && p->s_sh >= ((n_rows + 7) & ~(int64_t)7),
+                 KIVI_EALIGN, "kivi_gqa_decode: score rows must be 16-byte aligned and hold %lld scores", (long long)n_rows);
+    KIVI_REQUIRE((int64_t)(R - 1) * p->s_sh * 2 + n_rows * 2 + 16 < ((int64_t)1 << 32), KIVI_EINVAL, "kivi_gqa_decode: score rows too long");
     KIVI_REQUIRE(p->out != nullptr, KIVI_EINVAL, "kivi_gqa_decode: null output");
     const int nsbk = (int)((p->Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
     const int nseg = nsbk + KIVI_GQA_RES_SEGS;
@@ -537,6 +571,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.kres = (uint16_t*)p->kres; k.kres_sb = p->kres_sb; k.kres_sh = p->kres_sh; k.kres_st = p->kres_st;
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
     k.range = (const int*)p->kt_range;
+    k.dyn = (const MfStep*)p->dyn_step;
     static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
     static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};
@@ -557,18 +592,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.counters = (int*)p->workspace;
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
     v.range = (int*)p->vt_range;
-    if ((R == 1 && n <= 8192) || (R == 4 && n <= 9216)) {
-        // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
-        // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks of 8 waves per CU)
-        static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
-        const bool split = (p->flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow));
-        // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
-        // of a row block to take one super-block each (nh == nh_kv, <= 4096 packed keys): then one launch beats two whatever
-        // the batch (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79,
-        // profiles/r03_other_shapes.log)
-        const int min_units = R == 1 ? 192 : 128;
-        if (!split && (units >= min_units || (R == 1 && nsbk <= 8) || (p->flags & KIVI_GQA_FORCE_ROW))) return kivi_mf_run_row(&k, &v, units, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, s);
-    }
+    v.dyn = (const MfStep*)p->dyn_step;
+    // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
+    // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks per CU)
+    if (mf_one_launch(R, units, n_rows, nsbk, p->flags)) return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, s);
     int rc = skipk ? 0 : kivi_mf_run_k(&k, units, s);
     if (rc) return rc;
     if (timev) kivi_set_launch_events(held.start, held.stop);

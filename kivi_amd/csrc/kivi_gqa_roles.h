@@ -9,6 +9,14 @@ namespace {
 
 constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per unit)
 
+// The six lengths of a decode step in DEVICE memory (= kivi_mf_step of include/kivi_hip.h): when an argument block carries a
+// pointer to one, the kernels take the lengths from it instead of from their by-value arguments, so that a captured launch
+// (hipGraph) can be replayed step after step while the launch geometry -- sized by the super-block counts -- stays valid.
+struct MfStep {
+    long long Tq, Tv;
+    int k_res_len, v_res_len, v_win_start, v_flush;
+};
+
 struct GqaKArgs {
     const uint16_t* q;
     int64_t q_sb, q_sh;
@@ -33,6 +41,10 @@ struct GqaKArgs {
     int64_t knew_sb, knew_sh;
     int res_len;                // keys already in the residual; the new one becomes index res_len
     const int* range;           // [B * nh_kv] range flags of the K store (kivi_mfma_layout.h: a scale >= 256 was written)
+    const MfStep* dyn;          // device-resident lengths (or null): Tq, res_len are read from it
+    __device__ __forceinline__ void take_dyn() {
+        if (dyn) { Tq = dyn->Tq; res_len = dyn->k_res_len; }
+    }
 };
 
 // Residual role of the decode step: block (unit, j) scores keys [j c, (j + 1) c) of the residual (c = ceil(L / 4), L =
@@ -121,6 +133,10 @@ struct GqaVArgs {
     int win_rows;               // > 0: the window buffer is a RING of that many rows (row of token t = (win_start + t) % win_rows); 0: linear
     const int* sp_rows;         // kivi_gqa_output: [B][nh] exponent Sp of every probability row (mf_row_sp_kernel)
     int* range;                 // [B * nh_kv] range flags of the V store: read by every block, set by the V flush
+    const MfStep* dyn;          // device-resident lengths (or null): Tv, res_len, win_start, flush are read from it
+    __device__ __forceinline__ void take_dyn() {
+        if (dyn) { Tv = dyn->Tv; res_len = dyn->v_res_len; win_start = dyn->v_win_start; flush = dyn->v_flush; }
+    }
 };
 
 // softmax constants of the R rows of a unit from the segment statistics: M = max, 1 / sum exp(x - M).  Every lane of the

@@ -191,6 +191,7 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
     a.kt_superblocks = L->cap / 512; a.vt_superblocks = L->cap / 512;
     a.flags = L->flags;
     a.kt_range = L->kt_range; a.vt_range = L->vt_range;
+    a.dyn_step = nullptr;
     int rc = kivi_gqa_decode(&a, stream);
     if (rc) return rc;            // nothing of the step has been committed
     kres += 1;
@@ -207,4 +208,80 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
         if (rc) return rc;
     }
     return 0;
+}
+
+
+// The attend phase with device-resident lengths (hipGraph capture): include/kivi_hip.h, kivi_mf_step.
+extern "C" int kivi_mf_decode_layer_dyn(const kivi_mf_layer_desc* L, const kivi_mf_step* hs, const void* dev_step, const void* q,
+                                        int64_t q_sb, int64_t q_sh, int nh, const void* knew, int64_t kn_sb, int64_t kn_sh,
+                                        const void* vnew, int64_t vn_sb, int64_t vn_sh, const void* mask, int64_t mask_sb, void* out,
+                                        int64_t out_sb, int64_t out_sh, kivi_stream_t stream) {
+    KIVI_REQUIRE(L && hs && dev_step && q && knew && vnew && out, KIVI_EINVAL, "kivi_mf_decode_layer_dyn: null argument");
+    const int R = L->residual_length;
+    const int64_t kv = hs->Tq + hs->k_res_len;
+    KIVI_REQUIRE(R > 0 && R % 32 == 0 && R <= 128 && hs->Tq >= 0 && hs->Tq % 32 == 0 && hs->k_res_len >= 0 && hs->k_res_len < R && hs->Tv >= 0 &&
+                     hs->v_win_start >= 0 && hs->v_res_len >= 0 && hs->v_res_len <= R && kv == hs->Tv + hs->v_res_len &&
+                     (hs->v_flush != 0) == (hs->v_res_len + 1 > R),
+                 KIVI_EINVAL, "kivi_mf_decode_layer_dyn: inconsistent lengths (Tq=%lld kres=%d Tv=%lld vres=%d flush=%d R=%d)",
+                 (long long)hs->Tq, hs->k_res_len, (long long)hs->Tv, hs->v_res_len, hs->v_flush, R);
+    KIVI_REQUIRE(L->bits == 2 && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
+                 "kivi_mf_decode_layer_dyn: the MFMA cache layout covers 2-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
+                 L->bits, L->group_size, L->D);
+    KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL, "kivi_mf_decode_layer_dyn: bad shape (B=%d nh=%d nh_kv=%d)",
+                 L->B, nh, L->nh_kv);
+    KIVI_REQUIRE(L->kt && L->vt && L->k_res && L->v_res && L->scores && L->stats && L->workspace && L->kt_range && L->vt_range, KIVI_EINVAL,
+                 "kivi_mf_decode_layer_dyn: null cache buffer in the descriptor");
+    KIVI_REQUIRE((L->flags & KIVI_GQA_WINDOW_RING) != 0, KIVI_EUNSUPPORTED, "kivi_mf_decode_layer_dyn: needs the ring window (nothing to compact between replays)");
+    // the class of steps a capture of this one may be replayed for must fit the buffers: its longest row and the stores
+    const int64_t nsbk = (hs->Tq + 511) / 512;
+    KIVI_REQUIRE(L->cap % 512 == 0 && kv + 1 <= L->cap && nsbk * 512 + R <= L->s_pitch, KIVI_EINVAL,
+                 "kivi_mf_decode_layer_dyn: capacity %lld / score pitch %lld too small for the step's geometry class", (long long)L->cap,
+                 (long long)L->s_pitch);
+    kivi_gqa_decode_args a;
+    a.B = L->B; a.nh = nh; a.nh_kv = L->nh_kv; a.D = L->D; a.group_size = L->group_size; a.bits = L->bits;
+    a.inv_scale = L->inv_scale;
+    a.q = q; a.q_sb = q_sb; a.q_sh = q_sh;
+    a.mask = mask; a.mask_sb = mask_sb;
+    a.kt = L->kt; a.kt_sb = L->kt_sb; a.kt_sh = L->kt_sh; a.kt_ss = L->kt_ss; a.Tq = hs->Tq;
+    a.kres = L->k_res; a.kres_sb = L->kr_sb; a.kres_sh = L->kr_sh; a.kres_st = L->kr_st;
+    a.knew = knew; a.knew_sb = kn_sb; a.knew_sh = kn_sh; a.k_res_len = hs->k_res_len;
+    a.vt = L->vt; a.vt_sb = L->vt_sb; a.vt_sh = L->vt_sh; a.vt_ss = L->vt_ss; a.Tv = hs->Tv;
+    a.vres = L->v_res; a.vres_sb = L->vr_sb; a.vres_sh = L->vr_sh; a.vres_st = L->vr_st;
+    a.v_win_start = hs->v_win_start; a.v_res_len = hs->v_res_len;
+    a.vnew = vnew; a.vnew_sb = vn_sb; a.vnew_sh = vn_sh; a.v_flush = hs->v_flush;
+    a.scores = L->scores; a.s_sb = L->s_sb; a.s_sh = L->s_sh;
+    a.stats = L->stats; a.stats_bytes = L->stats_bytes;
+    a.workspace = L->workspace; a.workspace_bytes = L->workspace_bytes;
+    a.out = out; a.out_sb = out_sb; a.out_sh = out_sh;
+    a.residual_length = R; a.v_window_rows = L->v_window_rows;
+    a.kt_superblocks = L->cap / 512; a.vt_superblocks = L->cap / 512;
+    a.flags = L->flags;
+    a.kt_range = L->kt_range; a.vt_range = L->vt_range;
+    a.dyn_step = dev_step;
+    return kivi_gqa_decode(&a, stream);
+}
+
+extern "C" int kivi_mf_step_advance(kivi_mf_step* s, int R, int64_t window_rows) {
+    if (!s || R <= 0 || s->k_res_len < 0 || s->k_res_len >= R || s->v_res_len < 0 || s->v_res_len > R ||
+        s->Tq + s->k_res_len != s->Tv + s->v_res_len || window_rows < R + 1 || s->v_win_start < 0 || s->v_win_start >= window_rows)
+        return KIVI_EINVAL;
+    s->k_res_len += 1;                                 // the K append (llama_kivi.py:333-336)
+    if (s->v_res_len + 1 > R) {                        // the window was full: its oldest token was quantised (:386-399)
+        s->Tv += 1;
+        s->v_win_start = (int32_t)((s->v_win_start + 1) % window_rows);
+    } else {
+        s->v_res_len += 1;                             // the V append (:377)
+    }
+    s->v_flush = s->v_res_len + 1 > R;                 // what the NEXT step does
+    return s->k_res_len == R;
+}
+
+namespace {
+__global__ void mf_step_store_kernel(kivi_mf_step v, kivi_mf_step* dst) { *dst = v; }
+}  // namespace
+
+extern "C" int kivi_mf_step_upload(const kivi_mf_step* hs, void* dev_step, kivi_stream_t stream) {
+    KIVI_REQUIRE(hs && dev_step && (uintptr_t)dev_step % 8 == 0, KIVI_EINVAL, "kivi_mf_step_upload: null / misaligned argument");
+    hipLaunchKernelGGL(mf_step_store_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *hs, (kivi_mf_step*)dev_step);
+    return kivi_launch_status("mf_step_store");
 }

@@ -29,8 +29,10 @@ constexpr int mf_k_lds_words() { return (R == 1 ? 64 : 0) + R * 256; }   // R = 
 
 // DIAG (tuning builds, wrong results): 1 = nothing leaves the LDS (no flush), 2 = scores stored without the statistics
 template <int R, int W, int RING, int DIAG = 0>
-__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
+__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a_in, int spw) {
     extern __shared__ uint32_t lds_all[];
+    GqaKArgs a = a_in;
+    a.take_dyn();
     const int main_blocks = (int)gridDim.x - a.res_blocks;
     if ((int)blockIdx.x >= main_blocks) {                            // short residual blocks at the tail of the grid
         gqa_k_residual<R>(a, (int)blockIdx.x - main_blocks);
@@ -229,8 +231,10 @@ constexpr int MF_PW = 136;
 
 // HL (R = 4): hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>), as in mf_row4_kernel
 template <int R, int RING, bool PROB, bool HL = false>
-__global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a) {
+__global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
     extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
+    GqaVArgs a = a_in;
+    a.take_dyn();
     __shared__ uint16_t pw[R][MF_PW];
     const int bid = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -391,8 +395,12 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 // DBG (tools/mf_row_phases.py): every wave stamps the shader clock at its phase boundaries into av.dbg
 // DUMP (KIVI_GQA_DUMP_SCORES, tests): the fp16 row the softmax consumes (scaled, mask added) also goes to ak.out
 template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, bool DUMP = false>
-__global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
+__global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int NTH = NW * 64;
+    GqaKArgs ak = ak_in;
+    GqaVArgs av = av_in;
+    ak.take_dyn();
+    av.take_dyn();
     extern __shared__ uint16_t row[];                              // [n_pad] fp16 scores, then p''
     __shared__ float red[NW][128], resl[NW][128];
     __shared__ float zl[NW][128];
@@ -543,8 +551,12 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak, c
 // VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block; -3 % per launch
 // at BASELINE config 4, profiles/r04_row4_levers.log)
 template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak, const GqaVArgs av, int n_pad) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
+    GqaKArgs ak = ak_in;
+    GqaVArgs av = av_in;
+    ak.take_dyn();
+    av.take_dyn();
     extern __shared__ uint16_t rows[];                             // [R][n_pad]
     __shared__ float zl[NW][128];
     __shared__ uint16_t pw[R][MF_PW];
@@ -781,10 +793,12 @@ static int mf_lds_opt_in(K kernel, unsigned long long* done_mask, const char* wh
 // for <= 512 rows) or nh / nh_kv == 4 (rows <= 9216 keys: mf_row4_kernel, the four score rows of a unit in one block of 4
 // waves, 2 blocks per CU).  KIVI_EUNSUPPORTED (with a message) when the shape does not qualify.  dump != 0: the test
 // instantiations that also write the softmax input rows to the score buffer (KIVI_GQA_DUMP_SCORES).
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int dump, hipStream_t s) {
+// n_rows: the longest row the launch must hold (= Tq + k_res_len + 1, or the bound of the step's geometry class when the lengths
+// are device-resident).
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, hipStream_t s) {
     const GqaKArgs& k = *(const GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
-    const int64_t n = k.Tq + k.res_len + 1;
+    const int64_t n = n_rows;
     const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
     const dim3 grid((unsigned)units);
     if (k.ratio == 4) {

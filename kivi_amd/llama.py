@@ -128,7 +128,9 @@ class LlamaForCausalLM_KIVI(nn.Module):
     # (torch.cuda.CUDAGraph): per layer one graph from the block input to the rotated q / k / v, one from the attention
     # output to the block output, plus embedding and head; the KIVI step between them stays one eager
     # kivi_decode_layer call per layer (its lengths change every step).  Same kernels, same results as forward().
-    def _build_graphs(self, B: int, device):
+    # Round 4: when every layer's cache is in the matrix-pipe layout the attention launches read their lengths from device
+    # memory (kivi_amd/graph.py), so the WHOLE step -- dense parts and attention of all layers -- is ONE graph (whole=True).
+    def _build_graphs(self, B: int, device, whole: bool = False):
         cfg = self.config
         nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
         D, H = self.model.layers[0].self_attn.head_dim, cfg.hidden_size
@@ -137,7 +139,7 @@ class LlamaForCausalLM_KIVI(nn.Module):
                             cos=torch.zeros((1, 1, 1, D), dtype=dt, device=device),
                             sin=torch.zeros((1, 1, 1, D), dtype=dt, device=device),
                             x=[torch.zeros((B, 1, H), dtype=dt, device=device) for _ in range(len(self.model.layers) + 1)],
-                            attn=torch.zeros((B, nh, 1, D), dtype=dt, device=device), qkv=[], pre=[], post=[])
+                            attn=torch.zeros((B, nh, 1, D), dtype=dt, device=device), qkv=[], pre=[], post=[], whole=whole)
 
         def rot(t):
             return torch.cat((-t[..., D // 2:], t[..., : D // 2]), dim=-1)
@@ -166,6 +168,9 @@ class LlamaForCausalLM_KIVI(nn.Module):
             g.qkv.append((torch.zeros((B, nh, 1, D), dtype=dt, device=device),
                           torch.zeros((B, nkv, 1, D), dtype=dt, device=device),
                           torch.zeros((B, nkv, 1, D), dtype=dt, device=device)))
+        g.pre_fn, g.post_fn = pre, post
+        if whole:               # captured by kivi_amd.graph.GraphedDecode together with the attention launches
+            return g
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):          # warm-up outside capture (library workspaces, autotuning)
@@ -184,11 +189,11 @@ class LlamaForCausalLM_KIVI(nn.Module):
         g.tok.zero_()
         return g
 
-    def prepare_graphs(self, batch: int, device) -> None:
+    def prepare_graphs(self, batch: int, device, whole: bool = False) -> None:
         """Capture the decode graphs for this batch size now (otherwise on the first graphed step)."""
         g = getattr(self, "_graphs", None)
-        if g is None or g.B != batch:
-            self._graphs = self._build_graphs(batch, device)
+        if g is None or g.B != batch or g.whole != whole:
+            self._graphs = self._build_graphs(batch, device, whole)
 
     @torch.no_grad()
     def decode_graphed(self, tok: torch.LongTensor, past_key_values: List, position: int, steps: int) -> torch.LongTensor:
@@ -196,12 +201,35 @@ class LlamaForCausalLM_KIVI(nn.Module):
         hipGraphs; the caches in `past_key_values` are advanced in place.  Returns the (B, steps) tokens fed to the model
         (tok first); the token following them is left in the graph's token buffer (`self._graphs.tok`)."""
         from .attention import kivi_attention_decode
-        self.prepare_graphs(tok.shape[0], tok.device)
+        from .cache_mf import KiviLayerCacheMF
+        caches = [p.layer for p in past_key_values]
+        whole = all(isinstance(c, KiviLayerCacheMF) for c in caches)
+        self.prepare_graphs(tok.shape[0], tok.device, whole)
         g = self._graphs
         attn0 = self.model.layers[0].self_attn
-        caches = [p.layer for p in past_key_values]
         g.tok.copy_(tok)
         out = []
+        if whole:
+            from .graph import GraphedDecode, MfStepDriver
+            drv = MfStepDriver(caches)
+
+            def body():
+                for i in range(len(self.model.layers)):
+                    g.pre_fn(i)
+                    drv.enqueue(i, *g.qkv[i], g.attn)
+                    g.post_fn(i)
+
+            gd = GraphedDecode(drv, body)
+            for _ in range(steps):
+                out.append(g.tok.clone())
+                freqs = position * attn0.inv_freq.float()
+                emb = torch.cat((freqs, freqs), dim=-1)
+                g.cos.copy_(emb.cos().view(1, 1, 1, -1))
+                g.sin.copy_(emb.sin().view(1, 1, 1, -1))
+                gd.step()
+                position += 1
+            self._last_graph_stats = (gd.eager, gd.captures, gd.replays)
+            return torch.cat(out, dim=1)
         for _ in range(steps):
             out.append(g.tok.clone())
             freqs = position * attn0.inv_freq.float()

@@ -461,6 +461,59 @@ def test_product_python_reads_the_environment_only_through_the_tuning_module():
         importlib.reload(_tuning)
 
 
+@pytest.mark.parametrize("T0,R", [(0, 32), (5, 32), (70, 32), (300, 128), (511, 64), (4080, 32)])
+def test_step_advance_follows_the_reference_cache_policy(lib, T0, R):
+    """kivi_mf_step_advance + the caller's K flush = the length bookkeeping of the hook (llama_kivi.py:343-356, :386-399,
+    :425-452): after every step K holds floor(kv / R) * R packed + kv mod R residual keys, V max(kv - R, 0) packed + min(kv, R)
+    window values; the ring start moves with every quantised value; v_flush announces what the NEXT step does.  kivi_mf_step_key
+    changes exactly when a store gains a super-block (or the one- / two-launch decision flips)."""
+    import ctypes
+    from kivi_amd import _lib
+    rows = R + 1
+    hs = _lib.MfStep(Tq=(T0 // R) * R, Tv=max(T0 - R, 0), k_res_len=T0 % R, v_res_len=min(T0, R), v_win_start=0, v_flush=int(min(T0, R) + 1 > R))
+    kv, start = T0, 0
+    keys = []
+    for s in range(3 * R + 600):
+        keys.append(lib.kivi_mf_step_key(ctypes.byref(hs), 2, 8, 2, R, 4))
+        assert keys[-1] >= 0
+        rc = lib.kivi_mf_step_advance(ctypes.byref(hs), R, rows)
+        assert rc in (0, 1)
+        if kv >= R:
+            start = (start + 1) % rows
+        kv += 1
+        if rc == 1:
+            assert hs.k_res_len == R
+            hs.Tq += R
+            hs.k_res_len = 0
+        assert (hs.Tq, hs.k_res_len) == ((kv // R) * R, kv % R)
+        assert (hs.Tv, hs.v_res_len, hs.v_win_start) == (max(kv - R, 0), min(kv, R), start)
+        assert hs.v_flush == int(hs.v_res_len + 1 > R)
+    changes = sum(1 for a, b in zip(keys, keys[1:]) if a != b)
+    kv0, kv1 = T0, T0 + len(keys) - 1
+    sb = lambda t: (t + 511) // 512                      # noqa: E731
+    expect = (sb((kv1 // R) * R) - sb((kv0 // R) * R)) + (sb(max(kv1 - R, 0)) - sb(max(kv0 - R, 0)))
+    assert expect <= changes <= expect + 3, (changes, expect)      # + the first V flush / a one- vs two-launch flip
+    bad = _lib.MfStep(Tq=64, Tv=10, k_res_len=3, v_res_len=32, v_win_start=0, v_flush=1)
+    assert lib.kivi_mf_step_advance(ctypes.byref(bad), 32, 33) < 0
+    assert lib.kivi_mf_step_key(None, 1, 1, 1, 32, 0) == -1
+
+
+def test_decode_layer_dyn_refuses_before_launching(lib):
+    """kivi_mf_decode_layer_dyn validates the step being captured and the room its geometry class needs (score pitch, capacity)
+    without a device."""
+    import ctypes
+    from kivi_amd import _lib
+    d = _mf_layer_desc(s_pitch=600)
+    ok = _lib.MfStep(Tq=64, Tv=63, k_res_len=31, v_res_len=32, v_win_start=5, v_flush=1)
+    args = (0x1000, 8 * 128, 128, 8, 0x1000, 2 * 128, 128, 0x1000, 2 * 128, 128, None, 0, 0x1000, 8 * 128, 128, None)
+    for hs, dev, desc, msg in ((ok, None, d, b"null"), (_lib.MfStep(Tq=64, Tv=63, k_res_len=31, v_res_len=32, v_win_start=5, v_flush=0), 0x1000, d, b"inconsistent"),
+                               (ok, 0x1000, _mf_layer_desc(s_pitch=520), b"score pitch"), (ok, 0x1000, _mf_layer_desc(flags=0, s_pitch=600), b"ring window"),
+                               (ok, 0x1004, d, b"8-byte aligned")):
+        rc = lib.kivi_mf_decode_layer_dyn(ctypes.byref(desc), ctypes.byref(hs), dev, *args)
+        assert rc < 0 and msg in lib.kivi_last_error(), (rc, lib.kivi_last_error())
+    assert lib.kivi_mf_step_upload(None, None, None) < 0
+
+
 def test_tuning_build_still_compiles():
     """The product library carries no environment knob and no losing / diagnostic instantiation; they live behind
     -DKIVI_TUNING (tools/build_variant.sh tuning -DKIVI_TUNING).  That configuration is not built by __graft_entry__.build(),
