@@ -550,7 +550,8 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak_in
 // memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
 // VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block; -3 % per launch
 // at BASELINE config 4, profiles/r04_row4_levers.log)
-template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true>
+// WSM: the softmax of the four rows by one wave each (mf_row_softmax_wave) instead of the whole block row after row
+template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4)>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     GqaKArgs ak = ak_in;
@@ -657,12 +658,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
     // ---- [mask +] softmax of the four rows, one after the other (fp32, cast to fp16: :364-375); register resident per row
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
+    if constexpr (WSM) {
+        static_assert(!WSM || NW == R, "one wave per row");
+        const int sp = mf_row_softmax_wave<DUMP>(rows + wave * n_pad, n, n_pad, Tv, mrow, pw[wave], vbig,
+                                                 DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + wave) * ak.out_sh : nullptr);
+        if (lane == 0) sp_lds[wave] = sp;
+    } else {
 #pragma unroll 1
-    for (int r = 0; r < R; r++) {
-        const float mxr = r == 0 ? mxl[0] : (r == 1 ? mxl[1] : (r == 2 ? mxl[2] : mxl[3]));
-        const int sp = mf_row_softmax<NTH, (9216 + NTH * 4 - 1) / (NTH * 4), DUMP>(
-            rows + r * n_pad, n, n_pad, Tv, mxr, mrow, pw[r], sm_lds, vbig, DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
-        if (threadIdx.x == 0) sp_lds[r] = sp;
+        for (int r = 0; r < R; r++) {
+            const float mxr = r == 0 ? mxl[0] : (r == 1 ? mxl[1] : (r == 2 ? mxl[2] : mxl[3]));
+            const int sp = mf_row_softmax<NTH, (9216 + NTH * 4 - 1) / (NTH * 4), DUMP>(
+                rows + r * n_pad, n, n_pad, Tv, mxr, mrow, pw[r], sm_lds, vbig, DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
+            if (threadIdx.x == 0) sp_lds[r] = sp;
+        }
     }
     __syncthreads();
     stamp(7);
@@ -834,6 +842,7 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
         if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
         if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
         if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, false);
+        if (cfg == 2443) KIVI_ROW4_VARIANT(7, 4, 3, 4, false, false, true, false);      // + 2000: the block-wide softmax, row after row
 #undef KIVI_ROW4_VARIANT
 #endif
         const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");
