@@ -926,16 +926,20 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     typedef float f2v __attribute__((ext_vector_type(2)));
+    constexpr int NB = 4;                                          // chunks per batch: their LDS reads are issued before the first is used
     const int lane = threadIdx.x & 63;
     const int nch = (n + 255) >> 8;                                // 256-score chunks that hold scores
-    // ---- pass A: [mask in place,] maximum
-    h2v mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
-    for (int c = 0; c < nch; c++) {
+    const u32x2v ninf2 = {0xFC00FC00u, 0xFC00FC00u};
+    auto load = [&](int c) -> u32x2v {                             // chunk c of this lane; past the padded row: -inf (exp = 0)
         const int j0 = c * 256 + lane * 4;
-        if (j0 < n_pad) {
-            u32x2v raw = *(const u32x2v*)(row + j0);
-            if (mrow && j0 < n) {                                  // (:366-372: fp16 add, clamped at the fp16 minimum)
-                u16x4 rw = __builtin_bit_cast(u16x4, raw);
+        return j0 < n_pad ? *(const u32x2v*)(row + j0) : ninf2;
+    };
+    // ---- pass A: [mask in place,] maximum
+    if (mrow) {                                                    // masked rows: :366-372, fp16 add clamped at the fp16 minimum
+        for (int c = 0; c < nch; c++) {
+            const int j0 = c * 256 + lane * 4;
+            if (j0 < n) {
+                u16x4 rw = *(const u16x4*)(row + j0);
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     if (j0 + e < n) {
@@ -943,13 +947,22 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
                         if (v < -65504.0f) v = -65504.0f;
                         rw[e] = f2h_bits(v);
                     }
-                raw = __builtin_bit_cast(u32x2v, rw);
-                *(u32x2v*)(row + j0) = raw;                        // the same lane reads it back below
+                *(u16x4*)(row + j0) = rw;                          // the same lane reads it back below
             }
+        }
+    }
+    h2v mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
+    for (int c0 = 0; c0 < nch; c0 += NB) {
+        u32x2v raw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
             if constexpr (DUMP) {
-                if (dump && j0 < n) *(u32x2v*)(dump + j0) = raw;
+                const int j0 = (c0 + k) * 256 + lane * 4;
+                if (dump && j0 < n) *(u32x2v*)(dump + j0) = raw[k];
             }
-            const uint32_t w0 = raw[0], w1 = raw[1];
+            const uint32_t w0 = raw[k][0], w1 = raw[k][1];
             mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_max(__builtin_bit_cast(h2v, w0), __builtin_bit_cast(h2v, w1)));
         }
     }
@@ -957,15 +970,25 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
     const float mx = wave_max(__builtin_fmaxf(h2f_bits((uint16_t)(mb & 0xFFFFu)), h2f_bits((uint16_t)(mb >> 16))));
     const float nmx = -mx;
     const f2v l2e = {1.44269504088896340736f, 1.44269504088896340736f};
-    // ---- pass B: sum of exp
-    f2v acc = {0.f, 0.f};
-    for (int c = 0; c < nch; c++) {
-        const int j0 = c * 256 + lane * 4;
-        const u32x2v raw = *(const u32x2v*)(row + (j0 < n_pad ? j0 : n_pad - 4));     // past the row: -inf -> exp = 0
+    auto exps = [&](const u32x2v& raw, f2v& e01, f2v& e23) {       // kivi_exp(x - M) of the four scores of a chunk
         const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;
         const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
-        acc += (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
-        acc += (f2v){__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+        e01 = (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
+        e23 = (f2v){__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+    };
+    // ---- pass B: sum of exp
+    f2v acc = {0.f, 0.f};
+    for (int c0 = 0; c0 < nch; c0 += NB) {
+        u32x2v raw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            f2v e01, e23;
+            exps(raw[k], e01, e23);
+            acc += e01;
+            acc += e23;
+        }
     }
     const float sum = wave_sum(acc[0] + acc[1]);
     const float inv = 1.0f / sum;
@@ -974,16 +997,20 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
     const f2v inv2 = {inv, inv};
     // ---- pass C: p = fp16(e / sum) (:375), p'' back into the row (zeros from Tv on), the window's probabilities into pw_row
     const int nchp = (n_pad + 255) >> 8;
-    for (int c = 0; c < nchp; c++) {
-        const int j0 = c * 256 + lane * 4;
-        if (j0 < n_pad) {
+    for (int c0 = 0; c0 < nchp; c0 += NB) {
+        u32x2v raw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int j0 = (c0 + k) * 256 + lane * 4;
+            if (j0 >= n_pad) continue;
             u32x2v o = {0u, 0u};
             if (j0 < n) {
-                const u32x2v raw = *(const u32x2v*)(row + j0);
-                const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;
-                const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
-                const h2v p01 = __builtin_convertvector((f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])} * inv2, h2v);
-                const h2v p23 = __builtin_convertvector((f2v){__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])} * inv2, h2v);
+                f2v e01, e23;
+                exps(raw[k], e01, e23);
+                const h2v p01 = __builtin_convertvector(e01 * inv2, h2v);
+                const h2v p23 = __builtin_convertvector(e23 * inv2, h2v);
                 if (j0 + 4 <= Tv) {
                     const _Float16 m_a = (j0 & 4) ? (_Float16)64.0f : (_Float16)16.0f;
                     o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
