@@ -7,6 +7,7 @@
 #   bench            the driver's command (default workload)                  -> bench.json
 #   shapes           the other shapes of DESIGN section 5 through bench.py    -> shape_*.json + a one-line summary each
 #   trace            rocprofv3 --kernel-trace --stats of the bench command + per-kernel medians (tools/trace_median.py)
+#   trace_c4         the same for BASELINE config 4 only
 #   trace_gqa        the same for BASELINE config 4, the config-5 per-GPU slice and the 70B-like (64 / 8 heads) slice
 #   pmc              FETCH_SIZE / WRITE_SIZE passes (separate, kernel trace only) of the bench command + calibration
 #   pmc_c4           the same at BASELINE config 4
@@ -87,6 +88,7 @@ while [ $# -gt 0 ]; do
         timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/shape_70b_slice.json 2>> $O/shapes.err; line $O/shape_70b_slice.json
         KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN > $O/shape_headline_hook_layout.json 2>> $O/shapes.err; line $O/shape_headline_hook_layout.json ;;
     trace) trace_one bench 160 ;;
+    trace_c4) trace_one config4 96 $C4 --steps 10 --warmup 3 ;;
     trace_gqa)
         trace_one config4 96 $C4 --steps 10 --warmup 3
         trace_one config5slice 64 $C5 --steps 6 --warmup 2
