@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a_in, int s
     } else {
         // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
         const int hb = (4 * (lane >> 4)) % R;                       // heads hb .. hb + 3 sit in this lane's result registers
-        mf_k_seqR<R, RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
+        mf_k_seqR<R, RING, false>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
                            [&](int, int tt, int r, float v0, float v1) {
                                const uint32_t hp = mf_cvt_pair(v0, v1);
                                lds_o[(hb + r) * 512 + tt] = (uint16_t)(hp & 0xFFFFu);
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak_in
 // at BASELINE config 4, profiles/r04_row4_levers.log)
 // WSM: the softmax of the four rows by one wave each (mf_row_softmax_wave) instead of the whole block row after row
 template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4)>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NW == 6 ? 3 : 2)) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
@@ -563,6 +563,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     __shared__ uint16_t pw[R][MF_PW];
     __shared__ float sm_lds[2 * NW];
     __shared__ int sp_lds[R];
+    constexpr bool QL = NW != 4;                                   // more than four waves: q'' parked in LDS (the kernel must fit 168 / 128 registers)
+    __shared__ uint32_t qpark[QL ? NW : 1][QL ? 256 : 1];
     const int unit = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seqR<4, KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
+        mf_k_seqR<4, KRING, QL>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
             // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
             // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
             const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
             dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head r at tokens tt, tt + 16
             dst[16] = (uint16_t)(hs >> 16);
             mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
-        }, [](int, int) {});
+        }, [](int, int) {}, QL ? qpark[QL ? wave : 0] : nullptr);
     }
     float mxl[R];
 #pragma unroll
@@ -842,7 +844,20 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
         if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
         if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
         if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, false);
-        if (cfg == 2443) KIVI_ROW4_VARIANT(7, 4, 3, 4, false, false, true, false);      // + 2000: the block-wide softmax, row after row
+        // six / eight waves per block (three / four per SIMD: 168 / 128 registers, q'' parked in LDS, block-wide softmax)
+#define KIVI_ROW4_WIDE(KR, VR, NWV, VHLV)                                                                                          \
+    do {                                                                                                                           \
+        KIVI_LAUNCH_LDS((mf_row4_kernel<KR, VR, NWV, false, false, VHLV, false>), grid, dim3(64 * NWV), lds, s, k, v, n_pad);       \
+        return kivi_launch_status("mf_row4");                                                                                      \
+    } while (0)
+        if (cfg == 436) KIVI_ROW4_WIDE(4, 3, 6, true);
+        if (cfg == 236) KIVI_ROW4_WIDE(2, 3, 6, true);
+        if (cfg == 1436) KIVI_ROW4_WIDE(4, 3, 6, false);
+        if (cfg == 1236) KIVI_ROW4_WIDE(2, 3, 6, false);
+        if (cfg == 1226) KIVI_ROW4_WIDE(2, 2, 6, false);
+        if (cfg == 1238) KIVI_ROW4_WIDE(2, 3, 8, false);
+        if (cfg == 1228) KIVI_ROW4_WIDE(2, 2, 8, false);
+#undef KIVI_ROW4_WIDE
 #undef KIVI_ROW4_VARIANT
 #endif
         const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");

@@ -262,15 +262,16 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
 // (n = group, kb') = sum_d q[head (4 kb' + j) % R, d] * mn[d, group n] in score units (R = 4: register j = head j in every lane;
 // R = 8: heads 4 (kb' & 1) + j); `zmul`: 2^-sq of those heads.  `mv`: this lane's 4 x 16 bytes of the zero points of group n
 // (B layout = the row layout).
-template <int R>
-__device__ __forceinline__ void mf_k_zero(const MfQ<R>& Q, const u32x4* mv, const float* zmul, float* zz, int big) {
+// `qsrc(c)` returns the lane's q'' registers of channel chunk c (from registers, or from LDS when they are parked there).
+template <int R, typename QSrc>
+__device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const float* zmul, float* zz, int big) {
     f4 z = {0.f, 0.f, 0.f, 0.f};
     const uint32_t zf01 = mf_zfac(0, big), zf23 = mf_zfac(2, big);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         // A = q * 2^sq: q'' without the 2^aexp and the placement
-        const h8 aq = as_h8(pk_mul(Q.qq[c][0], zf01), pk_mul(Q.qq[c][1], zf01), pk_mul(Q.qq[c][2], zf23),
-                            pk_mul(Q.qq[c][3], zf23));
+        const u32x4 qc = qsrc(c);
+        const h8 aq = as_h8(pk_mul(qc[0], zf01), pk_mul(qc[1], zf01), pk_mul(qc[2], zf23), pk_mul(qc[3], zf23));
         z = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq, as_h8(mv[c][0], mv[c][1], mv[c][2], mv[c][3]), z, 0, 0, 0);
     }
 #pragma unroll
@@ -296,8 +297,11 @@ template <int V> struct mf_ic { static constexpr int value = V; };
 // instructions per group, the sums meeting through v_permlane16_swap -- : SQ_VALU_MFMA_BUSY_CYCLES fell from 0.74 to 0.40 of the
 // wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
 // profiles/r04_row4_levers.log.)
-template <int R, int RING, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
+// q_lds != nullptr (QL): the normalised q'' operand is parked in 256 words of this wave's LDS (slot (head, kb): 16 words) and read
+// back per round instead of living in 16 registers across the loop -- for the instantiations that must fit 168 registers.
+template <int R, int RING, bool QL = false, typename Sink, typename Done>
+__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done,
+                                          uint32_t* q_lds = nullptr) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
     constexpr int RR = R;                                           // rows per group
     constexpr int GPR = 16 / RR;                                     // groups per round
@@ -349,6 +353,19 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
         cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT + (big ? KIVI_MF_BIG_SHIFT : 0) - sqj);
     }
+    uint32_t* qslot = nullptr;
+    if constexpr (QL) {
+        qslot = q_lds + ((m % R) * 4 + kb) * 16;
+        if (m < R) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) *(u32x4*)(qslot + 4 * c) = u32x4{Q.qq[c][0], Q.qq[c][1], Q.qq[c][2], Q.qq[c][3]};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto qsrc = [&](int c) -> u32x4 {
+        if constexpr (QL) return *(const u32x4*)(qslot + 4 * c);
+        else return u32x4{Q.qq[c][0], Q.qq[c][1], Q.qq[c][2], Q.qq[c][3]};
+    };
     float zz[4] = {0.f, 0.f, 0.f, 0.f};
     // one round = GPR groups on ring slots S0 .. S0 + GPR - 1; a ring of several rounds walks S0 = 0, GPR, ... inside one loop
     // trip (so that every slot index is a constant)
@@ -357,17 +374,19 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         const int sbi = rq / RR;                                    // 16 / GPR = RR rounds per super-block
         const int rs = rq - sbi * RR;
         if (rs == 0) {                                              // a new super-block: its zero-point sums, then the next one's zero points
-            mf_k_zero<R>(Q, zv, zmul, zz, big);
+            mf_k_zero<R>(qsrc, zv, zmul, zz, big);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
         uint32_t Ah[4][4], Al[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < 4; c++) {
+            const u32x4 qc = qsrc(c);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                Ah[c][i] = pk_mul(Q.qq[c][i], sv[c][i]);
-                Al[c][i] = pk_fms(Q.qq[c][i], sv[c][i], Ah[c][i]);
+                Ah[c][i] = pk_mul(qc[i], sv[c][i]);
+                Al[c][i] = pk_fms(qc[i], sv[c][i], Ah[c][i]);
             }
+        }
         request_round(rq + 1 < n_round ? rq + 1 : rq, rq + 1 < n_round);
         __builtin_amdgcn_sched_barrier(0);
         // zero points of (group GPR rs + gl, heads (4 kb) % R + j) from the lane of that group in this 16-lane row

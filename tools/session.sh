@@ -55,7 +55,7 @@ trace_one() {  # <name> <skip> <bench args...>
 pmc_one() {  # <name> <config json> <bench args...>
     local name=$1 cfg=$2; shift 2
     cd /tmp && export TMPDIR=/tmp
-    rm -rf $O/pmc_f_$name $O/pmc_w_$name $O/pmc_calib
+    rm -rf $O/pmc_f_$name $O/pmc_w_$name
     timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$name -o b -- $BN --steps 3 --warmup 1 --no-kernel-events "$@" > /dev/null 2>&1
     timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$name -o b -- $BN --steps 3 --warmup 1 --no-kernel-events "$@" > /dev/null 2>&1
     [ -f $O/pmc_calib_done ] || { timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -o c -- $R/tools/hbm_read_bw.bin 2 > $O/hbm_bw.log 2>&1; touch $O/pmc_calib_done; }
