@@ -51,14 +51,15 @@ struct GqaKArgs {
 // res_len + 1 incl. the new key) for the R query heads of the unit, 8 lanes per (head, key) with 16-byte loads, fp32
 // accumulate, one rounding (the reference's fp16 torch.matmul, llama_kivi.py:337), writes the scaled scores and the
 // statistics of its segment, and appends the new key (:333-336).  Short, latency-bound blocks: first in the grid.
+// Tq / res_len: the step's lengths (from the arguments or, device-resident, from a.dyn: the callers resolve that).
 template <int R>
-__device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
+__device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid, long long Tq, int res_len) {
     constexpr int CH = 36;                                         // keys per segment: L <= 129 -> c <= 33
     __shared__ float xs[R][CH];
     const int unit = bid / KIVI_GQA_RES_SEGS, j = bid - unit * KIVI_GQA_RES_SEGS;
     const int b = unit / a.nh_kv, hk = unit - b * a.nh_kv;
     const int h0 = hk * a.ratio;
-    const int L = a.res_len + 1;
+    const int L = res_len + 1;
     const int c = (L + KIVI_GQA_RES_SEGS - 1) / KIVI_GQA_RES_SEGS;
     const int t0 = j * c;
     const int nt = (t0 + c <= L ? c : L - t0) > 0 ? (t0 + c <= L ? c : L - t0) : 0;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
     for (int idx = threadIdx.x; idx < R * nt * 8; idx += nthr) {
         const int sub = idx & 7, rt = idx >> 3;
         const int r = rt / nt, t = t0 + (rt - r * nt);
-        const uint16_t* krow = ((t < a.res_len) ? kres + (int64_t)t * a.kres_st : knew) + sub * 16;
+        const uint16_t* krow = ((t < res_len) ? kres + (int64_t)t * a.kres_st : knew) + sub * 16;
         const uint16_t* qrow = a.q + b * a.q_sb + (int64_t)(h0 + r) * a.q_sh + sub * 16;
         const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
         const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
@@ -78,7 +79,7 @@ __device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
         for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
 #pragma unroll
         for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
-        if (t == a.res_len && r == 0) {                             // append the new key
+        if (t == res_len && r == 0) {                               // append the new key
             *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16) = k0;
             *(u16x8*)(kres + (int64_t)t * a.kres_st + sub * 16 + 8) = k1;
         }
@@ -86,8 +87,8 @@ __device__ __forceinline__ void gqa_k_residual(const GqaKArgs& a, int bid) {
         sc += __shfl_xor(sc, 2);
         sc += __shfl_xor(sc, 4);
         if (sub == 0) {
-            const uint16_t x = kivi_scaled_score(f2h_bits(sc), a.inv_scale, mrow != nullptr, mrow ? mrow[a.Tq + t] : 0);
-            a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + a.Tq + t] = x;
+            const uint16_t x = kivi_scaled_score(f2h_bits(sc), a.inv_scale, mrow != nullptr, mrow ? mrow[Tq + t] : 0);
+            a.out[b * a.out_sb + (int64_t)(h0 + r) * a.out_sh + Tq + t] = x;
             xs[r][t - t0] = h2f_bits(x);
         }
     }

@@ -1,6 +1,8 @@
-// Round-3 matrix-pipe decode kernels over the KT / VT cache layouts (kivi_mfma_layout.h) for nh / nh_kv = R in {1, 4}:
+// Matrix-pipe decode kernels over the KT / VT cache layouts (kivi_mfma_layout.h) for nh / nh_kv = R in {1, 4, 8}:
 // the packed qK^T and sV of models/llama_kivi.py:324 / :382 (kernel quant/csrc/gemv_cuda.cu:348-427, head mapping
 // :361-365) and the whole decode step around them (:314-399).  Device bodies and the reasoning: kivi_mf_dev.h.
+// Every kernel takes the range flag of its unit's store(s) (kivi_mfma_layout.h: where q'' / p'' are placed so that the fp16
+// operands stay finite for any finite scale) and, optionally, the step's lengths from device memory (MfStep: hipGraph replay).
 //
 //   mf_k_kernel    one wave per super-block: scores (raw, or scaled + masked with softmax statistics per segment) + the
 //                  fp16 K-residual role (q . K_full, K append) in short blocks at the tail of the grid
@@ -10,6 +12,7 @@
 //   mf_row_kernel  R = 1 (MHA), rows <= 8192 keys: the whole step of a (batch row, head) in ONE block -- packed qK^T ->
 //                  LDS scores -> residual scores -> softmax -> window -> packed sV -> output; nothing but the output
 //                  and the cache appends goes to memory
+//   mf_row4_kernel the same for the four query heads of a kv head (R = 4, rows <= 9216 keys)
 #include <stdlib.h>
 #include <string.h>
 
@@ -29,13 +32,14 @@ constexpr int mf_k_lds_words() { return (R == 1 ? 64 : 0) + R * 256; }   // R = 
 
 // DIAG (tuning builds, wrong results): 1 = nothing leaves the LDS (no flush), 2 = scores stored without the statistics
 template <int R, int W, int RING, int DIAG = 0>
-__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a_in, int spw) {
+__global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
     extern __shared__ uint32_t lds_all[];
-    GqaKArgs a = a_in;
-    a.take_dyn();
+    // the step's lengths: by value, or device-resident (a.dyn).  (Only these two scalars: a mutable copy of the whole argument block
+    // cost 3-8 % of the raw-score launch -- the flush lambda then reads its fields from a local object instead of the kernarg segment.)
+    const long long Tq = a.dyn ? a.dyn->Tq : (long long)a.Tq;
     const int main_blocks = (int)gridDim.x - a.res_blocks;
     if ((int)blockIdx.x >= main_blocks) {                            // short residual blocks at the tail of the grid
-        gqa_k_residual<R>(a, (int)blockIdx.x - main_blocks);
+        gqa_k_residual<R>(a, (int)blockIdx.x - main_blocks, Tq, a.dyn ? a.dyn->k_res_len : a.res_len);
         return;
     }
     const int bid = (int)blockIdx.x;
@@ -111,14 +115,14 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a_in, int s
     seq.sb_stride = 1;
     seq.n_sb = (sb0 + spw <= a.nsb) ? spw : a.nsb - sb0;
     const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
-    seq.ng_total = (int)(((a.Tq < tok_end ? a.Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
+    seq.ng_total = (int)(((Tq < tok_end ? Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
     if constexpr (R == 1) {
         mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, big,
                         [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
         // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
         const int hb = (4 * (lane >> 4)) % R;                       // heads hb .. hb + 3 sit in this lane's result registers
-        mf_k_seqR<R, RING, false>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
+        mf_k_seqR<R, RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
                            [&](int, int tt, int r, float v0, float v1) {
                                const uint32_t hp = mf_cvt_pair(v0, v1);
                                lds_o[(hb + r) * 512 + tt] = (uint16_t)(hp & 0xFFFFu);
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak_in
 // at BASELINE config 4, profiles/r04_row4_levers.log)
 // WSM: the softmax of the four rows by one wave each (mf_row_softmax_wave) instead of the whole block row after row
 template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4)>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NW == 6 ? 3 : 2)) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int R = 4, NTH = NW * 64;
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
@@ -563,8 +567,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NW == 6 ? 3 : 2)) void mf_r
     __shared__ uint16_t pw[R][MF_PW];
     __shared__ float sm_lds[2 * NW];
     __shared__ int sp_lds[R];
-    constexpr bool QL = NW != 4;                                   // more than four waves: q'' parked in LDS (the kernel must fit 168 / 128 registers)
-    __shared__ uint32_t qpark[QL ? NW : 1][QL ? 256 : 1];
     const int unit = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NW == 6 ? 3 : 2)) void mf_r
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seqR<4, KRING, QL>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
+        mf_k_seqR<4, KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
             // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
             // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
             const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : (NW == 6 ? 3 : 2)) void mf_r
             dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head r at tokens tt, tt + 16
             dst[16] = (uint16_t)(hs >> 16);
             mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
-        }, [](int, int) {}, QL ? qpark[QL ? wave : 0] : nullptr);
+        }, [](int, int) {});
     }
     float mxl[R];
 #pragma unroll
@@ -844,20 +846,6 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
         if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
         if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
         if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, false);
-        // six / eight waves per block (three / four per SIMD: 168 / 128 registers, q'' parked in LDS, block-wide softmax)
-#define KIVI_ROW4_WIDE(KR, VR, NWV, VHLV)                                                                                          \
-    do {                                                                                                                           \
-        KIVI_LAUNCH_LDS((mf_row4_kernel<KR, VR, NWV, false, false, VHLV, false>), grid, dim3(64 * NWV), lds, s, k, v, n_pad);       \
-        return kivi_launch_status("mf_row4");                                                                                      \
-    } while (0)
-        if (cfg == 436) KIVI_ROW4_WIDE(4, 3, 6, true);
-        if (cfg == 236) KIVI_ROW4_WIDE(2, 3, 6, true);
-        if (cfg == 1436) KIVI_ROW4_WIDE(4, 3, 6, false);
-        if (cfg == 1236) KIVI_ROW4_WIDE(2, 3, 6, false);
-        if (cfg == 1226) KIVI_ROW4_WIDE(2, 2, 6, false);
-        if (cfg == 1238) KIVI_ROW4_WIDE(2, 3, 8, false);
-        if (cfg == 1228) KIVI_ROW4_WIDE(2, 2, 8, false);
-#undef KIVI_ROW4_WIDE
 #undef KIVI_ROW4_VARIANT
 #endif
         const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");

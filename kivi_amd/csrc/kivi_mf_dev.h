@@ -1,6 +1,6 @@
-// Round-3 device bodies of the matrix-pipe kernels over the KT / VT cache layouts (kivi_mfma_layout.h): the packed qK^T
+// Device bodies of the matrix-pipe kernels over the KT / VT cache layouts (kivi_mfma_layout.h): the packed qK^T
 // and sV products of quant/csrc/gemv_cuda.cu:348-427 (call sites models/llama_kivi.py:324 / :382) for R = nh / nh_kv
-// in {1, 4} query heads per kv head.
+// in {1, 4, 8} query heads per kv head (R = 8: round 4, rows = 2 groups x 8 heads / two row sets of (channel group, head)).
 //
 // What changed against the round-2 bodies (kivi_gqa.hip), per 32-token block of 128 channels (64 codes per lane):
 //   * qK^T: an MFMA ROW is a quantisation GROUP (R = 1: the 16 groups of a super-block; R = 4: 4 groups x 4 heads), not
@@ -106,7 +106,7 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
 //     and super-block: ~10 us of a 46 us launch, profiles/r03_mfk_ablation.log);
 //   * the scale / zero points of half h + 1 are requested right after the A operands of half h have been built from the
 //     registers they land in; the code ring runs across halves and super-blocks.
-constexpr uint32_t MF_DEAD_OFF = 0xFFFE0000u;    // + any in-super-block offset (< 25 KiB) stays below 2^32 and past every descriptor (a store within 128 KiB of 4 GiB would merely fetch)
+constexpr uint32_t MF_DEAD_OFF = 0xFFFE0000u;    // + any in-super-block offset (< 25 KiB) stays below 2^32; the host keeps every descriptor's extent <= this value (MF_DESC_LIMIT, kivi_gqa.hip), so such a request is out of range whatever the store's size
 
 struct MfKSeq {
     uint32_t sb_bytes;              // byte stride between consecutive super-blocks of the unit
@@ -297,11 +297,8 @@ template <int V> struct mf_ic { static constexpr int value = V; };
 // instructions per group, the sums meeting through v_permlane16_swap -- : SQ_VALU_MFMA_BUSY_CYCLES fell from 0.74 to 0.40 of the
 // wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
 // profiles/r04_row4_levers.log.)
-// q_lds != nullptr (QL): the normalised q'' operand is parked in 256 words of this wave's LDS (slot (head, kb): 16 words) and read
-// back per round instead of living in 16 registers across the loop -- for the instantiations that must fit 168 registers.
-template <int R, int RING, bool QL = false, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done,
-                                          uint32_t* q_lds = nullptr) {
+template <int R, int RING, typename Sink, typename Done>
+__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
     constexpr int RR = R;                                           // rows per group
     constexpr int GPR = 16 / RR;                                     // groups per round
@@ -353,19 +350,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
         cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT + (big ? KIVI_MF_BIG_SHIFT : 0) - sqj);
     }
-    uint32_t* qslot = nullptr;
-    if constexpr (QL) {
-        qslot = q_lds + ((m % R) * 4 + kb) * 16;
-        if (m < R) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) *(u32x4*)(qslot + 4 * c) = u32x4{Q.qq[c][0], Q.qq[c][1], Q.qq[c][2], Q.qq[c][3]};
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    auto qsrc = [&](int c) -> u32x4 {
-        if constexpr (QL) return *(const u32x4*)(qslot + 4 * c);
-        else return u32x4{Q.qq[c][0], Q.qq[c][1], Q.qq[c][2], Q.qq[c][3]};
-    };
+    auto qsrc = [&](int c) -> u32x4 { return u32x4{Q.qq[c][0], Q.qq[c][1], Q.qq[c][2], Q.qq[c][3]}; };
     float zz[4] = {0.f, 0.f, 0.f, 0.f};
     // one round = GPR groups on ring slots S0 .. S0 + GPR - 1; a ring of several rounds walks S0 = 0, GPR, ... inside one loop
     // trip (so that every slot index is a constant)
