@@ -398,8 +398,10 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 // The whole decode step of one (batch row, head) in one block of NW waves.  Dynamic LDS: the score / p'' row (n_pad halves).
 // DBG (tools/mf_row_phases.py): every wave stamps the shader clock at its phase boundaries into av.dbg
 // DUMP (KIVI_GQA_DUMP_SCORES, tests): the fp16 row the softmax consumes (scaled, mask added) also goes to ak.out
-template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, bool DUMP = false>
-__global__ __launch_bounds__(NW * 64, 4) void mf_row_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
+// OCC: waves per SIMD the register budget allows (4: 128 registers; 2: the few-rows instantiation with rings of 8 -- at most one
+// block per CU is resident anyway, so a wave may hold a half super-block of K and 8 blocks of V in flight)
+template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, bool DUMP = false, int OCC = 4>
+__global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int NTH = NW * 64;
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
@@ -878,7 +880,12 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
         else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, true, true>), grid, dim3(256), lds, s, k, v, n_pad);
         return kivi_launch_status("mf_row");
     }
-    if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
+    // at most one block per CU (<= 256 rows): a row's waves are alone on their SIMDs and each is bound by the round trips of its own
+    // ring (2 KiB of K / 3 KiB of V in flight stream ~3 GB/s per wave): rings of 8 blocks, 256 registers per wave
+    static const char* fdp = KIVI_TUNE_ENV("KIVI_MF_ROW_DEEP");          // tuning builds: 0 / 1 forces either
+    const bool deep = fdp ? atoi(fdp) != 0 : units <= 256;
+    if (deep) KIVI_LAUNCH_LDS((mf_row_kernel<8, 8, 8, false, true, false, 2>), grid, dim3(512), lds, s, k, v, n_pad);
+    else if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
     else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");
 }

@@ -108,6 +108,8 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
 //     registers they land in; the code ring runs across halves and super-blocks.
 constexpr uint32_t MF_DEAD_OFF = 0xFFFE0000u;    // + any in-super-block offset (< 25 KiB) stays below 2^32; the host keeps every descriptor's extent <= this value (MF_DESC_LIMIT, kivi_gqa.hip), so such a request is out of range whatever the store's size
 
+template <int V> struct mf_ic { static constexpr int value = V; };
+
 struct MfKSeq {
     uint32_t sb_bytes;              // byte stride between consecutive super-blocks of the unit
     int sb_first, sb_stride, n_sb;  // this wave's super-blocks
@@ -121,7 +123,7 @@ struct MfKSeq {
 // big: the unit's range flag (wave-uniform; mf_load_q).
 template <int RING, typename Sink, typename Done>
 __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, int big, Sink&& sink, Done&& done) {
-    static_assert(RING == 2 || RING == 4, "ring of 2 or 4 code blocks");
+    static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     const int gp = m & 7;
@@ -218,13 +220,15 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
         request_half(hq + 1 < n_half ? hq + 1 : hq, hq + 1 < n_half);   // lands during this half's groups (after the last one: nothing)
         __builtin_amdgcn_sched_barrier(0);
         float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int u = 0; u < 2; u++) {
+        // one quad of groups: rolled for rings of <= 4 (the slot of group j is a constant either way), unrolled for the ring of 8 --
+        // the few-rows instantiations, where a wave has the registers to keep a whole half super-block in flight
+        auto quad = [&](int u, auto ubase) {
+            constexpr int UB = decltype(ubase)::value;              // ring slot of the quad's first group
             const bool mine = (kb & 1) == u;                        // output rows 4 kb' + j: group 4 (kb' & 1) + j of the half
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int gi = hq * 8 + u * 4 + j;
-                const u32x4& w = wr[j % RING];
+                const u32x4& w = wr[(UB + j) % RING];
                 f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -235,9 +239,16 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
                 }
                 o0[j] = mine ? a0[j] : o0[j];
                 o1[j] = mine ? a1[j] : o1[j];
-                request_group(j % RING, gi + RING);                 // after the last use: the load lands in the slot directly
+                request_group((UB + j) % RING, gi + RING);          // after the last use: the load lands in the slot directly
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (RING == 8) {
+            quad(0, mf_ic<0>{});
+            quad(1, mf_ic<4>{});
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 2; u++) quad(u, mf_ic<0>{});
         }
         // lane (n, kb'), register j: the hi (kb' < 2) or lo part of group 4 (kb' & 1) + j of the half, tokens n (o0) / 16 + n (o1)
         const int sbi = hq >> 1;
@@ -291,8 +302,6 @@ __device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const fl
 // (4 kb) % R + r, i.e. r itself for R = 4 and 4 (kb & 1) + r for R = 8 (the two scores of a call share everything but the token
 // tile, so a sink can convert / scale / compare them as a packed pair); done(super-block index, its number of groups) is called
 // when the last score of a super-block has been handed to sink.  RING code blocks in flight, a multiple of the 16 / R groups of a round.
-template <int V> struct mf_ic { static constexpr int value = V; };
-
 // (Round 4 also built the walker with hi and lo of q'' * scale in ROWS -- 2 groups x (hi | lo) x 4 heads, 8 instead of 16 matrix
 // instructions per group, the sums meeting through v_permlane16_swap -- : SQ_VALU_MFMA_BUSY_CYCLES fell from 0.74 to 0.40 of the
 // wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
@@ -465,6 +474,7 @@ template <int RING> struct MfCentre;
 template <> struct MfCentre<2> { static constexpr uint32_t a = 0x83008300u, b = 0x80C080C0u; static constexpr float f = 3.0f; };
 template <> struct MfCentre<3> { static constexpr uint32_t a = 0x84808480u, b = 0x81208120u; static constexpr float f = 4.5f; };
 template <> struct MfCentre<4> { static constexpr uint32_t a = 0x86008600u, b = 0x81808180u; static constexpr float f = 6.0f; };
+template <> struct MfCentre<8> { static constexpr uint32_t a = 0x8A008A00u, b = 0x83008300u; static constexpr float f = 12.0f; };   // (-12 x 2^-16 is a normal fp16)
 
 // one 32-token block.  w: code words; ps: the lane's 8 scaled probabilities (tokens 8 kb + e of its row's head);
 // R = 1: sm[0] = scale (rows j < 2) or zero points (rows j >= 2), lomask = all ones in lo rows;
