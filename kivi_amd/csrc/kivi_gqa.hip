@@ -378,7 +378,7 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
 
 // One launch (true) or two for a step whose LONGEST row has n_rows keys (kivi_gqa_decode's rule; also part of kivi_mf_step_key)
 static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags) {
-    if (!((R == 1 && n_rows <= 8192) || (R == 4 && n_rows <= 9216))) return false;
+    if (!((R == 1 && n_rows <= 8192) || (R == 4 && n_rows <= 9216) || (R == 8 && n_rows <= 4608))) return false;
     static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
     if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return false;
     // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves

@@ -550,16 +550,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     }
 }
 
-// ------------------------------------------------------------------------------------------------ fused row, R = 4
-// The whole decode step of one (batch row, kv head) with its four query heads in one block of NW waves (grouped queries,
-// rows whose four score rows fit the LDS: 4 n fp16 <= 72 KiB, two blocks per CU): no score / statistics round trip through
-// memory, no second launch.  Dynamic LDS: [4][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
+// ------------------------------------------------------------------------------------------------ fused row, R = 4 / 8
+// The whole decode step of one (batch row, kv head) with its R = 4 (or, round 4, 8) query heads in one block of NW waves (grouped
+// queries, rows whose R score rows fit the LDS: R n fp16 <= 72 KiB -- 9216 keys for R = 4, 4608 for R = 8 --, two blocks per CU): no
+// score / statistics round trip through memory, no second launch.  Dynamic LDS: [R][n_pad] fp16 scores -> p''; reused for the
+// per-wave partial sums at the end.
 // VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block; -3 % per launch
 // at BASELINE config 4, profiles/r04_row4_levers.log)
 // WSM: the softmax of the four rows by one wave each (mf_row_softmax_wave) instead of the whole block row after row
-template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4)>
+template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4), int R = 4>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
-    constexpr int R = 4, NTH = NW * 64;
+    constexpr int NTH = NW * 64;
+    static_assert(R == 4 || (R == 8 && !VHL && WSM), "R = 8: chained hi / lo sV, two rows per wave in the softmax");
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
     ak.take_dyn();
@@ -593,7 +595,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     // ---- packed qK^T: wave w walks super-blocks w, w + NW, ...
     // per-lane maxima of the scores written: a packed pair per head while the K stream runs (one v_pk_max_f16 per two scores)
     typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
-    uint32_t mxp[R] = {0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u};
+    uint32_t mxp[4] = {0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u};     // (this lane's four result registers: heads hb .. hb + 3)
+    const int hb = (4 * (lane >> 4)) % R;
     {
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
         MfKSeq seq;
@@ -604,19 +607,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seqR<4, KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
+        mf_k_seqR<R, KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
             // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
             // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
             const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
-            uint16_t* dst = rows + r * n_pad + sb * KIVI_MF_SB_TOKENS + tt;
+            uint16_t* dst = rows + (hb + r) * n_pad + sb * KIVI_MF_SB_TOKENS + tt;
             dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head r at tokens tt, tt + 16
             dst[16] = (uint16_t)(hs >> 16);
             mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
         }, [](int, int) {});
     }
-    float mxl[R];
+    float mxl[4];                                                  // (block-wide softmax only: R = 4, where hb = 0 and register r is head r)
 #pragma unroll
-    for (int r = 0; r < R; r++) mxl[r] = __builtin_fmaxf(h2f_bits((uint16_t)(mxp[r] & 0xFFFFu)), h2f_bits((uint16_t)(mxp[r] >> 16)));
+    for (int r = 0; r < 4; r++) mxl[r] = __builtin_fmaxf(h2f_bits((uint16_t)(mxp[r] & 0xFFFFu)), h2f_bits((uint16_t)(mxp[r] >> 16)));
     stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
     const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
             rows[r * n_pad + Tq + t] = h;
             const float hv = h2f_bits(h);
 #pragma unroll
-            for (int rr = 0; rr < R; rr++) mxl[rr] = (rr == r) ? __builtin_fmaxf(mxl[rr], hv) : mxl[rr];
+            for (int rr = 0; rr < 4; rr++) mxl[rr] = (rr == r) ? __builtin_fmaxf(mxl[rr], hv) : mxl[rr];
         }
     }
     for (int j = (int)threadIdx.x; j < R * (n_pad - n); j += NTH) rows[(j / (n_pad - n)) * n_pad + n + j % (n_pad - n)] = 0xFC00u;   // -inf past the rows
@@ -665,10 +668,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     // ---- [mask +] softmax of the four rows, one after the other (fp32, cast to fp16: :364-375); register resident per row
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
     if constexpr (WSM) {
-        static_assert(!WSM || NW == R, "one wave per row");
-        const int sp = mf_row_softmax_wave<DUMP>(rows + wave * n_pad, n, n_pad, Tv, mrow, pw[wave], vbig,
-                                                 DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + wave) * ak.out_sh : nullptr);
-        if (lane == 0) sp_lds[wave] = sp;
+        static_assert(!WSM || R % NW == 0, "whole rows per wave");
+#pragma unroll 1
+        for (int r = wave; r < R; r += NW) {                       // (R = 4: one row per wave; R = 8: two)
+            const int sp = mf_row_softmax_wave<DUMP>(rows + r * n_pad, n, n_pad, Tv, mrow, pw[r], vbig,
+                                                     DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
+            if (lane == 0) sp_lds[r] = sp;
+        }
     } else {
 #pragma unroll 1
         for (int r = 0; r < R; r++) {
@@ -815,6 +821,24 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
     const int64_t n = n_rows;
     const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
     const dim3 grid((unsigned)units);
+    if (k.ratio == 8) {
+        // eight score rows in the LDS (two blocks per CU): up to 4608 keys -- the Llama-3-70B ratio at contexts up to 4.5k
+        KIVI_REQUIRE(n <= 4608, KIVI_EUNSUPPORTED, "mf_row8: rows of %lld keys do not fit the LDS (<= 4608)", (long long)n);
+        size_t lds = (size_t)8 * n_pad * 2;
+        const size_t fin = (size_t)2 * 4 * 8 * 128 * 4;           // the per-wave partial sums reuse the rows
+        if (lds < fin) lds = fin;
+        static unsigned long long opt8 = 0, opt8_dump = 0;
+        if (dump) {
+            const int rc = mf_lds_opt_in(mf_row4_kernel<4, 2, 4, false, true, false, true, 8>, &opt8_dump, "mf_row8");
+            if (rc) return rc;
+            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 2, 4, false, true, false, true, 8>), grid, dim3(256), lds, s, k, v, n_pad);
+            return kivi_launch_status("mf_row8");
+        }
+        const int rc = mf_lds_opt_in(mf_row4_kernel<4, 2, 4, false, false, false, true, 8>, &opt8, "mf_row8");
+        if (rc) return rc;
+        KIVI_LAUNCH_LDS((mf_row4_kernel<4, 2, 4, false, false, false, true, 8>), grid, dim3(256), lds, s, k, v, n_pad);
+        return kivi_launch_status("mf_row8");
+    }
     if (k.ratio == 4) {
         // four score rows in the LDS (two blocks per CU): up to 9216 keys
         KIVI_REQUIRE(n <= 9216, KIVI_EUNSUPPORTED, "mf_row4: rows of %lld keys do not fit the LDS (<= 9216)", (long long)n);

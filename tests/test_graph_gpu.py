@@ -20,7 +20,8 @@ def _tuples_equal(a, b):
 
 @pytest.mark.parametrize("B,nh,nh_kv,T0,R,form,masked", [(2, 4, 4, 70, 32, "row", False), (2, 8, 2, 1100, 128, "row", True),
                                                            (2, 4, 4, 600, 64, "split", True), (2, 8, 2, 500, 32, "split", False),
-                                                           (1, 16, 2, 480, 32, "split", False), (8, 32, 32, 4080, 32, "auto", False)])
+                                                           (1, 16, 2, 480, 32, "split", False), (2, 16, 2, 300, 32, "row", False),
+                                                           (8, 32, 32, 4080, 32, "auto", False)])
 def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked):
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache

@@ -82,7 +82,7 @@ def test_hook_matches_reference_class_fixtures(path, layout):
             if not isinstance(layer, KiviLayerCacheMF):
                 pytest.skip("shape outside the matrix-pipe layout: covered by layout=auto")
             if layout == "row":
-                if ratio not in (1, 4):
+                if ratio not in (1, 4, 8):
                     pytest.skip("no one-launch kernel for this head ratio")
                 layer.flags, expect = _lib.GQA_FORCE_ROW, (b"mf_row_kernel" if ratio == 1 else b"mf_row4_kernel")
             else:
