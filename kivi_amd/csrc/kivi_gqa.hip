@@ -385,7 +385,9 @@ static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags)
     // of a row block to take one super-block each (nh == nh_kv, <= 4096 packed keys): then one launch beats two whatever
     // the batch (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79,
     // profiles/r03_other_shapes.log)
-    const int min_units = R == 1 ? 192 : 128;
+    // (R = 8, 4000 keys: 128 units 1.65 ms per 32-layer step in one launch against 1.39 in two, 512 units 2.42 against 3.65;
+    // profiles/r04_other_shapes.log)
+    const int min_units = R == 4 ? 128 : 192;
     return units >= min_units || (R == 1 && nsbk <= 8) || (flags & KIVI_GQA_FORCE_ROW);
 }
 
