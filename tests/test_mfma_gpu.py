@@ -243,7 +243,7 @@ def _cmp_cache(t_gpu, t_ref):
                                                          (16, 2, 600, 64, False, "randn"), (8, 2, 1100, 128, True, "outlier"),
                                                          (32, 8, 300, 128, False, "outlier"), (2, 2, 5, 32, False, "randn"),
                                                          (3, 3, 70, 32, True, "outlier"), (4, 4, 600, 64, False, "outlier"),
-                                                         (2, 2, 1100, 128, True, "randn"), (16, 2, 1100, 128, True, "outlier")])
+                                                         (2, 2, 1100, 128, True, "randn"), (16, 2, 1100, 32, True, "outlier")])
 def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked, kind, form):
     """Every step of R + 9 (one K flush, V flushes, the window ring wrapping, cache growth, a partial last super-block), stage by
     stage against the reference logic (oracle/hook_ref.py), no step-level escape -- for keys with large-magnitude channels
@@ -414,7 +414,7 @@ def test_mf_decode_steps_dynamic_range(oracle, nh, nh_kv, m0, m1, form):
 @pytest.mark.parametrize("B,nh,nh_kv,T0,R,masked", [(2, 4, 4, 5, 32, False), (8, 32, 32, 1500, 32, True), (2, 2, 2, 8100, 32, False),
                                                      (4, 8, 8, 4080, 128, False), (2, 8, 2, 5, 32, False), (3, 16, 4, 1500, 64, True),
                                                      (2, 8, 2, 9000, 128, False), (8, 32, 8, 8000, 128, False),
-                                                     (2, 16, 2, 1500, 64, True), (4, 64, 8, 4400, 128, False)])
+                                                     (2, 16, 2, 1500, 64, True), (2, 64, 8, 4400, 32, False)])
 def test_mf_row_kernel_matches_two_launch_form(oracle, B, nh, nh_kv, T0, R, masked):
     """The one-launch row kernels (mf_row_kernel for nh == nh_kv, mf_row4_kernel for nh / nh_kv == 4 and -- rows up to 4608 keys --
     8: scores never leave the LDS) against the two-launch form of the same step (stage-checked above) on cloned caches: same packed qK^T arithmetic
