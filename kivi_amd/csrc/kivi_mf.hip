@@ -24,6 +24,30 @@
 
 namespace {
 
+// Tuning builds, KIVI_MF_XCD=1: the blocks of the two-launch form are renumbered so that consecutive LOGICAL blocks -- the
+// chunks / slices of one (batch row, kv head) -- run on ONE XCD (the hardware deals consecutive workgroup ids round-robin over
+// the 8 XCDs) and a unit sits on the same XCD in the qK^T and the sV launch: the score rows and statistics written by the first
+// are then read through the L2 that wrote them.  Measured, not adopted: profiles/r04_xcd_affinity.log.
+#ifdef KIVI_TUNING
+__device__ int mf_tune_xcd = 0;
+void mf_tune_sync() {
+    static int done = 0;
+    if (done) return;
+    const char* e = KIVI_TUNE_ENV("KIVI_MF_XCD");
+    const int v = e ? atoi(e) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mf_tune_xcd), &v, sizeof(int));
+    done = 1;
+}
+__device__ __forceinline__ int mf_block_id(int nblk) {
+    const int bid = (int)blockIdx.x;
+    if (!mf_tune_xcd) return bid;
+    const int nb8 = nblk & ~7;
+    return bid < nb8 ? (bid & 7) * (nb8 >> 3) + (bid >> 3) : bid;
+}
+#else
+__device__ __forceinline__ int mf_block_id(int) { return (int)blockIdx.x; }
+#endif
+
 // ------------------------------------------------------------------------------------------------ qK^T launch
 
 // per-wave LDS words of mf_k_kernel: [scale of the super-block: 1024 words, R = 4 only | R x 512 fp16 scores]
@@ -42,7 +66,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
         gqa_k_residual<R>(a, (int)blockIdx.x - main_blocks, Tq, a.dyn ? a.dyn->k_res_len : a.res_len);
         return;
     }
-    const int bid = (int)blockIdx.x;
+    const int bid = mf_block_id(main_blocks);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* lds_w = lds_all + wave * mf_k_lds_words<R>();
@@ -138,6 +162,9 @@ void launch_mf_k(const GqaKArgs& a, int units, int spw, hipStream_t s) {
 }
 
 int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
+#ifdef KIVI_TUNING
+    mf_tune_sync();
+#endif
     // a wave walks `spw` consecutive super-blocks of its unit (the next one's operands are requested while the current one is
     // multiplied): 2 when that still leaves >= 4 waves per SIMD, else 1; few super-blocks: one wave per block spreads them
     const int64_t total = (int64_t)units * a.nsb;
@@ -240,13 +267,13 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
     GqaVArgs a = a_in;
     a.take_dyn();
     __shared__ uint16_t pw[R][MF_PW];
-    const int bid = (int)blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WW = R * 256 + 128;                              // per-wave words
     uint16_t* lds_p = (uint16_t*)(lds_all + wave * WW);
     float* zl = (float*)(lds_all + wave * WW + R * 256);
     const int nstream = a.units * a.S;
+    const int bid = mf_block_id(nstream);                          // (window blocks, at the tail, keep their ids)
     const bool win_role = bid >= nstream;
     const int unit = win_role ? bid - nstream : bid / a.S;
     const int slice = win_role ? a.S : bid - unit * a.S;           // = the block's partial-sum slot
@@ -747,6 +774,9 @@ int kivi_mf_run_k(void* k_args, int units, hipStream_t s) { return run_mf_k(*(Gq
 int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
     const GqaVArgs& a = *(const GqaVArgs*)v_args;
     const int R = a.ratio;
+#ifdef KIVI_TUNING
+    mf_tune_sync();
+#endif
     const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
     const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
 #define KIVI_MV(RR, RG, PB) KIVI_LAUNCH_LDS((mf_v_kernel<RR, RG, PB>), grid, dim3(256), lds, s, a)

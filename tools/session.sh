@@ -18,6 +18,7 @@
 #   row4ab           mf_row4_kernel variants at BASELINE config 4 (tuning build: KIVI_MF_ROW4 = <K ring><V ring><waves>
 #                    + 1000 / 2000 for hi / lo rows in the qK^T / sV phase, KIVI_MF_STAG_US): parity of the variants through the
 #                    row-form tests, then same-box bench lines
+#   xcd              two-launch form with a unit's blocks on one XCD (tuning build, KIVI_MF_XCD) against the plain block order
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -126,6 +127,19 @@ while [ $# -gt 0 ]; do
         for cfg in 443 3443 3843; do
             for us in 8 14 20 28; do
                 KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg KIVI_MF_STAG_US=$us timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/c4_${cfg}_stag$us.json 2>> $O/row4ab.err; line $O/c4_${cfg}_stag$us.json
+            done
+        done ;;
+    xcd)
+        # two-launch form with a unit's blocks on ONE XCD (tuning build, KIVI_MF_XCD=1) against the plain block order: parity of the
+        # renumbered launches through the two-launch tests, then alternating bench lines on one box
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_XCD=1 timeout 600 python -m pytest tests/test_mfma_gpu.py -m gpu -x -q -k "gqa_scores or gqa_output or decode_steps" \
+            > $O/xcd_parity.log 2>&1; echo "xcd parity rc=$?" | tee -a $O/status.log; tail -3 $O/xcd_parity.log
+        for i in 1 2; do
+            for x in 0 1; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_XCD=$x timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/xcd${x}_c5_$i.json 2>> $O/xcd.err; line $O/xcd${x}_c5_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_XCD=$x timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/xcd${x}_70b_$i.json 2>> $O/xcd.err; line $O/xcd${x}_70b_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_XCD=$x timeout 300 $BN --batch 1 --prompt 32752 --steps 10 --warmup 3 > $O/xcd${x}_b1_32k_$i.json 2>> $O/xcd.err; line $O/xcd${x}_b1_32k_$i.json
             done
         done ;;
     sq)
