@@ -399,7 +399,7 @@ def main():
                                                                   Tq, bits, out=scratch[..., :Tq]), L, nbytes, label + ", hook-state layout")
             else:
                 from kivi_amd.quant import mfma
-                single_mf = time_kgemv(lambda i: mfma.gqa_scores(qs[0], layers[i].kt, Tq, scratch), L, nbytes,
+                single_mf = time_kgemv(lambda i: mfma.gqa_scores(qs[0], layers[i].kt, Tq, scratch, g, bits), L, nbytes,
                                        label + ", matrix-pipe layout (kivi_gqa_scores: raw fp16 scores to memory)")
                 single = single_mf
                 if not args.no_hook_kgemv and nh == nh_kv:
@@ -428,7 +428,7 @@ def main():
                 flush = lambda lc: new_pack.quantize_and_pack_k_tmajor(lc.k_res, g, bits, out=tuple(scratch_page), token_offset=0)
             else:
                 from kivi_amd.quant import mfma
-                spare = mfma.alloc_store(B, nh_kv, 1, dev)      # kivi_kt_pack of the R residual tokens into a spare super-block
+                spare = mfma.alloc_store(B, nh_kv, 1, dev, bits)      # kivi_kt_pack of the R residual tokens into a spare super-block
                 flush = lambda lc: mfma.kt_pack(lc.k_res[:, :, :R], spare, 0, g, bits)
             for rep in range(2):
                 for i, lc in enumerate(layers):

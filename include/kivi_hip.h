@@ -232,13 +232,15 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
 /* ------------------------------------ grouped queries on the matrix pipe --- */
 
 /*
- * MFMA-friendly cache layout (nh / nh_kv in {1, 4, 8}; 2-bit, group_size 32, head_dim 128): round 2 introduced it for
- * grouped-query models, round 3 uses it for multi-head models too (the matrix pipe takes the per-code multiply-adds
- * off the vector ALU, which is what bounds the hook-layout kernels).
+ * MFMA-friendly cache layout (group_size 32, head_dim 128; bits = 2: nh / nh_kv in {1, 4, 8}; bits = 4 (round 4): nh / nh_kv = 4,
+ * the reference's published Mistral-7B + KIVI-4 shape): round 2 introduced it for grouped-query models, round 3 uses it for
+ * multi-head models too (the matrix pipe takes the per-code multiply-adds off the vector ALU, which is what bounds the
+ * hook-layout kernels).  Every entry point below takes `bits` and refuses (KIVI_EUNSUPPORTED) what is outside these sets.
  * Same codes, scales and zero points as the hook-state tensors above -- kivi_kt_relayout / kivi_vt_relayout convert
  * both ways bit for bit -- stored so that one masked code word IS a B-operand register of v_mfma_f32_16x16x32_f16
  * (kivi_amd/csrc/kivi_mfma_layout.h): per (batch row, kv head) a sequence of super-blocks of 512 tokens,
- *   [ codes 16 x 256 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 6144 int32 words each,
+ *   [ codes 16 x 256 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 6144 int32 words each (bits = 2), or
+ *   [ codes 16 x 512 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 10240 words (bits = 4: sb_s >= 10240),
  * addressed as base + b*sb_b + hk*sb_h + (t / 512)*sb_s (strides in words).  Never-written slots must be ZERO.
  * RANGE FLAGS: every store comes with `range`, B * nh_kv int32 (index b * nh_kv + hk), zeroed by the caller together with
  *   the store.  The matrix pipe takes q * scale (qK^T) and p * scale (sV) as fp16 hi / lo pairs; with the default placement of
@@ -257,7 +259,7 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  *   layout at token 0 -- triton_quantize_and_pack_along_last_dim (new_pack.py:217-252) as llama_kivi.py:441-448 applies
  *   it to value_states[:, :, :-R], without the intermediate hook-state tensors.
  * kivi_kt_relayout / kivi_vt_relayout: to_ref != 0 writes tokens [0, T) of the hook-state tensors
- *   (K_code_T (B,nh_kv,D,T/16) / V_code (B,nh_kv,T,D/16) + scale, mn) from the layout, to_ref == 0 the reverse.
+ *   (K_code_T (B,nh_kv,D,T/fpi) / V_code (B,nh_kv,T,D/fpi), fpi = 32 / bits, + scale, mn) from the layout, to_ref == 0 the reverse.
  * kivi_gqa_scores: out[b, h, :T] = packed qK^T (the arithmetic of kivi_gemv_k: fp32 accumulate, one fp16 rounding; the
  *   q * scale products enter the matrix pipe as exact hi + lo fp16 pairs).  = cuda_bmm_fA_qB_outer at llama_kivi.py:324.
  * kivi_gqa_output (nh / nh_kv in {1, 4}): out[b, h, :128] = packed sV for given fp16 attention weights

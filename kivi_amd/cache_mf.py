@@ -70,14 +70,14 @@ class KiviLayerCacheMF:
                  dtype=torch.float16, num_heads: int = None):
         assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
         assert num_heads is not None and supported(cfg, head_dim, num_heads, num_kv_heads), \
-            "matrix-pipe layout: 2-bit, group 32, head_dim 128, nh / nh_kv in {1, 4, 8}, residual_length <= 128"
+            "matrix-pipe layout: group 32, head_dim 128, residual_length <= 128; 2-bit with nh / nh_kv in {1, 4, 8} or 4-bit with nh / nh_kv = 4"
         self.cfg = cfg
         R = cfg.residual_length
         self.B, self.nh_kv, self.D, self.nh = batch, num_kv_heads, head_dim, num_heads
         self.cap = ((max_len + R - 1) // R) * R
         self.n_sb = (self.cap + SB - 1) // SB
-        self.kt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
-        self.vt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device)
+        self.kt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device, cfg.k_bits)
+        self.vt = mfma.alloc_store(batch, num_kv_heads, self.n_sb, device, cfg.v_bits)
         self.k_res = torch.empty((batch, num_kv_heads, R, head_dim), dtype=dtype, device=device)
         # fp16 value window: a RING of R + 1 rows (row of window token t = (v_res_start + t) mod rows): nothing is ever compacted
         self.ring = True
@@ -101,7 +101,7 @@ class KiviLayerCacheMF:
         if n_sb > self.n_sb:
             for name in ("kt", "vt"):
                 old = getattr(self, name)
-                new = mfma.alloc_store(self.B, self.nh_kv, n_sb, old.device)
+                new = mfma.alloc_store(self.B, self.nh_kv, n_sb, old.device, self.cfg.k_bits)
                 mfma.copy_store(new, old)                      # super-blocks in use + the store's range flags
                 setattr(self, name, new)
             self.n_sb = n_sb
@@ -118,7 +118,7 @@ class KiviLayerCacheMF:
         other = copy.copy(self)
         for name in ("kt", "vt"):
             src = getattr(self, name)
-            dst = mfma.alloc_store(self.B, self.nh_kv, self.n_sb, src.device)
+            dst = mfma.alloc_store(self.B, self.nh_kv, self.n_sb, src.device, self.cfg.k_bits)
             mfma.copy_store(dst, src)
             setattr(other, name, dst)
         for name in ("k_res", "v_res"):

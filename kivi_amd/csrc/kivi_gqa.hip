@@ -270,12 +270,227 @@ __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* 
     }
 }
 
+// ---- 4-bit codes (KT4 / VT4, kivi_mfma_layout.h): the same four jobs on the shared quantiser's generic form (make_group +
+// quant_one<4>, the arithmetic of the hook-layout 4-bit packers in kivi_pack.hip).  One block per 32-token block; the codes
+// meet as bytes in LDS and leave as whole words, 4 (packers, K relayout) or 2 (V relayout) per thread.
+// word `wi` of a block -> (tile, n, kb, c)
+struct Mf4Word { int tile, n, kb, c; };
+__device__ __forceinline__ Mf4Word mf4_word_of(int wi) {
+    const int l = (wi & 255) >> 2;
+    return {wi >> 8, l & 15, l >> 4, wi & 3};
+}
+
+__global__ __launch_bounds__(128) void kt_pack4_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
+                                                       int* range, int64_t blk0, int nblk, int nh_kv) {
+    __shared__ uint8_t cds[32][136];
+    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+    const int b = unit / nh_kv, hk = unit - b * nh_kv;
+    const int d = threadIdx.x;                              // thread = channel: its group is the block's 32 tokens
+    const uint16_t* kp = k + b * k_sb + hk * k_sh + (int64_t)bi * 32 * k_st + d;
+    uint16_t x[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) x[t] = kp[(int64_t)t * k_st];
+    uint32_t kmin = 0xFFFFu, kmax = 0u;
+#pragma unroll
+    for (int t = 0; t < 32; t++) {
+        const uint32_t kk = h_key(x[t]);
+        kmin = kk < kmin ? kk : kmin;
+        kmax = kk > kmax ? kk : kmax;
+    }
+    const GroupQ gq = make_group(kmin, kmax, 15);
+#pragma unroll
+    for (int t = 0; t < 32; t++) cds[t][d] = (uint8_t)quant_one<4>(x[t], gq);
+    __syncthreads();
+    const int64_t blk = blk0 + bi;
+    uint32_t* sb = mf_sb(st, b, hk, blk >> 4);
+    uint32_t* cw = sb + (blk & 15) * KIVI_MF4_BLOCK_WORDS;
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+        const int wi = d + 128 * rep;
+        const Mf4Word q = mf4_word_of(wi);
+        const uint8_t* src = &cds[q.n + 16 * q.tile][32 * q.c + 8 * q.kb];
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) w |= (uint32_t)src[e] << (4 * (e >> 1) + 16 * (e & 1));
+        cw[wi] = w;
+    }
+    const int hidx = kt_sm_half((int)(blk & 15), d);
+    ((uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0))[hidx] = gq.scale;
+    ((uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0))[hidx] = gq.mn;
+    if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;   // range flag of the unit (kt_pack_kernel)
+}
+
+__global__ __launch_bounds__(128) void vt_pack4_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
+                                                       int* range, int64_t T, int nblk, int nh_kv) {
+    __shared__ uint8_t cds[32][136];
+    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+    const int b = unit / nh_kv, hk = unit - b * nh_kv;
+    const int tt = threadIdx.x >> 2, c = threadIdx.x & 3;   // thread = (token, channel group): 32 channels = 64 bytes
+    const int64_t t = (int64_t)bi * 32 + tt;
+    u16x8 xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        xv[i] = (t < T) ? *(const u16x8*)(v + b * v_sb + hk * v_sh + t * v_st + 32 * c + 8 * i) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t kmin = 0xFFFFu, kmax = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t kk = h_key(xv[i][e]);
+            kmin = kk < kmin ? kk : kmin;
+            kmax = kk > kmax ? kk : kmax;
+        }
+    const GroupQ gq = make_group(kmin, kmax, 15);            // tokens at or past T: all zeros -> scale 0, zero point 0, codes 0
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) cds[tt][32 * c + 8 * i + e] = (uint8_t)quant_one<4>(xv[i][e], gq);
+    __syncthreads();
+    uint32_t* sb = mf_sb(st, b, hk, bi >> 4);
+    uint32_t* cw = sb + (bi & 15) * KIVI_MF4_BLOCK_WORDS;
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+        const int wi = (int)threadIdx.x + 128 * rep;
+        const Mf4Word q = mf4_word_of(wi);
+        const int ch = 32 * q.c + 16 * q.tile + q.n;
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) w |= (uint32_t)cds[8 * q.kb + e][ch] << (4 * (e >> 1) + 16 * (e & 1));
+        cw[wi] = w;
+    }
+    ((uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0) + (bi & 15) * 128)[vt_half(tt, c)] = gq.scale;
+    ((uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0) + (bi & 15) * 128)[vt_half(tt, c)] = gq.mn;
+    if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+}
+
+// KT4 <-> K_code_T (B, nh_kv, D, T/8), K_scale_T / K_mn_T (B, nh_kv, D, T/32): 4 reference words per (channel, block)
+template <bool TO_REF>
+__global__ __launch_bounds__(128) void kt_relayout4_kernel(MfStore st, uint32_t* code, int64_t code_sb, int64_t code_sh,
+                                                           int64_t code_sr, uint16_t* scale, uint16_t* mn, int64_t sm_sb,
+                                                           int64_t sm_sh, int64_t sm_sr, int nblk, int nh_kv, int* range) {
+    __shared__ uint32_t lds[512];
+    const int unit = blockIdx.x / nblk, blk = blockIdx.x - unit * nblk;
+    const int b = unit / nh_kv, hk = unit - b * nh_kv;
+    const int d = threadIdx.x;
+    uint32_t* sb = mf_sb(st, b, hk, blk >> 4);
+    uint32_t* cw = sb + (blk & 15) * KIVI_MF4_BLOCK_WORDS;
+    uint16_t* ks = (uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0);
+    uint16_t* km = (uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0);
+    const int gsb = blk & 15;
+    uint32_t* cref = code + b * code_sb + hk * code_sh + (int64_t)d * code_sr + (int64_t)blk * 4;
+    const int64_t sidx = b * sm_sb + hk * sm_sh + (int64_t)d * sm_sr + blk;
+    if constexpr (TO_REF) {
+#pragma unroll
+        for (int rep = 0; rep < 4; rep++) lds[d + 128 * rep] = cw[d + 128 * rep];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) w |= ((lds[kt4_word(8 * j + i, d)] >> kt4_bit(d)) & 15u) << (4 * i);
+            cref[j] = w;
+        }
+        scale[sidx] = ks[kt_sm_half(gsb, d)];
+        mn[sidx] = km[kt_sm_half(gsb, d)];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) lds[4 * d + j] = cref[j];
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < 4; rep++) {
+            const int wi = d + 128 * rep;
+            const Mf4Word q = mf4_word_of(wi);
+            const int tt = q.n + 16 * q.tile;
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ch = 32 * q.c + 8 * q.kb + e;
+                w |= ((lds[4 * ch + (tt >> 3)] >> (4 * (tt & 7))) & 15u) << kt4_bit(ch);
+            }
+            cw[wi] = w;
+        }
+        const uint16_t sc = scale[sidx];
+        ks[kt_sm_half(gsb, d)] = sc;
+        km[kt_sm_half(gsb, d)] = mn[sidx];
+        if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+    }
+}
+
+// VT4 <-> V_code (B, nh_kv, T, D/8), V_scale / V_mn (B, nh_kv, T, D/32); tokens [0, T), the slots of the last block past T are zeros
+template <bool TO_REF>
+__global__ __launch_bounds__(256) void vt_relayout4_kernel(MfStore st, uint32_t* code, int64_t code_sb, int64_t code_sh,
+                                                           int64_t code_sr, uint16_t* scale, uint16_t* mn, int64_t sm_sb,
+                                                           int64_t sm_sh, int64_t sm_sr, int64_t T, int nblk, int nh_kv, int* range) {
+    __shared__ uint32_t lds[512];
+    const int unit = blockIdx.x / nblk, blk = blockIdx.x - unit * nblk;
+    const int b = unit / nh_kv, hk = unit - b * nh_kv;
+    const int tid = threadIdx.x;
+    uint32_t* sb = mf_sb(st, b, hk, blk >> 4);
+    uint32_t* cw = sb + (blk & 15) * KIVI_MF4_BLOCK_WORDS;
+    uint16_t* vs = (uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0) + (blk & 15) * 128;
+    uint16_t* vm = (uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0) + (blk & 15) * 128;
+    if constexpr (TO_REF) {
+        lds[tid] = cw[tid];
+        lds[tid + 256] = cw[tid + 256];
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const int idx = tid + 256 * rep, tt = idx >> 4, rw = idx & 15;    // reference word rw of token tt: channels 8 rw .. + 7
+            const int64_t t = (int64_t)blk * 32 + tt;
+            if (t < T) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) w |= ((lds[vt4_word(tt, 8 * rw + j)] >> vt4_bit(tt)) & 15u) << (4 * j);
+                code[b * code_sb + hk * code_sh + t * code_sr + rw] = w;
+            }
+        }
+        if (tid < 128) {
+            const int tt = tid >> 2, g = tid & 3;
+            const int64_t t = (int64_t)blk * 32 + tt;
+            if (t < T) {
+                scale[b * sm_sb + hk * sm_sh + t * sm_sr + g] = vs[vt_half(tt, g)];
+                mn[b * sm_sb + hk * sm_sh + t * sm_sr + g] = vm[vt_half(tt, g)];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const int idx = tid + 256 * rep, tt = idx >> 4, rw = idx & 15;
+            const int64_t t = (int64_t)blk * 32 + tt;
+            lds[idx] = (t < T) ? code[b * code_sb + hk * code_sh + t * code_sr + rw] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const int wi = tid + 256 * rep;
+            const Mf4Word q = mf4_word_of(wi);
+            const int ch = 32 * q.c + 16 * q.tile + q.n;
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int t2 = 8 * q.kb + e;
+                w |= ((lds[16 * t2 + (ch >> 3)] >> (4 * (ch & 7))) & 15u) << vt4_bit(t2);
+            }
+            cw[wi] = w;
+        }
+        if (tid < 128) {
+            const int tt = tid >> 2, g = tid & 3;
+            const int64_t t = (int64_t)blk * 32 + tt;
+            const uint16_t sc = (t < T) ? scale[b * sm_sb + hk * sm_sh + t * sm_sr + g] : (uint16_t)0;
+            vs[vt_half(tt, g)] = sc;
+            if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+            vm[vt_half(tt, g)] = (t < T) ? mn[b * sm_sb + hk * sm_sh + t * sm_sr + g] : (uint16_t)0;
+        }
+    }
+}
+
 // Largest byte extent a buffer descriptor over a unit's store may have: requests past the end of a wave's stream carry the
 // per-lane offset MF_DEAD_OFF (kivi_mf_dev.h) and must fall OUTSIDE the descriptor's range (zeros, no memory access)
 constexpr uint32_t MF_DESC_LIMIT = 0xFFFE0000u;
 
-bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
-    return base && (uintptr_t)base % 16 == 0 && sb_b % 4 == 0 && sb_h % 4 == 0 && sb_s % 4 == 0 && sb_s >= KIVI_MF_SB_WORDS;
+bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s, int bits = 2) {
+    return base && (uintptr_t)base % 16 == 0 && sb_b % 4 == 0 && sb_h % 4 == 0 && sb_s % 4 == 0 &&
+           sb_s >= (bits == 4 ? KIVI_MF4_SB_WORDS : KIVI_MF_SB_WORDS);
 }
 
 }  // namespace
@@ -283,8 +498,8 @@ bool mf_store_ok(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
 // ------------------------------------------------------------------------------------------------ C ABI
 
 #define KIVI_MF_SHAPE_CHECK(who)                                                                                       \
-    KIVI_REQUIRE(bits == 2 && group_size == 32 && D == 128, KIVI_EUNSUPPORTED,                                         \
-                 who ": the MFMA cache layout covers 2-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)", bits, \
+    KIVI_REQUIRE((bits == 2 || bits == 4) && group_size == 32 && D == 128, KIVI_EUNSUPPORTED,                           \
+                 who ": the MFMA cache layout covers 2- and 4-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)", bits, \
                  group_size, D);                                                                                       \
     KIVI_REQUIRE(B > 0 && nh_kv > 0, KIVI_EINVAL, who ": empty batch");                                                \
     KIVI_REQUIRE((int64_t)B * nh_kv * ((T + 31) / 32) < ((int64_t)1 << 31), KIVI_EINVAL, who ": grid too large")
@@ -297,13 +512,18 @@ extern "C" int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     KIVI_REQUIRE(T >= 0 && T % 32 == 0 && token_offset >= 0 && token_offset % 32 == 0, KIVI_EINVAL,
                  "kivi_kt_pack: T=%lld and token_offset=%lld must be multiples of the 32-token block", (long long)T,
                  (long long)token_offset);
-    KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss), KIVI_EALIGN, "kivi_kt_pack: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss, bits), KIVI_EALIGN, "kivi_kt_pack: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(k && (uintptr_t)k % 16 == 0 && k_sb % 8 == 0 && k_sh % 8 == 0 && k_st % 8 == 0, KIVI_EALIGN,
                  "kivi_kt_pack: key rows must be 16-byte aligned");
     if (T == 0) return 0;
     const int nblk = (int)(T / 32);
     const MfStore st = {(uint32_t*)kt, kt_sb, kt_sh, kt_ss};
     const int64_t ntile = (int64_t)B * nh_kv * nblk;
+    if (bits == 4) {
+        hipLaunchKernelGGL(kt_pack4_kernel, dim3((unsigned)ntile), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)k, k_sb, k_sh, k_st,
+                           st, (int*)kt_range, token_offset / 32, nblk, nh_kv);
+        return kivi_launch_status("kt_pack4");
+    }
     hipLaunchKernelGGL(kt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)k, k_sb, k_sh, k_st, st, (int*)kt_range, token_offset / 32, nblk, nh_kv, ntile);
     return kivi_launch_status("kt_pack");
@@ -315,13 +535,18 @@ extern "C" int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v
     KIVI_MF_SHAPE_CHECK("kivi_vt_pack");
     KIVI_REQUIRE(vt_range && (uintptr_t)vt_range % 4 == 0, KIVI_EINVAL, "kivi_vt_pack: null / misaligned range flags");
     KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_vt_pack: negative length");
-    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss), KIVI_EALIGN, "kivi_vt_pack: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss, bits), KIVI_EALIGN, "kivi_vt_pack: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(v && (uintptr_t)v % 16 == 0 && v_sb % 8 == 0 && v_sh % 8 == 0 && v_st % 8 == 0, KIVI_EALIGN,
                  "kivi_vt_pack: value rows must be 16-byte aligned");
     if (T == 0) return 0;
     const int nblk = (int)((T + 31) / 32);
     const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
     const int64_t ntile = (int64_t)B * nh_kv * nblk;
+    if (bits == 4) {
+        hipLaunchKernelGGL(vt_pack4_kernel, dim3((unsigned)ntile), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)v, v_sb, v_sh, v_st,
+                           st, (int*)vt_range, T, nblk, nh_kv);
+        return kivi_launch_status("vt_pack4");
+    }
     hipLaunchKernelGGL(vt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)v, v_sb, v_sh, v_st, st, (int*)vt_range, T, nblk, nh_kv, ntile);
     return kivi_launch_status("vt_pack");
@@ -333,12 +558,21 @@ extern "C" int kivi_kt_relayout(int to_ref, void* kt, int64_t kt_sb, int64_t kt_
                                 kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_kt_relayout");
     KIVI_REQUIRE(T >= 0 && T % 32 == 0, KIVI_EINVAL, "kivi_kt_relayout: T=%lld must be a multiple of 32", (long long)T);
-    KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss) && code && scale && mn, KIVI_EALIGN, "kivi_kt_relayout: bad buffers");
+    KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss, bits) && code && scale && mn, KIVI_EALIGN, "kivi_kt_relayout: bad buffers");
     KIVI_REQUIRE(to_ref || (kt_range && (uintptr_t)kt_range % 4 == 0), KIVI_EINVAL, "kivi_kt_relayout: writing a store needs its range flags");
     if (T == 0) return 0;
     const int nblk = (int)(T / 32);
     const MfStore st = {(uint32_t*)kt, kt_sb, kt_sh, kt_ss};
     const dim3 grid((unsigned)((int64_t)B * nh_kv * nblk));
+    if (bits == 4) {
+        if (to_ref)
+            hipLaunchKernelGGL(kt_relayout4_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
+                               code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv, (int*)kt_range);
+        else
+            hipLaunchKernelGGL(kt_relayout4_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
+                               code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv, (int*)kt_range);
+        return kivi_launch_status("kt_relayout4");
+    }
     if (to_ref)
         hipLaunchKernelGGL(kt_relayout_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
                            code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, nblk, nh_kv, (int*)kt_range);
@@ -354,12 +588,21 @@ extern "C" int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_
                                 kivi_stream_t stream) {
     KIVI_MF_SHAPE_CHECK("kivi_vt_relayout");
     KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_vt_relayout: negative length");
-    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss) && code && scale && mn, KIVI_EALIGN, "kivi_vt_relayout: bad buffers");
+    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss, bits) && code && scale && mn, KIVI_EALIGN, "kivi_vt_relayout: bad buffers");
     KIVI_REQUIRE(to_ref || (vt_range && (uintptr_t)vt_range % 4 == 0), KIVI_EINVAL, "kivi_vt_relayout: writing a store needs its range flags");
     if (T == 0) return 0;
     const int nblk = (int)((T + 31) / 32);
     const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
     const dim3 grid((unsigned)((int64_t)B * nh_kv * nblk));
+    if (bits == 4) {
+        if (to_ref)
+            hipLaunchKernelGGL(vt_relayout4_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
+                               code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv, (int*)vt_range);
+        else
+            hipLaunchKernelGGL(vt_relayout4_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
+                               code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv, (int*)vt_range);
+        return kivi_launch_status("vt_relayout4");
+    }
     if (to_ref)
         hipLaunchKernelGGL(vt_relayout_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, st, (uint32_t*)code, code_sb,
                            code_sh, code_sr, (uint16_t*)scale, (uint16_t*)mn, sm_sb, sm_sh, sm_sr, T, nblk, nh_kv, (int*)vt_range);
@@ -370,11 +613,11 @@ extern "C" int kivi_vt_relayout(int to_ref, void* vt, int64_t vt_sb, int64_t vt_
 }
 
 // the kernels (kivi_mf.hip); the argument blocks cross the translation-unit boundary as void*
-int kivi_mf_run_k(void* k_args, int units, hipStream_t s);
-int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s);
+int kivi_mf_run_k(void* k_args, int units, int bits, hipStream_t s);
+int kivi_mf_run_v(const void* v_args, int prob, int bits, hipStream_t s);
 int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int nh_kv, int64_t T, const int* range, int* sp,
                        hipStream_t s);
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, hipStream_t s);
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, hipStream_t s);
 
 // One launch (true) or two for a step whose LONGEST row has n_rows keys (kivi_gqa_decode's rule; also part of kivi_mf_step_key)
 static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags) {
@@ -411,8 +654,9 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     KIVI_MF_SHAPE_CHECK("kivi_gqa_scores");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_scores: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4, KIVI_EUNSUPPORTED, "kivi_gqa_scores: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, nh_kv);
     KIVI_REQUIRE(T >= 0 && T % 32 == 0, KIVI_EINVAL, "kivi_gqa_scores: T=%lld must be a multiple of 32", (long long)T);
-    KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss), KIVI_EALIGN, "kivi_gqa_scores: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss, bits), KIVI_EALIGN, "kivi_gqa_scores: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(kt_range && (uintptr_t)kt_range % 4 == 0, KIVI_EINVAL, "kivi_gqa_scores: null / misaligned range flags");
     KIVI_REQUIRE(((T + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS) * kt_ss * 4 <= (int64_t)MF_DESC_LIMIT, KIVI_EINVAL,
                  "kivi_gqa_scores: store too large for one descriptor");
@@ -432,7 +676,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     a.range = (const int*)kt_range;
     a.dyn = nullptr;
-    return kivi_mf_run_k(&a, B * nh_kv, (hipStream_t)stream);
+    return kivi_mf_run_k(&a, B * nh_kv, bits, (hipStream_t)stream);
 }
 
 // slices of the sV launch: ~1024 stream blocks (4 per CU) of 4 waves, a wave then streams 1-2 super-blocks (24 KiB each)
@@ -458,8 +702,9 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     KIVI_MF_SHAPE_CHECK("kivi_gqa_output");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_output: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4, KIVI_EUNSUPPORTED, "kivi_gqa_output: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, nh_kv);
     KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_gqa_output: negative length");
-    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss), KIVI_EALIGN, "kivi_gqa_output: cache storage must be 16-byte aligned super-blocks");
+    KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss, bits), KIVI_EALIGN, "kivi_gqa_output: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(probs && (uintptr_t)probs % 16 == 0 && p_sb % 8 == 0 && p_sh % 8 == 0 && p_sh >= ((T + 7) & ~(int64_t)7), KIVI_EALIGN,
                  "kivi_gqa_output: probability rows must be 16-byte aligned and padded to a multiple of 8");
     KIVI_REQUIRE(out != nullptr, KIVI_EINVAL, "kivi_gqa_output: null output");
@@ -489,7 +734,7 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     v.range = (int*)vt_range;        // (read only here: no V flush in this launch)
     int rc = kivi_mf_run_row_sp(probs, p_sb, p_sh, B, nh, nh_kv, T, (const int*)vt_range, (int*)v.sp_rows, s);
     if (rc) return rc;
-    return kivi_mf_run_v(&v, 1, s);
+    return kivi_mf_run_v(&v, 1, bits, s);
 }
 
 extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stream) {
@@ -499,6 +744,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_MF_SHAPE_CHECK("kivi_gqa_decode");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_decode: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4, KIVI_EUNSUPPORTED, "kivi_gqa_decode: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, nh_kv);
     const int R = nh / nh_kv;
     const int units = B * nh_kv;
     KIVI_REQUIRE(p->Tq >= 0 && p->Tq % 32 == 0 && p->Tv >= 0 && p->k_res_len >= 0 && p->k_res_len <= 128 && p->v_res_len >= 0 &&
@@ -528,7 +774,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
                  (long long)p->Tv, (long long)p->kt_superblocks, (long long)p->vt_superblocks);
     KIVI_REQUIRE(!p->v_flush || p->v_res_len == p->residual_length, KIVI_EINVAL,
                  "kivi_gqa_decode: v_flush with a window of %d values (residual_length %d)", p->v_res_len, p->residual_length);
-    KIVI_REQUIRE(mf_store_ok(p->kt, p->kt_sb, p->kt_sh, p->kt_ss) && mf_store_ok(p->vt, p->vt_sb, p->vt_sh, p->vt_ss), KIVI_EALIGN,
+    KIVI_REQUIRE(mf_store_ok(p->kt, p->kt_sb, p->kt_sh, p->kt_ss, bits) && mf_store_ok(p->vt, p->vt_sb, p->vt_sh, p->vt_ss, bits), KIVI_EALIGN,
                  "kivi_gqa_decode: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(p->q && (uintptr_t)p->q % 16 == 0 && p->q_sb % 8 == 0 && p->q_sh % 8 == 0, KIVI_EALIGN,
                  "kivi_gqa_decode: q rows must be 16-byte aligned");
@@ -597,9 +843,9 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.dyn = (const MfStep*)p->dyn_step;
     // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
     // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks per CU)
-    if (mf_one_launch(R, units, n_rows, nsbk, p->flags)) return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, s);
-    int rc = skipk ? 0 : kivi_mf_run_k(&k, units, s);
+    if (mf_one_launch(R, units, n_rows, nsbk, p->flags)) return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, s);
+    int rc = skipk ? 0 : kivi_mf_run_k(&k, units, bits, s);
     if (rc) return rc;
     if (timev) kivi_set_launch_events(held.start, held.stop);
-    return kivi_mf_run_v(&v, 0, s);
+    return kivi_mf_run_v(&v, 0, bits, s);
 }

@@ -36,6 +36,9 @@ __device__ __forceinline__ uint32_t pk_fms(uint32_t a, uint32_t b, uint32_t c) {
 }
 // A rows carry 2^(4 + 2 (i >> 1)) for the register i = 0..3 of an MFMA operand (kivi_mfma_layout.h)
 __device__ __forceinline__ constexpr int aexp(int i) { return KIVI_MF_SHIFT + 2 * (i >> 1); }
+// ... for BITS-wide codes: 4-bit codes all sit on mantissa bits 9:6, the four registers carry 2^6
+template <int BITS>
+__device__ __forceinline__ constexpr int aexp_b(int i) { return BITS == 2 ? aexp(i) : 6; }
 
 // Wave-wide max / sum with DPP inside the 16-lane rows and four v_readlane across them: no LDS round trips (the
 // __shfl_xor form is 6 dependent ds_bpermute, ~600 cycles per reduction; the softmax statistics need 2 R of them per

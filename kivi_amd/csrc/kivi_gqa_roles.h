@@ -230,9 +230,10 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 // Two halves, so that the loads fly while the caller does something else (the row kernels request before their softmax):
 // request() issues the loads of the first WPRE tokens of every wave (and of the token that leaves the window, and of the code
 // word it will be merged into), finish() consumes them once pw holds the probabilities and walks what is left in batches.
-template <int R, int NTH, int PW, int WPRE>
+template <int R, int NTH, int PW, int WPRE, int BITS = 2>
 struct GqaWindow {
     static constexpr int NW = NTH / 64, WB = 12;
+    typedef MfL<BITS> LY;
     uint32_t vv[WPRE];
     uint32_t wold;
     uint16_t xflush;
@@ -243,10 +244,12 @@ struct GqaWindow {
         if (a.win_rows) r = r >= a.win_rows ? r - a.win_rows : r;       // t <= residual_length < win_rows: one wrap at most
         return vbuf + (int64_t)r * a.vres_st;
     }
+    // the code word of the token that leaves the window (token Tv) for channel d (2 bits: shared by the channels d, d ^ 16)
     __device__ __forceinline__ static uint32_t* flush_word(const GqaVArgs& a, int b, int hk, int d) {
         const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
         const int kbq = tt >> 3, c = d >> 5, nn = d & 15;
-        return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * KIVI_MF_BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
+        if constexpr (BITS == 4) return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + vt4_word(tt, d);
+        return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
     }
 
     __device__ __forceinline__ void request(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher) {
@@ -256,7 +259,7 @@ struct GqaWindow {
         xflush = 0; wold = 0;
         if (flusher && threadIdx.x < 128) {
             xflush = wrow(a, vbuf, 0)[threadIdx.x];
-            if (((threadIdx.x >> 4) & 1) == 0) wold = *flush_word(a, b, hk, threadIdx.x);
+            if (BITS == 4 || ((threadIdx.x >> 4) & 1) == 0) wold = *flush_word(a, b, hk, threadIdx.x);
         }
 #pragma unroll
         for (int u = 0; u < WPRE; u++) {
@@ -309,25 +312,33 @@ struct GqaWindow {
                 kmin = o1 < kmin ? o1 : kmin;
                 kmax = o2 > kmax ? o2 : kmax;
             }
-            const GroupQ gq = make_group(kmin, kmax, 3);
-            const uint32_t code = quant_one<2>(xflush, gq);
+            const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+            const uint32_t code = quant_one<BITS>(xflush, gq);
             const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
             const int e = tt & 7, kbq = tt >> 3;
             const int c = d >> 5, tile = (d >> 4) & 1;
             const int sh = 16 * (e & 1);
-            uint32_t val = code << (mf_pos(tile, e >> 1) + sh);
-            val |= (uint32_t)__shfl_xor((int)val, 16);
-            uint32_t* sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
-            if (tile == 0) {
-                // the two fields of this token (channel tiles 0 / 1) are cleared first: a slot may hold stale codes of an earlier,
-                // longer sequence that used the same storage
-                const uint32_t clr = (3u << (mf_pos(0, e >> 1) + sh)) | (3u << (mf_pos(1, e >> 1) + sh));
-                *flush_word(a, b, hk, d) = (wold & ~clr) | val;
+            uint32_t* sbp;
+            if constexpr (BITS == 4) {
+                // every channel has its own word (8 tokens of the channel): the token's field is cleared first (stale codes, below)
+                const int pos = vt4_bit(tt);
+                sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+                *flush_word(a, b, hk, d) = (wold & ~(15u << pos)) | (code << pos);
+            } else {
+                uint32_t val = code << (mf_pos(tile, e >> 1) + sh);
+                val |= (uint32_t)__shfl_xor((int)val, 16);
+                sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+                if (tile == 0) {
+                    // the two fields of this token (channel tiles 0 / 1) are cleared first: a slot may hold stale codes of an earlier,
+                    // longer sequence that used the same storage
+                    const uint32_t clr = (3u << (mf_pos(0, e >> 1) + sh)) | (3u << (mf_pos(1, e >> 1) + sh));
+                    *flush_word(a, b, hk, d) = (wold & ~clr) | val;
+                }
             }
             if ((d & 31) == 0) {
                 const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
-                ((uint16_t*)(sbp + KIVI_MF_SB_SCALE_WORD0))[hidx] = gq.scale;
-                ((uint16_t*)(sbp + KIVI_MF_SB_MN_WORD0))[hidx] = gq.mn;
+                ((uint16_t*)(sbp + LY::SCALE_WORD0))[hidx] = gq.scale;
+                ((uint16_t*)(sbp + LY::MN_WORD0))[hidx] = gq.mn;
                 // range flag of the unit (kivi_mfma_layout.h): the token becomes part of the packed prefix with the NEXT step
                 if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) a.range[b * a.nh_kv + hk] = 1;
             }
@@ -335,10 +346,10 @@ struct GqaWindow {
     }
 };
 
-template <int R, int NTH, int PW>
+template <int R, int NTH, int PW, int BITS = 2>
 __device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
                                                 const uint16_t (*pw)[PW], float (*ow)[2]) {
-    GqaWindow<R, NTH, PW, 12> w;
+    GqaWindow<R, NTH, PW, 12, BITS> w;
     w.request(a, b, hk, w0, w1, flusher);
     w.finish(a, b, hk, w0, w1, flusher, pw, ow);
 }

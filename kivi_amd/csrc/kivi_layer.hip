@@ -126,16 +126,18 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
                  KIVI_EINVAL, "kivi_mf_decode_layer: inconsistent lengths (Tq=%lld kres=%lld Tv=%lld vres=%lld kv=%lld R=%d)",
                  (long long)Tq, (long long)kres, (long long)Tv, (long long)vres, (long long)kv, R);
     // everything the K flush (kivi_kt_pack, below) can reject is checked before anything is launched
-    KIVI_REQUIRE(L->bits == 2 && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
-                 "kivi_mf_decode_layer: the MFMA cache layout covers 2-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
+    KIVI_REQUIRE((L->bits == 2 || L->bits == 4) && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
+                 "kivi_mf_decode_layer: the MFMA cache layout covers 2- and 4-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
                  L->bits, L->group_size, L->D);
+    KIVI_REQUIRE(L->bits == 2 || (L->nh_kv > 0 && nh == 4 * L->nh_kv), KIVI_EUNSUPPORTED,
+                 "kivi_mf_decode_layer: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, L->nh_kv);
     KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL, "kivi_mf_decode_layer: bad shape (B=%d nh=%d nh_kv=%d)",
                  L->B, nh, L->nh_kv);
     KIVI_REQUIRE(L->kt && L->vt && L->k_res && L->v_res && L->scores && L->stats && L->workspace && L->kt_range && L->vt_range, KIVI_EINVAL,
                  "kivi_mf_decode_layer: null cache buffer in the descriptor");
     KIVI_REQUIRE((uintptr_t)L->kt_range % 4 == 0 && (uintptr_t)L->vt_range % 4 == 0, KIVI_EALIGN, "kivi_mf_decode_layer: range flags alignment");
     KIVI_REQUIRE(L->cap % 512 == 0 && kv + 1 <= L->cap, KIVI_EINVAL, "kivi_mf_decode_layer: cache capacity %lld exceeded", (long long)L->cap);
-    KIVI_REQUIRE((uintptr_t)L->kt % 16 == 0 && L->kt_sb % 4 == 0 && L->kt_sh % 4 == 0 && L->kt_ss % 4 == 0 && L->kt_ss >= 6144 &&
+    KIVI_REQUIRE((uintptr_t)L->kt % 16 == 0 && L->kt_sb % 4 == 0 && L->kt_sh % 4 == 0 && L->kt_ss % 4 == 0 && L->kt_ss >= (L->bits == 4 ? 10240 : 6144) &&
                      (uintptr_t)L->k_res % 4 == 0 && L->kr_sb % 2 == 0 && L->kr_sh % 2 == 0 && L->kr_st % 2 == 0,
                  KIVI_EALIGN, "kivi_mf_decode_layer: K store / residual alignment");
     KIVI_REQUIRE((int64_t)L->B * L->nh_kv * (R / 32) < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_mf_decode_layer: K flush grid too large");
@@ -224,8 +226,8 @@ extern "C" int kivi_mf_decode_layer_dyn(const kivi_mf_layer_desc* L, const kivi_
                      (hs->v_flush != 0) == (hs->v_res_len + 1 > R),
                  KIVI_EINVAL, "kivi_mf_decode_layer_dyn: inconsistent lengths (Tq=%lld kres=%d Tv=%lld vres=%d flush=%d R=%d)",
                  (long long)hs->Tq, hs->k_res_len, (long long)hs->Tv, hs->v_res_len, hs->v_flush, R);
-    KIVI_REQUIRE(L->bits == 2 && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
-                 "kivi_mf_decode_layer_dyn: the MFMA cache layout covers 2-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
+    KIVI_REQUIRE((L->bits == 2 || L->bits == 4) && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
+                 "kivi_mf_decode_layer_dyn: the MFMA cache layout covers 2- and 4-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
                  L->bits, L->group_size, L->D);
     KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL, "kivi_mf_decode_layer_dyn: bad shape (B=%d nh=%d nh_kv=%d)",
                  L->B, nh, L->nh_kv);

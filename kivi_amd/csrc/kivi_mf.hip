@@ -55,8 +55,9 @@ template <int R>
 constexpr int mf_k_lds_words() { return (R == 1 ? 64 : 0) + R * 256; }   // R = 1: 64 words for the q operand
 
 // DIAG (tuning builds, wrong results): 1 = nothing leaves the LDS (no flush), 2 = scores stored without the statistics
-template <int R, int W, int RING, int DIAG = 0>
+template <int R, int W, int RING, int DIAG = 0, int BITS = 2>
 __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
+    static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
     extern __shared__ uint32_t lds_all[];
     // the step's lengths: by value, or device-resident (a.dyn).  (Only these two scalars: a mutable copy of the whole argument block
     // cost 3-8 % of the raw-score launch -- the flush lambda then reads its fields from a local object instead of the kernarg segment.)
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     } else {
         // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
         const int hb = (4 * (lane >> 4)) % R;                       // heads hb .. hb + 3 sit in this lane's result registers
-        mf_k_seqR<R, RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
+        mf_k_seqR<R, RING, BITS>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
                            [&](int, int tt, int r, float v0, float v1) {
                                const uint32_t hp = mf_cvt_pair(v0, v1);
                                lds_o[(hb + r) * 512 + tt] = (uint16_t)(hp & 0xFFFFu);
@@ -155,13 +156,13 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     }
 }
 
-template <int R, int W, int RING, int DIAG = 0>
+template <int R, int W, int RING, int DIAG = 0, int BITS = 2>
 void launch_mf_k(const GqaKArgs& a, int units, int spw, hipStream_t s) {
     const size_t lds = (size_t)W * mf_k_lds_words<R>() * 4;
-    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING, DIAG>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a, spw);
+    KIVI_LAUNCH_LDS((mf_k_kernel<R, W, RING, DIAG, BITS>), dim3((unsigned)(a.res_blocks + units * a.sb_blocks)), dim3(64 * W), lds, s, a, spw);
 }
 
-int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
+int run_mf_k(GqaKArgs& a, int units, int bits, hipStream_t s) {
 #ifdef KIVI_TUNING
     mf_tune_sync();
 #endif
@@ -182,6 +183,10 @@ int run_mf_k(GqaKArgs& a, int units, hipStream_t s) {
     const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
     a.sb_blocks = (chunks + W - 1) / W;
     if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
+    if (bits == 4) {                                                // 4-bit codes (nh / nh_kv = 4: checked by the callers)
+        if (W == 4) launch_mf_k<4, 4, 4, 0, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4, 0, 4>(a, units, spw, s);
+        return kivi_launch_status("mf_k");
+    }
     // two code blocks in flight per wave: 39.2 us per BASELINE configs[1] launch against 40.8 with four (fewer registers, the
     // same bytes in flight per SIMD); -DKIVI_TUNING builds keep the four-deep ring for A/B
 #ifdef KIVI_TUNING
@@ -224,7 +229,7 @@ __device__ __forceinline__ void mf_probs_request(rsrc_t rx, uint32_t x_row_bytes
 #pragma unroll
     for (int r = 0; r < R; r++) xv[r] = buf_load<u32x4, false>(rx, (uint32_t)(r * x_row_bytes + (tok0 + lane * 8) * 2), 0);
 }
-template <int R, bool PROB>
+template <int R, bool PROB, int BITS = 2>
 __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, int64_t Tv, const float* M, const float* invS,
                                                const int* sp, uint16_t* lds_p) {
     typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
@@ -246,7 +251,7 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
                 const fp2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
                 pp = __builtin_convertvector(e * (fp2){invS[r], invS[r]}, hp2);
             }
-            const _Float16 m_a = (i >= 2) ? (_Float16)64.0f : (_Float16)16.0f;                          // tokens (e & 4): 2^6, else 2^4
+            const _Float16 m_a = (BITS == 4 || i >= 2) ? (_Float16)64.0f : (_Float16)16.0f;             // tokens (e & 4): 2^6, else 2^4 (4-bit codes: 2^6)
             o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});   // (order: see mf_row_softmax)
         }
         if (left < 8) {                                            // the end of the packed prefix falls into this lane's eight
@@ -261,8 +266,9 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
 constexpr int MF_PW = 136;
 
 // HL (R = 4): hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>), as in mf_row4_kernel
-template <int R, int RING, bool PROB, bool HL = false>
+template <int R, int RING, bool PROB, bool HL = false, int BITS = 2>
 __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
+    static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
     extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
     GqaVArgs a = a_in;
     a.take_dyn();
@@ -317,13 +323,13 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
         nb_last = nb_last > 16 ? 16 : nb_last;
         u32x4 xv[R];
         mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), (int64_t)sb_w0 * KIVI_MF_SB_TOKENS, xv);
-        MfVStream<R, RING, HL> vs;
+        MfVStream<R, RING, HL, BITS> vs;
         vs.prime(rv, sb_bytes, 0, 16 * (n_my - 1) + nb_last, sb_w0, 4);
         for (int i = 0; i < n_my; i++) {
             const int64_t tok0 = (int64_t)(sb_w0 + 4 * i) * KIVI_MF_SB_TOKENS;
             const int nb = (i == n_my - 1) ? nb_last : 16;
             __builtin_amdgcn_wave_barrier();                       // the previous super-block's LDS reads are over
-            mf_probs_store<R, PROB>(xv, tok0, a.Tv, M, invS, sp, lds_p);
+            mf_probs_store<R, PROB, BITS>(xv, tok0, a.Tv, M, invS, sp, lds_p);
             // the next super-block's scores fly during this one's stream
             if (i + 1 < n_my) mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), tok0 + 4 * KIVI_MF_SB_TOKENS, xv);
             __builtin_amdgcn_wave_barrier();
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
                 pw[rr][t] = PROB ? xw : f2h_bits(kivi_exp(h2f_bits(xw) - Mr) * Ir);
             }
             __syncthreads();
-            gqa_window_part<R, 256, MF_PW>(a, b, hk, w0, w1, flusher, pw, ow);
+            gqa_window_part<R, 256, MF_PW, BITS>(a, b, hk, w0, w1, flusher, pw, ow);
         } else {
 #pragma unroll
             for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R, RING, HL>(A, zl, Lf);                           // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
+    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf);                     // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
     if constexpr (HL) {
         for (int i = lane; i < R * 128; i += 64) Lf[i] += Lf[R * 128 + i];
         __builtin_amdgcn_wave_barrier();
@@ -585,10 +591,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
 // VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block; -3 % per launch
 // at BASELINE config 4, profiles/r04_row4_levers.log)
 // WSM: the softmax of the four rows by one wave each (mf_row_softmax_wave) instead of the whole block row after row
-template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4), int R = 4>
+template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4), int R = 4, int BITS = 2>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int NTH = NW * 64;
     static_assert(R == 4 || (R == 8 && !VHL && WSM), "R = 8: chained hi / lo sV, two rows per wave in the softmax");
+    static_assert(BITS == 2 || (R == 4 && WSM), "4-bit codes: nh / nh_kv = 4, one wave per softmax row");
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
     ak.take_dyn();
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         const int last = wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seqR<R, KRING>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
+        mf_k_seqR<R, KRING, BITS>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
             // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
             // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
             const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     const int nbw = (NB + NW - 1) / NW;
     const int b_lo = wave * nbw;
     const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
-    MfVStream<R, VRING, VHL> vs;
+    MfVStream<R, VRING, VHL, BITS> vs;
     vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
     // ---- residual scores q . [K_full | k_new] of the four heads (:337) + K append (:333-336)
     for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     stamp(5);
 
     // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
-    GqaWindow<R, NTH, MF_PW, (128 + NW) / NW> win;
+    GqaWindow<R, NTH, MF_PW, (128 + NW) / NW, BITS> win;
     win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
     // ---- [mask +] softmax of the four rows, one after the other (fp32, cast to fp16: :364-375); register resident per row
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
         static_assert(!WSM || R % NW == 0, "whole rows per wave");
 #pragma unroll 1
         for (int r = wave; r < R; r += NW) {                       // (R = 4: one row per wave; R = 8: two)
-            const int sp = mf_row_softmax_wave<DUMP>(rows + r * n_pad, n, n_pad, Tv, mrow, pw[r], vbig,
+            const int sp = mf_row_softmax_wave<DUMP, BITS>(rows + r * n_pad, n, n_pad, Tv, mrow, pw[r], vbig,
                                                      DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
             if (lane == 0) sp_lds[r] = sp;
         }
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     constexpr int NP = VHL ? 2 * NW : NW;                          // partial results of the quantised part (VHL: hi and lo of every wave)
     float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part
     float* resl = red + NP * R * 128;
-    mf_v_finish<R, VRING, VHL>(A, zl[wave], red + wave * (NP / NW) * R * 128);
+    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128);
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
         resl[wave * R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
@@ -757,21 +764,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
     }
 }
 
-bool mf_store_ok2(const void* base, int64_t sb_b, int64_t sb_h, int64_t sb_s) {
-    return base && (uintptr_t)base % 16 == 0 && sb_b % 4 == 0 && sb_h % 4 == 0 && sb_s % 4 == 0 && sb_s >= KIVI_MF_SB_WORDS;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host side (called from kivi_gqa.hip)
 
 // qK^T launch of the decode step / kivi_gqa_scores for nh / nh_kv in {1, 4}
 // (the argument blocks live in an anonymous namespace of a shared header: they cross the translation-unit boundary as void*)
-int kivi_mf_run_k(void* k_args, int units, hipStream_t s) { return run_mf_k(*(GqaKArgs*)k_args, units, s); }
+int kivi_mf_run_k(void* k_args, int units, int bits, hipStream_t s) { return run_mf_k(*(GqaKArgs*)k_args, units, bits, s); }
 
 // sV launch of the decode step (prob == 0) or of kivi_gqa_output (prob != 0: a.x rows hold fp16 probabilities, a.sp_rows
 // their exponents)
-int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
+int kivi_mf_run_v(const void* v_args, int prob, int bits, hipStream_t s) {
     const GqaVArgs& a = *(const GqaVArgs*)v_args;
     const int R = a.ratio;
 #ifdef KIVI_TUNING
@@ -779,6 +782,11 @@ int kivi_mf_run_v(const void* v_args, int prob, hipStream_t s) {
 #endif
     const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
     const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
+    if (bits == 4) {                                                // 4-bit codes (nh / nh_kv = 4: checked by the callers)
+        if (prob) KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, true, false, 4>), grid, dim3(256), lds, s, a);
+        else KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, false, false, 4>), grid, dim3(256), lds, s, a);
+        return kivi_launch_status("mf_v");
+    }
 #define KIVI_MV(RR, RG, PB) KIVI_LAUNCH_LDS((mf_v_kernel<RR, RG, PB>), grid, dim3(256), lds, s, a)
 #ifdef KIVI_TUNING
     static const char* fr0 = KIVI_TUNE_ENV("KIVI_MF_RING");
@@ -845,12 +853,13 @@ static int mf_lds_opt_in(K kernel, unsigned long long* done_mask, const char* wh
 // instantiations that also write the softmax input rows to the score buffer (KIVI_GQA_DUMP_SCORES).
 // n_rows: the longest row the launch must hold (= Tq + k_res_len + 1, or the bound of the step's geometry class when the lengths
 // are device-resident).
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, hipStream_t s) {
+int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, hipStream_t s) {
     const GqaKArgs& k = *(const GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = n_rows;
     const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
     const dim3 grid((unsigned)units);
+    KIVI_REQUIRE(bits == 2 || (bits == 4 && k.ratio == 4), KIVI_EUNSUPPORTED, "mf_row: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, k.ratio);
     if (k.ratio == 8) {
         // eight score rows in the LDS (two blocks per CU): up to 4608 keys -- the Llama-3-70B ratio at contexts up to 4.5k
         KIVI_REQUIRE(n <= 4608, KIVI_EUNSUPPORTED, "mf_row8: rows of %lld keys do not fit the LDS (<= 4608)", (long long)n);
@@ -877,7 +886,19 @@ int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n
         if (lds < fin) lds = fin;
         // 4 waves with up to 256 registers (two blocks per CU): 103 us per layer at BASELINE config 4 against 123 for 8 waves of
         // 128 registers (spills)
-        static unsigned long long opt_main = 0, opt_dump = 0;
+        static unsigned long long opt_main = 0, opt_dump = 0, opt4_main = 0, opt4_dump = 0;
+        if (bits == 4) {                                            // 4-bit codes: the same kernel over the two-tile blocks
+            if (dump) {
+                const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, true, true, true, 4, 4>, &opt4_dump, "mf_row4");
+                if (rc) return rc;
+                KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, true, true, true, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+                return kivi_launch_status("mf_row4");
+            }
+            const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, false, true, true, 4, 4>, &opt4_main, "mf_row4");
+            if (rc) return rc;
+            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, false, true, true, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+            return kivi_launch_status("mf_row4");
+        }
         if (dump) {
             const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, true>, &opt_dump, "mf_row4");
             if (rc) return rc;

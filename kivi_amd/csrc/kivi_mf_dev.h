@@ -48,6 +48,31 @@ __device__ __forceinline__ MfB mf_views(uint32_t w) {
     return r;
 }
 
+// The code words of one 32-token block a lane holds: 2 bits: one 16-byte load (every word feeds both tiles); 4 bits: two (tile 0,
+// tile 1: kivi_mfma_layout.h) -- a word is then the B operand of ONE matrix instruction after 4 shifts + 4 masks.
+template <int BITS> struct MfW { u32x4 w[BITS / 2]; };
+__device__ __forceinline__ h8 mf_views4(uint32_t w) {
+    constexpr uint32_t M = 0x03C003C0u;
+    return as_h8((w << 6) & M, (w << 2) & M, (w >> 2) & M, (w >> 6) & M);
+}
+template <int BITS>
+__device__ __forceinline__ MfB mf_views_c(const MfW<BITS>& x, int c) {
+    if constexpr (BITS == 2) {
+        return mf_views(x.w[0][c]);
+    } else {
+        MfB r;
+        r.b0 = mf_views4(x.w[0][c]);
+        r.b1 = mf_views4(x.w[1][c]);
+        return r;
+    }
+}
+// voff: per-lane byte offset of the lane's 16 bytes of tile 0 (or a dead offset), soff: the block's scalar byte offset
+template <int BITS>
+__device__ __forceinline__ void mf_load_block(MfW<BITS>& x, rsrc_t r, uint32_t voff, uint32_t soff) {
+    x.w[0] = buf_load<u32x4, true>(r, voff, soff);
+    if constexpr (BITS == 4) x.w[1] = buf_load<u32x4, true>(r, voff + 1024u, soff);
+}
+
 // ------------------------------------------------------------------------------------------------ q operand
 // Lane (m, kb) of a wave, m = lane & 15: the query of head r = m % R, channels 32 c + 8 kb + 2 i (+ 1) as fp16 pairs,
 // normalised to max |q| in [1, 2) (exponent sq) -- or, when the unit's store holds a scale >= 256 (`big`: the range flag of
@@ -62,11 +87,13 @@ struct MfQ {
 };
 
 // packed factor that takes a q'' register (times 2^aexp(i), placed at sa) to q * 2^sq: 2^-aexp(i), or 2^(10 - aexp(i))
+template <int BITS = 2>
 __device__ __forceinline__ uint32_t mf_zfac(int i, int big) {
+    if constexpr (BITS == 4) return big ? 0x4C004C00u : 0x24002400u;      // every register carries 2^6
     return i < 2 ? (big ? 0x54005400u : 0x2C002C00u) : (big ? 0x4C004C00u : 0x24002400u);
 }
 
-template <int R>
+template <int R, int BITS = 2>
 __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, MfQ<R>& Q, int big) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -91,8 +118,8 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
     for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), Q.sa + aexp(i));
-            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), Q.sa + aexp(i));
+            const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), Q.sa + aexp_b<BITS>(i));
+            const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), Q.sa + aexp_b<BITS>(i));
             Q.qq[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
         }
 }
@@ -274,10 +301,10 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
 // R = 8: heads 4 (kb' & 1) + j); `zmul`: 2^-sq of those heads.  `mv`: this lane's 4 x 16 bytes of the zero points of group n
 // (B layout = the row layout).
 // `qsrc(c)` returns the lane's q'' registers of channel chunk c (from registers, or from LDS when they are parked there).
-template <int R, typename QSrc>
+template <int R, int BITS = 2, typename QSrc>
 __device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const float* zmul, float* zz, int big) {
     f4 z = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t zf01 = mf_zfac(0, big), zf23 = mf_zfac(2, big);
+    const uint32_t zf01 = mf_zfac<BITS>(0, big), zf23 = mf_zfac<BITS>(2, big);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         // A = q * 2^sq: q'' without the 2^aexp and the placement
@@ -306,9 +333,10 @@ __device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const fl
 // instructions per group, the sums meeting through v_permlane16_swap -- : SQ_VALU_MFMA_BUSY_CYCLES fell from 0.74 to 0.40 of the
 // wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
 // profiles/r04_row4_levers.log.)
-template <int R, int RING, typename Sink, typename Done>
+template <int R, int RING, int BITS = 2, typename Sink, typename Done>
 __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
+    typedef MfL<BITS> LY;
     constexpr int RR = R;                                           // rows per group
     constexpr int GPR = 16 / RR;                                     // groups per round
     static_assert((RING >= GPR ? RING % GPR == 0 : GPR % RING == 0) && RING <= 8, "whole rounds per ring, or whole rings per round");
@@ -330,20 +358,20 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         const int g = (g0 & 15) + m / RR;
         const uint32_t dead = live ? 0u : MF_DEAD_OFF;
 #pragma unroll
-        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4) + dead, so);
+        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, (uint32_t)(LY::SCALE_WORD0 * 4 + kt_sm_word4(g, kb, c) * 4) + dead, so);
     };
     auto request_z = [&](int sbi, bool live) {
         const uint32_t dead = live ? 0u : MF_DEAD_OFF;
 #pragma unroll
-        for (int c = 0; c < 4; c++) zv[c] = buf_load<u32x4, true>(rk, (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kt_sm_word4(m, kb, c) * 4) + dead, sb_off(sbi));
+        for (int c = 0; c < 4; c++) zv[c] = buf_load<u32x4, true>(rk, (uint32_t)(LY::MN_WORD0 * 4 + kt_sm_word4(m, kb, c) * 4) + dead, sb_off(sbi));
     };
     request_round(0, true);
     request_z(0, true);
-    u32x4 wr[RING];
+    MfW<BITS> wr[RING];
     auto request_group = [&](int slot, int gi) {
         const bool live = gi <= g_last;
         const int gc = live ? gi : g_last;
-        wr[slot] = buf_load<u32x4, true>(rk, live ? (uint32_t)(lane * 16) : MF_DEAD_OFF, sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
+        mf_load_block<BITS>(wr[slot], rk, live ? (uint32_t)(lane * 16) : MF_DEAD_OFF, sb_off(gc >> 4) + (uint32_t)(gc & 15) * (uint32_t)(LY::BLOCK_WORDS * 4));
     };
 #pragma unroll
     for (int i = 0; i < RING; i++) {
@@ -351,7 +379,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         __builtin_amdgcn_sched_barrier(0);
     }
     MfQ<R> Q;
-    mf_load_q<R>(q_h0, q_sh, Q, big);
+    mf_load_q<R, BITS>(q_h0, q_sh, Q, big);
     float zmul[4], cmul[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -368,7 +396,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         const int sbi = rq / RR;                                    // 16 / GPR = RR rounds per super-block
         const int rs = rq - sbi * RR;
         if (rs == 0) {                                              // a new super-block: its zero-point sums, then the next one's zero points
-            mf_k_zero<R>(qsrc, zv, zmul, zz, big);
+            mf_k_zero<R, BITS>(qsrc, zv, zmul, zz, big);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
         uint32_t Ah[4][4], Al[4][4];
@@ -394,7 +422,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
             f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const MfB b = mf_views(wr[(S0 + j) % RING][c]);
+                const MfB b = mf_views_c<BITS>(wr[(S0 + j) % RING], c);
                 const h8 ah = as_h8(Ah[c][0], Ah[c][1], Ah[c][2], Ah[c][3]);
                 const h8 al = as_h8(Al[c][0], Al[c][1], Al[c][2], Al[c][3]);
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.b0, a0, 0, 0, 0);
@@ -470,11 +498,16 @@ __device__ __forceinline__ void mf_v_init(MfVAcc<R, HL>& A) {
 }
 
 // -1.5 * RING in the units of a masked code: registers 0, 1 hold code * 2^-16, registers 2, 3 code * 2^-18 (fp16 bits, both halves)
-template <int RING> struct MfCentre;
-template <> struct MfCentre<2> { static constexpr uint32_t a = 0x83008300u, b = 0x80C080C0u; static constexpr float f = 3.0f; };
-template <> struct MfCentre<3> { static constexpr uint32_t a = 0x84808480u, b = 0x81208120u; static constexpr float f = 4.5f; };
-template <> struct MfCentre<4> { static constexpr uint32_t a = 0x86008600u, b = 0x81808180u; static constexpr float f = 6.0f; };
-template <> struct MfCentre<8> { static constexpr uint32_t a = 0x8A008A00u, b = 0x83008300u; static constexpr float f = 12.0f; };   // (-12 x 2^-16 is a normal fp16)
+template <int RING, int BITS = 2> struct MfCentre;
+template <> struct MfCentre<2, 2> { static constexpr uint32_t a = 0x83008300u, b = 0x80C080C0u; static constexpr float f = 3.0f; };
+template <> struct MfCentre<3, 2> { static constexpr uint32_t a = 0x84808480u, b = 0x81208120u; static constexpr float f = 4.5f; };
+template <> struct MfCentre<4, 2> { static constexpr uint32_t a = 0x86008600u, b = 0x81808180u; static constexpr float f = 6.0f; };
+template <> struct MfCentre<8, 2> { static constexpr uint32_t a = 0x8A008A00u, b = 0x83008300u; static constexpr float f = 12.0f; };   // (-12 x 2^-16 is a normal fp16)
+// 4-bit codes: -7.5 * RING x 2^-18 in every register (ring 2: a subnormal, from 3 on a normal fp16)
+template <> struct MfCentre<2, 4> { static constexpr uint32_t a = 0x83C083C0u, b = 0x83C083C0u; static constexpr float f = 15.0f; };
+template <> struct MfCentre<3, 4> { static constexpr uint32_t a = 0x85A085A0u, b = 0x85A085A0u; static constexpr float f = 22.5f; };
+template <> struct MfCentre<4, 4> { static constexpr uint32_t a = 0x87808780u, b = 0x87808780u; static constexpr float f = 30.0f; };
+template <> struct MfCentre<8, 4> { static constexpr uint32_t a = 0x8B808B80u, b = 0x8B808B80u; static constexpr float f = 60.0f; };
 
 // one 32-token block.  w: code words; ps: the lane's 8 scaled probabilities (tokens 8 kb + e of its row's head);
 // R = 1: sm[0] = scale (rows j < 2) or zero points (rows j >= 2), lomask = all ones in lo rows;
@@ -482,10 +515,11 @@ template <> struct MfCentre<8> { static constexpr uint32_t a = 0x8A008A00u, b = 
 // R = 8: row (channel group 2 s + (m >> 3), head m & 7) for the row sets s = 0, 1: sm[s], mn[s]; channel chunk c multiplies with
 //        row set c >> 1 (its rows for channel group c are the useful ones).
 // CENTRE: this block also accumulates A x (-1.5 RING).
-template <int R, int RING, bool CENTRE, bool HL>
-__device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const u32x4& w, const u32x4& ps, const u32x4* sm, const u32x4* mn,
+template <int R, int RING, bool CENTRE, bool HL, int BITS = 2>
+__device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const MfW<BITS>& w, const u32x4& ps, const u32x4* sm, const u32x4* mn,
                                            uint32_t lomask) {
-    const h8 bc = as_h8(MfCentre<RING>::a, MfCentre<RING>::a, MfCentre<RING>::b, MfCentre<RING>::b);
+    typedef MfCentre<RING, BITS> CE;
+    const h8 bc = as_h8(CE::a, CE::a, CE::b, CE::b);
     if constexpr (HL) {
         // lomask: all ones in the lanes of a lo row.  hi rows: fp16(p'' s); lo rows: the exact remainder (cf. mf_k_seqR)
         uint32_t psm[4], a[2][4];
@@ -509,7 +543,7 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const u32x4& w, con
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const h8 av = as_h8(a[c >> 1][0], a[c >> 1][1], a[c >> 1][2], a[c >> 1][3]);
-            const MfB b = mf_views(w[c]);
+            const MfB b = mf_views_c<BITS>(w, c);
             f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
             if constexpr (CENTRE) {
                 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, x0, 0, 0, 0);
@@ -538,7 +572,7 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const u32x4& w, con
         const h8 av = as_h8(a[0], a[1], a[2], a[3]);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const MfB b = mf_views(w[c]);
+            const MfB b = mf_views_c<BITS>(w, c);
             f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
             if constexpr (CENTRE) {
                 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bc, x0, 0, 0, 0);
@@ -572,7 +606,7 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const u32x4& w, con
         for (int c = 0; c < 4; c++) {
             const int s = (NS == 2) ? (c >> 1) : 0;               // (a constant after unrolling)
             const h8 ah = as_h8(hi[s][0], hi[s][1], hi[s][2], hi[s][3]), al = as_h8(lo[s][0], lo[s][1], lo[s][2], lo[s][3]);
-            const MfB b = mf_views(w[c]);
+            const MfB b = mf_views_c<BITS>(w, c);
             f4 x0 = A.acc[c][0], x1 = A.acc[c][1];
             if constexpr (CENTRE) {
                 x0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bc, x0, 0, 0, 0);
@@ -590,10 +624,12 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const u32x4& w, con
 // sb_bytes = byte stride between consecutive super-blocks.  prime() requests the first RING blocks (callers do it as early
 // as they can: the fused row kernel before its softmax), run() consumes: ps_lds = the R rows of scaled probabilities
 // (halves), row pitch `pitch` halves, indexed by token - tok0.
-template <int R, int RING, bool HL = false>
+template <int R, int RING, bool HL = false, int BITS = 2>
 struct MfVStream {
     static constexpr int NS = MfVAcc<R, HL>::NS;
-    u32x4 wr[RING], sr[RING][NS], mr[R == 1 ? 1 : RING][NS];
+    typedef MfL<BITS> LY;
+    MfW<BITS> wr[RING];
+    u32x4 sr[RING][NS], mr[R == 1 ? 1 : RING][NS];
     uint32_t sm_off, mn_off, sb_bytes;
     int b_last;
     int sb_first, sb_stride;       // block q of the stream lives in super-block sb_first + (q >> 4) * sb_stride, block q & 15
@@ -604,7 +640,7 @@ struct MfVStream {
         const int bc = live ? bl : b_last;
         const uint32_t dead = live ? 0u : MF_DEAD_OFF;
         const uint32_t so = (uint32_t)(sb_first + (bc >> 4) * sb_stride) * sb_bytes;
-        wr[slot] = buf_load<u32x4, true>(rv, (uint32_t)(lane * 16) + dead, so + (uint32_t)(bc & 15) * 1024u);
+        mf_load_block<BITS>(wr[slot], rv, (uint32_t)(lane * 16) + dead, so + (uint32_t)(bc & 15) * (uint32_t)(LY::BLOCK_WORDS * 4));
 #pragma unroll
         for (int s = 0; s < NS; s++) {                             // (row set s: two channel groups = 32 bytes further)
             sr[slot][s] = buf_load<u32x4, true>(rv, sm_off + 32u * s + dead, so + (uint32_t)(bc & 15) * 256u);
@@ -617,8 +653,8 @@ struct MfVStream {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
         const int cg = (R == 8 || HL) ? (m >> 3) : (m >> 2), j = m & 3;   // channel group of the lane's row (row set 0)
-        sm_off = (uint32_t)(((R == 1 && j >= 2) ? KIVI_MF_SB_MN_WORD0 : KIVI_MF_SB_SCALE_WORD0) * 4 + kb * 64 + cg * 16);
-        mn_off = (uint32_t)(KIVI_MF_SB_MN_WORD0 * 4 + kb * 64 + cg * 16);
+        sm_off = (uint32_t)(((R == 1 && j >= 2) ? LY::MN_WORD0 : LY::SCALE_WORD0) * 4 + kb * 64 + cg * 16);
+        mn_off = (uint32_t)(LY::MN_WORD0 * 4 + kb * 64 + cg * 16);
         sb_bytes = sb_bytes_;
         sb_first = first;
         sb_stride = stride;
@@ -651,8 +687,8 @@ struct MfVStream {
                 // blocks past the range repeat the last block with zero probabilities
                 u32x4 ps = *(const u32x4*)(prow + (bl < b_hi ? bl : b_hi - 1) * 32);
                 if (bl >= b_hi) ps = u32x4{0, 0, 0, 0};
-                if (s == 0) mf_v_block<R, RING, true, HL>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
-                else mf_v_block<R, RING, false, HL>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+                if (s == 0) mf_v_block<R, RING, true, HL, BITS>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
+                else mf_v_block<R, RING, false, HL, BITS>(A, wr[s], ps, sr[s], mr[R == 1 ? 0 : s], lomask);
                 request(rv, s, bl + RING);
                 // nothing moves across this point: without it hipcc gathers all RING re-requests at the end of the round, i.e.
                 // a block's data is asked for one block before its use
@@ -665,18 +701,19 @@ struct MfVStream {
 // Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]; HL: [2][R][128], the hi and the lo
 // part of every output, to be added by the caller) -- 2^12 * (hi + lo sums) + zero-point term + 1.5 * sum p'' s.
 // `zl`: 128 floats of scratch LDS of this wave.
-template <int R, int RING, bool HL>
+template <int R, int RING, bool HL, int BITS = 2>
 __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, float* dst) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, kb = lane >> 4;
-    constexpr float CF = MfCentre<RING>::f;                       // what the centring blocks subtracted per unit of A
+    constexpr float CF = MfCentre<RING, BITS>::f;                 // what the centring blocks subtracted per unit of A
+    constexpr float W4 = BITS == 2 ? 0.0625f : 0.015625f;         // 2^-aexp of the registers 0, 1 (4-bit codes: 2^-6 like 2, 3)
     // per-lane dot sums -> LDS -> every lane gathers the four kb partials of the rows it needs
     if constexpr (HL) {
         // this lane's accumulator rows 4 kb + j = (channel group kb >> 1 of the row set, hi | lo = kb & 1, head j): the useful rows
         // of the channel chunks c = (kb >> 1) + 2 s.  The zero-point term was summed by the hi AND the lo lanes: half each.
 #pragma unroll
         for (int s = 0; s < 2; s++)
-            zl[64 * s + lane] = __builtin_fmaf(CF, A.c4[s] * 0.0625f + A.c6[s] * 0.015625f, A.z4[s] * 0.03125f + A.z6[s] * 0.0078125f);
+            zl[64 * s + lane] = __builtin_fmaf(CF, A.c4[s] * W4 + A.c6[s] * 0.015625f, A.z4[s] * (0.5f * W4) + A.z6[s] * 0.0078125f);
         __builtin_amdgcn_wave_barrier();
         float* dhl = dst + (kb & 1) * R * 128;
 #pragma unroll
@@ -699,8 +736,8 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
             }
         }
     } else if constexpr (R == 1) {
-        zl[lane] = A.z4[0] * 0.0625f + A.z6[0] * 0.015625f;
-        zl[64 + lane] = A.c4[0] * 0.0625f + A.c6[0] * 0.015625f;
+        zl[lane] = A.z4[0] * W4 + A.z6[0] * 0.015625f;
+        zl[64 + lane] = A.c4[0] * W4 + A.c6[0] * 0.015625f;
         __builtin_amdgcn_wave_barrier();
         // output lane (n, kb' = cg): sum p'' mn (rows 4 cg + 2) + CF * sum over the centring blocks of p'' s (rows 4 cg)
         float zc = 0.f, zm = 0.f;
@@ -722,7 +759,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
             dst[32 * kb + 16 * tile + n] = __builtin_fmaf(v0 + v1, (float)(1 << KIVI_MF_PROD_SHIFT), br);
         }
     } else if constexpr (R == 4) {
-        zl[lane] = __builtin_fmaf(CF, A.c4[0] * 0.0625f + A.c6[0] * 0.015625f, A.z4[0] * 0.0625f + A.z6[0] * 0.015625f);
+        zl[lane] = __builtin_fmaf(CF, A.c4[0] * W4 + A.c6[0] * 0.015625f, A.z4[0] * W4 + A.z6[0] * 0.015625f);
         __builtin_amdgcn_wave_barrier();
         float br[4];
 #pragma unroll
@@ -746,7 +783,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
         // useful rows of the channel chunks c = (kb >> 1) + 2 s, s = 0, 1
 #pragma unroll
         for (int s = 0; s < 2; s++)
-            zl[64 * s + lane] = __builtin_fmaf(CF, A.c4[s] * 0.0625f + A.c6[s] * 0.015625f, A.z4[s] * 0.0625f + A.z6[s] * 0.015625f);
+            zl[64 * s + lane] = __builtin_fmaf(CF, A.c4[s] * W4 + A.c6[s] * 0.015625f, A.z4[s] * W4 + A.z6[s] * 0.015625f);
         __builtin_amdgcn_wave_barrier();
         const int hb = 4 * (kb & 1);
 #pragma unroll
@@ -780,8 +817,9 @@ __device__ __forceinline__ int mf_sp(float sum, int big) {
     return (e < 0 ? 0 : (e > 14 ? 14 : e)) - (big ? KIVI_MF_BIG_SHIFT : 0);
 }
 // fp16 p -> p'' for token t: 2^(Sp + 4) for (t & 7) < 4, 2^(Sp + 6) otherwise (the register i = (t & 7) >> 1 of the operand)
+template <int BITS = 2>
 __device__ __forceinline__ uint16_t mf_scale_p(uint16_t p, int sp, int t) {
-    const int e = sp + ((t & 4) ? 6 : 4);
+    const int e = sp + ((BITS == 4 || (t & 4)) ? 6 : 4);
     return f2h_bits(__builtin_ldexpf(h2f_bits(p), e));
 }
 
@@ -933,7 +971,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
 // lane on 4 consecutive scores per 256-score chunk; the exponentials are computed twice rather than kept (a 9216-key row is 144
 // scores per lane).  The block version above spends most of its ~4 us per row in two block barriers and dependent LDS round
 // trips, four rows in sequence; profiles/r04_row4_levers.log.  Returns Sp (wave-uniform).
-template <bool DUMP>
+template <bool DUMP, int BITS = 2>
 __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_pad, int Tv, const uint16_t* mrow, uint16_t* pw_row, int big,
                                                    uint16_t* dump) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
@@ -1026,7 +1064,7 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
                 const h2v p01 = __builtin_convertvector(e01 * inv2, h2v);
                 const h2v p23 = __builtin_convertvector(e23 * inv2, h2v);
                 if (j0 + 4 <= Tv) {
-                    const _Float16 m_a = (j0 & 4) ? (_Float16)64.0f : (_Float16)16.0f;
+                    const _Float16 m_a = (BITS == 4 || (j0 & 4)) ? (_Float16)64.0f : (_Float16)16.0f;
                     o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
                     o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
                 } else {                                           // the chunk that holds the end of the packed prefix / the window
@@ -1037,7 +1075,7 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
                     for (int e = 0; e < 4; e++) {
                         const int j = j0 + e;
                         if (j >= Tv && j < n) pw_row[j - Tv] = pp[e];
-                        q[e] = (j < Tv) ? mf_scale_p(pp[e], sp, j) : (uint16_t)0;
+                        q[e] = (j < Tv) ? mf_scale_p<BITS>(pp[e], sp, j) : (uint16_t)0;
                     }
                     o[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
                     o[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);

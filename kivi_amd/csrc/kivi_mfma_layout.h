@@ -60,7 +60,35 @@
 #define KIVI_MF_BIG_SCALE_BITS 0x5C00u
 #define KIVI_MF_BIG_SHIFT 10
 
+// ---- 4-bit codes ("KT4" / "VT4"; round 4, nh / nh_kv = 4): the same super-block with TWO code tiles per 32-token block.  A word
+// holds the 8 reduction-axis elements one lane feeds to ONE matrix instruction (the 2-bit word holds both tiles' 2 x 8):
+//   block = 2048 B of codes = two 16-byte loads per lane: bytes [0, 1024) tile 0, [1024, 2048) tile 1; lane = n + 16 kb
+//   K block, token tt, channel d:  tile = tt >> 4, n = tt & 15, c = d >> 5, kb = (d >> 3) & 3, e = d & 7
+//   V block, token tt, channel d:  tile = (d >> 4) & 1, n = d & 15, c = d >> 5, kb = tt >> 3, e = tt & 7
+//        word tile * 256 + (n + 16 kb) * 4 + c, bits 4 (e >> 1) + 16 (e & 1)
+//   super-block = [ codes 16 x 512 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 10240 words = 40 KiB; scale / mn as above.
+// B operand: register i = shift_i(w) & 0x03C003C0 with shift = << 6, << 2, >> 2, >> 6: every code on mantissa bits 9:6 of an fp16
+// subnormal = code * 2^-18, ONE exponent for the four registers: the A operand carries 2^6 throughout (aexp), a product is
+// a * code * 2^-12 as for 2 bits; the centre of a code is -7.5.
+#define KIVI_MF4_BLOCK_WORDS 512
+#define KIVI_MF4_SB_SCALE_WORD0 8192
+#define KIVI_MF4_SB_MN_WORD0 9216
+#define KIVI_MF4_SB_WORDS 10240
+
 #ifdef __HIPCC__
+template <int BITS> struct MfL;        // per-width constants of the super-block
+template <> struct MfL<2> {
+    static constexpr int BLOCK_WORDS = KIVI_MF_BLOCK_WORDS, SCALE_WORD0 = KIVI_MF_SB_SCALE_WORD0, MN_WORD0 = KIVI_MF_SB_MN_WORD0,
+                         SB_WORDS = KIVI_MF_SB_WORDS;
+};
+template <> struct MfL<4> {
+    static constexpr int BLOCK_WORDS = KIVI_MF4_BLOCK_WORDS, SCALE_WORD0 = KIVI_MF4_SB_SCALE_WORD0, MN_WORD0 = KIVI_MF4_SB_MN_WORD0,
+                         SB_WORDS = KIVI_MF4_SB_WORDS;
+};
+__device__ __forceinline__ int kt4_word(int tt, int d) { return (tt >> 4) * 256 + ((tt & 15) + 16 * ((d >> 3) & 3)) * 4 + (d >> 5); }
+__device__ __forceinline__ int kt4_bit(int d) { return 4 * ((d & 7) >> 1) + 16 * (d & 1); }
+__device__ __forceinline__ int vt4_word(int tt, int d) { return ((d >> 4) & 1) * 256 + ((d & 15) + 16 * (tt >> 3)) * 4 + (d >> 5); }
+__device__ __forceinline__ int vt4_bit(int tt) { return 4 * ((tt & 7) >> 1) + 16 * (tt & 1); }
 __device__ __forceinline__ int kt_word(int tt, int d) { return ((tt & 15) + 16 * ((d >> 3) & 3)) * 4 + (d >> 5); }
 __device__ __forceinline__ int mf_pos(int tile, int i) { return ((tile ? 0xEA0C : 0x2648) >> (4 * i)) & 15; }
 __device__ __forceinline__ int kt_bit(int tt, int d) { return mf_pos(tt >> 4, (d & 7) >> 1) + 16 * (d & 1); }

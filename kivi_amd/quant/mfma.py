@@ -12,34 +12,42 @@ import torch
 from .. import _lib
 
 SB_TOKENS = 512
-SB_WORDS = 6144
+SB_WORDS = 6144            # 2-bit codes: [codes 4096 | scale 1024 | mn 1024] words per super-block
+SB_WORDS_4BIT = 10240      # 4-bit codes: [codes 8192 | scale 1024 | mn 1024] (kivi_mfma_layout.h, "KT4 / VT4")
 BLOCK_TOKENS = 32
 
 
+def sb_words(bits: int) -> int:
+    return {2: SB_WORDS, 4: SB_WORDS_4BIT}[bits]
+
+
 def supported(k_bits: int, v_bits: int, group_size: int, head_dim: int, residual_length: int, ratio: int) -> bool:
-    return (k_bits == 2 and v_bits == 2 and group_size == 32 and head_dim == 128 and residual_length % 32 == 0
-            and ratio in (1, 4, 8))
+    """2-bit K and V: nh / nh_kv in {1, 4, 8}; 4-bit K and V (round 4): nh / nh_kv = 4."""
+    if not (group_size == 32 and head_dim == 128 and residual_length % 32 == 0 and k_bits == v_bits):
+        return False
+    return (k_bits == 2 and ratio in (1, 4, 8)) or (k_bits == 4 and ratio == 4)
 
 
 def _flag_words(B: int, nh_kv: int) -> int:
     return (B * nh_kv + 63) // 64 * 64          # the flags take whole 256-byte lines behind the super-blocks
 
 
-def alloc_store(B: int, nh_kv: int, n_sb: int, device) -> torch.Tensor:
-    """Zero-initialised storage of n_sb super-blocks per (batch row, kv head): logical shape (B, nh_kv, n_sb, 6144) int32,
+def alloc_store(B: int, nh_kv: int, n_sb: int, device, bits: int = 2) -> torch.Tensor:
+    """Zero-initialised storage of n_sb super-blocks per (batch row, kv head): logical shape (B, nh_kv, n_sb, sb_words(bits)) int32,
     in memory the super-block index sits outside the head index (the super-blocks in use form one dense region).
     The store's RANGE FLAGS (include/kivi_hip.h: B * nh_kv int32, set by whatever writes a scale >= 256 into the store)
     live in the same allocation, right behind the super-blocks: `range_flags(store)` is the (B, nh_kv) view, and every
     wrapper below passes it along with the store."""
-    main = B * n_sb * nh_kv * SB_WORDS
+    W = sb_words(bits)
+    main = B * n_sb * nh_kv * W
     flat = torch.zeros(main + _flag_words(B, nh_kv), dtype=torch.int32, device=device)
-    return flat[:main].view(B, n_sb, nh_kv, SB_WORDS).permute(0, 2, 1, 3)
+    return flat[:main].view(B, n_sb, nh_kv, W).permute(0, 2, 1, 3)
 
 
 def range_flags(store: torch.Tensor) -> torch.Tensor:
     """(B, nh_kv) int32 view of a store's range flags (the store must come from alloc_store)."""
     B, nh_kv, n_sb = store.shape[0], store.shape[1], store.shape[2]
-    main = B * n_sb * nh_kv * SB_WORDS
+    main = B * n_sb * nh_kv * store.shape[3]
     stg = store.untyped_storage()
     if store.storage_offset() != 0 or stg.nbytes() != (main + _flag_words(B, nh_kv)) * 4:
         raise ValueError("not a store of kivi_amd.quant.mfma.alloc_store (its range flags live behind the super-blocks)")
@@ -52,8 +60,8 @@ def copy_store(dst: torch.Tensor, src: torch.Tensor) -> None:
     range_flags(dst).copy_(range_flags(src))
 
 
-def _st(store: torch.Tensor):
-    assert store.dtype == torch.int32 and store.dim() == 4 and store.shape[3] == SB_WORDS and store.stride(3) == 1
+def _st(store: torch.Tensor, bits: int = 2):
+    assert store.dtype == torch.int32 and store.dim() == 4 and store.shape[3] == sb_words(bits) and store.stride(3) == 1
     return _lib.ptr(store), store.stride(0), store.stride(1), store.stride(2), _lib.ptr(range_flags(store))
 
 
@@ -63,7 +71,7 @@ def kt_pack(k: torch.Tensor, store: torch.Tensor, token_offset: int = 0, group_s
     B, nh_kv, T, D = k.shape
     assert k.dtype == torch.float16 and k.stride(3) == 1 and (token_offset + T) <= store.shape[2] * SB_TOKENS
     lib = _lib.load()
-    _lib.check(lib.kivi_kt_pack(_lib.ptr(k), k.stride(0), k.stride(1), k.stride(2), *_st(store), token_offset, B, nh_kv, T, D,
+    _lib.check(lib.kivi_kt_pack(_lib.ptr(k), k.stride(0), k.stride(1), k.stride(2), *_st(store, bits), token_offset, B, nh_kv, T, D,
                                 group_size, bits, _lib.stream_ptr(k)), "kivi_kt_pack")
 
 
@@ -73,7 +81,7 @@ def vt_pack(v: torch.Tensor, store: torch.Tensor, group_size: int = 32, bits: in
     _lib.require_gpu(v, "v")
     B, nh_kv, T, D = v.shape
     assert v.dtype == torch.float16 and v.stride(3) == 1 and T <= store.shape[2] * SB_TOKENS
-    _lib.check(_lib.load().kivi_vt_pack(_lib.ptr(v), v.stride(0), v.stride(1), v.stride(2), *_st(store), B, nh_kv, T, D,
+    _lib.check(_lib.load().kivi_vt_pack(_lib.ptr(v), v.stride(0), v.stride(1), v.stride(2), *_st(store, bits), B, nh_kv, T, D,
                                         group_size, bits, _lib.stream_ptr(v)), "kivi_vt_pack")
 
 
@@ -81,15 +89,15 @@ def _relayout(fn, name, to_ref, store, code, scale, mn, T, D, group_size, bits):
     B, nh_kv = store.shape[0], store.shape[1]
     assert code.dtype == torch.int32 and scale.dtype == mn.dtype == torch.float16
     assert code.stride(3) == 1 and scale.stride(3) == 1 and scale.stride() == mn.stride()
-    _lib.check(fn(int(to_ref), *_st(store), _lib.ptr(code), code.stride(0), code.stride(1), code.stride(2), _lib.ptr(scale),
+    _lib.check(fn(int(to_ref), *_st(store, bits), _lib.ptr(code), code.stride(0), code.stride(1), code.stride(2), _lib.ptr(scale),
                   _lib.ptr(mn), scale.stride(0), scale.stride(1), scale.stride(2), B, nh_kv, T, D, group_size, bits,
                   _lib.stream_ptr(code)), name)
 
 
 def kt_to_ref(store: torch.Tensor, T: int, D: int = 128, group_size: int = 32, bits: int = 2):
-    """-> K_code_T (B, nh_kv, D, T/16) int32, K_scale_T, K_mn_T (B, nh_kv, D, T/32) fp16 of tokens [0, T)."""
+    """-> K_code_T (B, nh_kv, D, T / (32 / bits)) int32, K_scale_T, K_mn_T (B, nh_kv, D, T/32) fp16 of tokens [0, T)."""
     B, nh_kv = store.shape[0], store.shape[1]
-    code = torch.empty((B, nh_kv, D, T // 16), dtype=torch.int32, device=store.device)
+    code = torch.empty((B, nh_kv, D, T // (32 // bits)), dtype=torch.int32, device=store.device)
     scale = torch.empty((B, nh_kv, D, T // group_size), dtype=torch.float16, device=store.device)
     mn = torch.empty_like(scale)
     _relayout(_lib.load().kivi_kt_relayout, "kivi_kt_relayout", True, store, code, scale, mn, T, D, group_size, bits)
@@ -97,14 +105,14 @@ def kt_to_ref(store: torch.Tensor, T: int, D: int = 128, group_size: int = 32, b
 
 
 def kt_from_ref(store: torch.Tensor, code: torch.Tensor, scale: torch.Tensor, mn: torch.Tensor, group_size: int = 32, bits: int = 2):
-    T = code.shape[3] * 16
+    T = code.shape[3] * (32 // bits)
     _relayout(_lib.load().kivi_kt_relayout, "kivi_kt_relayout", False, store, code, scale, mn, T, code.shape[2], group_size, bits)
 
 
 def vt_to_ref(store: torch.Tensor, T: int, D: int = 128, group_size: int = 32, bits: int = 2):
-    """-> V_code (B, nh_kv, T, D/16) int32, V_scale, V_mn (B, nh_kv, T, D/32) fp16 of tokens [0, T)."""
+    """-> V_code (B, nh_kv, T, D / (32 / bits)) int32, V_scale, V_mn (B, nh_kv, T, D/32) fp16 of tokens [0, T)."""
     B, nh_kv = store.shape[0], store.shape[1]
-    code = torch.empty((B, nh_kv, T, D // 16), dtype=torch.int32, device=store.device)
+    code = torch.empty((B, nh_kv, T, D // (32 // bits)), dtype=torch.int32, device=store.device)
     scale = torch.empty((B, nh_kv, T, D // group_size), dtype=torch.float16, device=store.device)
     mn = torch.empty_like(scale)
     _relayout(_lib.load().kivi_vt_relayout, "kivi_vt_relayout", True, store, code, scale, mn, T, D, group_size, bits)
@@ -113,7 +121,7 @@ def vt_to_ref(store: torch.Tensor, T: int, D: int = 128, group_size: int = 32, b
 
 def vt_from_ref(store: torch.Tensor, code: torch.Tensor, scale: torch.Tensor, mn: torch.Tensor, group_size: int = 32, bits: int = 2):
     T = code.shape[2]
-    _relayout(_lib.load().kivi_vt_relayout, "kivi_vt_relayout", False, store, code, scale, mn, T, code.shape[3] * 16, group_size, bits)
+    _relayout(_lib.load().kivi_vt_relayout, "kivi_vt_relayout", False, store, code, scale, mn, T, code.shape[3] * (32 // bits), group_size, bits)
 
 
 def gqa_scores(q: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tensor, group_size: int = 32, bits: int = 2) -> None:
@@ -121,7 +129,7 @@ def gqa_scores(q: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tensor, 
     B, nh, _, D = q.shape
     nh_kv = store.shape[1]
     assert q.dtype == out.dtype == torch.float16 and q.stride(3) == 1 and out.stride(3) == 1
-    _lib.check(_lib.load().kivi_gqa_scores(_lib.ptr(q), q.stride(0), q.stride(1), *_st(store), _lib.ptr(out), out.stride(0),
+    _lib.check(_lib.load().kivi_gqa_scores(_lib.ptr(q), q.stride(0), q.stride(1), *_st(store, bits), _lib.ptr(out), out.stride(0),
                                            out.stride(1), B, nh, nh_kv, D, T, group_size, bits, _lib.stream_ptr(q)),
                "kivi_gqa_scores")
 
@@ -145,7 +153,7 @@ def gqa_output(probs: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tens
     if ws is None or ws.numel() < need:
         ws = torch.zeros(need, dtype=torch.uint8, device=probs.device)
         _OUT_WS[key] = ws
-    _lib.check(_lib.load().kivi_gqa_output(_lib.ptr(probs), probs.stride(0), probs.stride(1), *_st(store), _lib.ptr(out),
+    _lib.check(_lib.load().kivi_gqa_output(_lib.ptr(probs), probs.stride(0), probs.stride(1), *_st(store, bits), _lib.ptr(out),
                                            out.stride(0), out.stride(1), B, nh, nh_kv, 128, T, group_size, bits, _lib.ptr(ws),
                                            ws.numel(), _lib.stream_ptr(probs)), "kivi_gqa_output")
     return out

@@ -140,6 +140,10 @@ CASES = [
     # is for), multi-head and grouped
     ("flash_mha_outlier_b2_r32", "flash", 2, 4, 4, 128, 2, 32, 32, 90, 40, False),
     ("mistral_flash_gqa4_outlier_r32", "mistral_flash", 2, 8, 2, 128, 2, 32, 32, 70, 40, False),
+    # 4-bit K / V with four query heads per kv head: the reference's published Mistral-7B + KIVI-4 shape (docs/long_bench.md:35-53),
+    # across K flushes (R = 32) and with a mask over a longer prompt (R = 128)
+    ("mistral_flash_gqa4_b4_r32", "mistral_flash", 2, 8, 2, 128, 4, 32, 32, 70, 40, False),
+    ("flash_gqa4_b4_r128_mask", "flash", 1, 8, 2, 128, 4, 32, 128, 300, 12, True),
 ]
 
 

@@ -291,7 +291,9 @@ def _gqa_args(**over):
 
 @pytest.mark.parametrize("over,rc_expected,msg", [
     (dict(nh=6), -3, b"nh / nh_kv"),                        # ratio 3: not on the matrix pipe (KIVI_EUNSUPPORTED)
-    (dict(bits=4), -3, b"2-bit"),
+    (dict(bits=8), -3, b"2- and 4-bit"),
+    (dict(bits=4, nh=2), -3, b"4-bit codes on the matrix pipe need nh / nh_kv = 4"),       # 4-bit: grouped queries with ratio 4 only
+    (dict(bits=4, kt_ss=6144), None, b"16-byte aligned super-blocks"),                      # ... in 10240-word super-blocks
     (dict(Tq=500), None, b"inconsistent lengths"),          # packed keys come in whole 32-token blocks
     (dict(Tv=480), None, b"inconsistent lengths"),          # Tq + k_res != Tv + v_res
     (dict(s_sh=516), None, b"score rows"),                  # rows must hold the step and be 16-byte aligned
@@ -338,7 +340,7 @@ def _mf_layer_desc(**over):
     return _lib.MfLayerDesc(**f)
 
 
-@pytest.mark.parametrize("over,msg", [(dict(bits=4), b"2-bit"), (dict(residual_length=48), b"inconsistent lengths"),
+@pytest.mark.parametrize("over,msg", [(dict(bits=8), b"2- and 4-bit"), (dict(bits=4, nh_kv=4), b"need nh / nh_kv = 4"), (dict(residual_length=48), b"inconsistent lengths"),
                                       (dict(kt=None), b"null"), (dict(vt_range=None), b"null"), (dict(cap=64), b"capacity"), (dict(kt_ss=100), b"alignment"),
                                       (dict(v_window_rows=32), b"ring window"), (dict(s_pitch=90), b"score rows")])
 def test_mf_decode_layer_refuses_before_anything_is_committed(lib, over, msg):
@@ -386,7 +388,11 @@ def test_layer_cache_factory_picks_the_layout():
     assert isinstance(mha, KiviLayerCacheMF) and mha.n_sb == 2
     for kw in (dict(num_heads=24), dict(num_heads=16), dict(num_heads=None)):
         assert isinstance(make_layer_cache(KiviConfig(2, 2, 32, 128), 1, 8, 128, 1000, "cpu", **kw), KiviLayerCache)
-    assert isinstance(make_layer_cache(KiviConfig(4, 4, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
+    mf4 = make_layer_cache(KiviConfig(4, 4, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32)     # round 4: 4-bit K / V, nh / nh_kv = 4
+    assert isinstance(mf4, KiviLayerCacheMF) and mf4.kt.shape == (1, 8, 2, 10240) and mf4.vt.shape == (1, 8, 2, 10240)
+    for kw in (dict(num_heads=8), dict(num_heads=64)):                                          # ... other ratios: the hook-state layout
+        assert isinstance(make_layer_cache(KiviConfig(4, 4, 32, 128), 1, 8, 128, 1000, "cpu", **kw), KiviLayerCache)
+    assert isinstance(make_layer_cache(KiviConfig(4, 2, 32, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
     assert isinstance(make_layer_cache(KiviConfig(2, 2, 64, 128), 1, 8, 128, 1000, "cpu", num_heads=32), KiviLayerCache)
     mf.reserve(3000)
     assert mf.n_sb == 6 and mf.cap >= 3000

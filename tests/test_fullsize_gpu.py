@@ -40,7 +40,7 @@ def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False
                 stage_ab=False, outlier=False):
     """Full-size decode steps on the GPU; hook_ref on the sampled (b, kv head) slices.  Returns the kernels seen.
     layout "hook": the hook-state layout (KiviLayerCache, VALU kernels); "auto": what make_layer_cache picks for the shape
-    (the matrix-pipe layout for 2-bit / g=32 / D=128 with nh / nh_kv in {1, 4, 8}).
+    (the matrix-pipe layout for g=32 / D=128: 2-bit with nh / nh_kv in {1, 4, 8}, 4-bit with nh / nh_kv = 4).
     outlier: every 17th key channel x 12 (what per-channel K quantisation exists for).  With such keys the fp16 scores reach
     |s| ~ 100, where ONE ulp of a dominant score (0.0625 / sqrt(D)) moves its probability by 0.5 %, so the end-to-end bar is
     replaced by the stage check of tests/test_mfma_gpu.py (stage_ab, matrix-pipe layout only): A. the fp16 rows the softmax
@@ -157,6 +157,17 @@ def test_config4_shape_mf_row4_kernel_stages_on_outlier_keys(oracle):
     """BASELINE config 4 (32 / 8 heads, 8k keys, R = 128, B = 64: one mf_row4_kernel launch per layer) likewise."""
     seen, worst = run_sampled(B=64, nh=32, nh_kv=8, T0=8192 - 4, R=128, bits=2, g=32, steps=8, samples=[(0, 0), (63, 7), (32, 3)],
                               seed=22, expect_kernel="mf_row4_kernel", layout="auto", stage_ab=True, outlier=True)
+    print("worst ratio vs the 2e-3 attend bar:", worst)
+
+
+@pytest.mark.parametrize("B,T0,kernel", [(64, 8192 - 4, "mf_row4_kernel"), (2, 32768 + 125, "mf_k_kernel")])
+def test_4bit_gqa_shapes_on_the_matrix_pipe_stages(oracle, B, T0, kernel):
+    """4-bit K / V, 32 / 8 heads (the reference's Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53; round 4): BASELINE config 4's
+    geometry (B = 64, 8k keys, R = 128: one mf_row4_kernel launch per layer, across a K flush at step 4) and the config-5 slice's row
+    length (32k keys: mf_k_kernel + mf_v_kernel), keys with outlier channels, stage by stage (rows the softmax consumed within 1e-3,
+    attend half on those rows within 2e-3), 9-tuples of the sampled units bit-identical to the reference logic's."""
+    seen, worst = run_sampled(B=B, nh=32, nh_kv=8, T0=T0, R=128, bits=4, g=32, steps=8, samples=[(0, 0), (B - 1, 7), (B // 2, 3)],
+                              seed=23, expect_kernel=kernel, layout="auto", stage_ab=True, outlier=True, masked=(B == 2))
     print("worst ratio vs the 2e-3 attend bar:", worst)
 
 

@@ -264,7 +264,7 @@ def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked,
     _stage_ab_steps(nh, nh_kv, T0, R, masked, form, R + 9, k_prompt=mk, k_step=mk, v_prompt=mo, v_step=mo, q_step=mo)
 
 
-def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_prompt, v_step, q_step, check_at=None):
+def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_prompt, v_step, q_step, check_at=None, bits=2):
     """The stage A / B loop of test_mf_decode_steps_match_reference_logic over caller-made inputs (f(seed, heads, T))."""
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, KiviLayerCacheMF, kivi_attention_decode, make_layer_cache
@@ -272,13 +272,13 @@ def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_p
     if form == "row" and nh // nh_kv == 8 and T0 + steps + 1 > 4608:
         pytest.skip("nh / nh_kv = 8: the eight score rows of a unit fit the LDS up to 4608 keys")
     B, D, g = 2, 128, 32
-    cfg = KiviConfig(2, 2, g, R)
+    cfg = KiviConfig(bits, bits, g, R)
     k0, v0 = k_prompt(1, nh_kv, T0), v_prompt(2, nh_kv, T0)
     layer = make_layer_cache(cfg, B, nh_kv, D, T0 + 8, "cuda", num_heads=nh)    # small capacity: the cache must grow
     assert isinstance(layer, KiviLayerCacheMF)
     layer.flags = _lib.GQA_FORCE_SPLIT if form == "split" else (_lib.GQA_FORCE_ROW | _lib.GQA_DUMP_SCORES)
     layer.prefill(k0.cuda(), v0.cuda())
-    past = H.prefill_cache(k0, v0, 2, 2, g, R)
+    past = H.prefill_cache(k0, v0, bits, bits, g, R)
     _cmp_cache(layer.as_tuple(), past)
     gen = torch.Generator().manual_seed(5)
     worst_a = worst_b = 0.0
@@ -296,13 +296,13 @@ def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_p
         out = kivi_attention_decode(q.cuda(), kn.cuda(), vn.cuda(), layer, attention_mask=None if mask is None else mask.cuda())
         assert torch.isfinite(out).all(), s
         x_gpu = layer._native[4][0][:B, :nh, :, :n].cpu()                            # the row the softmax / the sV launch consumed
-        ref, past_ref, x_ref = H.decode_step(q, kn, vn, past, 2, 2, g, R, attention_mask=mask, return_scores=True)
+        ref, past_ref, x_ref = H.decode_step(q, kn, vn, past, bits, bits, g, R, attention_mask=mask, return_scores=True)
         assert torch.isfinite(x_ref.float()).all() and torch.isfinite(ref.float()).all(), "test inputs must keep the reference finite"
         live = x_ref.float() > -60000                                                # fully masked keys: both sides at the fp16 minimum
         ok, ra = gemv_close(torch.where(live, x_gpu.float(), 0.0), torch.where(live, x_ref.float(), 0.0), rtol=1e-3)
         assert ok, ("scores", s, ra)
         assert torch.equal(x_gpu[~live], x_ref[~live])
-        ref_b, past_b = H.decode_step(q, kn, vn, past, 2, 2, g, R, attention_mask=mask, scores_override=x_gpu)
+        ref_b, past_b = H.decode_step(q, kn, vn, past, bits, bits, g, R, attention_mask=mask, scores_override=x_gpu)
         ok, rb = gemv_close(out, ref_b, rtol=2e-3)
         assert ok, ("attend", s, rb)
         worst_a, worst_b = max(worst_a, ra), max(worst_b, rb)

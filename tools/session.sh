@@ -19,6 +19,7 @@
 #                    + 1000 / 2000 for hi / lo rows in the qK^T / sV phase, KIVI_MF_STAG_US): parity of the variants through the
 #                    row-form tests, then same-box bench lines
 #   xcd              two-launch form with a unit's blocks on one XCD (tuning build, KIVI_MF_XCD) against the plain block order
+#   mf4              4-bit K / V on the matrix pipe: parity tests, then config 4 at --bits 4 against the VALU path
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -141,6 +142,15 @@ while [ $# -gt 0 ]; do
                 KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_XCD=$x timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/xcd${x}_70b_$i.json 2>> $O/xcd.err; line $O/xcd${x}_70b_$i.json
                 KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_XCD=$x timeout 300 $BN --batch 1 --prompt 32752 --steps 10 --warmup 3 > $O/xcd${x}_b1_32k_$i.json 2>> $O/xcd.err; line $O/xcd${x}_b1_32k_$i.json
             done
+        done ;;
+    mf4)
+        # 4-bit K / V on the matrix pipe (nh / nh_kv = 4): its parity tests + the reference-class fixtures of that shape, then BASELINE
+        # config 4 at --bits 4 on the matrix pipe against the VALU kernels of the hook-state layout (same box)
+        timeout 1200 python -m pytest tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=40 -k "mfma4 or b4_r" > $O/mf4_tests.log 2>&1
+        echo "mf4 tests rc=$?" | tee -a $O/status.log; tail -60 $O/mf4_tests.log | cut -c1-400
+        for i in 1 2; do
+            timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/mf4_c4_$i.json 2>> $O/mf4.err; line $O/mf4_c4_$i.json
+            KIVI_TUNING=1 KIVI_NO_MFMA_LAYOUT=1 timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/mf4_c4_valu_$i.json 2>> $O/mf4.err; line $O/mf4_c4_valu_$i.json
         done ;;
     sq)
         name=$1; shift
