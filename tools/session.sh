@@ -20,6 +20,7 @@
 #                    row-form tests, then same-box bench lines
 #   xcd              two-launch form with a unit's blocks on one XCD (tuning build, KIVI_MF_XCD) against the plain block order
 #   mf4              4-bit K / V on the matrix pipe: parity tests, then config 4 at --bits 4 against the VALU path
+#   mf4prof          config 4 at --bits 4: kernel trace medians + HBM traffic; the config-5 slice at --bits 4 against the VALU path
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -152,6 +153,13 @@ while [ $# -gt 0 ]; do
             timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/mf4_c4_$i.json 2>> $O/mf4.err; line $O/mf4_c4_$i.json
             KIVI_TUNING=1 KIVI_NO_MFMA_LAYOUT=1 timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/mf4_c4_valu_$i.json 2>> $O/mf4.err; line $O/mf4_c4_valu_$i.json
         done ;;
+    mf4prof)
+        # BASELINE config 4 at --bits 4 on the matrix pipe: kernel trace medians + HBM traffic; the config-5 slice at --bits 4, matrix pipe
+        # (two launches) against the VALU kernels
+        trace_one config4_4bit 96 $C4 --bits 4 --steps 10 --warmup 3
+        pmc_one config4_4bit '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 4, "group": 32, "residual": 128}' $C4 --bits 4
+        timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5.json 2>> $O/mf4.err; line $O/mf4_c5.json
+        KIVI_TUNING=1 KIVI_NO_MFMA_LAYOUT=1 timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5_valu.json 2>> $O/mf4.err; line $O/mf4_c5_valu.json ;;
     sq)
         name=$1; shift
         extra=()
