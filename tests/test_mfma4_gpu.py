@@ -154,9 +154,11 @@ def test_gqa4_output_vs_oracle(mods, oracle, B, nh, nh_kv, T, kind):
 def test_gqa4_dynamic_range(mods, oracle, mag):
     """As tests/test_mfma_gpu.py::test_gqa_scores_dynamic_range / _output_: scales from the fp16 subnormals to ~4e3 (a 4-bit scale is
     a fifteenth of the range), the range flags set exactly for the units that hold a scale >= 256.
-    mag 1e-4 with the token magnitudes spread three decades below puts V values at 1e-7 and the V scales at 1-100 fp16-subnormal
-    ulps (2^-24): p'' * scale is then itself a subnormal fp16 and its hi / lo split is no longer exact -- measured 2.9e-3 of
-    max(|ref|, rms) there (the 2-bit scales are five times larger and stay inside 1.5e-3); the bar for that one case is 4e-3."""
+    mag 1e-4 with the token magnitudes spread three decades below puts V values at 1e-7, the V scales at 1-100 fp16-subnormal ulps
+    (2^-24) and the OUTPUTS into the fp16 subnormals (~100 ulps): p'' * scale is then itself a subnormal fp16, the lo part of small
+    probabilities falls below the grid, and the result lands within 2 subnormal ulps (1.2e-7) of the fp32-scale reference instead
+    of 1 (gemv_close's bar is rtol * max(|ref|, rms) + 1 ulp: ratio 1.9 measured; the 2-bit scales are five times larger and stay
+    inside it).  Known limit of the fp16 A operand, stated here and in DESIGN section 3.8: that one case is held to 3 ulps."""
     mfma, new_pack, matmul = mods
     B, nh, nh_kv, T = 2, 8, 2, 1056
     k = _ranged(3, B, nh_kv, T, mag, 3).cuda()
@@ -182,8 +184,8 @@ def test_gqa4_dynamic_range(mods, oracle, mag):
     o = mfma.gqa_output(probs, vst, T, None, 32, BITS)
     ref = matmul.cuda_bmm_fA_qB_outer(32, probs[..., :T], code, scale, mn, BITS)
     assert torch.isfinite(o).all() and torch.isfinite(ref).all()
-    ok, ratio = gemv_close(o, ref.cpu(), rtol=4e-3 if mag < 1e-3 else 1.5e-3)
-    assert ok, ("output", ratio)
+    ok, ratio = gemv_close(o, ref.cpu(), rtol=1.5e-3)
+    assert ratio <= (3.0 if mag < 1e-3 else 1.0), ("output", ratio)
 
 
 @pytest.mark.parametrize("form", ["split", "row"])
