@@ -12,6 +12,9 @@ steps).  Launches: rows whose scores fit the LDS (nh = nh_kv: <= 8192 keys, nh /
 one (mf_row_kernel / mf_row4_kernel); otherwise two (packed qK^T + residual scores + K append + softmax statistics, then
 softmax-on-the-fly + packed sV + fp16 window + V append / quantise).  Every store carries range flags (quant/mfma.py) that
 keep the fp16 operands of the matrix pipe finite for any finite scale.
+
+Round 4: also 4-bit K / V for nh / nh_kv = 4 (the reference's published Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53): the same
+state machine and calls over 10240-word super-blocks (kivi_mfma_layout.h, "KT4 / VT4").
 """
 from __future__ import annotations
 
@@ -62,7 +65,8 @@ def _scratch(device, B: int, nh: int, nh_kv: int, pitch: int, nseg: int, slices:
 
 
 class KiviLayerCacheMF:
-    """One layer's quantised KV cache (capacity `max_len` tokens, appended in place) for nh / nh_kv in {1, 4, 8}."""
+    """One layer's quantised KV cache (capacity `max_len` tokens, appended in place): 2-bit with nh / nh_kv in {1, 4, 8}, 4-bit with
+    nh / nh_kv = 4."""
 
     layout = "mfma"
 
