@@ -183,7 +183,8 @@ int run_mf_k(GqaKArgs& a, int units, int bits, hipStream_t s) {
     const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
     a.sb_blocks = (chunks + W - 1) / W;
     if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
-    if (bits == 4) {                                                // 4-bit codes (nh / nh_kv = 4: checked by the callers)
+    KIVI_REQUIRE(bits == 2 || (bits == 4 && a.ratio == 4), KIVI_EUNSUPPORTED, "mf_k: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, a.ratio);
+    if (bits == 4) {                                                // 4-bit codes: nh / nh_kv = 4
         if (W == 4) launch_mf_k<4, 4, 4, 0, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4, 0, 4>(a, units, spw, s);
         return kivi_launch_status("mf_k");
     }
@@ -782,7 +783,8 @@ int kivi_mf_run_v(const void* v_args, int prob, int bits, hipStream_t s) {
 #endif
     const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
     const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
-    if (bits == 4) {                                                // 4-bit codes (nh / nh_kv = 4: checked by the callers)
+    KIVI_REQUIRE(bits == 2 || (bits == 4 && R == 4), KIVI_EUNSUPPORTED, "mf_v: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, R);
+    if (bits == 4) {                                                // 4-bit codes: nh / nh_kv = 4
         if (prob) KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, true, false, 4>), grid, dim3(256), lds, s, a);
         else KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, false, false, 4>), grid, dim3(256), lds, s, a);
         return kivi_launch_status("mf_v");
