@@ -453,7 +453,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 accumulate over int2 codes, fp16 in/out", "data": "synthetic",
             "config": {"workload": "kivi_decode_attention_hotpath: per layer fused qK^T + residual + softmax + fused sV + "
                                    "residual + in-place KV append/quantise; 32 layers, no dense projections",
-                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (2-bit g=32 D=128 on the matrix-pipe layout: nh == nh_kv and rows <= 8192 keys 1 launch, else 2; other shapes on the hook-state layout: 1 decode-row launch or qK^T + [row softmax] + sV; +1 K flush every R steps)",
+                       "launches_per_layer": "composed (~20)" if args.unfused else "fused (g=32 D=128, 2-bit or 4-bit with nh / nh_kv = 4, on the matrix-pipe layout: rows that fit the LDS 1 launch, else 2; other shapes on the hook-state layout: 1 decode-row launch or qK^T + [row softmax] + sV; +1 K flush every R steps)",
                        "layers": L, "batch_per_gpu": B, "heads": nh, "kv_heads": nh_kv, "head_dim": D, "prompt_len": T0,
                        "kv_len_end": layers[0].kv_seq_len, "k_bits": bits, "v_bits": bits, "group_size": g,
                        "residual_length": R, "parallelism": f"batch-sharded replicas x{world} (no data-path collective)",

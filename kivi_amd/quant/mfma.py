@@ -140,7 +140,7 @@ _OUT_WS = {}
 def gqa_output(probs: torch.Tensor, store: torch.Tensor, T: int, out: torch.Tensor = None, group_size: int = 32, bits: int = 2) -> torch.Tensor:
     """out[b, h, 0, :] = packed sV over tokens [0, T) of a VT store for given fp16 attention weights probs (B, nh, 1, >= T)
     (rows 16-byte aligned, pitch a multiple of 8): cuda_bmm_fA_qB_outer at llama_kivi.py:382 on the matrix-pipe layout,
-    nh / nh_kv in {1, 4}."""
+    nh / nh_kv in {1, 4, 8} at 2 bits, 4 at 4 bits."""
     B, nh = probs.shape[0], probs.shape[1]
     nh_kv = store.shape[1]
     assert probs.dtype == torch.float16 and probs.stride(3) == 1
