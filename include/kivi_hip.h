@@ -293,7 +293,7 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * residual scores -> softmax -> window -> packed sV; `scores` / `stats` / `workspace` are validated but not touched) when the
  * score rows of a (batch row, kv head) unit fit the LDS and the units fill the chip:
  *   nh == nh_kv      rows of <= 8192 keys and (>= 192 units, or <= 4096 packed keys at any batch)      -> mf_row_kernel
- *   nh / nh_kv == 4  rows of <= 9216 keys and >= 128 units                                            -> mf_row4_kernel
+ *   nh / nh_kv == 4  rows of <= 9216 keys and >= 128 units (4-bit codes: >= 192)                       -> mf_row4_kernel
  *   nh / nh_kv == 8  rows of <= 4608 keys and >= 192 units                                            -> mf_row4_kernel<R = 8>
  * Otherwise two launches:
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies

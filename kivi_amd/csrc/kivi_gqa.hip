@@ -620,7 +620,7 @@ int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh,
 int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, hipStream_t s);
 
 // One launch (true) or two for a step whose LONGEST row has n_rows keys (kivi_gqa_decode's rule; also part of kivi_mf_step_key)
-static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags) {
+static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags, int bits = 2) {
     if (!((R == 1 && n_rows <= 8192) || (R == 4 && n_rows <= 9216) || (R == 8 && n_rows <= 4608))) return false;
     static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
     if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return false;
@@ -630,7 +630,9 @@ static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags)
     // profiles/r03_other_shapes.log)
     // (R = 8, 4000 keys: 128 units 1.65 ms per 32-layer step in one launch against 1.39 in two, 512 units 2.42 against 3.65;
     // profiles/r04_other_shapes.log)
-    const int min_units = R == 4 ? 128 : 192;
+    // (R = 4 at 4 bits, --bits 4 bench lines, ms per 32-layer step, one launch vs two: 128 units x 8k keys 1.97 vs 1.73, 256 units x 2k
+    // 1.02 vs 1.17, 512 units x 2k 1.51 vs 2.05; profiles/r04_mf4_config4.log)
+    const int min_units = R == 4 ? (bits == 4 ? 192 : 128) : 192;
     return units >= min_units || (R == 1 && nsbk <= 8) || (flags & KIVI_GQA_FORCE_ROW);
 }
 
@@ -843,7 +845,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.dyn = (const MfStep*)p->dyn_step;
     // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
     // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks per CU)
-    if (mf_one_launch(R, units, n_rows, nsbk, p->flags)) return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, s);
+    if (mf_one_launch(R, units, n_rows, nsbk, p->flags, bits)) return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, s);
     int rc = skipk ? 0 : kivi_mf_run_k(&k, units, bits, s);
     if (rc) return rc;
     if (timev) kivi_set_launch_events(held.start, held.stop);

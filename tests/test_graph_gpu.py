@@ -18,16 +18,17 @@ def _tuples_equal(a, b):
     assert ta[8] == tb[8]
 
 
-@pytest.mark.parametrize("B,nh,nh_kv,T0,R,form,masked", [(2, 4, 4, 70, 32, "row", False), (2, 8, 2, 1100, 128, "row", True),
-                                                           (2, 4, 4, 600, 64, "split", True), (2, 8, 2, 500, 32, "split", False),
-                                                           (1, 16, 2, 480, 32, "split", False), (2, 16, 2, 300, 32, "row", False),
-                                                           (8, 32, 32, 4080, 32, "auto", False)])
-def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked):
+@pytest.mark.parametrize("B,nh,nh_kv,T0,R,form,masked,bits", [(2, 4, 4, 70, 32, "row", False, 2), (2, 8, 2, 1100, 128, "row", True, 2),
+                                                                (2, 4, 4, 600, 64, "split", True, 2), (2, 8, 2, 500, 32, "split", False, 2),
+                                                                (1, 16, 2, 480, 32, "split", False, 2), (2, 16, 2, 300, 32, "row", False, 2),
+                                                                (8, 32, 32, 4080, 32, "auto", False, 2),
+                                                                (2, 8, 2, 460, 32, "row", True, 4), (2, 8, 2, 500, 32, "split", False, 4)])
+def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked, bits):
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
     from kivi_amd.graph import MfStepDriver
     D = 128
-    cfg = KiviConfig(2, 2, 32, R)
+    cfg = KiviConfig(bits, bits, 32, R)
     k0, v0 = make_kv(1, B, nh_kv, T0, D, "outlier").cuda(), make_kv(2, B, nh_kv, T0, D).cuda()
     a = make_layer_cache(cfg, B, nh_kv, D, T0 + 8, "cuda", num_heads=nh)          # small capacity: both must grow on the way
     a.flags = {"row": _lib.GQA_FORCE_ROW, "split": _lib.GQA_FORCE_SPLIT, "auto": 0}[form]
@@ -61,13 +62,14 @@ def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked):
     assert len(keys) >= 1 + crossings, (keys, crossings)     # a store gaining a super-block starts a new geometry class
 
 
-@pytest.mark.parametrize("B,nh,nh_kv,T0,R", [(2, 4, 4, 460, 32), (2, 8, 2, 900, 128), (4, 32, 32, 4080, 32), (1, 32, 32, 8100, 32)])
-def test_graph_replay_bit_identical_to_eager(B, nh, nh_kv, T0, R):
+@pytest.mark.parametrize("B,nh,nh_kv,T0,R,bits", [(2, 4, 4, 460, 32, 2), (2, 8, 2, 900, 128, 2), (4, 32, 32, 4080, 32, 2), (1, 32, 32, 8100, 32, 2),
+                                                  (2, 8, 2, 900, 128, 4)])
+def test_graph_replay_bit_identical_to_eager(B, nh, nh_kv, T0, R, bits):
     """Two layers replayed from one hipGraph (kivi_amd.graph.GraphedDecode) against the eager steps on cloned caches."""
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
     from kivi_amd.graph import GraphedDecode, MfStepDriver
     D, L = 128, 2
-    cfg = KiviConfig(2, 2, 32, R)
+    cfg = KiviConfig(bits, bits, 32, R)
     eager, graphed = [], []
     for layer in range(L):
         k0, v0 = make_kv(10 + layer, B, nh_kv, T0, D).cuda(), make_kv(20 + layer, B, nh_kv, T0, D).cuda()
