@@ -338,8 +338,10 @@ def main():
             if profs:           # HBM bytes per launch from the newest rocprofv3 --pmc passes of the same command (profiles/)
                 try:
                     pj = json.load(open(profs[-1]))
-                    ent = pj.get("kernels", {}).get(kname)
-                    if ent and ent.get("config") == {"B": B, "nh": nh, "nh_kv": nh_kv, "prompt": T0, "bits": bits, "group": g, "residual": R}:
+                    want = {"B": B, "nh": nh, "nh_kv": nh_kv, "prompt": T0, "bits": bits, "group": g, "residual": R}
+                    # (one entry per kernel and configuration: "<kernel>" or "<kernel>@<label>")
+                    ent = next((e for key, e in pj.get("kernels", {}).items() if key.split("@")[0] == kname and e.get("config") == want), None)
+                    if ent:
                         traffic = ent["hbm_bytes_per_launch"]
                         traffic_src = ("profiles/" + os.path.basename(profs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                        "passes of this command, x2 gfx950 FETCH_SIZE correction; a tracked measurement, not collected in this run)")
