@@ -289,12 +289,17 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
                     int group_size, int bits, void* workspace, int64_t workspace_bytes, kivi_stream_t stream);
 
 /*
- * kivi_gqa_decode: the whole decode step of one layer over the KT / VT layouts.  ONE launch (packed qK^T -> LDS scores ->
- * residual scores -> softmax -> window -> packed sV; `scores` / `stats` / `workspace` are validated but not touched) when the
- * score rows of a (batch row, kv head) unit fit the LDS and the units fill the chip:
+ * kivi_gqa_decode: the whole decode step of one layer over the KT / VT layouts.  ONE launch (packed qK^T -> LDS scores [softmax
+ * statistics per 512-token segment inside the K walk] -> residual scores -> window -> packed sV with the probabilities made on the
+ * fly) when the score rows of a (batch row, kv head) unit fit the LDS and the units fill the chip:
  *   nh == nh_kv      rows of <= 8192 keys and (>= 192 units, or <= 4096 packed keys at any batch)      -> mf_row_kernel
  *   nh / nh_kv == 4  rows of <= 9216 keys and >= 128 units (4-bit codes: >= 192)                       -> mf_row4_kernel
  *   nh / nh_kv == 8  rows of <= 4608 keys and >= 192 units                                            -> mf_row4_kernel<R = 8>
+ * For nh / nh_kv in {4, 8} LONGER rows (and rows of few units, to fill the chip) are cut into S slices of whole super-blocks, one
+ * block per slice, still in ONE launch: the slices of a unit exchange their (max, sum exp) through `stats` (arrival counters in the
+ * second half of the workspace's counter area), form the same probabilities a single block would, and their partial outputs meet
+ * in `workspace` (S slots per unit).  Blocks of such a launch wait for each other: every block is resident at once (<= 512), or
+ * block ids are handed out in start order by a ticket counter (the last word of the counter area).
  * Otherwise two launches:
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies
  *      1/sqrt(D) and the mask (:339, :364-372), writes the scaled scores to `scores` and (max, sum exp) of every
@@ -310,14 +315,16 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * kres), v_window_rows (v_win_start + v_res_len + 1 <= v_window_rows: the V append), vt_superblocks (Tv + 1 <= 512 *
  * vt_superblocks when v_flush), kt_superblocks (Tq <= 512 * kt_superblocks).
  * flags: KIVI_GQA_FORCE_SPLIT = the two-launch form even where the one-launch form applies, KIVI_GQA_FORCE_ROW = the
- * one-launch form for any number of units (rows that fit the LDS as above) -- tests and tuning.  KIVI_GQA_DUMP_SCORES
- * (tests): the one-launch form also writes the fp16 rows its softmax consumes (scaled, mask added: what the two-launch form
- * leaves in `scores`) to `scores`, through separate instantiations of the kernels.
+ * one-launch form for any number of units (rows that fit the LDS as above), KIVI_GQA_SLICES(n) = n slices per row (nh / nh_kv in
+ * {4, 8}) -- tests and tuning.  KIVI_GQA_DUMP_SCORES (tests): the one-launch form also writes the fp16 rows its softmax statistics
+ * are taken from (scaled, mask added: what the two-launch form leaves in `scores`) to `scores` -- nh / nh_kv in {4, 8}: the product
+ * kernel, through a run-time pointer; nh == nh_kv: separate instantiations.
  * kt_range / vt_range: the range flags of the two stores (see above); the V flush may set vt_range.
  */
 #define KIVI_GQA_FORCE_SPLIT 1
 #define KIVI_GQA_FORCE_ROW 2
 #define KIVI_GQA_DUMP_SCORES 8
+#define KIVI_GQA_SLICES(n) (((n) & 0xFF) << 8)
 /* the fp16 value window is a RING of v_window_rows rows (row of window token t = (v_win_start + t) mod v_window_rows):
  * residual_length + 1 rows suffice and nothing is ever compacted; nh / nh_kv in {1, 4} */
 #define KIVI_GQA_WINDOW_RING 4
@@ -355,6 +362,9 @@ typedef struct {
     const void* dyn_step;                              /* device kivi_mf_step or null (lengths from the fields above) */
 } kivi_gqa_decode_args;
 int kivi_gqa_decode(const kivi_gqa_decode_args* args, kivi_stream_t stream);
+/* the launch plan kivi_gqa_decode follows for a step of this geometry: 0 = two launches, S >= 1 = one launch with every row cut
+ * into S slices (1: a block per row); -1: bad arguments.  dyn != 0: the plan of the step's whole geometry class (dyn_step). */
+int kivi_mf_launch_plan(int B, int nh, int nh_kv, int64_t Tq, int k_res_len, int residual_length, int flags, int bits, int dyn);
 
 /* ------------------------------------------------------ layer step --- */
 
@@ -422,7 +432,8 @@ int kivi_mf_decode_layer_dyn(const kivi_mf_layer_desc* layer, const kivi_mf_step
                              int64_t q_sb, int64_t q_sh, int nh, const void* knew, int64_t kn_sb, int64_t kn_sh, const void* vnew,
                              int64_t vn_sb, int64_t vn_sh, const void* mask, int64_t mask_sb, void* out, int64_t out_sb,
                              int64_t out_sh, kivi_stream_t stream);
-/* geometry class of a step (-1: bad arguments); flags = the descriptor's KIVI_GQA_* flags */
+/* geometry class of a step (-1: bad arguments): the super-block counts of both stores and whether the step flushes a value; the
+ * launch plan (one launch / S slices / two launches) is a function of the class and of constants of the call (shape, bits, flags) */
 int64_t kivi_mf_step_key(const kivi_mf_step* step, int B, int nh, int nh_kv, int residual_length, int flags);
 /* lengths after the attend phase of one step (llama_kivi.py:333-336, :377, :386-399); returns 1 when the K residual is full
  * (the K flush of :343-356 is due), 0 otherwise, < 0 on inconsistent lengths.  window_rows: rows of the ring window buffer. */

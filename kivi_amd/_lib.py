@@ -96,6 +96,11 @@ class MfStep(ctypes.Structure):
 GQA_FORCE_SPLIT, GQA_FORCE_ROW, GQA_WINDOW_RING, GQA_DUMP_SCORES = 1, 2, 4, 8
 
 
+def gqa_slices(n: int) -> int:
+    """KIVI_GQA_SLICES(n): force the one-launch form with n slices per row (nh / nh_kv in {4, 8}; tests, tuning)."""
+    return (n & 0xFF) << 8
+
+
 class MfLayerDesc(ctypes.Structure):
     """kivi_mf_layer_desc (include/kivi_hip.h), field for field."""
     _fields_ = [
@@ -153,6 +158,7 @@ SIGNATURES = {
     "kivi_gqa_output": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _i32,
                                _i32, _vp, _i64, _vp]),
     "kivi_gqa_decode": (_i32, [ctypes.POINTER(GqaDecodeArgs), _vp]),
+    "kivi_mf_launch_plan": (_i32, [_i32, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32]),
     "kivi_mf_decode_layer": (_i32, [ctypes.POINTER(MfLayerDesc), ctypes.POINTER(_i64), _vp, _i64, _i64, _i32, _vp, _i64, _i64,
                                     _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "kivi_mf_decode_layer_dyn": (_i32, [ctypes.POINTER(MfLayerDesc), ctypes.POINTER(MfStep), _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64,

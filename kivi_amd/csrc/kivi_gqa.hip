@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void kt_pack_kernel(const uint16_t* k, int64_t
     const int hidx = kt_sm_half((int)(blk & 15), 2 * lane);    // channel 2l (even): the pair (2l, 2l+1) is one word
     (sb + KIVI_MF_SB_SCALE_WORD0)[hidx >> 1] = scale2;
     (sb + KIVI_MF_SB_MN_WORD0)[hidx >> 1] = mn2;
-    // range flag of the unit (kivi_mfma_layout.h): sticky, every writer stores the same value
-    if ((scale2 & 0xFFFFu) >= KIVI_MF_BIG_SCALE_BITS || (scale2 >> 16) >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+    // range marks of the unit (kivi_mfma_layout.h): sticky, every writer stores the same bytes
+    mf_range_mark(range + unit, scale2 & 0xFFFFu);
+    mf_range_mark(range + unit, scale2 >> 16);
 }
 
 // Per-token V quantise + pack of a prompt straight into the VT layout (prompt pass, models/llama_kivi.py:441-448: the
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* v, int64_t
     *(u32x4*)(cw + lane * 4) = *(const u32x4*)(tile + lane * 4);
     (sb + KIVI_MF_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;    // vt_half(8 kb + 2 ee, c) / 2 == lane
     (sb + KIVI_MF_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
-    if ((scale2 & 0xFFFFu) >= KIVI_MF_BIG_SCALE_BITS || (scale2 >> 16) >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;   // range flag (kt_pack_kernel)
+    mf_range_mark(range + unit, scale2 & 0xFFFFu);          // range marks (kt_pack_kernel)
+    mf_range_mark(range + unit, scale2 >> 16);
 }
 
 // KT <-> reference layout K_code_T (B, nh_kv, D, T/16), K_scale_T / K_mn_T (B, nh_kv, D, T/32) (llama_kivi.py:454-455).
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(128) void kt_relayout_kernel(MfStore st, uint32_t* 
         const uint16_t sc = scale[sidx];
         ks[kt_sm_half(gsb, d)] = sc;
         km[kt_sm_half(gsb, d)] = mn[sidx];
-        if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;      // range flag of the unit (kivi_mfma_layout.h)
+        mf_range_mark(range + unit, sc);                         // range marks of the unit (kivi_mfma_layout.h)
     }
 }
 
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* 
         if (wi < 4) {
             const uint16_t sc = (t < T) ? scale[b * sm_sb + hk * sm_sh + t * sm_sr + wi] : (uint16_t)0;
             vs[vt_half(tt, wi)] = sc;
-            if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;  // range flag of the unit (kivi_mfma_layout.h)
+            mf_range_mark(range + unit, sc);                     // range marks of the unit (kivi_mfma_layout.h)
             vm[vt_half(tt, wi)] = (t < T) ? mn[b * sm_sb + hk * sm_sh + t * sm_sr + wi] : (uint16_t)0;
         }
     }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(128) void kt_pack4_kernel(const uint16_t* k, int64_
     const int hidx = kt_sm_half((int)(blk & 15), d);
     ((uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0))[hidx] = gq.scale;
     ((uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0))[hidx] = gq.mn;
-    if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;   // range flag of the unit (kt_pack_kernel)
+    mf_range_mark(range + unit, gq.scale);                   // range marks of the unit (kt_pack_kernel)
 }
 
 __global__ __launch_bounds__(128) void vt_pack4_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(128) void vt_pack4_kernel(const uint16_t* v, int64_
     }
     ((uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0) + (bi & 15) * 128)[vt_half(tt, c)] = gq.scale;
     ((uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0) + (bi & 15) * 128)[vt_half(tt, c)] = gq.mn;
-    if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+    mf_range_mark(range + unit, gq.scale);
 }
 
 // KT4 <-> K_code_T (B, nh_kv, D, T/8), K_scale_T / K_mn_T (B, nh_kv, D, T/32): 4 reference words per (channel, block)
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(128) void kt_relayout4_kernel(MfStore st, uint32_t*
         const uint16_t sc = scale[sidx];
         ks[kt_sm_half(gsb, d)] = sc;
         km[kt_sm_half(gsb, d)] = mn[sidx];
-        if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+        mf_range_mark(range + unit, sc);
     }
 }
 
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void vt_relayout4_kernel(MfStore st, uint32_t*
             const int64_t t = (int64_t)blk * 32 + tt;
             const uint16_t sc = (t < T) ? scale[b * sm_sb + hk * sm_sh + t * sm_sr + g] : (uint16_t)0;
             vs[vt_half(tt, g)] = sc;
-            if (sc >= KIVI_MF_BIG_SCALE_BITS) range[unit] = 1;
+            mf_range_mark(range + unit, sc);
             vm[vt_half(tt, g)] = (t < T) ? mn[b * sm_sb + hk * sm_sh + t * sm_sr + g] : (uint16_t)0;
         }
     }
@@ -617,23 +619,49 @@ int kivi_mf_run_k(void* k_args, int units, int bits, hipStream_t s);
 int kivi_mf_run_v(const void* v_args, int prob, int bits, hipStream_t s);
 int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int nh_kv, int64_t T, const int* range, int* sp,
                        hipStream_t s);
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, hipStream_t s);
+int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, hipStream_t s);
 
-// One launch (true) or two for a step whose LONGEST row has n_rows keys (kivi_gqa_decode's rule; also part of kivi_mf_step_key)
-static bool mf_one_launch(int R, int units, int64_t n_rows, int nsbk, int flags, int bits = 2) {
-    if (!((R == 1 && n_rows <= 8192) || (R == 4 && n_rows <= 9216) || (R == 8 && n_rows <= 4608))) return false;
+// Launch plan of a step whose LONGEST row has n_rows keys (nsbk super-blocks of packed keys + up to res_cap + 1 fp16 ones):
+//   0      two launches (mf_k_kernel -> score rows + statistics in memory -> mf_v_kernel)
+//   S >= 1 one launch, every unit's row cut into S slices of whole super-blocks, one block each (nh == nh_kv: mf_row_kernel, S = 1;
+//          nh / nh_kv in {4, 8}: mf_row4_kernel -- S > 1 when the R score rows of a whole row do not fit the LDS, or to fill the chip
+//          when there are few units; the slices exchange their softmax statistics inside the launch)
+// A pure function of the step's geometry class (kivi_mf_step_key) and the call's constants, so eager and replayed steps agree.
+// KIVI_GQA_SLICES(n) in the flags forces n slices (tests, tuning).
+static int mf_plan(int R, int units, int64_t n_rows, int nsbk, int res_cap, int flags, int bits = 2) {
     static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
-    if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return false;
-    // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
-    // of a row block to take one super-block each (nh == nh_kv, <= 4096 packed keys): then one launch beats two whatever
-    // the batch (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79,
-    // profiles/r03_other_shapes.log)
-    // (R = 8, 4000 keys: 128 units 1.65 ms per 32-layer step in one launch against 1.39 in two, 512 units 2.42 against 3.65;
-    // profiles/r04_other_shapes.log)
-    // (R = 4 at 4 bits, --bits 4 bench lines, ms per 32-layer step, one launch vs two: 128 units x 8k keys 1.97 vs 1.73, 256 units x 2k
-    // 1.02 vs 1.17, 512 units x 2k 1.51 vs 2.05; profiles/r04_mf4_config4.log)
-    const int min_units = R == 4 ? (bits == 4 ? 192 : 128) : 192;
-    return units >= min_units || (R == 1 && nsbk <= 8) || (flags & KIVI_GQA_FORCE_ROW);
+    if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return 0;
+    if (R == 1) {
+        if (n_rows > 8192) return 0;
+        // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
+        // of a row block to take one super-block each (<= 4096 packed keys): then one launch beats two whatever the batch
+        // (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79, profiles/r03_other_shapes.log)
+        return (units >= 192 || nsbk <= 8 || (flags & KIVI_GQA_FORCE_ROW)) ? 1 : 0;
+    }
+    if (R != 4 && R != 8) return 0;
+    const int64_t cap = R == 4 ? 9216 : 4608;                       // keys whose R score rows fit the LDS of a block (mf_row4_kernel)
+    auto blk_rows = [&](int S) -> int64_t {                         // the longest row of a block when a row is cut into S slices
+        if (S <= 1) return n_rows;
+        const int spb = (nsbk + S - 1) / S;
+        return (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1;
+    };
+    const int forced = (flags & KIVI_GQA_FORCE_ROW) ? 1 : ((flags >> 8) & 0xFF);          // FORCE_ROW: a block per row
+    if (forced) return (forced <= (nsbk > 1 ? nsbk : 1) && forced <= 64 && blk_rows(forced) <= cap && (forced == 1 || units <= KIVI_GQA_WS_COUNTERS / 2 - 1)) ? forced : 0;
+    int S = 1;
+    while (S <= nsbk && S <= 64 && blk_rows(S) > cap) S++;
+    if (S > nsbk || S > 64) return 0;
+    // few units: more, shorter slices while a slice keeps >= 4 super-blocks (one per wave of its block in the K walk) and the grid
+    // stays within the 2 blocks per CU that are resident at once
+    while ((int64_t)units * S * 2 <= 512 && (nsbk + 2 * S - 1) / (2 * S) >= 4 && 2 * S <= 64 && blk_rows(2 * S) <= cap) S *= 2;
+    if (S > 1 && units > KIVI_GQA_WS_COUNTERS / 2 - 1) S = blk_rows(1) <= cap ? 1 : 0;
+    if (S == 1) {
+        // (R = 8, 4000 keys: 128 units 1.65 ms per 32-layer step in one launch against 1.39 in two, 512 units 2.42 against 3.65;
+        // R = 4 at 4 bits, one launch vs two: 128 units x 8k keys 1.97 vs 1.73, 256 units x 2k 1.02 vs 1.17, 512 units x 2k 1.51 vs 2.05;
+        // profiles/r04_other_shapes.log, r04_mf4_config4.log)
+        const int min_units = R == 4 ? (bits == 4 ? 192 : 128) : 192;
+        return units >= min_units ? 1 : 0;
+    }
+    return S;
 }
 
 static_assert(sizeof(MfStep) == sizeof(kivi_mf_step) && offsetof(MfStep, Tv) == offsetof(kivi_mf_step, Tv) &&
@@ -641,13 +669,21 @@ static_assert(sizeof(MfStep) == sizeof(kivi_mf_step) && offsetof(MfStep, Tv) == 
               "the kernels read a kivi_mf_step through MfStep");
 
 // Geometry class of a decode step (include/kivi_hip.h): launches captured for one step may be replayed for every later step
-// with the same key.
+// with the same key -- the super-block counts of both stores and whether the step flushes a value.  The launch plan (mf_plan) is a
+// function of the class and of constants of the call (shape, bits, flags), so it needs no bit of its own.
 extern "C" int64_t kivi_mf_step_key(const kivi_mf_step* st, int B, int nh, int nh_kv, int residual_length, int flags) {
     if (!st || nh_kv <= 0 || nh <= 0 || nh % nh_kv) return -1;
-    const int R = nh / nh_kv;
+    (void)B; (void)residual_length; (void)flags;
     const int64_t nsbk = (st->Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS, nsbv = (st->Tv + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS;
-    const int64_t n_rows = nsbk * KIVI_MF_SB_TOKENS + residual_length;
-    return (nsbk << 40) | (nsbv << 16) | ((int64_t)(st->v_flush != 0) << 1) | (int64_t)mf_one_launch(R, B * nh_kv, n_rows, (int)nsbk, flags);
+    return (nsbk << 40) | (nsbv << 16) | ((int64_t)(st->v_flush != 0) << 1);
+}
+
+// The plan kivi_gqa_decode follows for a step (include/kivi_hip.h): 0 = two launches, S >= 1 = one launch with S slices per row
+extern "C" int kivi_mf_launch_plan(int B, int nh, int nh_kv, int64_t Tq, int k_res_len, int residual_length, int flags, int bits, int dyn) {
+    if (B <= 0 || nh_kv <= 0 || nh <= 0 || nh % nh_kv || Tq < 0 || k_res_len < 0 || residual_length <= 0) return -1;
+    const int nsbk = (int)((Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
+    const int64_t n_rows = dyn ? (int64_t)nsbk * KIVI_MF_SB_TOKENS + residual_length : Tq + k_res_len + 1;
+    return mf_plan(nh / nh_kv, B * nh_kv, n_rows, nsbk, residual_length, flags, bits);
 }
 
 extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh,
@@ -678,6 +714,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     a.range = (const int*)kt_range;
     a.dyn = nullptr;
+    a.dump = 0; a.xcount = nullptr; a.ticket = nullptr;
     return kivi_mf_run_k(&a, B * nh_kv, bits, (hipStream_t)stream);
 }
 
@@ -804,8 +841,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
     static const char* wt = KIVI_TUNE_ENV("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
     const int win_blocks = (nsbv > 0 && !(wt && atoi(wt) == 0)) ? units : 0;
-    const int nslot = S + (win_blocks ? 1 : 0);
-    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (int64_t)units * nslot * 2 * R * 128 * 4;
+    // launch plan: one launch (rows, or slices of rows, in the LDS) or two
+    const int plan = mf_plan(R, units, n_rows, nsbk, p->residual_length, p->flags, bits);
+    const int nslot = plan > 1 ? plan : (S + (win_blocks ? 1 : 0));
+    const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (plan == 1 ? 0 : (int64_t)units * nslot * 2 * R * 128 * 4);
     KIVI_REQUIRE(p->workspace && (uintptr_t)p->workspace % 16 == 0 && p->workspace_bytes >= need, KIVI_EINVAL,
                  "kivi_gqa_decode: workspace too small (%lld bytes needed)", (long long)need);
     hipStream_t s = (hipStream_t)stream;
@@ -822,6 +861,10 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.knew = (const uint16_t*)p->knew; k.knew_sb = p->knew_sb; k.knew_sh = p->knew_sh; k.res_len = p->k_res_len;
     k.range = (const int*)p->kt_range;
     k.dyn = (const MfStep*)p->dyn_step;
+    // sliced one-launch form: the second half of the counter area holds the statistics-exchange counters, its last word the ticket
+    k.dump = (p->flags & KIVI_GQA_DUMP_SCORES) != 0;
+    k.xcount = (int*)p->workspace + KIVI_GQA_WS_COUNTERS / 2;
+    k.ticket = (int*)p->workspace + KIVI_GQA_WS_COUNTERS - 1;
     static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
     static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};
@@ -843,9 +886,12 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     v.ws = (float*)((char*)p->workspace + (size_t)KIVI_GQA_WS_COUNTERS * 4);
     v.range = (int*)p->vt_range;
     v.dyn = (const MfStep*)p->dyn_step;
-    // rows that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of 4 waves per CU;
-    // nh / nh_kv == 4: the four score rows of a unit in one block, 2 blocks per CU)
-    if (mf_one_launch(R, units, n_rows, nsbk, p->flags, bits)) return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, s);
+    // rows (or slices of rows) that fit the LDS: the whole step of a (batch row, kv head) in one launch (nh == nh_kv: 4 blocks of
+    // 4 waves per CU; nh / nh_kv in {4, 8}: the R score rows of a unit / a slice in one block, 2 blocks per CU)
+    if (plan >= 1) {
+        if (plan > 1) { v.S = plan; v.nslot = plan; v.win_blocks = 0; }
+        return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, plan, p->residual_length, s);
+    }
     int rc = skipk ? 0 : kivi_mf_run_k(&k, units, bits, s);
     if (rc) return rc;
     if (timev) kivi_set_launch_events(held.start, held.stop);

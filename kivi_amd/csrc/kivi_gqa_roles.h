@@ -40,8 +40,15 @@ struct GqaKArgs {
     const uint16_t* knew;
     int64_t knew_sb, knew_sh;
     int res_len;                // keys already in the residual; the new one becomes index res_len
-    const int* range;           // [B * nh_kv] range flags of the K store (kivi_mfma_layout.h: a scale >= 256 was written)
+    const int* range;           // [B * nh_kv] range words of the K store (kivi_mfma_layout.h: marks for scales >= 256 / >= 2^-8)
     const MfStep* dyn;          // device-resident lengths (or null): Tq, res_len are read from it
+    // one-launch form (mf_row4_kernel): dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the fp16 rows the softmax statistics are taken
+    // from (scaled, mask added) also go to `out`; rows cut into S > 1 slices: `stats` is the exchange buffer [unit][slice][R][2]
+    // of the slices' (max, sum exp), `xcount` [units] their arrival counters (zero between launches), `ticket` (or null: every
+    // block of the grid is resident at once) one counter that hands out the block ids in the order the blocks START
+    int dump;
+    int* xcount;
+    int* ticket;
     __device__ __forceinline__ void take_dyn() {
         if (dyn) { Tq = dyn->Tq; res_len = dyn->k_res_len; }
     }
@@ -133,7 +140,7 @@ struct GqaVArgs {
     unsigned long long* dbg;    // phase time stamps or null
     int win_rows;               // > 0: the window buffer is a RING of that many rows (row of token t = (win_start + t) % win_rows); 0: linear
     const int* sp_rows;         // kivi_gqa_output: [B][nh] exponent Sp of every probability row (mf_row_sp_kernel)
-    int* range;                 // [B * nh_kv] range flags of the V store: read by every block, set by the V flush
+    int* range;                 // [B * nh_kv] range words of the V store: read by every block, marked by the V flush
     const MfStep* dyn;          // device-resident lengths (or null): Tv, res_len, win_start, flush are read from it
     __device__ __forceinline__ void take_dyn() {
         if (dyn) { Tv = dyn->Tv; res_len = dyn->v_res_len; win_start = dyn->v_win_start; flush = dyn->v_flush; }
@@ -180,8 +187,11 @@ __device__ __forceinline__ void gqa_row_consts(const GqaVArgs& a, int b, int h0,
 
 // Combine of a unit's partial sums by the block that arrives last (hand-off as in gemv_v_kernel<SPLIT>: write-through
 // payload, drained, one relaxed arrival counter; cdna_hip_programming.md G16).
+// also_reset: a second per-unit counter the last block puts back to zero (the statistics exchange of the sliced one-launch form:
+// a block arrives here only after it has left that exchange, so nobody still reads the counter).
 template <int R>
-__device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0) {
+__device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0,
+                                                       int* also_reset = nullptr) {
     __shared__ int last_flag;
     constexpr int RD = R * 128;
     // part_lds = [quantised part | window part] of this block; workspace [unit][slot][2][RD]
@@ -193,7 +203,10 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(a.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (old == a.nslot - 1);
-        if (last) __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+        if (last) {                                                 // next launch
+            __hip_atomic_store(a.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (also_reset) __hip_atomic_store(also_reset, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         last_flag = last;
     }
     __syncthreads();
@@ -339,8 +352,8 @@ struct GqaWindow {
                 const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
                 ((uint16_t*)(sbp + LY::SCALE_WORD0))[hidx] = gq.scale;
                 ((uint16_t*)(sbp + LY::MN_WORD0))[hidx] = gq.mn;
-                // range flag of the unit (kivi_mfma_layout.h): the token becomes part of the packed prefix with the NEXT step
-                if (gq.scale >= KIVI_MF_BIG_SCALE_BITS) a.range[b * a.nh_kv + hk] = 1;
+                // range marks of the unit (kivi_mfma_layout.h): the token becomes part of the packed prefix with the NEXT step
+                mf_range_mark(a.range + b * a.nh_kv + hk, gq.scale);
             }
         }
     }

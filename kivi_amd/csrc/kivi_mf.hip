@@ -58,7 +58,7 @@ constexpr int mf_k_lds_words() { return (R == 1 ? 64 : 0) + R * 256; }   // R = 
 template <int R, int W, int RING, int DIAG = 0, int BITS = 2>
 __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
     static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
-    extern __shared__ uint32_t lds_all[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     // the step's lengths: by value, or device-resident (a.dyn).  (Only these two scalars: a mutable copy of the whole argument block
     // cost 3-8 % of the raw-score launch -- the flush lambda then reads its fields from a local object instead of the kernarg segment.)
     const long long Tq = a.dyn ? a.dyn->Tq : (long long)a.Tq;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     };
 
     const rsrc_t rk = make_rsrc(mf_sb(a.kt, b, hk, 0), (uint32_t)((int64_t)a.nsb * a.kt.sb_s * 4));
-    const int big = __builtin_amdgcn_readfirstlane(a.range[unit]);  // range flag of the unit's K store (kivi_mfma_layout.h)
+    const int rsh = mf_range_shift(__builtin_amdgcn_readfirstlane(a.range[unit]));  // range shift of the unit's K store (kivi_mfma_layout.h)
     MfKSeq seq;
     seq.sb_bytes = (uint32_t)(a.kt.sb_s * 4);
     seq.sb_first = sb0;
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
     seq.ng_total = (int)(((Tq < tok_end ? Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
     if constexpr (R == 1) {
-        mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, big,
+        mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, rsh,
                         [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
         // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
         const int hb = (4 * (lane >> 4)) % R;                       // heads hb .. hb + 3 sit in this lane's result registers
-        mf_k_seqR<R, RING, BITS>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, big,
+        mf_k_seqR<R, RING, BITS>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, a.q_sh, rsh,
                            [&](int, int tt, int r, float v0, float v1) {
                                const uint32_t hp = mf_cvt_pair(v0, v1);
                                lds_o[(hb + r) * 512 + tt] = (uint16_t)(hp & 0xFFFFu);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void mf_probs_request(rsrc_t rx, uint32_t x_row_bytes
 }
 template <int R, bool PROB, int BITS = 2>
 __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, int64_t Tv, const float* M, const float* invS,
-                                               const int* sp, uint16_t* lds_p) {
+                                               const int* sp, int rsh, uint16_t* lds_p) {
     typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
     typedef float fp2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
@@ -240,7 +240,7 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
     const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp[r]);      // 2^-10 .. 2^14
+        const _Float16 m_sp = mf_p_mul_sp(sp[r], rsh);             // 2^-10 .. 2^14
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -252,8 +252,8 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
                 const fp2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
                 pp = __builtin_convertvector(e * (fp2){invS[r], invS[r]}, hp2);
             }
-            const _Float16 m_a = (BITS == 4 || i >= 2) ? (_Float16)64.0f : (_Float16)16.0f;             // tokens (e & 4): 2^6, else 2^4 (4-bit codes: 2^6)
-            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});   // (order: see mf_row_softmax)
+            const _Float16 m_a = mf_p_mul_a(BITS == 4 || i >= 2, rsh);                                 // tokens (e & 4): 2^6, else 2^4 (4-bit codes: 2^6)
+            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});   // (order: see mf_p_mul_a)
         }
         if (left < 8) {                                            // the end of the packed prefix falls into this lane's eight
 #pragma unroll
@@ -270,7 +270,7 @@ constexpr int MF_PW = 136;
 template <int R, int RING, bool PROB, bool HL = false, int BITS = 2>
 __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
     static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
-    extern __shared__ uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
     GqaVArgs a = a_in;
     a.take_dyn();
     __shared__ uint16_t pw[R][MF_PW];
@@ -289,20 +289,21 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
 
     float M[R], invS[R];
     int sp[R];
+    // range shift of the unit's V store: the blocks of a unit may read different words in the step whose V flush marks it (the token
+    // the mark is for is not part of this step's packed prefix); every block undoes its own 2^Sp before the hand-off
+    const int rsh = mf_range_shift(__builtin_amdgcn_readfirstlane(a.range[unit]));
     if constexpr (PROB) {
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
             M[rr] = 0.f;
             invS[rr] = 1.f;
-            sp[rr] = a.sp_rows[(int64_t)b * a.nh + h0 + rr];          // (mf_row_sp_kernel has applied the range flag)
+            // (mf_row_sp_kernel read the same word: nothing marks a store between the two launches of kivi_gqa_output)
+            sp[rr] = a.sp_rows[(int64_t)b * a.nh + h0 + rr];
         }
     } else {
-        // range flag of the unit's V store: the blocks of a unit may read different values in the step whose V flush sets it
-        // (the token it is set for is not part of this step's packed prefix); every block undoes its own 2^Sp before the hand-off
-        const int big = __builtin_amdgcn_readfirstlane(a.range[unit]);
         gqa_row_consts<R>(a, b, h0, M, invS);
 #pragma unroll
-        for (int rr = 0; rr < R; rr++) sp[rr] = mf_sp(1.0f / invS[rr], big);
+        for (int rr = 0; rr < R; rr++) sp[rr] = mf_sp(1.0f / invS[rr], rsh);
     }
 
     const rsrc_t rx = make_rsrc(a.x + b * a.x_sb + (int64_t)h0 * a.x_sh, (uint32_t)((R - 1) * a.x_sh * 2 + ((a.Tv + 7) & ~(int64_t)7) * 2));
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
             const int64_t tok0 = (int64_t)(sb_w0 + 4 * i) * KIVI_MF_SB_TOKENS;
             const int nb = (i == n_my - 1) ? nb_last : 16;
             __builtin_amdgcn_wave_barrier();                       // the previous super-block's LDS reads are over
-            mf_probs_store<R, PROB, BITS>(xv, tok0, a.Tv, M, invS, sp, lds_p);
+            mf_probs_store<R, PROB, BITS>(xv, tok0, a.Tv, M, invS, sp, rsh, lds_p);
             // the next super-block's scores fly during this one's stream
             if (i + 1 < n_my) mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), tok0 + 4 * KIVI_MF_SB_TOKENS, xv);
             __builtin_amdgcn_wave_barrier();
@@ -422,8 +423,8 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
     if (threadIdx.x == 0) {
         int e = 0;
         if (m > 0.f && m < __builtin_inff()) e = -((int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u) - 127);
-        // range flag of the (batch row, kv head) the row reads (mf_sp)
-        sp[row] = (e < 0 ? 0 : (e > 14 ? 14 : e)) - (range[b * nh_kv + h / (nh / nh_kv)] ? KIVI_MF_BIG_SHIFT : 0);
+        // + the range shift of the (batch row, kv head) the row reads (mf_sp)
+        sp[row] = (e < 0 ? 0 : (e > 14 ? 14 : e)) + mf_range_shift(range[b * nh_kv + h / (nh / nh_kv)]);
     }
 }
 
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     GqaVArgs av = av_in;
     ak.take_dyn();
     av.take_dyn();
-    extern __shared__ uint16_t row[];                              // [n_pad] fp16 scores, then p''
+    extern __shared__ __attribute__((aligned(16))) uint16_t row[];  // [n_pad] fp16 scores, then p''
     __shared__ float red[NW][128], resl[NW][128];
     __shared__ float zl[NW][128];
     __shared__ uint32_t q_lds[NW][64];
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     const int L = ak.res_len + 1;                                  // residual keys incl. the new one
     const int n = Tq + L;                                          // row length
     // range flags of the unit's stores (kivi_mfma_layout.h): where q'' / p'' are placed; read before this step's V flush can set one
-    const int kbig = __builtin_amdgcn_readfirstlane(ak.range[unit]), vbig = __builtin_amdgcn_readfirstlane(av.range[unit]);
+    const int krsh = mf_range_shift(__builtin_amdgcn_readfirstlane(ak.range[unit])), vrsh = mf_range_shift(__builtin_amdgcn_readfirstlane(av.range[unit]));
 
     const uint16_t* qrow = ak.q + b * ak.q_sb + (int64_t)hk * ak.q_sh;
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
         const int last = wave + (seq.n_sb - 1) * NW;                // this wave's last super-block
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], kbig,
+        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], krsh,
                          [&](int sb, int tt, float v) {
                              const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
                              row[sb * KIVI_MF_SB_TOKENS + tt] = h;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4), DUMP>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vbig,
+    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4), DUMP>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
                                                               DUMP ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
     __syncthreads();
     stamp(7);
@@ -585,158 +586,364 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
 }
 
 // ------------------------------------------------------------------------------------------------ fused row, R = 4 / 8
-// The whole decode step of one (batch row, kv head) with its R = 4 (or, round 4, 8) query heads in one block of NW waves (grouped
-// queries, rows whose R score rows fit the LDS: R n fp16 <= 72 KiB -- 9216 keys for R = 4, 4608 for R = 8 --, two blocks per CU): no
-// score / statistics round trip through memory, no second launch.  Dynamic LDS: [R][n_pad] fp16 scores -> p''; reused for the
-// per-wave partial sums at the end.
-// VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block; -3 % per launch
-// at BASELINE config 4, profiles/r04_row4_levers.log)
-// WSM: the softmax of the four rows by one wave each (mf_row_softmax_wave) instead of the whole block row after row
-template <int KRING, int VRING, int NW, bool DBG = false, bool DUMP = false, bool VHL = true, bool WSM = (NW == 4), int R = 4, int BITS = 2>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
+// The whole decode step of one (batch row, kv head) with its R = 4 (or 8) query heads in ONE launch: no score / statistics round
+// trip through memory, no second launch.  Round 5: the softmax is no longer a phase of its own --
+//   * its statistics come out of the K walk: when a wave has finished a 512-token super-block it takes (max, sum exp(x - max)) of
+//     that segment of the R rows from the LDS (the arithmetic of mf_k_kernel's flush: [+ mask,] one exponential per score) while
+//     its code ring keeps flying;
+//   * after ONE block barrier every wave merges the segments (+ the fp16 residual's scores) into (M, 1 / sum) of the R rows;
+//   * the probabilities p = fp16(exp(x - M) / sum) (the reference's cast, llama_kivi.py:375) times 2^(Sp + 4 | 6) are made in place,
+//     15-16 blocks at a time, by the wave that streams those blocks of the packed V (mf_probs_inplace), under its own ring.
+// (Round 4 ran three passes over the rows between two barriers, 16 of the launch's ~98 us at BASELINE config 4 with nothing streaming.)
+// Rows that do not fit the LDS (or too few units to fill the chip) are cut into S SLICES of whole super-blocks, one block each: a
+// slice's block walks its own keys and values; the slices of a unit exchange their (max, sum exp) through memory (one arrival
+// counter; blocks WAIT for each other: every block of the grid is resident at once, or the block ids are handed out by a ticket
+// counter in the order the blocks start, so a waiting block's partners have started or will start as soon as any older unit
+// finishes), form the same p as one block would, and their partial outputs meet in the workspace (gqa_arrive_and_combine).  The
+// last slice holds the tokens from the super-block of token Tv on -- the fp16 residual, the window, the appends and the V flush.
+// Dynamic LDS: [R][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
+// VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block)
+constexpr int MF_NSEG = 20;                                        // 512-token segments the rows of a block can hold (9216 / 512 = 18)
+
+__device__ __forceinline__ uint16_t mf_add_mask(uint16_t h, uint16_t m) {      // fp16(x + mask), clamped at the fp16 minimum (:366-372)
+    float v = (float)(_Float16)(h2f_bits(h) + h2f_bits(m));
+    if (v < -65504.0f) v = -65504.0f;
+    return f2h_bits(v);
+}
+
+// p'' of the tokens [t0, t0 + ntok) (indices into the block's rows; t0 a multiple of 32) of the R rows, in place: lane l owns tokens
+// 8 l .. 8 l + 7 of every head (mf_probs_store on LDS-resident scores).  `left0`: tokens of the piece inside the packed prefix.
+template <int R, int BITS>
+__device__ __forceinline__ void mf_probs_inplace(uint16_t* rows, int pitch, int t0, int ntok, int left0, const float* M, const float* invS,
+                                                 const int* sp, int rsh) {
+    typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+    typedef float fp2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    if (lane * 8 >= ntok) return;
+    const int left = left0 - lane * 8;
+    const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint16_t* p = rows + r * pitch + t0 + lane * 8;
+        const u32x4 xv = *(const u32x4*)p;
+        const _Float16 m_sp = mf_p_mul_sp(sp[r], rsh);             // 2^-10 .. 2^14
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t xw = xv[i];
+            const fp2 d = (fp2){mf_sub_lo(xw, -M[r]), mf_sub_hi(xw, -M[r])} * l2e;                     // kivi_exp(x - M)
+            const fp2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+            const hp2 pp = __builtin_convertvector(e * (fp2){invS[r], invS[r]}, hp2);
+            const _Float16 m_a = mf_p_mul_a(BITS == 4 || i >= 2, rsh);                                 // tokens (e & 4): 2^6, else 2^4 (4-bit codes: 2^6)
+            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});
+        }
+        if (left < 8) {                                            // the end of the packed prefix falls into (or before) this lane's eight
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] = (2 * i >= left) ? 0u : ((2 * i + 1 >= left) ? (o[i] & 0xFFFFu) : o[i]);
+        }
+        *(u32x4*)p = o;
+    }
+}
+
+template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2>
+__global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
     constexpr int NTH = NW * 64;
-    static_assert(R == 4 || (R == 8 && !VHL && WSM), "R = 8: chained hi / lo sV, two rows per wave in the softmax");
-    static_assert(BITS == 2 || (R == 4 && WSM), "4-bit codes: nh / nh_kv = 4, one wave per softmax row");
+    static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
+    static_assert(R == 4 || (R == 8 && !VHL), "R = 8: chained hi / lo sV");
+    static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
     ak.take_dyn();
     av.take_dyn();
-    extern __shared__ uint16_t rows[];                             // [R][n_pad]
+    extern __shared__ __attribute__((aligned(16))) uint16_t rows[];   // [R][n_pad]
     __shared__ float zl[NW][128];
     __shared__ uint16_t pw[R][MF_PW];
-    __shared__ float sm_lds[2 * NW];
+    __shared__ float st_lds[R][MF_NSEG][2];                        // (max, sum exp) of every 512-token segment of the R rows
     __shared__ int sp_lds[R];
-    const int unit = (int)blockIdx.x;
+    __shared__ int bid_lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = (int)blockIdx.x;
+    if (ak.ticket) {                                               // block ids in the order the blocks start (see above)
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(ak.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (int)gridDim.x - 1) __hip_atomic_store(ak.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+            bid_lds = t;
+        }
+        __syncthreads();
+        bid = __builtin_amdgcn_readfirstlane(bid_lds);
+    }
     auto stamp = [&](int i) {                                      // tools/mf_row_phases.py, slots as in mf_row_kernel
         if constexpr (DBG) {
             const unsigned long long tck = __builtin_amdgcn_s_memtime();
-            if (lane == 0) av.dbg[((size_t)blockIdx.x * NW + wave) * 16 + i] = tck;
+            if (lane == 0) av.dbg[((size_t)bid * NW + wave) * 16 + i] = tck;
         }
     };
     stamp(0);
-    if (DBG && lane == 0) av.dbg[((size_t)blockIdx.x * NW + wave) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (DBG && lane == 0) av.dbg[((size_t)bid * NW + wave) * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+    const int unit = bid / S, slice = bid - unit * S;
     const int b = unit / ak.nh_kv, hk = unit - b * ak.nh_kv;
     const int h0 = hk * R;
     const int Tq = (int)ak.Tq, Tv = (int)av.Tv;
     const int L = ak.res_len + 1;
-    const int n = Tq + L;
-    const int kbig = __builtin_amdgcn_readfirstlane(ak.range[unit]), vbig = __builtin_amdgcn_readfirstlane(av.range[unit]);   // see mf_row_kernel
+    const int krsh = mf_range_shift(__builtin_amdgcn_readfirstlane(ak.range[unit])), vrsh = mf_range_shift(__builtin_amdgcn_readfirstlane(av.range[unit]));   // range shifts: see mf_row_kernel
     const uint16_t* q_h0 = ak.q + b * ak.q_sb + (int64_t)h0 * ak.q_sh;
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
+    const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
+    uint16_t* dump0 = ak.dump ? ak.out + b * ak.out_sb + (int64_t)h0 * ak.out_sh : nullptr;
 
-    // ---- packed qK^T: wave w walks super-blocks w, w + NW, ...
-    // per-lane maxima of the scores written: a packed pair per head while the K stream runs (one v_pk_max_f16 per two scores)
-    typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
-    uint32_t mxp[4] = {0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u};     // (this lane's four result registers: heads hb .. hb + 3)
+    // ---- the slice: super-blocks [sb_lo, sb_hi) of the unit's packed keys, the packed values of the same tokens; `last`: the slice
+    // that also owns the fp16 residual, the window, the appends and the V flush -- it starts no later than the super-block of token
+    // Tv (the window's probabilities come from scores of packed keys when Tv < Tq), so it may be up to one super-block longer
+    int sb_lo = 0, sb_hi = ak.nsb;
+    bool last = true;
+    if (S > 1) {
+        const int spb = (ak.nsb + S - 1) / S;
+        int last_start = (S - 1) * spb;
+        if ((Tv >> 9) < last_start) last_start = Tv >> 9;
+        last = slice == S - 1;
+        const int lo = slice * spb, hi = lo + spb;
+        sb_lo = last ? last_start : (lo < last_start ? lo : last_start);
+        sb_hi = last ? ak.nsb : (hi < last_start ? hi : last_start);
+    }
+    const int tok0 = sb_lo * KIVI_MF_SB_TOKENS;                   // the rows are indexed by token - tok0
+
+    // ---- packed qK^T: wave w walks super-blocks sb_lo + w, sb_lo + w + NW, ...; the rows hold the SCALED scores
+    // fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed conversion, two v_fma_mix
     const int hb = (4 * (lane >> 4)) % R;
     {
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
         MfKSeq seq;
         seq.sb_bytes = (uint32_t)(ak.kt.sb_s * 4);
-        seq.sb_first = wave;
+        seq.sb_first = sb_lo + wave;
         seq.sb_stride = NW;
-        seq.n_sb = ak.nsb > wave ? (ak.nsb - wave + NW - 1) / NW : 0;
-        const int last = wave + (seq.n_sb - 1) * NW;
+        seq.n_sb = sb_hi > sb_lo + wave ? (sb_hi - sb_lo - wave + NW - 1) / NW : 0;
+        const int lastsb = sb_lo + wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
-        seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seqR<R, KRING, BITS>(rk, seq, q_h0, ak.q_sh, kbig, [&](int sb, int tt, int r, float v0, float v1) {
-            // the rows hold the SCALED scores fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed
-            // conversion, two v_fma_mix, one packed maximum instead of ~9 scalar-half instructions per score
-            const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
-            uint16_t* dst = rows + (hb + r) * n_pad + sb * KIVI_MF_SB_TOKENS + tt;
-            dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head r at tokens tt, tt + 16
-            dst[16] = (uint16_t)(hs >> 16);
-            mxp[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(hp2, mxp[r]), __builtin_bit_cast(hp2, hs)));   // r is a constant after unrolling
-        }, [](int, int) {});
-    }
-    float mxl[4];                                                  // (block-wide softmax only: R = 4, where hb = 0 and register r is head r)
+        seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * lastsb) < 16 ? (NG - 16 * lastsb) : 16) : 0;
+        // a finished super-block: [mask in place (:366-372),] (max, sum exp(x - max)) of the segment of every row
+        auto seg_done = [&](int sb, int ng) {
+            typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+            typedef float fp2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_wave_barrier();
+            const int seg = sb - sb_lo;
+            const bool valid = lane * 8 < ng * 32;
+            uint16_t mk[8];
+            if (mrow) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) mxl[r] = __builtin_fmaxf(h2f_bits((uint16_t)(mxp[r] & 0xFFFFu)), h2f_bits((uint16_t)(mxp[r] >> 16)));
+                for (int e = 0; e < 8; e++) mk[e] = valid ? mrow[(int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8 + e] : (uint16_t)0;
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                uint16_t* p = rows + rr * n_pad + seg * KIVI_MF_SB_TOKENS + lane * 8;
+                u32x4 v = valid ? *(const u32x4*)p : u32x4{0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u};
+                float m;
+                if (mrow) {
+                    m = -__builtin_inff();
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint16_t lo = mf_add_mask((uint16_t)(v[i] & 0xFFFFu), mk[2 * i]);
+                        const uint16_t hi = mf_add_mask((uint16_t)(v[i] >> 16), mk[2 * i + 1]);
+                        v[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                        m = __builtin_fmaxf(m, __builtin_fmaxf(h2f_bits(lo), h2f_bits(hi)));
+                    }
+                    if (valid) *(u32x4*)p = v;
+                } else {
+                    // (scalar copies: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0)
+                    const uint32_t w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3];
+                    const hp2 m2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(hp2, w0), __builtin_bit_cast(hp2, w1)),
+                                                             __builtin_elementwise_max(__builtin_bit_cast(hp2, w2), __builtin_bit_cast(hp2, w3)));
+                    const uint32_t mb = __builtin_bit_cast(uint32_t, m2);
+                    m = __builtin_fmaxf(h2f_bits((uint16_t)(mb & 0xFFFFu)), h2f_bits((uint16_t)(mb >> 16)));
+                }
+                if (dump0 && valid) *(u32x4*)(dump0 + (int64_t)rr * ak.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
+                m = wave_max(valid ? m : -__builtin_inff());
+                const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+                fp2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t xw = v[i];
+                    const fp2 d = (fp2){mf_sub_lo(xw, -m), mf_sub_hi(xw, -m)} * l2e;       // kivi_exp(x - m)
+                    acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                }
+                const float l = wave_sum(valid ? acc[0] + acc[1] : 0.f);
+                if (lane == 0) {
+                    st_lds[rr][seg][0] = m;
+                    st_lds[rr][seg][1] = l;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        mf_k_seqR<R, KRING, BITS>(rk, seq, q_h0, ak.q_sh, krsh, [&](int sb, int tt, int r, float v0, float v1) {
+            const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
+            uint16_t* dst = rows + (hb + r) * n_pad + (sb - sb_lo) * KIVI_MF_SB_TOKENS + tt;
+            dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head hb + r at tokens tt, tt + 16
+            dst[16] = (uint16_t)(hs >> 16);
+        }, seg_done);
+    }
     stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
+    // the first packed V blocks of this wave are requested now: they fly during the residual scores, the statistics and the window
     const rsrc_t rv = make_rsrc(mf_sb(av.vt, b, hk, 0), (uint32_t)((int64_t)av.nsb * av.vt.sb_s * 4));
-    const int NB = (Tv + 31) >> 5;
-    const int nbw = (NB + NW - 1) / NW;
-    const int b_lo = wave * nbw;
-    const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
+    const int vb_lo = tok0 >> 5;
+    int vb_hi = ((sb_hi * KIVI_MF_SB_TOKENS < Tv ? sb_hi * KIVI_MF_SB_TOKENS : Tv) + 31) >> 5;
+    if (vb_hi < vb_lo) vb_hi = vb_lo;
+    const int nbw = (vb_hi - vb_lo + NW - 1) / NW;
+    const int b_lo = vb_lo + wave * nbw;
+    const int b_hi = (b_lo + nbw < vb_hi) ? b_lo + nbw : vb_hi;
     MfVStream<R, VRING, VHL, BITS> vs;
     vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
-    // ---- residual scores q . [K_full | k_new] of the four heads (:337) + K append (:333-336)
-    for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
-        const int sub = idx & 7, rt = idx >> 3;
-        const int r = rt / L, t = rt - r * L;
-        const uint16_t* krow = ((t < ak.res_len) ? kres + (int64_t)t * ak.kres_st : knew) + sub * 16;
-        const uint16_t* qrow = q_h0 + (int64_t)r * ak.q_sh + sub * 16;
-        const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
-        const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
-        float sc = 0.f;
+    // ---- residual scores q . [K_full | k_new] of the R heads (:337) [+ mask] + K append (:333-336): the last slice
+    if (last) {
+        for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
+            const int sub = idx & 7, rt = idx >> 3;
+            const int r = rt / L, t = rt - r * L;
+            const uint16_t* krow = ((t < ak.res_len) ? kres + (int64_t)t * ak.kres_st : knew) + sub * 16;
+            const uint16_t* qrow = q_h0 + (int64_t)r * ak.q_sh + sub * 16;
+            const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
+            const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
+            float sc = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
+            for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
 #pragma unroll
-        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
-        if (t == ak.res_len && r == 0) {
-            *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = k0;
-            *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = k1;
-        }
-        sc += __shfl_xor(sc, 1);
-        sc += __shfl_xor(sc, 2);
-        sc += __shfl_xor(sc, 4);
-        if (sub == 0) {
-            const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, false, 0);
-            rows[r * n_pad + Tq + t] = h;
-            const float hv = h2f_bits(h);
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) mxl[rr] = (rr == r) ? __builtin_fmaxf(mxl[rr], hv) : mxl[rr];
+            for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
+            if (t == ak.res_len && r == 0) {
+                *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = k0;
+                *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = k1;
+            }
+            sc += __shfl_xor(sc, 1);
+            sc += __shfl_xor(sc, 2);
+            sc += __shfl_xor(sc, 4);
+            if (sub == 0) {
+                const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, mrow != nullptr, mrow ? mrow[Tq + t] : (uint16_t)0);
+                rows[r * n_pad + (Tq - tok0) + t] = h;
+                if (dump0) dump0[(int64_t)r * ak.out_sh + Tq + t] = h;
+            }
         }
     }
-    for (int j = (int)threadIdx.x; j < R * (n_pad - n); j += NTH) rows[(j / (n_pad - n)) * n_pad + n + j % (n_pad - n)] = 0xFC00u;   // -inf past the rows
     stamp(4);
+    // the fp16 window rows (and the token leaving it) are requested before the barrier and used after the statistics
+    GqaWindow<R, NTH, MF_PW, (128 + NW) / NW, BITS> win;
+    if (last) win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
     __syncthreads();
     stamp(5);
 
-    // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
-    GqaWindow<R, NTH, MF_PW, (128 + NW) / NW, BITS> win;
-    win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
-    // ---- [mask +] softmax of the four rows, one after the other (fp32, cast to fp16: :364-375); register resident per row
-    const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    if constexpr (WSM) {
-        static_assert(!WSM || R % NW == 0, "whole rows per wave");
-#pragma unroll 1
-        for (int r = wave; r < R; r += NW) {                       // (R = 4: one row per wave; R = 8: two)
-            const int sp = mf_row_softmax_wave<DUMP, BITS>(rows + r * n_pad, n, n_pad, Tv, mrow, pw[r], vbig,
-                                                     DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
-            if (lane == 0) sp_lds[r] = sp;
+    // ---- (M, sum exp(x - M)) of the R rows: every wave merges the slice's segments + (last slice) the residual scores; S > 1: the
+    // slices of the unit exchange theirs
+    float M[R], invS[R];
+    int sp[R];
+    {
+        const int nseg_loc = sb_hi - sb_lo;
+        float Ls[R];
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            const float sm = lane < nseg_loc ? st_lds[rr][lane][0] : -__builtin_inff();
+            const float sl = lane < nseg_loc ? st_lds[rr][lane][1] : 0.f;
+            float x0 = -__builtin_inff(), x1 = -__builtin_inff(), x2 = -__builtin_inff();
+            if (last) {
+                const uint16_t* rp = rows + rr * n_pad + (Tq - tok0);
+                if (lane < L) x0 = h2f_bits(rp[lane]);
+                if (lane + 64 < L) x1 = h2f_bits(rp[lane + 64]);
+                if (lane + 128 < L) x2 = h2f_bits(rp[lane + 128]);
+            }
+            const float m = wave_max(__builtin_fmaxf(__builtin_fmaxf(sm, x0), __builtin_fmaxf(x1, x2)));
+            const float ms = m == -__builtin_inff() ? 0.f : m;     // (an empty slice: no exp(-inf + inf))
+            M[rr] = m;
+            Ls[rr] = wave_sum(sl * kivi_exp(sm - ms) + kivi_exp(x0 - ms) + (kivi_exp(x1 - ms) + kivi_exp(x2 - ms)));
         }
-    } else {
-#pragma unroll 1
-        for (int r = 0; r < R; r++) {
-            const float mxr = r == 0 ? mxl[0] : (r == 1 ? mxl[1] : (r == 2 ? mxl[2] : mxl[3]));
-            const int sp = mf_row_softmax<NTH, (9216 + NTH * 4 - 1) / (NTH * 4), DUMP>(
-                rows + r * n_pad, n, n_pad, Tv, mxr, mrow, pw[r], sm_lds, vbig, DUMP ? ak.out + b * ak.out_sb + (int64_t)(h0 + r) * ak.out_sh : nullptr);
-            if (threadIdx.x == 0) sp_lds[r] = sp;
+        if (S > 1) {
+            __shared__ int xok_lds;
+            uint32_t* xs = reinterpret_cast<uint32_t*>(ak.stats) + (size_t)unit * S * R * 2;
+            if (wave == 0) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++) {
+                        __hip_atomic_store(xs + (slice * R + rr) * 2, __builtin_bit_cast(uint32_t, M[rr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(xs + (slice * R + rr) * 2 + 1, __builtin_bit_cast(uint32_t, Ls[rr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (payload written through before the arrival: cdna_hip_programming.md G16)
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(ak.xcount + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // bounded: a partner that never arrives (a launch the library's residency rule does not cover) poisons the
+                    // unit's output with NaN after ~1 s instead of hanging the device
+                    int it = 0;
+                    while (__hip_atomic_load(ak.xcount + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S && it < (1 << 21)) {
+                        __builtin_amdgcn_s_sleep(16);
+                        it++;
+                    }
+                    xok_lds = it < (1 << 21);
+                }
+            }
+            __syncthreads();
+            const bool ok = xok_lds != 0;
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                float sm = -__builtin_inff(), sl = 0.f;
+                if (lane < S) {
+                    sm = __builtin_bit_cast(float, __hip_atomic_load(xs + (lane * R + rr) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    sl = __builtin_bit_cast(float, __hip_atomic_load(xs + (lane * R + rr) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                const float m = wave_max(sm);
+                const float ms = sm == -__builtin_inff() ? m : sm; // (an empty slice's term: 0 * exp(0))
+                M[rr] = ok ? m : __builtin_nanf("");
+                Ls[rr] = wave_sum(sl * kivi_exp(ms - m));
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            invS[rr] = 1.0f / Ls[rr];
+            sp[rr] = mf_sp(Ls[rr], vrsh);
         }
     }
-    __syncthreads();
+    // the window's probabilities fp16(exp(x - M) / sum) (:375) of the rows wave, wave + NW, ...
+    if (last) {
+        const int Lw = av.res_len + 1;
+#pragma unroll 1
+        for (int rr = wave; rr < R; rr += NW) {
+            float Mr = M[0], Ir = invS[0];
+#pragma unroll
+            for (int q = 1; q < R; q++)
+                if (rr == q) { Mr = M[q]; Ir = invS[q]; }
+            const uint16_t* rp = rows + rr * n_pad + (Tv - tok0);
+            for (int j = lane; j < Lw; j += 64) pw[rr][j] = f2h_bits(kivi_exp(h2f_bits(rp[j]) - Mr) * Ir);
+        }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) sp_lds[rr] = sp[rr];
+    }
+    __syncthreads();                                               // pw complete; nobody reads scores past Tv any more
     stamp(7);
 
-    // ---- fp16 window of the four heads, V append, quantisation of the token leaving the window (:377-399)
+    // ---- fp16 window of the R heads, V append, quantisation of the token leaving the window (:377-399)
     float ow[R][2];
-    win.finish(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+    if (last) win.finish(av, b, hk, 0, av.res_len + 1, av.flush != 0, pw, ow);
+    else {
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
+    }
     stamp(8);
 
-    // ---- packed sV
+    // ---- packed sV: this wave's blocks, PB at a time: their p'' in place, then the stream over them
     MfVAcc<R, VHL> A;
     mf_v_init(A);
     __builtin_amdgcn_s_setprio(0);
-    vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0);
+    constexpr int PB = (16 / VRING) * VRING;                       // whole ring rounds, <= 512 tokens (8 per lane)
+    for (int bp = b_lo; bp < b_hi; bp += PB) {
+        const int nb = (b_hi - bp) < PB ? (b_hi - bp) : PB;
+        mf_probs_inplace<R, BITS>(rows, n_pad, bp * 32 - tok0, nb * 32, Tv - bp * 32, M, invS, sp, vrsh);
+        __builtin_amdgcn_wave_barrier();
+        vs.run(A, rv, bp, bp + nb, rows, n_pad, tok0);
+        __builtin_amdgcn_wave_barrier();
+    }
     stamp(9);
     __syncthreads();                                               // every wave is done with the p'' rows: their memory is reused
     constexpr int NP = VHL ? 2 * NW : NW;                          // partial results of the quantised part (VHL: hi and lo of every wave)
-    float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part
+    float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part | [2][R * 128]
     float* resl = red + NP * R * 128;
+    float* lf = resl + NW * R * 128;                               // the block's sums (hand-off between slices)
     mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128);
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
@@ -752,12 +959,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mf_row4_kernel(const
 #pragma unroll
         for (int w = 0; w < NW; w++) ws += resl[w * R * 128 + i];
         qs = __builtin_ldexpf(qs, -sp_lds[rr]);
-        const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
-        av.out[b * av.out_sb + (int64_t)(h0 + rr) * av.out_sh + d] = o;
+        if (S > 1) {
+            lf[i] = qs;
+            lf[R * 128 + i] = ws;
+        } else {
+            // fp16(quantised part) + fp16(window part), rounded: the reference's `attn_output += matmul(...)` (llama_kivi.py:382-384)
+            const uint16_t o = (Tv > 0) ? f2h_bits(h2f_bits(f2h_bits(qs)) + h2f_bits(f2h_bits(ws))) : f2h_bits(ws);
+            av.out[b * av.out_sb + (int64_t)(h0 + rr) * av.out_sh + d] = o;
+        }
+    }
+    if (S > 1) {
+        __syncthreads();
+        gqa_arrive_and_combine<R>(av, unit, slice, lf, b, h0, ak.xcount + unit);
     }
     stamp(11);
     if (DBG && lane == 0) {
-        unsigned long long* rec = av.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
+        unsigned long long* rec = av.dbg + ((size_t)bid * NW + wave) * 16;
         rec[10] = rec[9];                                          // (no separate stamp between the barrier and the final sum)
         rec[12] = __builtin_amdgcn_s_memrealtime();
         rec[13] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
@@ -849,89 +1066,78 @@ static int mf_lds_opt_in(K kernel, unsigned long long* done_mask, const char* wh
     return 0;
 }
 
+// compute units of the current device (0 if the query fails: then every sliced launch takes its block ids from the ticket counter)
+static int mf_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int& c = cus[dev & 63];
+    if (c == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) c = v;
+    }
+    return c;
+}
+
 // The whole step in one launch: nh == nh_kv (rows <= 8192 keys: mf_row_kernel, 4 blocks of 4 waves per CU, 8 waves per row
-// for <= 512 rows) or nh / nh_kv == 4 (rows <= 9216 keys: mf_row4_kernel, the four score rows of a unit in one block of 4
-// waves, 2 blocks per CU).  KIVI_EUNSUPPORTED (with a message) when the shape does not qualify.  dump != 0: the test
-// instantiations that also write the softmax input rows to the score buffer (KIVI_GQA_DUMP_SCORES).
+// for <= 512 rows) or nh / nh_kv in {4, 8} (mf_row4_kernel: the R score rows of a unit -- or, S > 1, of one of the S slices of its
+// row -- in one block of 4 waves, 2 blocks per CU).  KIVI_EUNSUPPORTED (with a message) when the shape does not qualify.
+// dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the rows the softmax statistics are taken from also go to the score buffer (nh == nh_kv:
+// separate instantiations; nh / nh_kv in {4, 8}: the product instantiation, a run-time pointer).
 // n_rows: the longest row the launch must hold (= Tq + k_res_len + 1, or the bound of the step's geometry class when the lengths
-// are device-resident).
-int kivi_mf_run_row(const void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, hipStream_t s) {
-    const GqaKArgs& k = *(const GqaKArgs*)k_args;
+// are device-resident).  S: slices per row (1 for nh == nh_kv); res_cap: residual_length (the fp16 keys a last slice may hold).
+int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, hipStream_t s) {
+    GqaKArgs& k = *(GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = n_rows;
-    const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
-    const dim3 grid((unsigned)units);
     KIVI_REQUIRE(bits == 2 || (bits == 4 && k.ratio == 4), KIVI_EUNSUPPORTED, "mf_row: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, k.ratio);
-    if (k.ratio == 8) {
-        // eight score rows in the LDS (two blocks per CU): up to 4608 keys -- the Llama-3-70B ratio at contexts up to 4.5k
-        KIVI_REQUIRE(n <= 4608, KIVI_EUNSUPPORTED, "mf_row8: rows of %lld keys do not fit the LDS (<= 4608)", (long long)n);
-        size_t lds = (size_t)8 * n_pad * 2;
-        const size_t fin = (size_t)2 * 4 * 8 * 128 * 4;           // the per-wave partial sums reuse the rows
+    if (k.ratio == 4 || k.ratio == 8) {
+        const int R = k.ratio;
+        const int64_t cap = R == 4 ? 9216 : 4608;                  // keys whose R score rows fit 72 KiB of LDS (two blocks per CU)
+        KIVI_REQUIRE(S >= 1 && S <= 64 && (S == 1 || S <= k.nsb), KIVI_EINVAL, "mf_row%d: %d slices for %d super-blocks", R, S, k.nsb);
+        // the longest row of a block: the whole row, or (S > 1) max(ceil(nsb / S), 2) super-blocks + the residual (mf_row4_kernel)
+        int64_t n_blk = n;
+        if (S > 1) {
+            const int spb = (k.nsb + S - 1) / S;
+            n_blk = (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1;
+        }
+        KIVI_REQUIRE(n_blk <= cap, KIVI_EUNSUPPORTED, "mf_row%d: rows of %lld keys do not fit the LDS (<= %lld)", R, (long long)n_blk, (long long)cap);
+        const int n_pad = (int)((n_blk + 4 + 31) / 32 * 32);
+        size_t lds = (size_t)R * n_pad * 2;
+        const size_t fin = (size_t)(2 * 4 + 4 + 2) * R * 128 * 4;  // the per-wave partial sums + the block's sums reuse the rows
         if (lds < fin) lds = fin;
-        static unsigned long long opt8 = 0, opt8_dump = 0;
-        if (dump) {
-            const int rc = mf_lds_opt_in(mf_row4_kernel<4, 2, 4, false, true, false, true, 8>, &opt8_dump, "mf_row8");
-            if (rc) return rc;
-            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 2, 4, false, true, false, true, 8>), grid, dim3(256), lds, s, k, v, n_pad);
-            return kivi_launch_status("mf_row8");
-        }
-        const int rc = mf_lds_opt_in(mf_row4_kernel<4, 2, 4, false, false, false, true, 8>, &opt8, "mf_row8");
-        if (rc) return rc;
-        KIVI_LAUNCH_LDS((mf_row4_kernel<4, 2, 4, false, false, false, true, 8>), grid, dim3(256), lds, s, k, v, n_pad);
-        return kivi_launch_status("mf_row8");
-    }
-    if (k.ratio == 4) {
-        // four score rows in the LDS (two blocks per CU): up to 9216 keys
-        KIVI_REQUIRE(n <= 9216, KIVI_EUNSUPPORTED, "mf_row4: rows of %lld keys do not fit the LDS (<= 9216)", (long long)n);
-        size_t lds = (size_t)4 * n_pad * 2;
-        const size_t fin = (size_t)2 * 8 * 4 * 128 * 4;           // the per-wave partial sums reuse the rows
-        if (lds < fin) lds = fin;
-        // 4 waves with up to 256 registers (two blocks per CU): 103 us per layer at BASELINE config 4 against 123 for 8 waves of
-        // 128 registers (spills)
-        static unsigned long long opt_main = 0, opt_dump = 0, opt4_main = 0, opt4_dump = 0;
-        if (bits == 4) {                                            // 4-bit codes: the same kernel over the two-tile blocks
-            if (dump) {
-                const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, true, true, true, 4, 4>, &opt4_dump, "mf_row4");
-                if (rc) return rc;
-                KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, true, true, true, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-                return kivi_launch_status("mf_row4");
-            }
-            const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, false, true, true, 4, 4>, &opt4_main, "mf_row4");
-            if (rc) return rc;
-            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, false, true, true, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-            return kivi_launch_status("mf_row4");
-        }
-        if (dump) {
-            const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4, false, true>, &opt_dump, "mf_row4");
-            if (rc) return rc;
-            KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4, false, true>), grid, dim3(256), lds, s, k, v, n_pad);   // (VHL as the product kernel)
-            return kivi_launch_status("mf_row4");
-        }
-#ifdef KIVI_TUNING
-        static unsigned long long opt_t[16] = {0};
-        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<waves><K ring><V ring>"
-        const int cfg = fr4 ? atoi(fr4) : 443;
-        // (8 waves of 128 registers spill: 123-139 us, profiles/r03_config4_row4.log)
-#define KIVI_ROW4_VARIANT(IDX, ...)                                                                \
+        const dim3 grid((unsigned)((int64_t)units * S));
+        // blocks that wait for each other (S > 1) must not wait for blocks that cannot start: with more blocks than the chip holds at
+        // once (2 per CU) the block ids come from the ticket counter (start order)
+        k.dump = dump;
+        if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; }
+        else if ((int64_t)units * S <= 2 * (int64_t)mf_cu_count()) k.ticket = nullptr;
+        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0;
+#define KIVI_ROW4_LAUNCH(OPT, ...)                                                                 \
     do {                                                                                           \
-        const int rc = mf_lds_opt_in(mf_row4_kernel<__VA_ARGS__>, &opt_t[IDX], "mf_row4");         \
+        const int rc = mf_lds_opt_in(mf_row4_kernel<__VA_ARGS__>, &OPT, "mf_row4");                \
         if (rc) return rc;                                                                         \
-        KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad);      \
+        KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad, S);   \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
-        // <K ring><V ring><waves>; + 1000: the sV phase with hi and lo as two chained operands (the round-3 form)
-        if (v.dbg) KIVI_ROW4_VARIANT(0, 4, 3, 4, true);
-        if (cfg == 423) KIVI_ROW4_VARIANT(1, 2, 3, 4);
-        if (cfg == 483) KIVI_ROW4_VARIANT(2, 8, 3, 4);
-        if (cfg == 444) KIVI_ROW4_VARIANT(4, 4, 4, 4);
-        if (cfg == 1443) KIVI_ROW4_VARIANT(6, 4, 3, 4, false, false, false);
-#undef KIVI_ROW4_VARIANT
+        if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
+        if (bits == 4) KIVI_ROW4_LAUNCH(opt44, 4, 3, 4, false, true, 4, 4);
+#ifdef KIVI_TUNING
+        static unsigned long long opt_t[8] = {0};
+        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<K ring><V ring><waves>"; + 1000: chained hi / lo in the sV phase
+        const int cfg = fr4 ? atoi(fr4) : 434;
+        if (v.dbg) KIVI_ROW4_LAUNCH(opt_t[0], 4, 3, 4, true);
+        if (cfg == 234) KIVI_ROW4_LAUNCH(opt_t[1], 2, 3, 4);
+        if (cfg == 834) KIVI_ROW4_LAUNCH(opt_t[2], 8, 3, 4);
+        if (cfg == 444) KIVI_ROW4_LAUNCH(opt_t[3], 4, 4, 4);
+        if (cfg == 424) KIVI_ROW4_LAUNCH(opt_t[4], 4, 2, 4);
+        if (cfg == 1434) KIVI_ROW4_LAUNCH(opt_t[5], 4, 3, 4, false, false);
 #endif
-        const int rc = mf_lds_opt_in(mf_row4_kernel<4, 3, 4>, &opt_main, "mf_row4");
-        if (rc) return rc;
-        KIVI_LAUNCH_LDS((mf_row4_kernel<4, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
-        return kivi_launch_status("mf_row4");
+        KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
+#undef KIVI_ROW4_LAUNCH
     }
+    const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
+    const dim3 grid((unsigned)units);
     KIVI_REQUIRE(k.ratio == 1 && n <= 8192, KIVI_EUNSUPPORTED, "mf_row: nh / nh_kv = %d with rows of %lld keys has no one-launch kernel",
                  k.ratio, (long long)n);
     const size_t lds = (size_t)n_pad * 2;

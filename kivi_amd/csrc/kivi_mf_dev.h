@@ -75,9 +75,10 @@ __device__ __forceinline__ void mf_load_block(MfW<BITS>& x, rsrc_t r, uint32_t v
 
 // ------------------------------------------------------------------------------------------------ q operand
 // Lane (m, kb) of a wave, m = lane & 15: the query of head r = m % R, channels 32 c + 8 kb + 2 i (+ 1) as fp16 pairs,
-// normalised to max |q| in [1, 2) (exponent sq) -- or, when the unit's store holds a scale >= 256 (`big`: the range flag of
-// kivi_mfma_layout.h), to [2^-10, 2^-9) (exponent sa = sq - 10), so that A = q'' * scale * 2^(4 | 6) is a finite fp16 for EVERY
-// finite scale -- and pre-multiplied by 2^aexp(i).  The same registers are the A operand's q factor (row m) and, because a
+// normalised to max |q| in [1, 2) (exponent sq) and placed by the unit's range shift `rsh` (mf_range_shift of the store's range
+// word, kivi_mfma_layout.h; exponent sa = sq + rsh): 2^10 lower when the store holds a scale >= 256, so that A = q'' * scale *
+// 2^(4 | 6) is a finite fp16 for EVERY finite scale, 2^8 higher when all its scales are < 2^-8, so that A keeps a normal hi part
+// down to subnormal scales -- and pre-multiplied by 2^aexp(i).  The same registers are the A operand's q factor (row m) and, because a
 // lane's A row and B column have the same index, the B operand of the zero-point product (column m -> head m % R): that
 // product takes them back to [1, 2) first (mf_zfac), so the zero-point sums do not depend on the placement.
 template <int R>
@@ -86,15 +87,16 @@ struct MfQ {
     int sq, sa;        // exponent of the zero-point operand, exponent of the A operand
 };
 
-// packed factor that takes a q'' register (times 2^aexp(i), placed at sa) to q * 2^sq: 2^-aexp(i), or 2^(10 - aexp(i))
+// packed factor that takes a q'' register (times 2^aexp(i), placed at sa = sq + rsh) to q * 2^sq: 2^(-aexp(i) - rsh), a normal
+// fp16 for rsh in {-10, 0, 8} (2^6 ... 2^-14)
 template <int BITS = 2>
-__device__ __forceinline__ uint32_t mf_zfac(int i, int big) {
-    if constexpr (BITS == 4) return big ? 0x4C004C00u : 0x24002400u;      // every register carries 2^6
-    return i < 2 ? (big ? 0x54005400u : 0x2C002C00u) : (big ? 0x4C004C00u : 0x24002400u);
+__device__ __forceinline__ uint32_t mf_zfac(int i, int rsh) {
+    const uint32_t h = (uint32_t)(15 - aexp_b<BITS>(i) - rsh) << 10;
+    return h | (h << 16);
 }
 
 template <int R, int BITS = 2>
-__device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, MfQ<R>& Q, int big) {
+__device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, MfQ<R>& Q, int rsh) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     const uint16_t* qrow = q_h0 + (int64_t)(m % R) * q_sh + 8 * kb;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void mf_load_q(const uint16_t* q_h0, int64_t q_sh, Mf
     amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32));
     const int ex = (int)(amax >> 10);                              // biased exponent of the row maximum (0: zero / subnormal)
     Q.sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);               // inf / nan rows: no scaling (they poison the row anyway)
-    Q.sa = Q.sq - (big ? KIVI_MF_BIG_SHIFT : 0);
+    Q.sa = Q.sq + rsh;
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -147,9 +149,9 @@ struct MfKSeq {
 // done(super-block index, its number of groups) is called when the last score of a super-block has been handed to sink.
 // q_lds: 64 words of this wave's LDS (the normalised q operand is parked there: kept in registers, it and the loop-invariant
 // B operand of the zero-point product hipcc derives from it hold 32 registers across the whole loop).
-// big: the unit's range flag (wave-uniform; mf_load_q).
+// rsh: the unit's range shift (wave-uniform; mf_load_q).
 template <int RING, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, int big, Sink&& sink, Done&& done) {
+__device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, int rsh, Sink&& sink, Done&& done) {
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -200,8 +202,8 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     amax = max(amax, (uint32_t)__shfl_xor((int)amax, 32));
     const int ex = (int)(amax >> 10);
     const int sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);
-    const int sa = sq - (big ? KIVI_MF_BIG_SHIFT : 0);               // placement of the A operand (mf_load_q)
-    const uint32_t zf01 = mf_zfac(0, big), zf23 = mf_zfac(2, big);
+    const int sa = sq + rsh;                                        // placement of the A operand (mf_load_q)
+    const uint32_t zf01 = mf_zfac(0, rsh), zf23 = mf_zfac(2, rsh);
     {
         uint32_t qq0[4][4];
 #pragma unroll
@@ -302,9 +304,9 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
 // (B layout = the row layout).
 // `qsrc(c)` returns the lane's q'' registers of channel chunk c (from registers, or from LDS when they are parked there).
 template <int R, int BITS = 2, typename QSrc>
-__device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const float* zmul, float* zz, int big) {
+__device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const float* zmul, float* zz, int rsh) {
     f4 z = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t zf01 = mf_zfac<BITS>(0, big), zf23 = mf_zfac<BITS>(2, big);
+    const uint32_t zf01 = mf_zfac<BITS>(0, rsh), zf23 = mf_zfac<BITS>(2, rsh);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         // A = q * 2^sq: q'' without the 2^aexp and the placement
@@ -334,7 +336,7 @@ __device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const fl
 // wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
 // profiles/r04_row4_levers.log.)
 template <int R, int RING, int BITS = 2, typename Sink, typename Done>
-__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int big, Sink&& sink, Done&& done) {
+__device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int rsh, Sink&& sink, Done&& done) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
     typedef MfL<BITS> LY;
     constexpr int RR = R;                                           // rows per group
@@ -379,13 +381,13 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         __builtin_amdgcn_sched_barrier(0);
     }
     MfQ<R> Q;
-    mf_load_q<R, BITS>(q_h0, q_sh, Q, big);
+    mf_load_q<R, BITS>(q_h0, q_sh, Q, rsh);
     float zmul[4], cmul[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int sqj = __shfl(Q.sq, hb + j);                       // lane h (kb = 0, row h) holds head h's exponent
         zmul[j] = __builtin_ldexpf(1.0f, -sqj);
-        cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT + (big ? KIVI_MF_BIG_SHIFT : 0) - sqj);
+        cmul[j] = __builtin_ldexpf(1.0f, KIVI_MF_PROD_SHIFT - rsh - sqj);
     }
     auto qsrc = [&](int c) -> u32x4 { return u32x4{Q.qq[c][0], Q.qq[c][1], Q.qq[c][2], Q.qq[c][3]}; };
     float zz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -396,7 +398,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         const int sbi = rq / RR;                                    // 16 / GPR = RR rounds per super-block
         const int rs = rq - sbi * RR;
         if (rs == 0) {                                              // a new super-block: its zero-point sums, then the next one's zero points
-            mf_k_zero<R, BITS>(qsrc, zv, zmul, zz, big);
+            mf_k_zero<R, BITS>(qsrc, zv, zmul, zz, rsh);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
         uint32_t Ah[4][4], Al[4][4];
@@ -810,12 +812,20 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
 }
 
 // Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = clamp(floor(log2 sum), 0, 14),
-// so that p'' * scale stays a normal fp16 whatever the row length; `big` (the range flag of the unit's V store,
-// kivi_mfma_layout.h): 2^KIVI_MF_BIG_SHIFT lower, so that p'' * scale <= 2^-4 * scale is finite for every finite scale.
-__device__ __forceinline__ int mf_sp(float sum, int big) {
+// so that p'' * scale stays a normal fp16 whatever the row length; plus `rsh`, the range shift of the unit's V store
+// (mf_range_shift, kivi_mfma_layout.h): 2^10 lower when it holds a scale >= 256, so that p'' * scale <= 2^-4 * scale is finite for
+// every finite scale; 2^8 higher when all its scales are < 2^-8 (p'' <= 2^15), so that p'' * scale keeps a normal hi part.
+__device__ __forceinline__ int mf_sp(float sum, int rsh) {
     const int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
-    return (e < 0 ? 0 : (e > 14 ? 14 : e)) - (big ? KIVI_MF_BIG_SHIFT : 0);
+    return (e < 0 ? 0 : (e > 14 ? 14 : e)) + rsh;
 }
+// The two exact power-of-two factors that take a fp16 probability p to p'' = p * 2^(Sp + 4 | 6): first 2^(4 | 6) (times 2^8 for
+// a unit placed higher: p <= 1, the product is exact and <= 2^14), then 2^(Sp - max(rsh, 0)) = 2^-10 .. 2^14 (exact for an exponent
+// >= 0; with a negative one the smallest probabilities of a row round once, 2^-19 of the row's largest p'' at worst).
+__device__ __forceinline__ _Float16 mf_p_mul_a(bool reg23, int rsh) {       // reg23: registers 2, 3 of the operand (2^6), else 2^4
+    return (_Float16)__builtin_ldexpf(1.0f, (reg23 ? 6 : 4) + (rsh > 0 ? rsh : 0));
+}
+__device__ __forceinline__ _Float16 mf_p_mul_sp(int sp, int rsh) { return (_Float16)__builtin_ldexpf(1.0f, sp - (rsh > 0 ? rsh : 0)); }
 // fp16 p -> p'' for token t: 2^(Sp + 4) for (t & 7) < 4, 2^(Sp + 6) otherwise (the register i = (t & 7) >> 1 of the operand)
 template <int BITS = 2>
 __device__ __forceinline__ uint16_t mf_scale_p(uint16_t p, int sp, int t) {
@@ -861,11 +871,11 @@ __device__ __forceinline__ uint32_t mf_scale_pair(uint32_t hpair, float inv) {
     return d;
 }
 
-// big: the range flag of the unit's V store (mf_sp).  dump (test instantiations: KIVI_GQA_DUMP_SCORES): the fp16 row as the
+// rsh: the range shift of the unit's V store (mf_sp).  dump (test instantiations: KIVI_GQA_DUMP_SCORES): the fp16 row as the
 // softmax consumes it (scaled, mask added) also goes to this row of the caller's score buffer.
 template <int NTH, int SMC, bool DUMP = false>
 __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
-                                              uint16_t* pw_row, float* sm_lds, int big, uint16_t* dump = nullptr) {
+                                              uint16_t* pw_row, float* sm_lds, int rsh, uint16_t* dump = nullptr) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -927,8 +937,9 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
 #pragma unroll
     for (int w = 1; w < NW; w++) sum += sm_lds[NW + w];
     const float inv = 1.0f / sum;
-    const int sp = mf_sp(sum, big);
-    const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp);   // 2^-10 .. 2^14
+    const int sp = mf_sp(sum, rsh);
+    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                   // 2^-10 .. 2^14
+    const _Float16 m_a4 = mf_p_mul_a(false, rsh), m_a6 = mf_p_mul_a(true, rsh);
     const f2v inv2 = {inv, inv};
 #pragma unroll
     for (int c = 0; c < SMC; c++) {
@@ -936,13 +947,11 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
         if (j0 < n_pad) {
             u32x2v o = {0u, 0u};
             if (c < nch) {
-                // p = fp16(e / sum) first (the reference's cast, :375), then the power-of-two scalings: 2^(4 | 6) first (p <= 1:
-                // exact), then 2^Sp (exact for Sp >= 0; with the range flag Sp may be negative and the smallest probabilities
-                // of a row round once, 2^-19 of the row's largest p'' at worst)
+                // p = fp16(e / sum) first (the reference's cast, :375), then the two power-of-two scalings (mf_p_mul_a, mf_p_mul_sp)
                 const h2v p01 = __builtin_convertvector(xe[c][0] * inv2, h2v);
                 const h2v p23 = __builtin_convertvector(xe[c][1] * inv2, h2v);
                 if (j0 + 4 <= Tv) {
-                    const _Float16 m_a = (j0 & 4) ? (_Float16)64.0f : (_Float16)16.0f;
+                    const _Float16 m_a = (j0 & 4) ? m_a6 : m_a4;
                     o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
                     o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
                 } else {                                           // the chunk that holds the end of the packed prefix / the window
@@ -955,127 +964,6 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
                         const int j = j0 + e;
                         if (j >= Tv && j < n) pw_row[j - Tv] = pp[e];
                         q[e] = (j < Tv) ? mf_scale_p(pp[e], sp, j) : (uint16_t)0;
-                    }
-                    o[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
-                    o[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);
-                }
-            }
-            *(u32x2v*)(row + j0) = o;
-        }
-    }
-    return sp;
-}
-
-// The same for ONE WAVE per row (mf_row4_kernel: wave r takes head r; the four rows of a unit at once instead of one after the
-// other, nothing block-wide inside): three passes over the row in LDS -- [mask +] maximum, sum of exp(x - M), write of p'' -- each
-// lane on 4 consecutive scores per 256-score chunk; the exponentials are computed twice rather than kept (a 9216-key row is 144
-// scores per lane).  The block version above spends most of its ~4 us per row in two block barriers and dependent LDS round
-// trips, four rows in sequence; profiles/r04_row4_levers.log.  Returns Sp (wave-uniform).
-template <bool DUMP, int BITS = 2>
-__device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_pad, int Tv, const uint16_t* mrow, uint16_t* pw_row, int big,
-                                                   uint16_t* dump) {
-    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    constexpr int NB = 4;                                          // chunks per batch: their LDS reads are issued before the first is used
-    const int lane = threadIdx.x & 63;
-    const int nch = (n + 255) >> 8;                                // 256-score chunks that hold scores
-    const u32x2v ninf2 = {0xFC00FC00u, 0xFC00FC00u};
-    auto load = [&](int c) -> u32x2v {                             // chunk c of this lane; past the padded row: -inf (exp = 0)
-        const int j0 = c * 256 + lane * 4;
-        return j0 < n_pad ? *(const u32x2v*)(row + j0) : ninf2;
-    };
-    // ---- pass A: [mask in place,] maximum
-    if (mrow) {                                                    // masked rows: :366-372, fp16 add clamped at the fp16 minimum
-        for (int c = 0; c < nch; c++) {
-            const int j0 = c * 256 + lane * 4;
-            if (j0 < n) {
-                u16x4 rw = *(const u16x4*)(row + j0);
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (j0 + e < n) {
-                        float v = (float)(_Float16)(h2f_bits(rw[e]) + h2f_bits(mrow[j0 + e]));
-                        if (v < -65504.0f) v = -65504.0f;
-                        rw[e] = f2h_bits(v);
-                    }
-                *(u16x4*)(row + j0) = rw;                          // the same lane reads it back below
-            }
-        }
-    }
-    h2v mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
-    for (int c0 = 0; c0 < nch; c0 += NB) {
-        u32x2v raw[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            if constexpr (DUMP) {
-                const int j0 = (c0 + k) * 256 + lane * 4;
-                if (dump && j0 < n) *(u32x2v*)(dump + j0) = raw[k];
-            }
-            const uint32_t w0 = raw[k][0], w1 = raw[k][1];
-            mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_max(__builtin_bit_cast(h2v, w0), __builtin_bit_cast(h2v, w1)));
-        }
-    }
-    const uint32_t mb = __builtin_bit_cast(uint32_t, mx2);
-    const float mx = wave_max(__builtin_fmaxf(h2f_bits((uint16_t)(mb & 0xFFFFu)), h2f_bits((uint16_t)(mb >> 16))));
-    const float nmx = -mx;
-    const f2v l2e = {1.44269504088896340736f, 1.44269504088896340736f};
-    auto exps = [&](const u32x2v& raw, f2v& e01, f2v& e23) {       // kivi_exp(x - M) of the four scores of a chunk
-        const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;
-        const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
-        e01 = (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
-        e23 = (f2v){__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
-    };
-    // ---- pass B: sum of exp
-    f2v acc = {0.f, 0.f};
-    for (int c0 = 0; c0 < nch; c0 += NB) {
-        u32x2v raw[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            f2v e01, e23;
-            exps(raw[k], e01, e23);
-            acc += e01;
-            acc += e23;
-        }
-    }
-    const float sum = wave_sum(acc[0] + acc[1]);
-    const float inv = 1.0f / sum;
-    const int sp = mf_sp(sum, big);
-    const _Float16 m_sp = (_Float16)__builtin_ldexpf(1.0f, sp);
-    const f2v inv2 = {inv, inv};
-    // ---- pass C: p = fp16(e / sum) (:375), p'' back into the row (zeros from Tv on), the window's probabilities into pw_row
-    const int nchp = (n_pad + 255) >> 8;
-    for (int c0 = 0; c0 < nchp; c0 += NB) {
-        u32x2v raw[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const int j0 = (c0 + k) * 256 + lane * 4;
-            if (j0 >= n_pad) continue;
-            u32x2v o = {0u, 0u};
-            if (j0 < n) {
-                f2v e01, e23;
-                exps(raw[k], e01, e23);
-                const h2v p01 = __builtin_convertvector(e01 * inv2, h2v);
-                const h2v p23 = __builtin_convertvector(e23 * inv2, h2v);
-                if (j0 + 4 <= Tv) {
-                    const _Float16 m_a = (BITS == 4 || (j0 & 4)) ? (_Float16)64.0f : (_Float16)16.0f;
-                    o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
-                    o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
-                } else {                                           // the chunk that holds the end of the packed prefix / the window
-                    const uint32_t w01 = __builtin_bit_cast(uint32_t, p01), w23 = __builtin_bit_cast(uint32_t, p23);
-                    const uint16_t pp[4] = {(uint16_t)(w01 & 0xFFFFu), (uint16_t)(w01 >> 16), (uint16_t)(w23 & 0xFFFFu), (uint16_t)(w23 >> 16)};
-                    uint16_t q[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int j = j0 + e;
-                        if (j >= Tv && j < n) pw_row[j - Tv] = pp[e];
-                        q[e] = (j < Tv) ? mf_scale_p<BITS>(pp[e], sp, j) : (uint16_t)0;
                     }
                     o[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
                     o[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);

@@ -52,13 +52,21 @@
 #define KIVI_MF_PROD_SHIFT 12          // accumulated products = a * code * 2^-12
 // Range of the fp16 A operands (q * scale, p * scale).  With q normalised to [1, 2) (times up to 2^6) and the probabilities
 // of a row to <= 2^6, a group scale >= 512 would overflow the fp16 hi part where the reference's fp32 scale * code + zero
-// (quant/csrc/gemv_cuda.cu:407-413) stays finite.  Every kernel that WRITES scales into a store (kivi_kt_pack, kivi_vt_pack,
-// the relayouts, the V flush of the decode step) records a sticky per-(batch row, kv head) flag when it sees a scale whose
-// fp16 bits are >= KIVI_MF_BIG_SCALE_BITS (256.0; NaN / inf included); the consumers then place q (or the probabilities)
-// 2^KIVI_MF_BIG_SHIFT lower for that unit: 128 * 65504 * 2^-10 < 2^13, so every finite fp16 scale is safe, and units
-// that never saw such a scale compute bit for bit what they did before the flag existed.
+// (quant/csrc/gemv_cuda.cu:407-413) stays finite -- and group scales in the fp16 subnormals (values ~1e-7) would push the hi part
+// into the subnormals and the lo part (the exact remainder) below the grid, where the reference still carries 24 bits.  Every
+// kernel that WRITES scales into a store (kivi_kt_pack, kivi_vt_pack, the relayouts, the V flush of the decode step) records two
+// sticky per-(batch row, kv head) marks in the unit's range word (one BYTE each, written with byte stores: concurrent writers
+// never lose each other's mark):
+//   byte 0  a scale whose fp16 bits are >= KIVI_MF_BIG_SCALE_BITS (256.0; NaN / inf included) was written
+//   byte 1  a scale >= KIVI_MF_SMALL_SCALE_BITS (2^-8) was written
+// The consumers place q (or the probabilities) by mf_range_shift(word): 2^KIVI_MF_BIG_SHIFT LOWER for a unit with byte 0 set
+// (128 * 65504 * 2^-10 < 2^13: every finite fp16 scale is safe), 2^KIVI_MF_SMALL_SHIFT HIGHER for a unit whose scales are ALL
+// below 2^-8 (round 5; q'' / p'' <= 2^15, the A operand < 2^7: a scale of 2^-24 still gives a hi part with all its bits), and
+// as before otherwise: units whose scales straddle neither bound compute bit for bit what they did before the marks existed.
 #define KIVI_MF_BIG_SCALE_BITS 0x5C00u
 #define KIVI_MF_BIG_SHIFT 10
+#define KIVI_MF_SMALL_SCALE_BITS 0x1C00u
+#define KIVI_MF_SMALL_SHIFT 8
 
 // ---- 4-bit codes ("KT4" / "VT4"; round 4, nh / nh_kv = 4): the same super-block with TWO code tiles per 32-token block.  A word
 // holds the 8 reduction-axis elements one lane feeds to ONE matrix instruction (the 2-bit word holds both tiles' 2 x 8):
@@ -76,6 +84,15 @@
 #define KIVI_MF4_SB_WORDS 10240
 
 #ifdef __HIPCC__
+// placement of q'' / p'' for a unit from its range word: -KIVI_MF_BIG_SHIFT, 0 or +KIVI_MF_SMALL_SHIFT (see above)
+__device__ __forceinline__ int mf_range_shift(int word) {
+    return (word & 0xFF) ? -KIVI_MF_BIG_SHIFT : ((word & 0xFF00) ? 0 : KIVI_MF_SMALL_SHIFT);
+}
+// the marks a writer leaves for a scale with these fp16 bits (sticky; byte stores)
+__device__ __forceinline__ void mf_range_mark(int* word, uint32_t scale_bits) {
+    if (scale_bits >= KIVI_MF_BIG_SCALE_BITS) reinterpret_cast<volatile unsigned char*>(word)[0] = 1;
+    if (scale_bits >= KIVI_MF_SMALL_SCALE_BITS) reinterpret_cast<volatile unsigned char*>(word)[1] = 1;
+}
 template <int BITS> struct MfL;        // per-width constants of the super-block
 template <> struct MfL<2> {
     static constexpr int BLOCK_WORDS = KIVI_MF_BLOCK_WORDS, SCALE_WORD0 = KIVI_MF_SB_SCALE_WORD0, MN_WORD0 = KIVI_MF_SB_MN_WORD0,

@@ -35,9 +35,9 @@ def _flag_words(B: int, nh_kv: int) -> int:
 def alloc_store(B: int, nh_kv: int, n_sb: int, device, bits: int = 2) -> torch.Tensor:
     """Zero-initialised storage of n_sb super-blocks per (batch row, kv head): logical shape (B, nh_kv, n_sb, sb_words(bits)) int32,
     in memory the super-block index sits outside the head index (the super-blocks in use form one dense region).
-    The store's RANGE FLAGS (include/kivi_hip.h: B * nh_kv int32, set by whatever writes a scale >= 256 into the store)
-    live in the same allocation, right behind the super-blocks: `range_flags(store)` is the (B, nh_kv) view, and every
-    wrapper below passes it along with the store."""
+    The store's RANGE WORDS (include/kivi_hip.h: B * nh_kv int32; byte 0 marked by whatever writes a scale >= 256 into the unit,
+    byte 1 by whatever writes a scale >= 2^-8: `range_big` / `range_small`) live in the same allocation, right behind the
+    super-blocks: `range_flags(store)` is the (B, nh_kv) view, and every wrapper below passes it along with the store."""
     W = sb_words(bits)
     main = B * n_sb * nh_kv * W
     flat = torch.zeros(main + _flag_words(B, nh_kv), dtype=torch.int32, device=device)
@@ -52,6 +52,16 @@ def range_flags(store: torch.Tensor) -> torch.Tensor:
     if store.storage_offset() != 0 or stg.nbytes() != (main + _flag_words(B, nh_kv)) * 4:
         raise ValueError("not a store of kivi_amd.quant.mfma.alloc_store (its range flags live behind the super-blocks)")
     return torch.empty(0, dtype=torch.int32, device=store.device).set_(stg, main, (B, nh_kv), (nh_kv, 1))
+
+
+def range_big(store: torch.Tensor) -> torch.Tensor:
+    """(B, nh_kv) bool: a scale >= 256 was written into the unit (q'' / p'' are placed 2^10 lower: kivi_mfma_layout.h)."""
+    return (range_flags(store) & 0xFF) != 0
+
+
+def range_small(store: torch.Tensor) -> torch.Tensor:
+    """(B, nh_kv) bool: every scale written into the unit so far is < 2^-8 (q'' / p'' are placed 2^8 higher)."""
+    return (range_flags(store) & 0xFFFF) == 0
 
 
 def copy_store(dst: torch.Tensor, src: torch.Tensor) -> None:

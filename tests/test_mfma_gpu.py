@@ -264,6 +264,22 @@ def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked,
     _stage_ab_steps(nh, nh_kv, T0, R, masked, form, R + 9, k_prompt=mk, k_step=mk, v_prompt=mo, v_step=mo, q_step=mo)
 
 
+@pytest.mark.parametrize("nh,nh_kv,T0,R,masked,kind,S,bits", [
+    (8, 2, 1100, 128, True, "outlier", 2, 2),        # two slices of one super-block each; a K flush adds a third super-block
+    (8, 2, 1100, 96, False, "randn", 3, 2),          # R = 96: token Tv sits a super-block before the last -> an EMPTY middle slice, a last slice of two
+    (16, 2, 2100, 32, True, "outlier", 4, 2),        # nh / nh_kv = 8, five super-blocks in four slices of two: an empty third slice
+    (8, 2, 1100, 128, False, "outlier", 2, 4),       # 4-bit codes
+])
+def test_mf_sliced_rows_match_reference_logic(oracle, nh, nh_kv, T0, R, masked, kind, S, bits):
+    """The one-launch form with every row cut into S slices (mf_row4_kernel, S > 1: a block per slice, the slices of a unit exchange
+    their softmax statistics inside the launch and meet in the workspace): stage A / B at every step exactly as for the other two
+    forms, 9-tuples bit-identical -- incl. slices that are empty, a last slice that starts at the super-block of token Tv, masks
+    (added per segment inside the K walk), V flushes by the last slice only."""
+    mk = lambda seed, h, T: make_kv(seed, 2, h, T, 128, kind)        # noqa: E731
+    mo = lambda seed, h, T: make_kv(seed, 2, h, T, 128)              # noqa: E731
+    _stage_ab_steps(nh, nh_kv, T0, R, masked, f"slices{S}", min(R + 9, 72), k_prompt=mk, k_step=mk, v_prompt=mo, v_step=mo, q_step=mo, bits=bits)
+
+
 def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_prompt, v_step, q_step, check_at=None, bits=2):
     """The stage A / B loop of test_mf_decode_steps_match_reference_logic over caller-made inputs (f(seed, heads, T))."""
     from kivi_amd import _lib
@@ -276,8 +292,14 @@ def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_p
     k0, v0 = k_prompt(1, nh_kv, T0), v_prompt(2, nh_kv, T0)
     layer = make_layer_cache(cfg, B, nh_kv, D, T0 + 8, "cuda", num_heads=nh)    # small capacity: the cache must grow
     assert isinstance(layer, KiviLayerCacheMF)
-    layer.flags = _lib.GQA_FORCE_SPLIT if form == "split" else (_lib.GQA_FORCE_ROW | _lib.GQA_DUMP_SCORES)
+    if form.startswith("slices"):                                                # the one-launch form with the rows cut into S slices
+        layer.flags = _lib.gqa_slices(int(form[6:])) | _lib.GQA_DUMP_SCORES
+    else:
+        layer.flags = _lib.GQA_FORCE_SPLIT if form == "split" else (_lib.GQA_FORCE_ROW | _lib.GQA_DUMP_SCORES)
     layer.prefill(k0.cuda(), v0.cuda())
+    if form.startswith("slices"):
+        plan = _lib.load().kivi_mf_launch_plan(B, nh, nh_kv, layer.k_quant_len, layer.k_res_len, R, layer.flags, bits, 0)
+        assert plan == int(form[6:]), ("the shape must take the sliced form from the first step on", plan)
     past = H.prefill_cache(k0, v0, bits, bits, g, R)
     _cmp_cache(layer.as_tuple(), past)
     gen = torch.Generator().manual_seed(5)
@@ -345,7 +367,8 @@ def test_gqa_scores_dynamic_range(mods, oracle, B, nh, nh_kv, T, mag):
     mfma.kt_pack(k, store, 0)
     code, scale, mn = new_pack.quantize_and_pack_k_tmajor(k, 32, 2)
     big = (scale.float() >= 256).flatten(2).any(-1)
-    assert torch.equal(mfma.range_flags(store).bool(), big) and bool(big.any()) == (mag >= 1e3)
+    assert torch.equal(mfma.range_big(store), big) and bool(big.any()) == (mag >= 1e3)
+    assert torch.equal(mfma.range_small(store), (scale.float() < 2.0 ** -8).flatten(2).all(-1))
     out = torch.full((B, nh, 1, T + 8), 7.0, dtype=torch.float16, device="cuda")
     mfma.gqa_scores(q, store, T, out)
     assert torch.isfinite(out).all()
@@ -372,7 +395,8 @@ def test_gqa_output_dynamic_range(mods, oracle, B, nh, nh_kv, T, mag):
     mfma.vt_pack(v, store)
     code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(v, 32, 2)
     big = (scale.float() >= 256).flatten(2).any(-1)
-    assert torch.equal(mfma.range_flags(store).bool(), big) and bool(big.any()) == (mag >= 1e3)
+    assert torch.equal(mfma.range_big(store), big) and bool(big.any()) == (mag >= 1e3)
+    assert torch.equal(mfma.range_small(store), (scale.float() < 2.0 ** -8).flatten(2).all(-1))
     pitch = (T + 7) // 8 * 8 + 8
     probs = torch.zeros((B, nh, 1, pitch), dtype=torch.float16, device="cuda")
     probs[..., :T] = _probs("softmax", B, nh, T, 5).cuda()
@@ -392,7 +416,7 @@ def test_gqa_output_dynamic_range(mods, oracle, B, nh, nh_kv, T, mag):
 
 
 @pytest.mark.parametrize("form", ["split", "row"])
-@pytest.mark.parametrize("m0,m1", [(1e-4, 1e-4), (1.0, 1e3), (1e3, 1.0), (1e3, 1e3), (3e4, 3e4)])
+@pytest.mark.parametrize("m0,m1", [(1e-4, 1e-4), (1e-4, 1.0), (1.0, 1e3), (1e3, 1.0), (1e3, 1e3), (3e4, 3e4)])
 @pytest.mark.parametrize("nh,nh_kv", [(2, 2), (8, 2), (8, 1)])
 def test_mf_decode_steps_dynamic_range(oracle, nh, nh_kv, m0, m1, form):
     """The whole step, stage by stage as above, with a prompt of magnitude m0 and new tokens of magnitude m1 (K and V both):
@@ -408,7 +432,9 @@ def test_mf_decode_steps_dynamic_range(oracle, nh, nh_kv, m0, m1, form):
         q_step=lambda seed, h, T: (make_kv(seed, 2, h, T, 128) * qmag).half(), check_at=(0, 5, R - 1, R, R + 2))
     from kivi_amd.quant import mfma
     expect = max(m0, m1) >= 1e3
-    assert bool(mfma.range_flags(layer.kt).any()) == expect and bool(mfma.range_flags(layer.vt).any()) == expect
+    assert bool(mfma.range_big(layer.kt).any()) == expect and bool(mfma.range_big(layer.vt).any()) == expect
+    if max(m0, m1) <= 1e-4:
+        assert bool(mfma.range_small(layer.kt).all()) and bool(mfma.range_small(layer.vt).all())
 
 
 @pytest.mark.parametrize("B,nh,nh_kv,T0,R,masked", [(2, 4, 4, 5, 32, False), (8, 32, 32, 1500, 32, True), (2, 2, 2, 8100, 32, False),
