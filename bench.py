@@ -135,33 +135,46 @@ def barrier(dist):
         dist.barrier()
 
 
-def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=15.0):
+def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=25.0, threads=None):
     """The reference's pure-PyTorch fake-quant path (oracle/torch_fakequant.py port) on the host cores, on a bounded
     sample of the same workload: ONE batch row of ONE layer (nh heads x T tokens), decode-equivalent work =
     unpack+dequantise K and V + the two GEMVs (the cache is already packed in a decode step; pack is timed and
     reported separately).  Extrapolated to tokens/s for `layers` layers."""
     from oracle import torch_fakequant as TF
+    # a FIXED thread count (the box's cores, at most 32: the sample is one batch row x nh heads -- more threads than heads only add
+    # scheduling noise, which made the round-4 line swing 2x between boxes), >= 30 repetitions after 3 warm-up ones, median reported
+    ncpu = os.cpu_count() or 1
+    nthr = threads or max(1, min(32, ncpu))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(nthr)
     torch.manual_seed(0)
     k = torch.randn((1, nh, T, D)).half()
     v = torch.randn((1, nh, T, D)).half()
     q = torch.randn((1, nh, 1, D)).half()
     a = torch.softmax(torch.randn((1, nh, 1, T)), -1).half()
-    reps, dec_s, pack_s, t_start = 0, 0.0, 0.0, time.perf_counter()
+    dec, pack, t_start = [], [], time.perf_counter()
+    for _ in range(3):                              # warm-up (first-touch of the fp32 intermediates, thread pool start)
+        TF.fakequant_decode_layer(q, a, k, v, g, bits)
     while True:
         _, _, st = TF.fakequant_decode_layer(q, a, k, v, g, bits)
-        reps += 1
-        dec_s += st["dequant_s"] + st["gemv_s"]
-        pack_s += st["pack_s"]
-        if time.perf_counter() - t_start > budget_s or reps >= 200:
+        dec.append(st["dequant_s"] + st["gemv_s"])
+        pack.append(st["pack_s"])
+        if (len(dec) >= 30 and time.perf_counter() - t_start > budget_s) or len(dec) >= 200 or time.perf_counter() - t_start > 4 * budget_s:
             break
-    per_layer_row = dec_s / reps
+    torch.set_num_threads(prev)
+    reps = len(dec)
+    ds = sorted(dec)
+    per_layer_row = ds[reps // 2]                   # median
     return {
-        "value": 1.0 / (per_layer_row * layers), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"ONE batch row (of the {B} the GPU step processes) x {nh} heads x T={T} x 1 layer, {reps} reps: "
-                  f"unpack+dequant K,V + 2 matmuls {per_layer_row * 1e3:.0f} ms per row and layer (pack of a full {T}-token "
-                  f"prompt {pack_s / reps * 1e3:.0f} ms, not in value); value = 1 / (that x {layers} layers) = tokens/s of one "
-                  f"sequence, extrapolated linearly over the batch (a batch of {B} takes {B}x as long per step and yields "
-                  f"{B} tokens: same tokens/s)",
+        "value": 1.0 / (per_layer_row * layers), "unit": "tokens/s", "cores": nthr, "host_cpus": ncpu, "kind": "port",
+        "value_at_min": 1.0 / (ds[0] * layers), "value_at_max": 1.0 / (ds[-1] * layers),
+        "ms_per_row_and_layer": {"median": round(per_layer_row * 1e3, 2), "min": round(ds[0] * 1e3, 2), "max": round(ds[-1] * 1e3, 2),
+                                 "p10": round(ds[reps // 10] * 1e3, 2), "p90": round(ds[(9 * reps) // 10] * 1e3, 2)},
+        "sample": f"ONE batch row (of the {B} the GPU step processes) x {nh} heads x T={T} x 1 layer, {reps} reps after 3 warm-up, "
+                  f"torch.set_num_threads({nthr}): unpack+dequant K,V + 2 matmuls, median {per_layer_row * 1e3:.0f} ms per row and layer "
+                  f"(pack of a full {T}-token prompt {sorted(pack)[reps // 2] * 1e3:.0f} ms, not in value); value = 1 / (median x {layers} "
+                  f"layers) = tokens/s of one sequence, extrapolated linearly over the batch (a batch of {B} takes {B}x as long per "
+                  f"step and yields {B} tokens: same tokens/s)",
         "port_of": "quant/new_pack.py:51-83 unpack_and_dequant_{k,v}cache + torch.matmul (procedure of quant/test.py:187-195), "
                    "vectorised (oracle/torch_fakequant.py, checked bit for bit against the C oracle)",
     }
@@ -213,6 +226,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step's launches from ONE hipGraph (device-resident lengths: kivi_amd/graph.py); matrix-pipe layout only")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: a sleep per step (launcher / reduction / JSON plumbing on CPU, gloo)")
+    ap.add_argument("--form", default="auto", help="matrix-pipe layout, A/B: auto (the library's launch plan) | split (two launches) | "
+                                                   "row (one launch, a block per row) | slicesN (one launch, N slices per row)")
+    ap.add_argument("--kgemv-passes", type=int, default=10, help="timed passes over the rotating caches of the single-layer K-GEMV lines")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # plain `python bench.py --gpus N`: start the ranks ourselves
@@ -242,6 +258,11 @@ def main():
         v = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
         lc.prefill(k, v)
         del k, v
+        if args.form != "auto":
+            from kivi_amd import _lib as _l
+            assert getattr(lc, "layout", "hook") == "mfma", "--form applies to the matrix-pipe layout"
+            lc.flags = (_l.GQA_FORCE_SPLIT if args.form == "split" else _l.GQA_FORCE_ROW if args.form == "row"
+                        else _l.gqa_slices(int(args.form[6:])))
         layers.append(lc)
     qs = [torch.randn((B, nh, 1, D), device=dev, dtype=torch.float16) for _ in range(L)]
     ks = [torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16) for _ in range(L)]
@@ -372,10 +393,10 @@ def main():
         single_mf = None
 
         def time_kgemv(launch, ncaches, nbytes, label):
-            """`launch(layer_index)` enqueues one qK^T launch with a pending event pair; 6 passes over the layer caches, the
-            first is warm-up."""
+            """`launch(layer_index)` enqueues one qK^T launch with a pending event pair; 1 warm-up + args.kgemv_passes timed passes
+            over the caches (>= 100 timed launches: SURVEY section 8d)."""
             ev1 = []
-            for rep in range(6):
+            for rep in range(1 + max(1, args.kgemv_passes)):
                 for i in range(ncaches):
                     pair = (klib.kivi_event_create(), klib.kivi_event_create())
                     klib.kivi_set_launch_events(*pair)
@@ -385,10 +406,15 @@ def main():
             torch.cuda.synchronize()
             us1 = sorted(klib.kivi_event_elapsed_us(a, b) for a, b in ev1)
             med = us1[len(us1) // 2]
+            avg = sum(us1) / len(us1)
             return {"workload": label, "kernel": (klib.kivi_last_timed_kernel() or b"").decode().split("<")[0].strip("( "),
-                    "launches": len(us1), "median_launch_us": round(med, 2), "min_launch_us": round(us1[0], 2),
+                    "launches": len(us1), "median_launch_us": round(med, 2), "avg_launch_us": round(avg, 2), "min_launch_us": round(us1[0], 2),
+                    "p10_launch_us": round(us1[len(us1) // 10], 2), "p90_launch_us": round(us1[(9 * len(us1)) // 10], 2),
+                    "algorithmic_bytes_per_launch": nbytes,
                     "achieved": round(nbytes / (med * 1e-6) / 1e9, 1), "unit": "GB/s",
-                    "frac": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                    "frac": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_at_avg": round(nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_at_min": round(nbytes / (us1[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
 
         if roof is not None and layers[0].k_quant_len:
             Tq = layers[0].k_quant_len

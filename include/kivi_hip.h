@@ -16,6 +16,25 @@
  *   K_code_T (B, nh_kv, D, Tq/fpi) int32   K_scale_T, K_mn_T (B, nh_kv, D, Tq/g) fp16
  *   V_code   (B, nh_kv, Tv, D/fpi) int32   V_scale,  V_mn    (B, nh_kv, Tv, D/g) fp16
  * Strides are in ELEMENTS of the tensor they describe (int32 words / halves).
+ *
+ * SURFACE.  The reference's boundary for this path is two functions (pybind.cpp:5-8) + the Python pack module; what a
+ * caller is meant to bind here is correspondingly small:
+ *   SUPPORTED   pack / unpack:  kivi_quant_pack_lastdim, kivi_quant_pack_k_tmajor, kivi_unpack_dequant_lastdim,
+ *                               kivi_pack_codes_lastdim, kivi_unpack_codes_lastdim
+ *               fused GEMVs:    kivi_gemv_k, kivi_gemv_v (hook-state tensors), kivi_gemv_outer_dim, kivi_gemv_awq (the
+ *                               reference extension's own argument layouts)
+ *               a layer step:   kivi_decode_layer (hook-state cache: any 2- / 4-bit shape), kivi_mf_decode_layer and its
+ *                               hipGraph form kivi_mf_decode_layer_dyn + kivi_mf_step_* (matrix-pipe cache: g = 32, D = 128,
+ *                               2-bit with nh / nh_kv in {1, 4, 8} or 4-bit with nh / nh_kv = 4), with the packers of that
+ *                               cache: kivi_kt_pack, kivi_vt_pack, kivi_kt_relayout, kivi_vt_relayout
+ *   BUILDING BLOCKS (what the layer steps are composed of; exported for tests, tools and callers that keep their own cache
+ *               bookkeeping -- same contracts, but no stability promise beyond the ABI version):  kivi_gemv_k_paged,
+ *               kivi_decode_scores, kivi_softmax_scaled, kivi_decode_output, kivi_decode_softmax_output, kivi_decode_attend,
+ *               kivi_gqa_scores, kivi_gqa_output, kivi_gqa_decode, kivi_mf_launch_plan
+ *   INSTRUMENTATION (bench.py, tools/, the parity sweeps; not part of the drop-in):  kivi_gemv_{k,v}_variant*, kivi_event_*,
+ *               kivi_set_launch_events, kivi_last_timed_kernel, kivi_debug_set_stamps
+ * Environment: the product library reads no environment variable; tuning knobs, losing / result-changing kernel variants and the
+ * stamping instantiations exist only in -DKIVI_TUNING builds (tools/build_variant.sh).
  */
 #ifndef KIVI_HIP_H
 #define KIVI_HIP_H
@@ -469,8 +488,9 @@ void kivi_set_launch_events(void* start, void* stop);
 float kivi_event_elapsed_us(void* start, void* stop);
 /* source text of the kernel instantiation the last consumed event pair bracketed ("" if none yet) */
 const char* kivi_last_timed_kernel(void);
-/* Diagnostic: device buffer of (blocks x 4 waves x 16) uint64 that decode_row_kernel fills with per-wave phase time
- * stamps (shader clock; slot 1 = 100 MHz realtime at entry); null switches it off (default). */
+/* Diagnostic, -DKIVI_TUNING builds only (the product library accepts the call and ignores it): device buffer of (blocks x 4 waves
+ * x 16) uint64 that the stamping instantiations of the row kernels fill with per-wave phase time stamps (shader clock; slot 1 =
+ * 100 MHz realtime at entry); null switches it off (default). */
 void kivi_debug_set_stamps(void* device_buffer);
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import warnings
 from typing import Optional, Tuple
 
 import torch
@@ -77,6 +78,24 @@ def _fusion_level(layer, nh: int, kv_len: int) -> int:
     if _FUSION_ENV:
         return {"attend": 2, "softmax": 1, "separate": 0}[_FUSION_ENV]
     return 2
+
+
+class KiviPerformanceWarning(UserWarning):
+    """A decode step left the fused kernels for a slower composition (results unchanged)."""
+
+
+def _drop_fusion(layer, attr: str, what: str, why: str = "") -> None:
+    """Mark `layer` as unable to use one fusion level and say so ONCE per layer and level: a shape without a tuned kernel otherwise
+    runs the slower composition forever without a word."""
+    if getattr(layer, attr, False):
+        return
+    setattr(layer, attr, True)
+    if _FUSION_ENV:          # a tuning session asked for the lower level
+        return
+    c = layer.cfg
+    warnings.warn(f"kivi_amd: {what} for this cache (k_bits={c.k_bits} v_bits={c.v_bits} group={c.group_size} "
+                  f"residual={c.residual_length} head_dim={layer.D} kv_heads={layer.nh_kv}){': ' + why if why else ''} -- the step "
+                  f"runs as more, slower launches from now on; results are unchanged", KiviPerformanceWarning, stacklevel=4)
 
 
 def _matmul_mod():
@@ -171,9 +190,9 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
     flushed = None
     level = _fusion_level(layer, nh, kv_seq_len)
     if level < 2:
-        layer._attend_unfusable = True
+        _drop_fusion(layer, "_attend_unfusable", "fusion level lowered")
     if level < 1:
-        layer._softmax_unfusable = True
+        _drop_fusion(layer, "_softmax_unfusable", "fusion level lowered")
     if not getattr(layer, "_attend_unfusable", False):
         # two launches: packed qK^T GEMV (:324), then residual scores + K append + softmax + output + V append/flush
         # only the launches that may be refused sit inside the try (they write scratch rows until the attend launch
@@ -183,8 +202,8 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
                 gemv_k_paged(cfg.group_size, query_states, layer.k_code, layer.k_scale, layer.k_mn, layer.k_quant_len,
                              cfg.k_bits, out=scores[..., : layer.k_quant_len])
             flushed = fused.decode_attend(layer, query_states, key_states, value_states, scores, out, inv, attention_mask)
-        except KiviUnsupported:
-            layer._attend_unfusable = True       # e.g. rows too long for the LDS: use the three-launch form below
+        except KiviUnsupported as e:             # e.g. rows too long for the LDS: use the three-launch form below
+            _drop_fusion(layer, "_attend_unfusable", "the fused attend launch (residual scores + softmax + output in one launch) is not available", str(e))
         else:
             layer.k_res_len += 1
             layer.maybe_flush_k()                                          # :343-356
@@ -195,8 +214,8 @@ def _decode_fused(query_states, key_states, value_states, layer: KiviLayerCache,
         if not getattr(layer, "_softmax_unfusable", False):
             try:   # scale + mask + softmax (:339, :364-375) inside the sV launch (:377-399)
                 flushed = fused.decode_output(layer, scores, value_states, out, softmax_inv_scale=inv, mask=attention_mask)
-            except KiviUnsupported:
-                layer._softmax_unfusable = True  # keep the softmax as its own launch
+            except KiviUnsupported as e:         # keep the softmax as its own launch
+                _drop_fusion(layer, "_softmax_unfusable", "the softmax cannot be folded into the sV launch", str(e))
     if flushed is None:
         fused.softmax_scaled(scores, probs, kv_seq_len, inv, attention_mask)
         try:
@@ -240,12 +259,13 @@ def _attention_decode(query_states, key_states, value_states, layer: KiviLayerCa
                 and not getattr(layer, "_attend_unfusable", False)):
             try:
                 return _decode_native(query_states, key_states, value_states, layer, attention_mask, out)
-            except KiviUnsupported:
-                layer._attend_unfusable = True   # the Python path below picks the next fusion level
+            except KiviUnsupported as e:         # the Python path below picks the next fusion level
+                _drop_fusion(layer, "_attend_unfusable", "the one-call layer step (kivi_decode_layer) is not available", str(e))
         try:
             return _decode_fused(query_states, key_states, value_states, layer, attention_mask)
-        except KiviUnsupported:
-            layer._fused_unsupported = True   # shape without a tuned kernel: compose the unfused ops from now on
+        except KiviUnsupported as e:          # shape without a tuned kernel: compose the unfused ops from now on
+            _drop_fusion(layer, "_fused_unsupported", "no fused decode kernel covers the shape: composing the reference's op sequence "
+                         "from the fused GEMVs and torch ops", str(e))
     nh_kv = layer.nh_kv
     rep = nh // nh_kv
     kv_seq_len = layer.kv_seq_len + 1                                    # llama_kivi.py:307-309

@@ -49,8 +49,14 @@ extern "C" float kivi_event_elapsed_us(void* start, void* stop) {
     return ms * 1000.0f;
 }
 
-// ---- phase time stamps of the fused decode-row kernel (tools/row_phases.py): a caller-owned device buffer of
-// grid x 4 waves x 16 uint64; null (the default) compiles to one uniform branch per stamp
+// ---- phase time stamps of the fused row kernels (tools/row_phases.py, tools/mf_row_phases.py): a caller-owned device buffer of
+// grid x 4 waves x 16 uint64.  Only -DKIVI_TUNING builds carry the stamping instantiations and remember the pointer; in the product
+// library the call is accepted and does nothing (no process-global state, no diagnostic kernels).
+#ifdef KIVI_TUNING
 static unsigned long long* g_stamps = nullptr;
 unsigned long long* kivi_debug_stamps() { return g_stamps; }
 extern "C" void kivi_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
+#else
+unsigned long long* kivi_debug_stamps() { return nullptr; }
+extern "C" void kivi_debug_set_stamps(void*) {}
+#endif

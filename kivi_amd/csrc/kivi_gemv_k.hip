@@ -107,24 +107,28 @@ const KVariant k_variants[] = {
     KV(2, 32, 2, 1, 1, 8, 2, 1),
     KV(2, 32, 2, 1, 1, 16, 2, 1),
     KV(2, 32, 2, 4, 1, 2, 2, 1),
-    KV(2, 32, 2, 4, 1, 4, 4, 1),
-    KV(2, 32, 2, 4, 1, 2, 4, 1),
     KV(2, 32, 4, 4, 1, 2, 2, 1),
     KV(2, 32, 4, 2, 1, 2, 2, 1),
-    KV(2, 32, 4, 2, 1, 4, 4, 1),
     KV(2, 32, 2, 2, 1, 4, 2, 1),
-    // unpack-strategy A/B on two geometries
+    // the plain bit-field unpack (v_bfe + v_cvt + v_fma) on two geometries: an independent arithmetic the parity tests cross-check
+    // the FMA-mix kernels with
     KV(2, 32, 4, 2, 1, 4, 0, 0),
-    KV(2, 32, 4, 2, 1, 4, 1, 0),
     KV(2, 32, 2, 4, 1, 4, 0, 0),
+#ifdef KIVI_TUNING
+    // -DKIVI_TUNING builds only (tools/build_variant.sh): unpack-strategy A/B forms the dispatch never picks ...
+    KV(2, 32, 2, 4, 1, 4, 4, 1),
+    KV(2, 32, 2, 4, 1, 2, 4, 1),
+    KV(2, 32, 4, 2, 1, 4, 4, 1),
+    KV(2, 32, 4, 2, 1, 4, 1, 0),
     KV(2, 32, 2, 4, 1, 4, 1, 0),
-    // memory-side ceiling of each geometry (diagnostic, excluded from dispatch and parity tests)
+    // ... and the memory-side ceiling of each geometry: the unpack skipped, WRONG RESULTS (diagnostic)
     KV(2, 32, 2, 4, 1, 4, 3, 1),
     KV(2, 32, 2, 2, 1, 8, 3, 1),
     KV(2, 32, 2, 1, 1, 8, 3, 1),
     KV(2, 32, 4, 4, 1, 4, 3, 1),
     KV(2, 32, 4, 2, 1, 4, 3, 1),
     KV(2, 32, 4, 1, 1, 8, 3, 1),
+#endif
     // ---- 2-bit, other group sizes
     KV(2, 64, 2, 4, 1, 4, 2, 1),
     KV(2, 64, 4, 2, 1, 4, 2, 0),

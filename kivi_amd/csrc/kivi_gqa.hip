@@ -272,9 +272,9 @@ __global__ __launch_bounds__(256) void vt_relayout_kernel(MfStore st, uint32_t* 
     }
 }
 
-// ---- 4-bit codes (KT4 / VT4, kivi_mfma_layout.h): the same four jobs on the shared quantiser's generic form (make_group +
-// quant_one<4>, the arithmetic of the hook-layout 4-bit packers in kivi_pack.hip).  One block per 32-token block; the codes
-// meet as bytes in LDS and leave as whole words, 4 (packers, K relayout) or 2 (V relayout) per thread.
+// ---- 4-bit codes (KT4 / VT4, kivi_mfma_layout.h): the same four jobs.  Packers: the packed 16-bit reciprocal quantiser of the
+// hook-layout 4-bit packers (pk16_pair_quantN, kivi_quant.h).  Relayouts: one block per 32-token block, whole words, 4 (K) or 2
+// (V) per thread.
 // word `wi` of a block -> (tile, n, kb, c)
 struct Mf4Word { int tile, n, kb, c; };
 __device__ __forceinline__ Mf4Word mf4_word_of(int wi) {
@@ -282,87 +282,129 @@ __device__ __forceinline__ Mf4Word mf4_word_of(int wi) {
     return {wi >> 8, l & 15, l >> 4, wi & 3};
 }
 
-__global__ __launch_bounds__(128) void kt_pack4_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
-                                                       int* range, int64_t blk0, int nblk, int nh_kv) {
-    __shared__ uint8_t cds[32][136];
-    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+// Round 5: the structure of the 2-bit packers (four waves per workgroup, one 32-token block each; the 32 x 128 tile comes in through
+// LDS with 16-byte loads, packed 16-bit statistics and quantiser on the lane's two channels / tokens at once, the block's 512 code
+// words meet in LDS and leave as two 1 KiB stores) -- the round-4 kernels (one 128-thread block per 32 tokens, scalar keys, codes
+// as bytes through LDS) ran at 0.59 / 0.49 of the HBM roofline against 0.78 / 0.72 for the 2-bit ones.
+__global__ __launch_bounds__(256) void kt_pack4_kernel(const uint16_t* k, int64_t k_sb, int64_t k_sh, int64_t k_st, MfStore st,
+                                                       int* range, int64_t blk0, int nblk, int nh_kv, int64_t ntile) {
+    const int wave = threadIdx.x >> 6;
+    int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const bool live_tile = tile_id < ntile;
+    if (!live_tile) tile_id = ntile - 1;                   // (its stores are skipped)
+    const int unit = (int)(tile_id / nblk), bi = (int)(tile_id - (int64_t)unit * nblk);
     const int b = unit / nh_kv, hk = unit - b * nh_kv;
-    const int d = threadIdx.x;                              // thread = channel: its group is the block's 32 tokens
-    const uint16_t* kp = k + b * k_sb + hk * k_sh + (int64_t)bi * 32 * k_st + d;
-    uint16_t x[32];
+    const int lane = threadIdx.x & 63;
+    constexpr int PITCH = 68;
+    __shared__ uint32_t stage[4][32 * PITCH];              // per wave: the fp16 tile, then (reused) the block's 512 code words
+    uint32_t* stw = stage[wave];
+    {
+        const uint16_t* tb = k + b * k_sb + hk * k_sh + (int64_t)bi * 32 * k_st;
+        u32x4 in[8];
 #pragma unroll
-    for (int t = 0; t < 32; t++) x[t] = kp[(int64_t)t * k_st];
-    uint32_t kmin = 0xFFFFu, kmax = 0u;
+        for (int j = 0; j < 8; j++) in[j] = __builtin_nontemporal_load((const u32x4*)(tb + (int64_t)(4 * j + (lane >> 4)) * k_st + 8 * (lane & 15)));
+#pragma unroll
+        for (int j = 0; j < 8; j++) *(u32x4*)(stw + (4 * j + (lane >> 4)) * PITCH + 4 * (lane & 15)) = in[j];
+    }
+    __builtin_amdgcn_wave_barrier();                       // (every region of `stage` belongs to one wave)
+    uint32_t x[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) x[t] = stw[t * PITCH + lane];      // the lane's channel pair (2 l, 2 l + 1) down the 32 tokens
+    uint32_t cq[32], scale2, mn2;
+    pk16_pair_quantN<32, 4>(x, cq, scale2, mn2);
+    __builtin_amdgcn_wave_barrier();                       // the tile has been read: its memory takes the code words
+    // word (tile, n, kb, c) = the 8 channels 32 c + 8 kb + e of token n + 16 tile, element e at bits 4 (e >> 1) + 16 (e & 1): this lane
+    // holds e = 2 i, 2 i + 1 (i = l & 3) in the halves of cq[t]; the four lanes of a quad complete a word
+    const int i = lane & 3;
+    const int c = lane >> 4, kb = (lane >> 2) & 3;
 #pragma unroll
     for (int t = 0; t < 32; t++) {
-        const uint32_t kk = h_key(x[t]);
-        kmin = kk < kmin ? kk : kmin;
-        kmax = kk > kmax ? kk : kmax;
+        uint32_t w = cq[t] << (4 * i);
+        w |= dpp_or<0xB1>(w);
+        w |= dpp_or<0x4E>(w);
+        if ((t >> 3) == i) stw[(t >> 4) * 256 + ((t & 15) + 16 * kb) * 4 + c] = w;
     }
-    const GroupQ gq = make_group(kmin, kmax, 15);
-#pragma unroll
-    for (int t = 0; t < 32; t++) cds[t][d] = (uint8_t)quant_one<4>(x[t], gq);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    if (!live_tile) return;
     const int64_t blk = blk0 + bi;
     uint32_t* sb = mf_sb(st, b, hk, blk >> 4);
     uint32_t* cw = sb + (blk & 15) * KIVI_MF4_BLOCK_WORDS;
-#pragma unroll
-    for (int rep = 0; rep < 4; rep++) {
-        const int wi = d + 128 * rep;
-        const Mf4Word q = mf4_word_of(wi);
-        const uint8_t* src = &cds[q.n + 16 * q.tile][32 * q.c + 8 * q.kb];
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) w |= (uint32_t)src[e] << (4 * (e >> 1) + 16 * (e & 1));
-        cw[wi] = w;
-    }
-    const int hidx = kt_sm_half((int)(blk & 15), d);
-    ((uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0))[hidx] = gq.scale;
-    ((uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0))[hidx] = gq.mn;
-    mf_range_mark(range + unit, gq.scale);                   // range marks of the unit (kt_pack_kernel)
+    *(u32x4*)(cw + lane * 4) = *(const u32x4*)(stw + lane * 4);
+    *(u32x4*)(cw + 256 + lane * 4) = *(const u32x4*)(stw + 256 + lane * 4);
+    const int hidx = kt_sm_half((int)(blk & 15), 2 * lane);    // channel 2 l (even): the pair (2 l, 2 l + 1) is one word
+    (sb + KIVI_MF4_SB_SCALE_WORD0)[hidx >> 1] = scale2;
+    (sb + KIVI_MF4_SB_MN_WORD0)[hidx >> 1] = mn2;
+    mf_range_mark(range + unit, scale2 & 0xFFFFu);          // range marks of the unit (kt_pack_kernel)
+    mf_range_mark(range + unit, scale2 >> 16);
 }
 
-__global__ __launch_bounds__(128) void vt_pack4_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
-                                                       int* range, int64_t T, int nblk, int nh_kv) {
-    __shared__ uint8_t cds[32][136];
-    const int unit = blockIdx.x / nblk, bi = blockIdx.x - unit * nblk;
+// Lane (kb, c, ee) = 16 kb + 4 c + ee owns the token PAIR (8 kb + 2 ee, + 1) of channel group c (cf. vt_pack_kernel): even token in
+// the low halves, odd token in the high halves of x[j], j = channel inside the group.  Tokens at or past T read as zeros.
+__global__ __launch_bounds__(256) void vt_pack4_kernel(const uint16_t* v, int64_t v_sb, int64_t v_sh, int64_t v_st, MfStore st,
+                                                       int* range, int64_t T, int nblk, int nh_kv, int64_t ntile) {
+    const int wave = threadIdx.x >> 6;
+    int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const bool live_tile = tile_id < ntile;
+    if (!live_tile) tile_id = ntile - 1;
+    const int unit = (int)(tile_id / nblk), bi = (int)(tile_id - (int64_t)unit * nblk);
     const int b = unit / nh_kv, hk = unit - b * nh_kv;
-    const int tt = threadIdx.x >> 2, c = threadIdx.x & 3;   // thread = (token, channel group): 32 channels = 64 bytes
-    const int64_t t = (int64_t)bi * 32 + tt;
-    u16x8 xv[4];
+    const int lane = threadIdx.x & 63;
+    const int kb = lane >> 4, c = (lane >> 2) & 3, ee = lane & 3;
+    constexpr int PITCH = 68;                              // words per staged row (256 bytes + 16: rows start 4 banks apart)
+    __shared__ uint32_t stage[4][32 * PITCH];              // per wave: the fp16 tile, then (reused) the block's 512 code words
+    uint32_t* stw = stage[wave];
+    {
+        const uint16_t* tb = v + b * v_sb + hk * v_sh + (int64_t)bi * 32 * v_st;
+        u32x4 in[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        xv[i] = (t < T) ? *(const u16x8*)(v + b * v_sb + hk * v_sh + t * v_st + 32 * c + 8 * i) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t kmin = 0xFFFFu, kmax = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t kk = h_key(xv[i][e]);
-            kmin = kk < kmin ? kk : kmin;
-            kmax = kk > kmax ? kk : kmax;
+        for (int j = 0; j < 8; j++) {
+            const int r = 4 * j + (lane >> 4);
+            in[j] = ((int64_t)bi * 32 + r < T) ? __builtin_nontemporal_load((const u32x4*)(tb + (int64_t)r * v_st + 8 * (lane & 15))) : u32x4{0, 0, 0, 0};
         }
-    const GroupQ gq = make_group(kmin, kmax, 15);            // tokens at or past T: all zeros -> scale 0, zero point 0, codes 0
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 8; j++) *(u32x4*)(stw + (4 * j + (lane >> 4)) * PITCH + 4 * (lane & 15)) = in[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    u32x4 ra[4], rb[4];                                   // 32 channels of the even / odd token
+    {
+        const uint32_t* pa = stw + (8 * kb + 2 * ee) * PITCH + 16 * c;
 #pragma unroll
-        for (int e = 0; e < 8; e++) cds[tt][32 * c + 8 * i + e] = (uint8_t)quant_one<4>(xv[i][e], gq);
-    __syncthreads();
+        for (int q = 0; q < 4; q++) {
+            ra[q] = *(const u32x4*)(pa + 4 * q);
+            rb[q] = *(const u32x4*)(pa + PITCH + 4 * q);
+        }
+    }
+    uint32_t x[32];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const uint32_t a = ra[q][kk], bq = rb[q][kk];   // channels 8 q + 2 kk, + 1
+            x[8 * q + 2 * kk] = __builtin_amdgcn_perm(bq, a, 0x05040100u);       // (a.lo, b.lo)
+            x[8 * q + 2 * kk + 1] = __builtin_amdgcn_perm(bq, a, 0x07060302u);   // (a.hi, b.hi)
+        }
+    uint32_t cq[32], scale2, mn2;
+    pk16_pair_quantN<32, 4>(x, cq, scale2, mn2);
+    __builtin_amdgcn_wave_barrier();                       // the tile has been read: its memory takes the code words
+    // word (tile, n, kb, c) = the 8 tokens 8 kb + e of channel 32 c + 16 tile + n, element e at bits 4 (e >> 1) + 16 (e & 1): this lane
+    // holds e = 2 ee, 2 ee + 1 in the halves of cq[j], j = 16 tile + n; the four lanes of a quad (ee) complete a word
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        uint32_t w = cq[j] << (4 * ee);
+        w |= dpp_or<0xB1>(w);
+        w |= dpp_or<0x4E>(w);
+        if ((j >> 3) == ee) stw[(j >> 4) * 256 + ((j & 15) + 16 * kb) * 4 + c] = w;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!live_tile) return;
     uint32_t* sb = mf_sb(st, b, hk, bi >> 4);
     uint32_t* cw = sb + (bi & 15) * KIVI_MF4_BLOCK_WORDS;
-#pragma unroll
-    for (int rep = 0; rep < 4; rep++) {
-        const int wi = (int)threadIdx.x + 128 * rep;
-        const Mf4Word q = mf4_word_of(wi);
-        const int ch = 32 * q.c + 16 * q.tile + q.n;
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) w |= (uint32_t)cds[8 * q.kb + e][ch] << (4 * (e >> 1) + 16 * (e & 1));
-        cw[wi] = w;
-    }
-    ((uint16_t*)(sb + KIVI_MF4_SB_SCALE_WORD0) + (bi & 15) * 128)[vt_half(tt, c)] = gq.scale;
-    ((uint16_t*)(sb + KIVI_MF4_SB_MN_WORD0) + (bi & 15) * 128)[vt_half(tt, c)] = gq.mn;
-    mf_range_mark(range + unit, gq.scale);
+    *(u32x4*)(cw + lane * 4) = *(const u32x4*)(stw + lane * 4);
+    *(u32x4*)(cw + 256 + lane * 4) = *(const u32x4*)(stw + 256 + lane * 4);
+    (sb + KIVI_MF4_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;   // vt_half(8 kb + 2 ee, c) / 2 == lane
+    (sb + KIVI_MF4_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
+    mf_range_mark(range + unit, scale2 & 0xFFFFu);
+    mf_range_mark(range + unit, scale2 >> 16);
 }
 
 // KT4 <-> K_code_T (B, nh_kv, D, T/8), K_scale_T / K_mn_T (B, nh_kv, D, T/32): 4 reference words per (channel, block)
@@ -522,8 +564,8 @@ extern "C" int kivi_kt_pack(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     const MfStore st = {(uint32_t*)kt, kt_sb, kt_sh, kt_ss};
     const int64_t ntile = (int64_t)B * nh_kv * nblk;
     if (bits == 4) {
-        hipLaunchKernelGGL(kt_pack4_kernel, dim3((unsigned)ntile), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)k, k_sb, k_sh, k_st,
-                           st, (int*)kt_range, token_offset / 32, nblk, nh_kv);
+        hipLaunchKernelGGL(kt_pack4_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)k, k_sb, k_sh, k_st,
+                           st, (int*)kt_range, token_offset / 32, nblk, nh_kv, ntile);
         return kivi_launch_status("kt_pack4");
     }
     hipLaunchKernelGGL(kt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
@@ -545,8 +587,8 @@ extern "C" int kivi_vt_pack(const void* v, int64_t v_sb, int64_t v_sh, int64_t v
     const MfStore st = {(uint32_t*)vt, vt_sb, vt_sh, vt_ss};
     const int64_t ntile = (int64_t)B * nh_kv * nblk;
     if (bits == 4) {
-        hipLaunchKernelGGL(vt_pack4_kernel, dim3((unsigned)ntile), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)v, v_sb, v_sh, v_st,
-                           st, (int*)vt_range, T, nblk, nh_kv);
+        hipLaunchKernelGGL(vt_pack4_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v, v_sb, v_sh, v_st,
+                           st, (int*)vt_range, T, nblk, nh_kv, ntile);
         return kivi_launch_status("vt_pack4");
     }
     hipLaunchKernelGGL(vt_pack_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, (hipStream_t)stream,

@@ -432,10 +432,10 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 
 // The whole decode step of one (batch row, head) in one block of NW waves.  Dynamic LDS: the score / p'' row (n_pad halves).
 // DBG (tools/mf_row_phases.py): every wave stamps the shader clock at its phase boundaries into av.dbg
-// DUMP (KIVI_GQA_DUMP_SCORES, tests): the fp16 row the softmax consumes (scaled, mask added) also goes to ak.out
+// ak.dump (KIVI_GQA_DUMP_SCORES, tests): the fp16 row the softmax consumes (scaled, mask added) also goes to ak.out
 // OCC: waves per SIMD the register budget allows (4: 128 registers; 2: the few-rows instantiation with rings of 8 -- at most one
 // block per CU is resident anyway, so a wave may hold a half super-block of K and 8 blocks of V in flight)
-template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, bool DUMP = false, int OCC = 4>
+template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, int OCC = 4>
 __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int NTH = NW * 64;
     GqaKArgs ak = ak_in;
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4), DUMP>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
-                                                              DUMP ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
+    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4)>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
+                                                        ak.dump ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
     __syncthreads();
     stamp(7);
 
@@ -645,7 +645,10 @@ __device__ __forceinline__ void mf_probs_inplace(uint16_t* rows, int pitch, int 
     }
 }
 
-template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2>
+// LSTAT: the statistics of a wave's segments are carried per LANE through the K walk (a running (max, sum exp) of the lane's eight
+// scores per segment and head, rescaled when the maximum moves) and reduced across the wave ONCE at the end of the walk, instead
+// of two wave reductions per segment and head (each a chain of ~10 dependent DPP / readlane operations)
+template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, bool LSTAT = true>
 __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
     constexpr int NTH = NW * 64;
     static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
@@ -712,6 +715,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
     // ---- packed qK^T: wave w walks super-blocks sb_lo + w, sb_lo + w + NW, ...; the rows hold the SCALED scores
     // fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed conversion, two v_fma_mix
     const int hb = (4 * (lane >> 4)) % R;
+    float lm[R], ll[R];                                            // LSTAT: this lane's running (max, sum exp(x - max)) of every head
+#pragma unroll
+    for (int rr = 0; rr < R; rr++) { lm[rr] = -__builtin_inff(); ll[rr] = 0.f; }
     {
         const rsrc_t rk = make_rsrc(mf_sb(ak.kt, b, hk, 0), (uint32_t)((int64_t)ak.nsb * ak.kt.sb_s * 4));
         MfKSeq seq;
@@ -758,19 +764,36 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
                     m = __builtin_fmaxf(h2f_bits((uint16_t)(mb & 0xFFFFu)), h2f_bits((uint16_t)(mb >> 16)));
                 }
                 if (dump0 && valid) *(u32x4*)(dump0 + (int64_t)rr * ak.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
-                m = wave_max(valid ? m : -__builtin_inff());
                 const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
-                fp2 acc = {0.f, 0.f};
+                if constexpr (LSTAT) {
+                    if (valid) {                                   // (no cross-lane step inside: lanes past the segment's end just skip it)
+                        const float mo = lm[rr];
+                        const float mn_ = __builtin_fmaxf(mo, m);
+                        const float ms = mn_ == -__builtin_inff() ? 0.f : mn_;             // (a lane whose scores are all -inf so far)
+                        fp2 acc = {ll[rr] * kivi_exp(mo - ms), 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t xw = v[i];
-                    const fp2 d = (fp2){mf_sub_lo(xw, -m), mf_sub_hi(xw, -m)} * l2e;       // kivi_exp(x - m)
-                    acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
-                }
-                const float l = wave_sum(valid ? acc[0] + acc[1] : 0.f);
-                if (lane == 0) {
-                    st_lds[rr][seg][0] = m;
-                    st_lds[rr][seg][1] = l;
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t xw = v[i];
+                            const fp2 d = (fp2){mf_sub_lo(xw, -ms), mf_sub_hi(xw, -ms)} * l2e;   // kivi_exp(x - m)
+                            acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                        }
+                        lm[rr] = mn_;
+                        ll[rr] = acc[0] + acc[1];
+                    }
+                } else {
+                    m = wave_max(valid ? m : -__builtin_inff());
+                    fp2 acc = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t xw = v[i];
+                        const fp2 d = (fp2){mf_sub_lo(xw, -m), mf_sub_hi(xw, -m)} * l2e;   // kivi_exp(x - m)
+                        acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                    }
+                    const float l = wave_sum(valid ? acc[0] + acc[1] : 0.f);
+                    if (lane == 0) {
+                        st_lds[rr][seg][0] = m;
+                        st_lds[rr][seg][1] = l;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -781,6 +804,18 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
             dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head hb + r at tokens tt, tt + 16
             dst[16] = (uint16_t)(hs >> 16);
         }, seg_done);
+    }
+    if constexpr (LSTAT) {                                         // the wave's (max, sum exp) of every head: one entry per wave
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            const float m = wave_max(lm[rr]);
+            const float ms = m == -__builtin_inff() ? 0.f : m;
+            const float l = wave_sum(ll[rr] * kivi_exp(lm[rr] - ms));
+            if (lane == 0) {
+                st_lds[rr][wave][0] = m;
+                st_lds[rr][wave][1] = l;
+            }
+        }
     }
     stamp(3);
     __builtin_amdgcn_s_setprio(3);                                  // the latency-bound middle of the step (see mf_row_kernel)
@@ -794,31 +829,55 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
     const int b_hi = (b_lo + nbw < vb_hi) ? b_lo + nbw : vb_hi;
     MfVStream<R, VRING, VHL, BITS> vs;
     vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
-    // ---- residual scores q . [K_full | k_new] of the R heads (:337) [+ mask] + K append (:333-336): the last slice
+    // ---- residual scores q . [K_full | k_new] of the R heads (:337: fp32 accumulate, one rounding = the reference's fp16 matmul)
+    // [+ mask] + K append (:333-336): the last slice.  Eight lanes per key (16 channels each) take the key against ALL R heads: a
+    // key row is read once, every load of the phase is issued before the first product -- one memory round trip for up to 129 keys
+    // (round 4 walked (head, key) pairs, 16 dependent round trips at residual_length 128)
     if (last) {
-        for (int idx = threadIdx.x; idx < R * L * 8; idx += NTH) {
-            const int sub = idx & 7, rt = idx >> 3;
-            const int r = rt / L, t = rt - r * L;
-            const uint16_t* krow = ((t < ak.res_len) ? kres + (int64_t)t * ak.kres_st : knew) + sub * 16;
+        constexpr int TPP = NTH / 8, KP = (129 + TPP - 1) / TPP;   // keys per pass, passes
+        const int sub = threadIdx.x & 7, ts = threadIdx.x >> 3;
+        u16x8 qa[R], qb[R], ka[KP], kc[KP];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
             const uint16_t* qrow = q_h0 + (int64_t)r * ak.q_sh + sub * 16;
-            const u16x8 k0 = *(const u16x8*)krow, k1 = *(const u16x8*)(krow + 8);
-            const u16x8 q0 = *(const u16x8*)qrow, q1 = *(const u16x8*)(qrow + 8);
-            float sc = 0.f;
+            qa[r] = *(const u16x8*)qrow;
+            qb[r] = *(const u16x8*)(qrow + 8);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q0[e]), h2f_bits(k0[e]), sc);
-#pragma unroll
-            for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(q1[e]), h2f_bits(k1[e]), sc);
-            if (t == ak.res_len && r == 0) {
-                *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = k0;
-                *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = k1;
+        for (int p = 0; p < KP; p++) {
+            const int t = ts + p * TPP;
+            ka[p] = kc[p] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < L) {
+                const uint16_t* krow = ((t < ak.res_len) ? kres + (int64_t)t * ak.kres_st : knew) + sub * 16;
+                ka[p] = *(const u16x8*)krow;
+                kc[p] = *(const u16x8*)(krow + 8);
             }
-            sc += __shfl_xor(sc, 1);
-            sc += __shfl_xor(sc, 2);
-            sc += __shfl_xor(sc, 4);
-            if (sub == 0) {
-                const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, mrow != nullptr, mrow ? mrow[Tq + t] : (uint16_t)0);
-                rows[r * n_pad + (Tq - tok0) + t] = h;
-                if (dump0) dump0[(int64_t)r * ak.out_sh + Tq + t] = h;
+        }
+#pragma unroll
+        for (int p = 0; p < KP; p++) {
+            const int t = ts + p * TPP;
+            if (t < L) {                                           // (the eight lanes of a key agree)
+                if (t == ak.res_len) {
+                    *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = ka[p];
+                    *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = kc[p];
+                }
+                const uint16_t mk = mrow ? mrow[Tq + t] : (uint16_t)0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    float sc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qa[r][e]), h2f_bits(ka[p][e]), sc);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qb[r][e]), h2f_bits(kc[p][e]), sc);
+                    sc += dpp_f<0xB1>(sc);                         // the eight lanes of the key (order of the additions as before:
+                    sc += dpp_f<0x4E>(sc);                         // neighbours, pairs, the two quads)
+                    sc += dpp_f<0x141>(sc);
+                    if (sub == 0) {
+                        const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, mrow != nullptr, mk);
+                        rows[r * n_pad + (Tq - tok0) + t] = h;
+                        if (dump0) dump0[(int64_t)r * ak.out_sh + Tq + t] = h;
+                    }
+                }
             }
         }
     }
@@ -834,7 +893,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
     float M[R], invS[R];
     int sp[R];
     {
-        const int nseg_loc = sb_hi - sb_lo;
+        const int nseg_loc = LSTAT ? NW : sb_hi - sb_lo;          // entries of st_lds: one per wave, or one per segment
         float Ls[R];
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
@@ -897,6 +956,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
             sp[rr] = mf_sp(Ls[rr], vrsh);
         }
     }
+    stamp(6);
     // the window's probabilities fp16(exp(x - M) / sum) (:375) of the rows wave, wave + NW, ...
     if (last) {
         const int Lw = av.res_len + 1;
@@ -1082,8 +1142,8 @@ static int mf_cu_count() {
 // The whole step in one launch: nh == nh_kv (rows <= 8192 keys: mf_row_kernel, 4 blocks of 4 waves per CU, 8 waves per row
 // for <= 512 rows) or nh / nh_kv in {4, 8} (mf_row4_kernel: the R score rows of a unit -- or, S > 1, of one of the S slices of its
 // row -- in one block of 4 waves, 2 blocks per CU).  KIVI_EUNSUPPORTED (with a message) when the shape does not qualify.
-// dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the rows the softmax statistics are taken from also go to the score buffer (nh == nh_kv:
-// separate instantiations; nh / nh_kv in {4, 8}: the product instantiation, a run-time pointer).
+// dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the rows the softmax (statistics) are taken from also go to the score buffer -- a run-time
+// pointer in the PRODUCT instantiations (round 4 used separate ones).
 // n_rows: the longest row the launch must hold (= Tq + k_res_len + 1, or the bound of the step's geometry class when the lengths
 // are device-resident).  S: slices per row (1 for nh == nh_kv); res_cap: residual_length (the fp16 keys a last slice may hold).
 int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, hipStream_t s) {
@@ -1123,15 +1183,20 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
         if (bits == 4) KIVI_ROW4_LAUNCH(opt44, 4, 3, 4, false, true, 4, 4);
 #ifdef KIVI_TUNING
-        static unsigned long long opt_t[8] = {0};
-        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<K ring><V ring><waves>"; + 1000: chained hi / lo in the sV phase
+        static unsigned long long opt_t[16] = {0};
+        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<K ring><V ring><waves>"; + 1000: chained hi / lo in the sV phase; + 2000: statistics by wave reductions per segment
         const int cfg = fr4 ? atoi(fr4) : 434;
+        if (v.dbg && cfg == 844) KIVI_ROW4_LAUNCH(opt_t[9], 8, 4, 4, true);
+        if (v.dbg && cfg == 2434) KIVI_ROW4_LAUNCH(opt_t[10], 4, 3, 4, true, true, 4, 2, false);
         if (v.dbg) KIVI_ROW4_LAUNCH(opt_t[0], 4, 3, 4, true);
         if (cfg == 234) KIVI_ROW4_LAUNCH(opt_t[1], 2, 3, 4);
         if (cfg == 834) KIVI_ROW4_LAUNCH(opt_t[2], 8, 3, 4);
         if (cfg == 444) KIVI_ROW4_LAUNCH(opt_t[3], 4, 4, 4);
-        if (cfg == 424) KIVI_ROW4_LAUNCH(opt_t[4], 4, 2, 4);
-        if (cfg == 1434) KIVI_ROW4_LAUNCH(opt_t[5], 4, 3, 4, false, false);
+        if (cfg == 844) KIVI_ROW4_LAUNCH(opt_t[4], 8, 4, 4);
+        if (cfg == 424) KIVI_ROW4_LAUNCH(opt_t[5], 4, 2, 4);
+        if (cfg == 1434) KIVI_ROW4_LAUNCH(opt_t[6], 4, 3, 4, false, false);
+        if (cfg == 2434) KIVI_ROW4_LAUNCH(opt_t[7], 4, 3, 4, false, true, 4, 2, false);
+        if (cfg == 2844) KIVI_ROW4_LAUNCH(opt_t[8], 8, 4, 4, false, true, 4, 2, false);
 #endif
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH
@@ -1158,16 +1223,12 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
     // few rows (under ~2 four-wave blocks per CU): eight waves per row, the row's own waves hide the latency
     static const char* f8 = KIVI_TUNE_ENV("KIVI_MF_ROW_NW8");            // tuning builds: 0 / 1 forces either
     const bool nw8 = f8 ? atoi(f8) != 0 : units <= 512;         // 256 rows: 30.3 -> 26.8 us, 384: 39.7 -> 37.0, 512: 45.8 -> 44.0, 768: 61.1 vs 65.4 (profiles/r03_other_shapes.log)
-    if (dump) {
-        if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8, false, true, true>), grid, dim3(512), lds, s, k, v, n_pad);
-        else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, true, true>), grid, dim3(256), lds, s, k, v, n_pad);
-        return kivi_launch_status("mf_row");
-    }
+    k.dump = dump;
     // at most one block per CU (<= 256 rows): a row's waves are alone on their SIMDs and each is bound by the round trips of its own
     // ring (2 KiB of K / 3 KiB of V in flight stream ~3 GB/s per wave): rings of 8 blocks, 256 registers per wave
     static const char* fdp = KIVI_TUNE_ENV("KIVI_MF_ROW_DEEP");          // tuning builds: 0 / 1 forces either
     const bool deep = fdp ? atoi(fdp) != 0 : units <= 256;
-    if (deep) KIVI_LAUNCH_LDS((mf_row_kernel<8, 8, 8, false, true, false, 2>), grid, dim3(512), lds, s, k, v, n_pad);
+    if (deep) KIVI_LAUNCH_LDS((mf_row_kernel<8, 8, 8, false, true, 2>), grid, dim3(512), lds, s, k, v, n_pad);
     else if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
     else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);
     return kivi_launch_status("mf_row");

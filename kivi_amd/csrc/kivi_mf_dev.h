@@ -871,9 +871,10 @@ __device__ __forceinline__ uint32_t mf_scale_pair(uint32_t hpair, float inv) {
     return d;
 }
 
-// rsh: the range shift of the unit's V store (mf_sp).  dump (test instantiations: KIVI_GQA_DUMP_SCORES): the fp16 row as the
-// softmax consumes it (scaled, mask added) also goes to this row of the caller's score buffer.
-template <int NTH, int SMC, bool DUMP = false>
+// rsh: the range shift of the unit's V store (mf_sp).  dump (KIVI_GQA_DUMP_SCORES, tests; a run-time pointer, null otherwise: the
+// PRODUCT instantiation is the one the stage-A checks run on): the fp16 row as the softmax consumes it (scaled, mask added) also
+// goes to this row of the caller's score buffer.
+template <int NTH, int SMC>
 __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
                                               uint16_t* pw_row, float* sm_lds, int rsh, uint16_t* dump = nullptr) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
@@ -919,9 +920,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
         if (c < nch) {
             const int j0 = c * SCH + (int)threadIdx.x * 4;
             const u32x2v raw = *(const u32x2v*)(row + (j0 < n_pad ? j0 : n_pad - 4));     // past the row: -inf -> exp = 0
-            if constexpr (DUMP) {
-                if (dump && j0 < n) *(u32x2v*)(dump + j0) = raw;    // (rows are padded to a multiple of 8 scores)
-            }
+            if (dump && j0 < n) *(u32x2v*)(dump + j0) = raw;        // (rows are padded to a multiple of 8 scores)
             const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;   // kivi_exp(x - M), two at a time
             const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
             xe[c][0] = (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};

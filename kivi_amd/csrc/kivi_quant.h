@@ -162,3 +162,36 @@ __device__ __forceinline__ void pk16_pair_quant2(const uint32_t* x, uint32_t* cq
         cq[t] = pk_code2(db, t0, t1, dt) & live;
     }
 }
+
+// The 4- / 8-bit codes of the two channels (or rows) a lane holds in the halves of x[0..N): the reciprocal quantiser of
+// quant_pack_lastdimN_kernel / quant_pack_k_tmajor_tiled (kivi_pack.hip: scale = fp16(range * fp32(1 / maxq)), code =
+// rint(clamp(fp16(d * fp32(1 / scale)))) through the 1024 magic add -- equal to the reference's divisions for every fp16 pair, checked
+// exhaustively on the CPU) on both halves at once.  cq[t] = code of the low half | code of the high half << 16.
+template <int N, int BITS>
+__device__ __forceinline__ void pk16_pair_quantN(const uint32_t* x, uint32_t* cq, uint32_t& scale2, uint32_t& mn2) {
+    static_assert(BITS == 4 || BITS == 8, "2 bits: pk16_pair_quant2");
+    constexpr int MAXQ = (1 << BITS) - 1;
+    uint32_t mnb, mxb;
+    pk16_pair_minmax<N>(x, mnb, mxb);
+    const uint16_t mn0 = (uint16_t)(mnb & 0xFFFFu), mn1 = (uint16_t)(mnb >> 16);
+    const uint16_t r0 = f2h_bits(h2f_bits((uint16_t)(mxb & 0xFFFFu)) - h2f_bits(mn0));       // new_pack.py:238 (mx - mn)
+    const uint16_t r1 = f2h_bits(h2f_bits((uint16_t)(mxb >> 16)) - h2f_bits(mn1));
+    const uint16_t sc0 = f2h_bits(h2f_bits(r0) * (1.0f / (float)MAXQ)), sc1 = f2h_bits(h2f_bits(r1) * (1.0f / (float)MAXQ));
+    scale2 = (uint32_t)sc0 | ((uint32_t)sc1 << 16);
+    mn2 = (uint32_t)mn0 | ((uint32_t)mn1 << 16);
+    const float rc0 = 1.0f / h2f_bits(sc0), rc1 = 1.0f / h2f_bits(sc1);                      // IEEE; inf for scale 0, 0 for scale inf
+    const hf2 mnv = __builtin_bit_cast(hf2, mn2);
+    const hf2 zero2 = {(_Float16)0.0f, (_Float16)0.0f}, maxq2 = {(_Float16)(float)MAXQ, (_Float16)(float)MAXQ};
+    const hf2 magic = {(_Float16)1024.0f, (_Float16)1024.0f};
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        const uint32_t xt = x[t];
+        const hf2 d = __builtin_bit_cast(hf2, xt) - mnv;                                      // :239
+        hf2 q;
+        q[0] = (_Float16)((float)d[0] * rc0);                                                 // :240 through the reciprocal
+        q[1] = (_Float16)((float)d[1] * rc1);
+        const hf2 cl = __builtin_elementwise_min(__builtin_elementwise_max(q, zero2), maxq2);  // :241 clamp_ (NaN -> 0)
+        cq[t] = __builtin_bit_cast(uint32_t, cl + magic) & (BITS == 4 ? 0x000F000Fu : 0x00FF00FFu);   // round_ + to(int32)
+    }
+}
+

@@ -29,13 +29,17 @@ class MfStepDriver:
         c0 = caches[0]
         self.caches = caches
         self.lib = _lib.load()
-        self.host = c0.host_step()
-        for c in caches[1:]:
+        self.resync()
+        self.dev = torch.zeros(4, dtype=torch.int64, device=c0.kt.device)       # kivi_mf_step in device memory (32 bytes)
+        self._ptrs = None
+
+    def resync(self) -> None:
+        """Take the lengths from the caches again (they may have been advanced by eager steps or a new prompt since the last call)."""
+        self.host = self.caches[0].host_step()
+        for c in self.caches[1:]:
             h = c.host_step()
             assert (h.Tq, h.Tv, h.k_res_len, h.v_res_len, h.v_win_start) == (self.host.Tq, self.host.Tv, self.host.k_res_len, self.host.v_res_len, self.host.v_win_start), \
                 "the layers of a model advance together"
-        self.dev = torch.zeros(4, dtype=torch.int64, device=c0.kt.device)       # kivi_mf_step in device memory (32 bytes)
-        self._ptrs = None
 
     # -- per step, in this order: prepare() [-> capture or replay the launches] -> finish()
     def key(self) -> int:

@@ -63,6 +63,13 @@ print(f"blocks {nblk}, entry spread {span_rt:.2f} us (realtime), kernel span {en
 names = {3: "packed qK^T (prologue + stream)", 4: "V ring request + residual scores", 5: "barrier (wait for the slowest wave)",
          7: "softmax", 8: "window PV + flush", 9: "V stream loop",
          10: "per-wave result + combine barrier", 11: "final sum + store"}
+slots = (3, 4, 5, 7, 8, 9, 10, 11)
+if (s[:, :, 6] != 0).all():     # mf_row4_kernel (round 5): no softmax phase -- statistics merge [+ exchange between slices], then the window's probabilities
+    names[3] = "packed qK^T + statistics per segment"
+    names[6] = "statistics merge [+ slice exchange]"
+    names[7] = "window probabilities + barrier"
+    names[9] = "V stream loop (p'' made on the fly)"
+    slots = (3, 4, 5, 6, 7, 8, 9, 10, 11)
 mhz = float(os.environ.get("CLOCK_MHZ", "0"))
 if not mhz:
     # calibrate the shader clock against the 100 MHz realtime counter (slot 1 at entry, slot 12 at exit of every wave)
@@ -71,7 +78,7 @@ if not mhz:
     mhz = float(np.median(dt_sh / np.maximum(dt_rt, 1e-3)))
 prev = 0
 print(f"{'phase':38s} {'median':>9s} {'p10':>9s} {'p90':>9s}   (us at {mhz:.0f} MHz)   in-block spread of the boundary (median / p90 us)")
-for i in (3, 4, 5, 7, 8, 9, 10, 11):
+for i in slots:
     d = (s[:, :, i] - s[:, :, prev]).reshape(-1) / mhz
     spread = (s[:, :, i].max(axis=1) - s[:, :, i].min(axis=1)) / mhz
     print(f"{names[i]:38s} {np.median(d):9.2f} {np.percentile(d, 10):9.2f} {np.percentile(d, 90):9.2f}"

@@ -21,6 +21,8 @@
 #   xcd              two-launch form with a unit's blocks on one XCD (tuning build, KIVI_MF_XCD) against the plain block order
 #   mf4              4-bit K / V on the matrix pipe: parity tests, then config 4 at --bits 4 against the VALU path
 #   mf4prof          config 4 at --bits 4: kernel trace medians + HBM traffic; the config-5 slice at --bits 4 against the VALU path
+#   forms            round 5: the library's launch plan against forced forms (two launches / a block per row / N slices per row) at BASELINE
+#                    config 4, the config-5 slice, the 70B-like slice, R = 8 at B = 64 and small grouped-query batches (bench.py --form)
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -90,7 +92,12 @@ while [ $# -gt 0 ]; do
         timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/shape_config5_slice.json 2>> $O/shapes.err; line $O/shape_config5_slice.json
         timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/shape_70b_slice.json 2>> $O/shapes.err; line $O/shape_70b_slice.json
         KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN > $O/shape_headline_hook_layout.json 2>> $O/shapes.err; line $O/shape_headline_hook_layout.json ;;
-    trace) trace_one bench 160 ;;
+    trace)
+        # the driver's command incl. the BASELINE configs[1] loop through the reference's operator (cuda_bmm_fA_qB_outer -> gemv_k_kernel),
+        # so that the kernel stats / trace medians carry a gemv_k_kernel row (the kernel the north-star target is written about)
+        BN_SAVE=$BN; BN="python $R/bench.py --no-cpu-baseline"
+        trace_one bench 160
+        BN=$BN_SAVE ;;
     trace_c4) trace_one config4 96 $C4 --steps 10 --warmup 3 ;;
     trace_gqa)
         trace_one config4 96 $C4 --steps 10 --warmup 3
@@ -160,6 +167,54 @@ while [ $# -gt 0 ]; do
         pmc_one config4_4bit '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 4, "group": 32, "residual": 128}' $C4 --bits 4
         timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5.json 2>> $O/mf4.err; line $O/mf4_c5.json
         KIVI_TUNING=1 KIVI_NO_MFMA_LAYOUT=1 timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5_valu.json 2>> $O/mf4.err; line $O/mf4_c5_valu.json ;;
+    r5a)
+        # round 5, first look: the restructured mf_row4_kernel (statistics in the K walk, probabilities in the V stream, slices) and the
+        # second range mark through their parity tests, then BASELINE config 4 / config-5 slice / 70B slice, plan vs two launches
+        timeout 1500 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_graph_gpu.py -m gpu -q --tb=short --maxfail=12 \
+            -k "sliced or match_reference_logic or two_launch_form or full_size or dynamic_range or graph or dyn" > $O/r5a_tests.log 2>&1
+        echo "r5a tests rc=$?" | tee -a $O/status.log; tail -40 $O/r5a_tests.log | cut -c1-300
+        for f in auto split; do
+            timeout 300 $BN $C4 --steps 10 --warmup 3 --form $f > $O/r5a_c4_$f.json 2>> $O/r5a.err; line $O/r5a_c4_$f.json
+            timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/r5a_c5_$f.json 2>> $O/r5a.err; line $O/r5a_c5_$f.json
+            timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/r5a_c70_$f.json 2>> $O/r5a.err; line $O/r5a_c70_$f.json
+        done
+        timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/r5a_c4_4bit.json 2>> $O/r5a.err; line $O/r5a_c4_4bit.json
+        tail -5 $O/r5a.err ;;
+    r5b)
+        # round 5, second look: parity of the rewritten residual phase / lane-local statistics / 4-bit packers, then one-box A/B at BASELINE
+        # config 4: the round-4 tree (_r4/, git worktree of 96aba04) against this tree's default and ring / statistics variants (tuning build)
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=12 \
+            -k "sliced or two_launch_form or kt4_pack or vt4_pack or (mf4_decode_steps_match and row)" > $O/r5b_tests.log 2>&1
+        echo "r5b tests rc=$?" | tee -a $O/status.log; tail -25 $O/r5b_tests.log | cut -c1-200
+        BITS=4 timeout 200 python tools/mf_prefill_time.py > $O/r5b_pack4_time.log 2>&1; tail -6 $O/r5b_pack4_time.log
+        for i in 1 2; do
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5b_c4_r4tree_$i.json 2>> $O/r5b.err ); line $O/r5b_c4_r4tree_$i.json
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5b_c4_new_$i.json 2>> $O/r5b.err; line $O/r5b_c4_new_$i.json
+            for cfg in 2434 844 2844 444; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5b_c4_${cfg}_$i.json 2>> $O/r5b.err; line $O/r5b_c4_${cfg}_$i.json
+            done
+        done
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5b_row4_phases.log 2>&1; tail -24 $O/r5b_row4_phases.log
+        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5b_c5.json 2>> $O/r5b.err; line $O/r5b_c5.json
+        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5b_c70.json 2>> $O/r5b.err; line $O/r5b_c70.json
+        tail -5 $O/r5b.err ;;
+    forms)
+        # round 5: the launch plan (auto) against the forced forms, same box, alternating: BASELINE config 4, the config-5 per-GPU slice,
+        # the 70B-like slice, R = 8 at B = 64, and small grouped-query batches
+        for i in 1 2; do
+            for f in auto split; do
+                timeout 300 $BN $C4 --steps 10 --warmup 3 --form $f > $O/forms_c4_${f}_$i.json 2>> $O/forms.err; line $O/forms_c4_${f}_$i.json
+                timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/forms_c5_${f}_$i.json 2>> $O/forms.err; line $O/forms_c5_${f}_$i.json
+                timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/forms_c70_${f}_$i.json 2>> $O/forms.err; line $O/forms_c70_${f}_$i.json
+                timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 --form $f > $O/forms_r8b64_${f}_$i.json 2>> $O/forms.err; line $O/forms_r8b64_${f}_$i.json
+                timeout 300 $BN --batch 4 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/forms_b4_8k_${f}_$i.json 2>> $O/forms.err; line $O/forms_b4_8k_${f}_$i.json
+                timeout 300 $BN --batch 32 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/forms_b32_8k_${f}_$i.json 2>> $O/forms.err; line $O/forms_b32_8k_${f}_$i.json
+            done
+        done
+        timeout 300 $BN --batch 32 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form row > $O/forms_b32_8k_row.json 2>> $O/forms.err; line $O/forms_b32_8k_row.json
+        timeout 300 $BN $C4 --steps 10 --warmup 3 --form slices2 > $O/forms_c4_slices2.json 2>> $O/forms.err; line $O/forms_c4_slices2.json
+        timeout 300 $BN $C5 --steps 6 --warmup 2 --form slices8 > $O/forms_c5_slices8.json 2>> $O/forms.err; line $O/forms_c5_slices8.json ;;
     sq)
         name=$1; shift
         extra=()
