@@ -261,13 +261,15 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  *   [ codes 16 x 256 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 6144 int32 words each (bits = 2), or
  *   [ codes 16 x 512 words | scale 16 x 128 halves | mn 16 x 128 halves ] = 10240 words (bits = 4: sb_s >= 10240),
  * addressed as base + b*sb_b + hk*sb_h + (t / 512)*sb_s (strides in words).  Never-written slots must be ZERO.
- * RANGE FLAGS: every store comes with `range`, B * nh_kv int32 (index b * nh_kv + hk), zeroed by the caller together with
- *   the store.  The matrix pipe takes q * scale (qK^T) and p * scale (sV) as fp16 hi / lo pairs; with the default placement of
- *   q and p a group scale >= 512 would overflow them where the reference's fp32 `scale * code + zero`
- *   (quant/csrc/gemv_cuda.cu:407-413) stays finite.  So every entry point that WRITES scales (kivi_kt_pack, kivi_vt_pack, the
- *   relayouts towards the layout, the V flush inside kivi_gqa_decode) sets range[b * nh_kv + hk] = 1 when it writes a scale
- *   >= 256 (inf / NaN included), and the consumers place q / p 2^10 lower for such a unit: finite for every finite fp16 scale.
- *   Sticky (never cleared by the library); units that never saw such a scale compute exactly what they did without the flag.
+ * RANGE WORDS ("range flags"): every store comes with `range`, B * nh_kv int32 (index b * nh_kv + hk), zeroed by the caller
+ *   together with the store.  The matrix pipe takes q * scale (qK^T) and p * scale (sV) as fp16 hi / lo pairs; with the default
+ *   placement of q and p a group scale >= 512 would overflow them where the reference's fp32 `scale * code + zero`
+ *   (quant/csrc/gemv_cuda.cu:407-413) stays finite, and group scales in the fp16 subnormals would leave the hi part without its
+ *   low bits.  So every entry point that WRITES scales (kivi_kt_pack, kivi_vt_pack, the relayouts towards the layout, the V flush
+ *   inside kivi_gqa_decode) marks BYTE 0 of the unit's word when it writes a scale >= 256 (inf / NaN included) and BYTE 1 when it
+ *   writes a scale >= 2^-8 (byte stores: concurrent writers never lose a mark), and the consumers place q / p 2^10 lower for a unit
+ *   with byte 0 set (finite for every finite fp16 scale), 2^8 higher for a unit with neither byte set (all its scales < 2^-8),
+ *   unchanged otherwise.  Sticky (never cleared by the library); a caller that copies a store copies its words.
  * The reference has no counterpart: it expands codes / scale / mn nh / nh_kv times (models/mistral_kivi.py:58-67,
  * :381-385, :441-445) or lets the CUDA kernel map heads (quant/csrc/gemv_cuda.cu:361-365).
  *

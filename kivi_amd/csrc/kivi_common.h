@@ -86,6 +86,12 @@ __device__ __forceinline__ float kivi_block_reduce(float v, bool is_max, float* 
     return lo;
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0) first: a wave
+// that has requested global data ahead (the first blocks of its packed-V ring, the fp16 window rows) would stall at the barrier until
+// all of it has landed -- measured 6.7 us from "residual scores done" to "past the barrier" in mf_row4_kernel (profiles/r05_row4_phases.log).
+// Here only this wave's LDS (and scalar) operations are waited for; global loads stay in flight, global stores are not ordered.
+__device__ __forceinline__ void kivi_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // exp() of the softmax kernels: one v_exp_f32 on x * log2(e).  The argument product rounds at 2^-24 relative, i.e. the
 // result carries a relative error <= ~|x| * 1e-7 (x <= 0 here, |x| < 100 where the result matters) -- three orders
 // below the fp16 rounding of the probabilities, and a tenth of the instructions of the libm expf.  Every softmax in

@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256) void kt_pack_kernel(const uint16_t* k, int64_t
     (sb + KIVI_MF_SB_SCALE_WORD0)[hidx >> 1] = scale2;
     (sb + KIVI_MF_SB_MN_WORD0)[hidx >> 1] = mn2;
     // range marks of the unit (kivi_mfma_layout.h): sticky, every writer stores the same bytes
-    mf_range_mark(range + unit, scale2 & 0xFFFFu);
-    mf_range_mark(range + unit, scale2 >> 16);
+    mf_range_mark(range + unit, scale2 & 0xFFFFu, scale2 >> 16);
 }
 
 // Per-token V quantise + pack of a prompt straight into the VT layout (prompt pass, models/llama_kivi.py:441-448: the
@@ -162,8 +161,7 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* v, int64_t
     *(u32x4*)(cw + lane * 4) = *(const u32x4*)(tile + lane * 4);
     (sb + KIVI_MF_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;    // vt_half(8 kb + 2 ee, c) / 2 == lane
     (sb + KIVI_MF_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
-    mf_range_mark(range + unit, scale2 & 0xFFFFu);          // range marks (kt_pack_kernel)
-    mf_range_mark(range + unit, scale2 >> 16);
+    mf_range_mark(range + unit, scale2 & 0xFFFFu, scale2 >> 16);          // range marks (kt_pack_kernel)
 }
 
 // KT <-> reference layout K_code_T (B, nh_kv, D, T/16), K_scale_T / K_mn_T (B, nh_kv, D, T/32) (llama_kivi.py:454-455).
@@ -334,8 +332,7 @@ __global__ __launch_bounds__(256) void kt_pack4_kernel(const uint16_t* k, int64_
     const int hidx = kt_sm_half((int)(blk & 15), 2 * lane);    // channel 2 l (even): the pair (2 l, 2 l + 1) is one word
     (sb + KIVI_MF4_SB_SCALE_WORD0)[hidx >> 1] = scale2;
     (sb + KIVI_MF4_SB_MN_WORD0)[hidx >> 1] = mn2;
-    mf_range_mark(range + unit, scale2 & 0xFFFFu);          // range marks of the unit (kt_pack_kernel)
-    mf_range_mark(range + unit, scale2 >> 16);
+    mf_range_mark(range + unit, scale2 & 0xFFFFu, scale2 >> 16);          // range marks of the unit (kt_pack_kernel)
 }
 
 // Lane (kb, c, ee) = 16 kb + 4 c + ee owns the token PAIR (8 kb + 2 ee, + 1) of channel group c (cf. vt_pack_kernel): even token in
@@ -403,8 +400,7 @@ __global__ __launch_bounds__(256) void vt_pack4_kernel(const uint16_t* v, int64_
     *(u32x4*)(cw + 256 + lane * 4) = *(const u32x4*)(stw + 256 + lane * 4);
     (sb + KIVI_MF4_SB_SCALE_WORD0 + (bi & 15) * 64)[lane] = scale2;   // vt_half(8 kb + 2 ee, c) / 2 == lane
     (sb + KIVI_MF4_SB_MN_WORD0 + (bi & 15) * 64)[lane] = mn2;
-    mf_range_mark(range + unit, scale2 & 0xFFFFu);
-    mf_range_mark(range + unit, scale2 >> 16);
+    mf_range_mark(range + unit, scale2 & 0xFFFFu, scale2 >> 16);
 }
 
 // KT4 <-> K_code_T (B, nh_kv, D, T/8), K_scale_T / K_mn_T (B, nh_kv, D, T/32): 4 reference words per (channel, block)
@@ -661,7 +657,7 @@ int kivi_mf_run_k(void* k_args, int units, int bits, hipStream_t s);
 int kivi_mf_run_v(const void* v_args, int prob, int bits, hipStream_t s);
 int kivi_mf_run_row_sp(const void* p, int64_t p_sb, int64_t p_sh, int B, int nh, int nh_kv, int64_t T, const int* range, int* sp,
                        hipStream_t s);
-int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, hipStream_t s);
+int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, int slice_kernel, hipStream_t s);
 
 // Launch plan of a step whose LONGEST row has n_rows keys (nsbk super-blocks of packed keys + up to res_cap + 1 fp16 ones):
 //   0      two launches (mf_k_kernel -> score rows + statistics in memory -> mf_v_kernel)
@@ -674,6 +670,13 @@ static int mf_plan(int R, int units, int64_t n_rows, int nsbk, int res_cap, int 
     static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
     if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return 0;
     if (R == 1) {
+        const int f1 = (flags >> 8) & 0xFF;                         // KIVI_GQA_SLICES(n): the sliced form of multi-head rows (tests, tuning)
+        if (f1 == 1 && !(flags & KIVI_GQA_FORCE_ROW)) return n_rows <= 8192 ? 1 : 0;
+        if (f1 > 1 && !(flags & KIVI_GQA_FORCE_ROW)) {
+            const int spb = (nsbk + f1 - 1) / f1;
+            const bool ok = f1 <= nsbk && f1 <= 64 && (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1 <= 8192 && units <= KIVI_GQA_WS_COUNTERS / 2 - 1;
+            return ok ? f1 : 0;
+        }
         if (n_rows > 8192) return 0;
         // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
         // of a row block to take one super-block each (<= 4096 packed keys): then one launch beats two whatever the batch
@@ -932,7 +935,8 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     // 4 waves per CU; nh / nh_kv in {4, 8}: the R score rows of a unit / a slice in one block, 2 blocks per CU)
     if (plan >= 1) {
         if (plan > 1) { v.S = plan; v.nslot = plan; v.win_blocks = 0; }
-        return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, plan, p->residual_length, s);
+        return kivi_mf_run_row(&k, &v, units, n_rows, (p->flags & KIVI_GQA_DUMP_SCORES) != 0, bits, plan, p->residual_length,
+                               ((p->flags >> 8) & 0xFF) != 0, s);
     }
     int rc = skipk ? 0 : kivi_mf_run_k(&k, units, bits, s);
     if (rc) return rc;

@@ -237,6 +237,152 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 
 // Window role of the sV launch: out_w[r][2 lane, 2 lane + 1] += probs[r, Tv + t] * V_window[t] for the window tokens
 // t in [w0, w1) (llama_kivi.py:384; the last token is the new value, appended here, :377), and -- `flusher` -- the
+// quantisation of the token leaving the window into its VT slot (:386-399).  NTH threads; `pw`: R x PW halves of LDS
+// that hold the fp16 probabilities of tokens [w0, w1) at index t - w0 and ZEROS from w1 - w0 up to NW * TW.  A lane owns two
+// channels; wave w takes the TW (a multiple of 8) consecutive tokens w0 + w TW ..., so the probabilities of eight tokens of a head
+// are ONE 16-byte LDS read and the whole walk is branch-free (round 4 walked tokens w, w + NW, ... with two branches and R
+// two-byte LDS reads per token, each behind its own wait: 6.7 us per block at residual_length 128, profiles/r05_row4_phases.log).
+// Two halves, so that the loads fly while the caller does something else (the row kernels request before their softmax):
+// request() issues the loads of the first WPRE tokens of every wave (and of the token that leaves the window, and of the code
+// word it will be merged into), finish() loads what is left in one batch and consumes everything once pw holds the probabilities.
+template <int R, int NTH, int PW, int WPRE, int BITS = 2>
+struct GqaWindow {
+    static constexpr int NW = NTH / 64;
+    static constexpr int TW = (((129 + NW - 1) / NW) + 7) / 8 * 8;       // tokens per wave: 40 (4 waves), 24 (8 waves)
+    static constexpr int NPRE = WPRE < TW ? WPRE : TW;
+    static_assert(PW >= NW * TW && PW % 8 == 0, "a probability row holds NW * TW halves, rows 16-byte aligned");
+    typedef MfL<BITS> LY;
+    uint32_t vv[NPRE];
+    uint32_t wold;
+    uint16_t xflush;
+
+    __device__ __forceinline__ static uint16_t* wrow(const GqaVArgs& a, uint16_t* vbuf, int t) {
+        // row of window token t: a ring of win_rows rows (no compaction, residual_length + 1 rows suffice) or the linear buffer
+        int r = a.win_start + t;
+        if (a.win_rows) r = r >= a.win_rows ? r - a.win_rows : r;       // t <= residual_length < win_rows: one wrap at most
+        return vbuf + (int64_t)r * a.vres_st;
+    }
+    // the code word of the token that leaves the window (token Tv) for channel d (2 bits: shared by the channels d, d ^ 16)
+    __device__ __forceinline__ static uint32_t* flush_word(const GqaVArgs& a, int b, int hk, int d) {
+        const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+        const int kbq = tt >> 3, c = d >> 5, nn = d & 15;
+        if constexpr (BITS == 4) return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + vt4_word(tt, d);
+        return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
+    }
+    // the two channels (2 lane, 2 lane + 1) of window token t, zeros past w1
+    __device__ __forceinline__ static uint32_t vload(const GqaVArgs& a, uint16_t* vbuf, const uint16_t* vnew, int t, int w1) {
+        const int lane = threadIdx.x & 63;
+        const uint16_t* vrow = (t < a.res_len) ? wrow(a, vbuf, t) : vnew;
+        return (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+    }
+
+    __device__ __forceinline__ void request(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher) {
+        const int wave = threadIdx.x >> 6;
+        uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+        xflush = 0; wold = 0;
+        if (flusher && threadIdx.x < 128) {
+            xflush = wrow(a, vbuf, 0)[threadIdx.x];
+            if (BITS == 4 || ((threadIdx.x >> 4) & 1) == 0) wold = *flush_word(a, b, hk, threadIdx.x);
+        }
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) vv[u] = vload(a, vbuf, vnew, w0 + wave * TW + u, w1);
+    }
+
+    __device__ __forceinline__ void finish(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
+                                           const uint16_t (*pw)[PW], float (*ow)[2]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
+        const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
+        // the tokens request() did not prefetch are loaded a group of eight ahead of their use
+        uint32_t nx[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) nx[e] = (e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * TW + e, w1) : 0u;
+#pragma unroll
+        for (int g = 0; g < TW / 8; g++) {
+            uint32_t cur[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) cur[e] = (8 * g + e < NPRE) ? vv[8 * g + e < NPRE ? 8 * g + e : 0] : nx[e];
+            if (g + 1 < TW / 8) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) nx[e] = (8 * (g + 1) + e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * TW + 8 * (g + 1) + e, w1) : 0u;
+            }
+            constexpr int RH = R > 4 ? 4 : R;                      // heads per pass (R = 8: two passes: 16 instead of 32 registers of probabilities)
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += RH) {
+                u32x4 pv[RH];                                      // the probabilities of 8 tokens of these heads (zeros past the window)
+#pragma unroll
+                for (int rr = 0; rr < RH; rr++) pv[rr] = *(const u32x4*)(&pw[r0 + rr][wave * TW + 8 * g]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t v = cur[e];
+                    const float v0 = h2f_bits((uint16_t)(v & 0xFFFFu)), v1 = h2f_bits((uint16_t)(v >> 16));
+#pragma unroll
+                    for (int rr = 0; rr < RH; rr++) {
+                        const uint32_t pp = pv[rr][e >> 1];
+                        const float p = h2f_bits((uint16_t)((e & 1) ? (pp >> 16) : (pp & 0xFFFFu)));
+                        ow[r0 + rr][0] = __builtin_fmaf(p, v0, ow[r0 + rr][0]);
+                        ow[r0 + rr][1] = __builtin_fmaf(p, v1, ow[r0 + rr][1]);
+                    }
+                }
+            }
+            // (with loads inside the walk: nothing moves across a group's end -- hipcc otherwise hoists every load of the walk to its
+            // top and the kernel pays for TW more registers)
+            if constexpr (NPRE < TW) __builtin_amdgcn_sched_barrier(0);
+        }
+        // V append (:377): the new value becomes window row res_len -- by the wave that owns that token
+        if (a.res_len >= w0 && a.res_len < w1 && (a.res_len - w0) / TW == wave)
+            *(uint32_t*)(wrow(a, vbuf, a.res_len) + 2 * lane) = *(const uint32_t*)(vnew + 2 * lane);
+        if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
+            const int d = threadIdx.x;
+            const uint32_t key = h_key(xflush);
+            uint32_t kmin = key, kmax = key;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+                const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, m), o2 = (uint32_t)__shfl_xor((int)kmax, m);
+                kmin = o1 < kmin ? o1 : kmin;
+                kmax = o2 > kmax ? o2 : kmax;
+            }
+            const GroupQ gq = make_group(kmin, kmax, (1 << BITS) - 1);
+            const uint32_t code = quant_one<BITS>(xflush, gq);
+            const int tt = (int)(a.Tv & 31), blk = (int)((a.Tv >> 5) & 15);
+            const int e = tt & 7, kbq = tt >> 3;
+            const int c = d >> 5, tile = (d >> 4) & 1;
+            const int sh = 16 * (e & 1);
+            uint32_t* sbp;
+            if constexpr (BITS == 4) {
+                // every channel has its own word (8 tokens of the channel): the token's field is cleared first (stale codes, below)
+                const int pos = vt4_bit(tt);
+                sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+                *flush_word(a, b, hk, d) = (wold & ~(15u << pos)) | (code << pos);
+            } else {
+                uint32_t val = code << (mf_pos(tile, e >> 1) + sh);
+                val |= (uint32_t)__shfl_xor((int)val, 16);
+                sbp = mf_sb(a.vt, b, hk, a.Tv >> 9);
+                if (tile == 0) {
+                    // the two fields of this token (channel tiles 0 / 1) are cleared first: a slot may hold stale codes of an earlier,
+                    // longer sequence that used the same storage
+                    const uint32_t clr = (3u << (mf_pos(0, e >> 1) + sh)) | (3u << (mf_pos(1, e >> 1) + sh));
+                    *flush_word(a, b, hk, d) = (wold & ~clr) | val;
+                }
+            }
+            if ((d & 31) == 0) {
+                const int hidx = blk * 128 + kbq * 32 + c * 8 + e;
+                ((uint16_t*)(sbp + LY::SCALE_WORD0))[hidx] = gq.scale;
+                ((uint16_t*)(sbp + LY::MN_WORD0))[hidx] = gq.mn;
+                // range marks of the unit (kivi_mfma_layout.h): the token becomes part of the packed prefix with the NEXT step
+                mf_range_mark(a.range + b * a.nh_kv + hk, gq.scale);
+            }
+        }
+    }
+};
+
+// The window role as the two-launch form runs it (mf_v_kernel: window blocks at the tail of the grid, or shares inside the stream
+// blocks; register-lean -- the sV stream sets that kernel's occupancy): wave w takes tokens w0 + w, w0 + w + NW, ...
+// Window role of the sV launch: out_w[r][2 lane, 2 lane + 1] += probs[r, Tv + t] * V_window[t] for the window tokens
+// t in [w0, w1) (llama_kivi.py:384; the last token is the new value, appended here, :377), and -- `flusher` -- the
 // quantisation of the token leaving the window into its VT slot (:386-399).  NTH threads; `pw`: R x >= 136 halves of LDS
 // that already hold the fp16 probabilities of tokens [w0, w1) (index t - w0).  A lane owns two channels, wave w takes
 // tokens w0 + w, w0 + w + NW, ...; all loads of a batch in flight.
@@ -244,7 +390,7 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 // request() issues the loads of the first WPRE tokens of every wave (and of the token that leaves the window, and of the code
 // word it will be merged into), finish() consumes them once pw holds the probabilities and walks what is left in batches.
 template <int R, int NTH, int PW, int WPRE, int BITS = 2>
-struct GqaWindow {
+struct GqaWindowStrided {
     static constexpr int NW = NTH / 64, WB = 12;
     typedef MfL<BITS> LY;
     uint32_t vv[WPRE];
@@ -362,7 +508,7 @@ struct GqaWindow {
 template <int R, int NTH, int PW, int BITS = 2>
 __device__ __forceinline__ void gqa_window_part(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
                                                 const uint16_t (*pw)[PW], float (*ow)[2]) {
-    GqaWindow<R, NTH, PW, 12, BITS> w;
+    GqaWindowStrided<R, NTH, PW, 12, BITS> w;
     w.request(a, b, hk, w0, w1, flusher);
     w.finish(a, b, hk, w0, w1, flusher, pw, ow);
 }

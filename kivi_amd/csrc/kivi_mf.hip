@@ -264,11 +264,11 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
 }
 
 // PW: window probabilities per head kept in LDS
-constexpr int MF_PW = 136;
+constexpr int MF_PW = 200;                                       // >= NW * TW of GqaWindow (4 x 40, 8 x 24), rows 16-byte aligned
 
 // HL (R = 4): hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>), as in mf_row4_kernel
 template <int R, int RING, bool PROB, bool HL = false, int BITS = 2>
-__global__ __launch_bounds__(256) void mf_v_kernel(const GqaVArgs a_in) {
+__global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArgs a_in) {   // (R = 8: two blocks per CU, gqa_v_slices)
     static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
     GqaVArgs a = a_in;
@@ -536,6 +536,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
     GqaWindow<1, NTH, MF_PW, (NW == 8 ? 5 : 9)> win;
     win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
+    for (int j = threadIdx.x; j < MF_PW; j += NTH) pw[0][j] = 0;    // (the window walk reads whole 8-token groups: zeros past the window;
+                                                                   //  the softmax writes the probabilities behind its two barriers)
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
@@ -648,11 +650,13 @@ __device__ __forceinline__ void mf_probs_inplace(uint16_t* rows, int pitch, int 
 // LSTAT: the statistics of a wave's segments are carried per LANE through the K walk (a running (max, sum exp) of the lane's eight
 // scores per segment and head, rescaled when the maximum moves) and reduced across the wave ONCE at the end of the walk, instead
 // of two wave reductions per segment and head (each a chain of ~10 dependent DPP / readlane operations)
-template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, bool LSTAT = true>
-__global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
+// R = 1 (nh == nh_kv; OCC = 4: four blocks per CU in <= 128 registers): the same block over mf_k_seq1 / MfVStream<1> -- the sliced form of
+// multi-head rows (mf_row_kernel keeps the unsliced one)
+template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, bool LSTAT = true, int OCC = 2>
+__global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
     constexpr int NTH = NW * 64;
     static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
-    static_assert(R == 4 || (R == 8 && !VHL), "R = 8: chained hi / lo sV");
+    static_assert((R == 4) || ((R == 8 || R == 1) && !VHL), "R = 1 / 8: chained hi / lo sV");
     static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
@@ -664,6 +668,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
     __shared__ float st_lds[R][MF_NSEG][2];                        // (max, sum exp) of every 512-token segment of the R rows
     __shared__ int sp_lds[R];
     __shared__ int bid_lds;
+    __shared__ uint32_t q_lds[R == 1 ? NW : 1][64];                // R = 1: the normalised q operand of mf_k_seq1
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bid = (int)blockIdx.x;
@@ -798,12 +803,18 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
             }
             __builtin_amdgcn_wave_barrier();
         };
-        mf_k_seqR<R, KRING, BITS>(rk, seq, q_h0, ak.q_sh, krsh, [&](int sb, int tt, int r, float v0, float v1) {
-            const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
-            uint16_t* dst = rows + (hb + r) * n_pad + (sb - sb_lo) * KIVI_MF_SB_TOKENS + tt;
-            dst[0] = (uint16_t)(hs & 0xFFFFu);                     // head hb + r at tokens tt, tt + 16
-            dst[16] = (uint16_t)(hs >> 16);
-        }, seg_done);
+        if constexpr (R == 1) {
+            mf_k_seq1<KRING>(rk, seq, q_h0, q_lds[wave], krsh, [&](int sb, int tt, float v) {
+                rows[(sb - sb_lo) * KIVI_MF_SB_TOKENS + tt] = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
+            }, seg_done);
+        } else {
+            mf_k_seqR<R, KRING, BITS>(rk, seq, q_h0, ak.q_sh, krsh, [&](int sb, int tt, int r, float v0, float v1) {
+                const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
+                uint16_t* dst = rows + (hb + r) * n_pad + (sb - sb_lo) * KIVI_MF_SB_TOKENS + tt;
+                dst[0] = (uint16_t)(hs & 0xFFFFu);                 // head hb + r at tokens tt, tt + 16
+                dst[16] = (uint16_t)(hs >> 16);
+            }, seg_done);
+        }
     }
     if constexpr (LSTAT) {                                         // the wave's (max, sum exp) of every head: one entry per wave
 #pragma unroll
@@ -835,14 +846,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
     // (round 4 walked (head, key) pairs, 16 dependent round trips at residual_length 128)
     if (last) {
         constexpr int TPP = NTH / 8, KP = (129 + TPP - 1) / TPP;   // keys per pass, passes
+        constexpr int RH = R > 4 ? 4 : R;                          // heads per q load (R = 8: two rounds over the key registers)
         const int sub = threadIdx.x & 7, ts = threadIdx.x >> 3;
-        u16x8 qa[R], qb[R], ka[KP], kc[KP];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const uint16_t* qrow = q_h0 + (int64_t)r * ak.q_sh + sub * 16;
-            qa[r] = *(const u16x8*)qrow;
-            qb[r] = *(const u16x8*)(qrow + 8);
-        }
+        u16x8 ka[KP], kc[KP];
 #pragma unroll
         for (int p = 0; p < KP; p++) {
             const int t = ts + p * TPP;
@@ -854,28 +860,38 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
             }
         }
 #pragma unroll
-        for (int p = 0; p < KP; p++) {
-            const int t = ts + p * TPP;
-            if (t < L) {                                           // (the eight lanes of a key agree)
-                if (t == ak.res_len) {
-                    *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = ka[p];
-                    *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = kc[p];
-                }
-                const uint16_t mk = mrow ? mrow[Tq + t] : (uint16_t)0;
+        for (int r0 = 0; r0 < R; r0 += RH) {
+            u16x8 qa[RH], qb[RH];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    float sc = 0.f;
+            for (int r = 0; r < RH; r++) {
+                const uint16_t* qrow = q_h0 + (int64_t)(r0 + r) * ak.q_sh + sub * 16;
+                qa[r] = *(const u16x8*)qrow;
+                qb[r] = *(const u16x8*)(qrow + 8);
+            }
 #pragma unroll
-                    for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qa[r][e]), h2f_bits(ka[p][e]), sc);
+            for (int p = 0; p < KP; p++) {
+                const int t = ts + p * TPP;
+                if (t < L) {                                       // (the eight lanes of a key agree)
+                    if (r0 == 0 && t == ak.res_len) {
+                        *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = ka[p];
+                        *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = kc[p];
+                    }
+                    const uint16_t mk = mrow ? mrow[Tq + t] : (uint16_t)0;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qb[r][e]), h2f_bits(kc[p][e]), sc);
-                    sc += dpp_f<0xB1>(sc);                         // the eight lanes of the key (order of the additions as before:
-                    sc += dpp_f<0x4E>(sc);                         // neighbours, pairs, the two quads)
-                    sc += dpp_f<0x141>(sc);
-                    if (sub == 0) {
-                        const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, mrow != nullptr, mk);
-                        rows[r * n_pad + (Tq - tok0) + t] = h;
-                        if (dump0) dump0[(int64_t)r * ak.out_sh + Tq + t] = h;
+                    for (int r = 0; r < RH; r++) {
+                        float sc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qa[r][e]), h2f_bits(ka[p][e]), sc);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) sc = __builtin_fmaf(h2f_bits(qb[r][e]), h2f_bits(kc[p][e]), sc);
+                        sc += dpp_f<0xB1>(sc);                     // the eight lanes of the key (order of the additions as before:
+                        sc += dpp_f<0x4E>(sc);                     // neighbours, pairs, the two quads)
+                        sc += dpp_f<0x141>(sc);
+                        if (sub == 0) {
+                            const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, mrow != nullptr, mk);
+                            rows[(r0 + r) * n_pad + (Tq - tok0) + t] = h;
+                            if (dump0) dump0[(int64_t)(r0 + r) * ak.out_sh + Tq + t] = h;
+                        }
                     }
                 }
             }
@@ -883,9 +899,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
     }
     stamp(4);
     // the fp16 window rows (and the token leaving it) are requested before the barrier and used after the statistics
-    GqaWindow<R, NTH, MF_PW, (128 + NW) / NW, BITS> win;
+    // (prefetched window rows per wave: all 40 where the registers allow it)
+    GqaWindow<R, NTH, MF_PW, (R == 8 ? 16 : (BITS == 4 ? 24 : 40)), BITS> win;
     if (last) win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
-    __syncthreads();
+    kivi_lds_barrier();                                            // (the V ring and the window rows stay in flight)
     stamp(5);
 
     // ---- (M, sum exp(x - M)) of the R rows: every wave merges the slice's segments + (last slice) the residual scores; S > 1: the
@@ -967,14 +984,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mf_row4_kernel(const GqaKArgs ak_i
             for (int q = 1; q < R; q++)
                 if (rr == q) { Mr = M[q]; Ir = invS[q]; }
             const uint16_t* rp = rows + rr * n_pad + (Tv - tok0);
-            for (int j = lane; j < Lw; j += 64) pw[rr][j] = f2h_bits(kivi_exp(h2f_bits(rp[j]) - Mr) * Ir);
+            for (int j = lane; j < NW * decltype(win)::TW; j += 64)     // (zeros past the window: its walk reads whole 8-token groups)
+                pw[rr][j] = j < Lw ? f2h_bits(kivi_exp(h2f_bits(rp[j]) - Mr) * Ir) : (uint16_t)0;
         }
     }
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int rr = 0; rr < R; rr++) sp_lds[rr] = sp[rr];
     }
-    __syncthreads();                                               // pw complete; nobody reads scores past Tv any more
+    kivi_lds_barrier();                                            // pw complete; nobody reads scores past Tv any more
     stamp(7);
 
     // ---- fp16 window of the R heads, V append, quantisation of the token leaving the window (:377-399)
@@ -1145,15 +1163,17 @@ static int mf_cu_count() {
 // dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the rows the softmax (statistics) are taken from also go to the score buffer -- a run-time
 // pointer in the PRODUCT instantiations (round 4 used separate ones).
 // n_rows: the longest row the launch must hold (= Tq + k_res_len + 1, or the bound of the step's geometry class when the lengths
-// are device-resident).  S: slices per row (1 for nh == nh_kv); res_cap: residual_length (the fp16 keys a last slice may hold).
-int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, hipStream_t s) {
+// are device-resident).  S: slices per row; res_cap: residual_length (the fp16 keys a last slice may hold); slice_kernel: nh == nh_kv
+// with S = 1 through mf_row4_kernel<R = 1> instead of mf_row_kernel (KIVI_GQA_SLICES(1): A/B).
+int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows, int dump, int bits, int S, int res_cap, int slice_kernel, hipStream_t s) {
     GqaKArgs& k = *(GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = n_rows;
     KIVI_REQUIRE(bits == 2 || (bits == 4 && k.ratio == 4), KIVI_EUNSUPPORTED, "mf_row: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, k.ratio);
-    if (k.ratio == 4 || k.ratio == 8) {
+    KIVI_REQUIRE(S == 1 || k.ratio == 1 || k.ratio == 4 || k.ratio == 8, KIVI_EUNSUPPORTED, "mf_row: no sliced form for nh / nh_kv = %d", k.ratio);
+    if (k.ratio == 4 || k.ratio == 8 || (k.ratio == 1 && (S > 1 || slice_kernel))) {
         const int R = k.ratio;
-        const int64_t cap = R == 4 ? 9216 : 4608;                  // keys whose R score rows fit 72 KiB of LDS (two blocks per CU)
+        const int64_t cap = R == 4 ? 9216 : (R == 8 ? 4608 : 8192);    // keys whose R score rows fit the LDS of a block (R = 4 / 8: 72 KiB, two blocks per CU)
         KIVI_REQUIRE(S >= 1 && S <= 64 && (S == 1 || S <= k.nsb), KIVI_EINVAL, "mf_row%d: %d slices for %d super-blocks", R, S, k.nsb);
         // the longest row of a block: the whole row, or (S > 1) max(ceil(nsb / S), 2) super-blocks + the residual (mf_row4_kernel)
         int64_t n_blk = n;
@@ -1165,14 +1185,15 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         const int n_pad = (int)((n_blk + 4 + 31) / 32 * 32);
         size_t lds = (size_t)R * n_pad * 2;
         const size_t fin = (size_t)(2 * 4 + 4 + 2) * R * 128 * 4;  // the per-wave partial sums + the block's sums reuse the rows
+        const int occ = R == 1 ? 4 : 2;                             // blocks per CU
         if (lds < fin) lds = fin;
         const dim3 grid((unsigned)((int64_t)units * S));
         // blocks that wait for each other (S > 1) must not wait for blocks that cannot start: with more blocks than the chip holds at
         // once (2 per CU) the block ids come from the ticket counter (start order)
         k.dump = dump;
         if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; }
-        else if ((int64_t)units * S <= 2 * (int64_t)mf_cu_count()) k.ticket = nullptr;
-        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0;
+        else if ((int64_t)units * S <= occ * (int64_t)mf_cu_count()) k.ticket = nullptr;
+        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0;
 #define KIVI_ROW4_LAUNCH(OPT, ...)                                                                 \
     do {                                                                                           \
         const int rc = mf_lds_opt_in(mf_row4_kernel<__VA_ARGS__>, &OPT, "mf_row4");                \
@@ -1180,6 +1201,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad, S);   \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
+        if (R == 1) KIVI_ROW4_LAUNCH(opt1, 2, 3, 4, false, false, 1, 2, true, 4);
         if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
         if (bits == 4) KIVI_ROW4_LAUNCH(opt44, 4, 3, 4, false, true, 4, 4);
 #ifdef KIVI_TUNING

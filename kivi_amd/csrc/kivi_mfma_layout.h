@@ -88,10 +88,16 @@
 __device__ __forceinline__ int mf_range_shift(int word) {
     return (word & 0xFF) ? -KIVI_MF_BIG_SHIFT : ((word & 0xFF00) ? 0 : KIVI_MF_SMALL_SHIFT);
 }
-// the marks a writer leaves for a scale with these fp16 bits (sticky; byte stores)
-__device__ __forceinline__ void mf_range_mark(int* word, uint32_t scale_bits) {
-    if (scale_bits >= KIVI_MF_BIG_SCALE_BITS) reinterpret_cast<volatile unsigned char*>(word)[0] = 1;
-    if (scale_bits >= KIVI_MF_SMALL_SCALE_BITS) reinterpret_cast<volatile unsigned char*>(word)[1] = 1;
+// The marks a writer leaves for (up to two) scales with these fp16 bits: sticky, byte stores.  The word is READ first and a byte is
+// stored only when its mark is missing: nearly every scale of ordinary data is >= 2^-8, and an unconditional store of byte 1 by
+// every lane of every packing wave serialised on the unit's one address (measured: kivi_kt_pack 10x slower).  A stale read costs a
+// redundant store, never a lost mark.
+__device__ __forceinline__ void mf_range_mark(int* word, uint32_t scale_bits, uint32_t scale_bits2 = 0u) {
+    const uint32_t top = scale_bits > scale_bits2 ? scale_bits : scale_bits2;
+    if (top < KIVI_MF_SMALL_SCALE_BITS) return;
+    const int cur = *reinterpret_cast<const volatile int*>(word);
+    if ((cur & 0xFF00) == 0) reinterpret_cast<volatile unsigned char*>(word)[1] = 1;
+    if (top >= KIVI_MF_BIG_SCALE_BITS && (cur & 0xFF) == 0) reinterpret_cast<volatile unsigned char*>(word)[0] = 1;
 }
 template <int BITS> struct MfL;        // per-width constants of the super-block
 template <> struct MfL<2> {

@@ -269,6 +269,8 @@ def test_mf_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked,
     (8, 2, 1100, 96, False, "randn", 3, 2),          # R = 96: token Tv sits a super-block before the last -> an EMPTY middle slice, a last slice of two
     (16, 2, 2100, 32, True, "outlier", 4, 2),        # nh / nh_kv = 8, five super-blocks in four slices of two: an empty third slice
     (8, 2, 1100, 128, False, "outlier", 2, 4),       # 4-bit codes
+    (4, 4, 1100, 32, True, "outlier", 2, 2),         # nh == nh_kv through the slice kernel (mf_row4_kernel<R = 1>): two slices
+    (2, 2, 1100, 128, False, "randn", 1, 2),         # ... and unsliced (KIVI_GQA_SLICES(1): the A/B form against mf_row_kernel)
 ])
 def test_mf_sliced_rows_match_reference_logic(oracle, nh, nh_kv, T0, R, masked, kind, S, bits):
     """The one-launch form with every row cut into S slices (mf_row4_kernel, S > 1: a block per slice, the slices of a unit exchange

@@ -199,6 +199,30 @@ while [ $# -gt 0 ]; do
         timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5b_c5.json 2>> $O/r5b.err; line $O/r5b_c5.json
         timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5b_c70.json 2>> $O/r5b.err; line $O/r5b_c70.json
         tail -5 $O/r5b.err ;;
+    r5c)
+        # round 5, third look: barriers that keep global loads in flight, the contiguous window walk, read-before-store range marks, the
+        # slice kernel for nh == nh_kv
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=8 \
+            -k "sliced or two_launch_form or kt4_pack or vt4_pack or kt_pack_equals or vt_pack_equals or (mf4_decode_steps_match and row) or (fixtures and (row or default))" > $O/r5c_tests.log 2>&1
+        echo "r5c tests rc=$?" | tee -a $O/status.log; tail -14 $O/r5c_tests.log | cut -c1-200
+        BITS=4 timeout 200 python tools/mf_prefill_time.py > $O/r5c_pack4_time.log 2>&1; tail -4 $O/r5c_pack4_time.log
+        BITS=2 timeout 200 python tools/mf_prefill_time.py > $O/r5c_pack2_time.log 2>&1; tail -4 $O/r5c_pack2_time.log
+        for i in 1 2; do
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5c_c4_r4tree_$i.json 2>> $O/r5c.err ); line $O/r5c_c4_r4tree_$i.json
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5c_c4_new_$i.json 2>> $O/r5c.err; line $O/r5c_c4_new_$i.json
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/r5c_hl_r4tree_$i.json 2>> $O/r5c.err ); line $O/r5c_hl_r4tree_$i.json
+            timeout 300 $BN > $O/r5c_hl_new_$i.json 2>> $O/r5c.err; line $O/r5c_hl_new_$i.json
+            timeout 300 $BN --form slices1 > $O/r5c_hl_slices1_$i.json 2>> $O/r5c.err; line $O/r5c_hl_slices1_$i.json
+            timeout 300 $BN --form slices2 > $O/r5c_hl_slices2_$i.json 2>> $O/r5c.err; line $O/r5c_hl_slices2_$i.json
+        done
+        timeout 300 $BN $C4 --steps 10 --warmup 3 --form slices2 > $O/r5c_c4_slices2.json 2>> $O/r5c.err; line $O/r5c_c4_slices2.json
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5c_row4_phases.log 2>&1; sed -n 2,14p $O/r5c_row4_phases.log
+        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5c_c5.json 2>> $O/r5c.err; line $O/r5c_c5.json
+        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5c_c70.json 2>> $O/r5c.err; line $O/r5c_c70.json
+        timeout 300 $BN --batch 4 --steps 10 --warmup 3 > $O/r5c_b4.json 2>> $O/r5c.err; line $O/r5c_b4.json
+        timeout 300 $BN --batch 4 --steps 10 --warmup 3 --form slices2 > $O/r5c_b4_slices2.json 2>> $O/r5c.err; line $O/r5c_b4_slices2.json
+        tail -5 $O/r5c.err ;;
     forms)
         # round 5: the launch plan (auto) against the forced forms, same box, alternating: BASELINE config 4, the config-5 per-GPU slice,
         # the 70B-like slice, R = 8 at B = 64, and small grouped-query batches
