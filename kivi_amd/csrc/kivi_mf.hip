@@ -613,38 +613,34 @@ __device__ __forceinline__ uint16_t mf_add_mask(uint16_t h, uint16_t m) {      /
     return f2h_bits(v);
 }
 
-// p'' of the tokens [t0, t0 + ntok) (indices into the block's rows; t0 a multiple of 32) of the R rows, in place: lane l owns tokens
-// 8 l .. 8 l + 7 of every head (mf_probs_store on LDS-resident scores).  `left0`: tokens of the piece inside the packed prefix.
-template <int R, int BITS>
-__device__ __forceinline__ void mf_probs_inplace(uint16_t* rows, int pitch, int t0, int ntok, int left0, const float* M, const float* invS,
-                                                 const int* sp, int rsh) {
+// p'' of the tokens [t0, t0 + ntok) (indices into the block's rows; t0 a multiple of 32) of ONE row, in place: lane l owns tokens
+// 8 l .. 8 l + 7 (mf_probs_store on LDS-resident scores).  `left0`: tokens of the piece inside the packed prefix.
+template <int BITS>
+__device__ __forceinline__ void mf_probs_inplace_row(uint16_t* row, int t0, int ntok, int left0, float M, float invS, int sp, int rsh) {
     typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
     typedef float fp2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     if (lane * 8 >= ntok) return;
     const int left = left0 - lane * 8;
     const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+    uint16_t* p = row + t0 + lane * 8;
+    const u32x4 xv = *(const u32x4*)p;
+    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                    // 2^-10 .. 2^14
+    u32x4 o;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        uint16_t* p = rows + r * pitch + t0 + lane * 8;
-        const u32x4 xv = *(const u32x4*)p;
-        const _Float16 m_sp = mf_p_mul_sp(sp[r], rsh);             // 2^-10 .. 2^14
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t xw = xv[i];
-            const fp2 d = (fp2){mf_sub_lo(xw, -M[r]), mf_sub_hi(xw, -M[r])} * l2e;                     // kivi_exp(x - M)
-            const fp2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
-            const hp2 pp = __builtin_convertvector(e * (fp2){invS[r], invS[r]}, hp2);
-            const _Float16 m_a = mf_p_mul_a(BITS == 4 || i >= 2, rsh);                                 // tokens (e & 4): 2^6, else 2^4 (4-bit codes: 2^6)
-            o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});
-        }
-        if (left < 8) {                                            // the end of the packed prefix falls into (or before) this lane's eight
-#pragma unroll
-            for (int i = 0; i < 4; i++) o[i] = (2 * i >= left) ? 0u : ((2 * i + 1 >= left) ? (o[i] & 0xFFFFu) : o[i]);
-        }
-        *(u32x4*)p = o;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t xw = xv[i];
+        const fp2 d = (fp2){mf_sub_lo(xw, -M), mf_sub_hi(xw, -M)} * l2e;                               // kivi_exp(x - M)
+        const fp2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+        const hp2 pp = __builtin_convertvector(e * (fp2){invS, invS}, hp2);
+        const _Float16 m_a = mf_p_mul_a(BITS == 4 || i >= 2, rsh);                                     // tokens (e & 4): 2^6, else 2^4 (4-bit codes: 2^6)
+        o[i] = __builtin_bit_cast(uint32_t, (pp * (hp2){m_a, m_a}) * (hp2){m_sp, m_sp});
     }
+    if (left < 8) {                                                // the end of the packed prefix falls into (or before) this lane's eight
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = (2 * i >= left) ? 0u : ((2 * i + 1 >= left) ? (o[i] & 0xFFFFu) : o[i]);
+    }
+    *(u32x4*)p = o;
 }
 
 // LSTAT: the statistics of a wave's segments are carried per LANE through the K walk (a running (max, sum exp) of the lane's eight
@@ -652,7 +648,12 @@ __device__ __forceinline__ void mf_probs_inplace(uint16_t* rows, int pitch, int 
 // of two wave reductions per segment and head (each a chain of ~10 dependent DPP / readlane operations)
 // R = 1 (nh == nh_kv; OCC = 4: four blocks per CU in <= 128 registers): the same block over mf_k_seq1 / MfVStream<1> -- the sliced form of
 // multi-head rows (mf_row_kernel keeps the unsliced one)
-template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, bool LSTAT = true, int OCC = 2>
+// PSM ("phase softmax", unsliced rows only): the round-4 flow -- the K walk only writes the scores, every wave then takes whole rows
+// through the three-pass softmax (mf_row_softmax_wave) between the two barriers, the V stream reads finished p''.  Kept because it
+// measures FASTER than the in-stream form for a block that holds a whole row (BASELINE config 4, one box, alternating: 97.8 us
+// against 104.0-104.8: the exponentials cost the same wherever they run, and inside the streams they delay a wave's next request
+// -- profiles/r05_row4_flows.log); the in-stream form is what makes slices possible (their statistics must exist before the exchange).
+template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, bool LSTAT = true, int OCC = 2, bool PSM = false>
 __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
     constexpr int NTH = NW * 64;
     static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
@@ -737,6 +738,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
         auto seg_done = [&](int sb, int ng) {
             typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
             typedef float fp2 __attribute__((ext_vector_type(2)));
+            if constexpr (PSM) return;
             __builtin_amdgcn_wave_barrier();
             const int seg = sb - sb_lo;
             const bool valid = lane * 8 < ng * 32;
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
             }, seg_done);
         }
     }
-    if constexpr (LSTAT) {                                         // the wave's (max, sum exp) of every head: one entry per wave
+    if constexpr (LSTAT && !PSM) {                                 // the wave's (max, sum exp) of every head: one entry per wave
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
             const float m = wave_max(lm[rr]);
@@ -876,7 +878,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
                         *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16) = ka[p];
                         *(u16x8*)(kres + (int64_t)t * ak.kres_st + sub * 16 + 8) = kc[p];
                     }
-                    const uint16_t mk = mrow ? mrow[Tq + t] : (uint16_t)0;
+                    const bool rmask = !PSM && mrow != nullptr;    // (PSM: the softmax adds the mask over the whole row)
+                    const uint16_t mk = rmask ? mrow[Tq + t] : (uint16_t)0;
 #pragma unroll
                     for (int r = 0; r < RH; r++) {
                         float sc = 0.f;
@@ -888,14 +891,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
                         sc += dpp_f<0x4E>(sc);                     // neighbours, pairs, the two quads)
                         sc += dpp_f<0x141>(sc);
                         if (sub == 0) {
-                            const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, mrow != nullptr, mk);
+                            const uint16_t h = kivi_scaled_score(f2h_bits(sc), ak.inv_scale, rmask, mk);
                             rows[(r0 + r) * n_pad + (Tq - tok0) + t] = h;
-                            if (dump0) dump0[(int64_t)(r0 + r) * ak.out_sh + Tq + t] = h;
+                            if (!PSM && dump0) dump0[(int64_t)(r0 + r) * ak.out_sh + Tq + t] = h;
                         }
                     }
                 }
             }
         }
+    }
+    if constexpr (PSM) {                                           // -inf past the rows (the softmax reads whole 4-score chunks)
+        const int n = Tq + L;
+        for (int j = (int)threadIdx.x; j < R * (n_pad - n); j += NTH) rows[(j / (n_pad - n)) * n_pad + n + j % (n_pad - n)] = 0xFC00u;
     }
     stamp(4);
     // the fp16 window rows (and the token leaving it) are requested before the barrier and used after the statistics
@@ -909,7 +916,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     // slices of the unit exchange theirs
     float M[R], invS[R];
     int sp[R];
-    {
+    if constexpr (PSM) {
+        // ---- [mask +] softmax of the rows wave, wave + NW, ... (fp32, cast to fp16: :364-375): p'' in place, the window's into pw
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) { M[rr] = 0.f; invS[rr] = 1.f; sp[rr] = 0; }
+#pragma unroll 1
+        for (int r = wave; r < R; r += NW) {
+            for (int j = lane; j < NW * decltype(win)::TW; j += 64) pw[r][j] = 0;      // (zeros past the window: its walk reads whole 8-token groups)
+            __builtin_amdgcn_wave_barrier();
+            const int spr = mf_row_softmax_wave<BITS>(rows + r * n_pad, Tq + L, n_pad, Tv, mrow, pw[r], vrsh,
+                                                      dump0 ? dump0 + (int64_t)r * ak.out_sh : nullptr);
+            if (lane == 0) sp_lds[r] = spr;
+        }
+    } else {
         const int nseg_loc = LSTAT ? NW : sb_hi - sb_lo;          // entries of st_lds: one per wave, or one per segment
         float Ls[R];
 #pragma unroll
@@ -975,7 +994,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     }
     stamp(6);
     // the window's probabilities fp16(exp(x - M) / sum) (:375) of the rows wave, wave + NW, ...
-    if (last) {
+    if (!PSM && last) {
         const int Lw = av.res_len + 1;
 #pragma unroll 1
         for (int rr = wave; rr < R; rr += NW) {
@@ -988,7 +1007,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
                 pw[rr][j] = j < Lw ? f2h_bits(kivi_exp(h2f_bits(rp[j]) - Mr) * Ir) : (uint16_t)0;
         }
     }
-    if (threadIdx.x == 0) {
+    if (!PSM && threadIdx.x == 0) {
 #pragma unroll
         for (int rr = 0; rr < R; rr++) sp_lds[rr] = sp[rr];
     }
@@ -1008,13 +1027,34 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     MfVAcc<R, VHL> A;
     mf_v_init(A);
     __builtin_amdgcn_s_setprio(0);
-    constexpr int PB = (16 / VRING) * VRING;                       // whole ring rounds, <= 512 tokens (8 per lane)
-    for (int bp = b_lo; bp < b_hi; bp += PB) {
-        const int nb = (b_hi - bp) < PB ? (b_hi - bp) : PB;
-        mf_probs_inplace<R, BITS>(rows, n_pad, bp * 32 - tok0, nb * 32, Tv - bp * 32, M, invS, sp, vrsh);
+    // pieces of PB blocks (whole ring rounds, <= 512 tokens: 8 per lane).  The first piece's p'' are made before the stream starts;
+    // from then on ONE row of the next piece is converted after every ring round of the current one, under the loads that round has
+    // just requested: converting a whole piece (R rows) at once let the ring run dry five times per wave (+8 us on the sV phase at
+    // BASELINE config 4, profiles/r05_row4_phases.log)
+    constexpr int PB = (16 / VRING) * VRING, NR = PB / VRING;
+    static_assert(R <= NR, "a row of the next piece per ring round");
+    if constexpr (PSM) {
+        vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0);                 // (the rows hold finished p'')
+    } else {
+        const int nb0 = (b_hi - b_lo) < PB ? (b_hi - b_lo) : PB;
+        if (nb0 > 0) {
+#pragma unroll
+            for (int rr = 0; rr < R; rr++)
+                mf_probs_inplace_row<BITS>(rows + rr * n_pad, b_lo * 32 - tok0, nb0 * 32, Tv - b_lo * 32, M[rr], invS[rr], sp[rr], vrsh);
+        }
         __builtin_amdgcn_wave_barrier();
-        vs.run(A, rv, bp, bp + nb, rows, n_pad, tok0);
-        __builtin_amdgcn_wave_barrier();
+        for (int bp = b_lo; bp < b_hi; bp += PB) {
+            const int pe = (bp + PB < b_hi) ? bp + PB : b_hi;      // end of this piece
+            const int nbn = (b_hi - pe) < PB ? (b_hi - pe) : PB;   // blocks of the next one (<= 0: none)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int b0 = bp + r * VRING;
+                if (b0 < pe) vs.run(A, rv, b0, (b0 + VRING < pe) ? b0 + VRING : pe, rows, n_pad, tok0);
+                if (r < R && nbn > 0)
+                    mf_probs_inplace_row<BITS>(rows + r * n_pad, pe * 32 - tok0, nbn * 32, Tv - pe * 32, M[r], invS[r], sp[r], vrsh);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     stamp(9);
     __syncthreads();                                               // every wave is done with the p'' rows: their memory is reused
@@ -1193,7 +1233,13 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         k.dump = dump;
         if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; }
         else if ((int64_t)units * S <= occ * (int64_t)mf_cu_count()) k.ticket = nullptr;
-        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0;
+        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0, opt8p = 0, opt4p = 0, opt44p = 0;
+        // a block per row (S = 1): the phase-softmax flow (PSM, see mf_row4_kernel); slices: the in-stream flow
+        bool psm = S == 1 && R != 1;
+#ifdef KIVI_TUNING
+        static const char* fl = KIVI_TUNE_ENV("KIVI_MF_ROW4_FLOW");      // A/B: "stream" = the in-stream flow for unsliced rows too
+        if (fl && !strcmp(fl, "stream")) psm = false;
+#endif
 #define KIVI_ROW4_LAUNCH(OPT, ...)                                                                 \
     do {                                                                                           \
         const int rc = mf_lds_opt_in(mf_row4_kernel<__VA_ARGS__>, &OPT, "mf_row4");                \
@@ -1202,12 +1248,15 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
         if (R == 1) KIVI_ROW4_LAUNCH(opt1, 2, 3, 4, false, false, 1, 2, true, 4);
+        if (R == 8 && psm) KIVI_ROW4_LAUNCH(opt8p, 4, 2, 4, false, false, 8, 2, true, 2, true);
         if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
+        if (bits == 4 && psm) KIVI_ROW4_LAUNCH(opt44p, 4, 3, 4, false, true, 4, 4, true, 2, true);
         if (bits == 4) KIVI_ROW4_LAUNCH(opt44, 4, 3, 4, false, true, 4, 4);
 #ifdef KIVI_TUNING
         static unsigned long long opt_t[16] = {0};
         static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<K ring><V ring><waves>"; + 1000: chained hi / lo in the sV phase; + 2000: statistics by wave reductions per segment
         const int cfg = fr4 ? atoi(fr4) : 434;
+        if (v.dbg && psm) KIVI_ROW4_LAUNCH(opt_t[11], 4, 3, 4, true, true, 4, 2, true, 2, true);
         if (v.dbg && cfg == 844) KIVI_ROW4_LAUNCH(opt_t[9], 8, 4, 4, true);
         if (v.dbg && cfg == 2434) KIVI_ROW4_LAUNCH(opt_t[10], 4, 3, 4, true, true, 4, 2, false);
         if (v.dbg) KIVI_ROW4_LAUNCH(opt_t[0], 4, 3, 4, true);
@@ -1220,6 +1269,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (cfg == 2434) KIVI_ROW4_LAUNCH(opt_t[7], 4, 3, 4, false, true, 4, 2, false);
         if (cfg == 2844) KIVI_ROW4_LAUNCH(opt_t[8], 8, 4, 4, false, true, 4, 2, false);
 #endif
+        if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, true, 2, true);
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH
     }

@@ -974,4 +974,126 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
     return sp;
 }
 
+// The same for ONE WAVE per row (mf_row4_kernel: wave r takes head r; the four rows of a unit at once instead of one after the
+// other, nothing block-wide inside): three passes over the row in LDS -- [mask +] maximum, sum of exp(x - M), write of p'' -- each
+// lane on 4 consecutive scores per 256-score chunk; the exponentials are computed twice rather than kept (a 9216-key row is 144
+// scores per lane).  The block version above spends most of its ~4 us per row in two block barriers and dependent LDS round
+// trips, four rows in sequence; profiles/r04_row4_levers.log.  Returns Sp (wave-uniform).
+template <int BITS = 2>
+__device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_pad, int Tv, const uint16_t* mrow, uint16_t* pw_row, int rsh,
+                                                   uint16_t* dump) {
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    constexpr int NB = 4;                                          // chunks per batch: their LDS reads are issued before the first is used
+    const int lane = threadIdx.x & 63;
+    const int nch = (n + 255) >> 8;                                // 256-score chunks that hold scores
+    const u32x2v ninf2 = {0xFC00FC00u, 0xFC00FC00u};
+    auto load = [&](int c) -> u32x2v {                             // chunk c of this lane; past the padded row: -inf (exp = 0)
+        const int j0 = c * 256 + lane * 4;
+        return j0 < n_pad ? *(const u32x2v*)(row + j0) : ninf2;
+    };
+    // ---- pass A: [mask in place,] maximum
+    if (mrow) {                                                    // masked rows: :366-372, fp16 add clamped at the fp16 minimum
+        for (int c = 0; c < nch; c++) {
+            const int j0 = c * 256 + lane * 4;
+            if (j0 < n) {
+                u16x4 rw = *(const u16x4*)(row + j0);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (j0 + e < n) {
+                        float v = (float)(_Float16)(h2f_bits(rw[e]) + h2f_bits(mrow[j0 + e]));
+                        if (v < -65504.0f) v = -65504.0f;
+                        rw[e] = f2h_bits(v);
+                    }
+                *(u16x4*)(row + j0) = rw;                          // the same lane reads it back below
+            }
+        }
+    }
+    h2v mx2 = {(_Float16)(-__builtin_inff()), (_Float16)(-__builtin_inff())};
+    for (int c0 = 0; c0 < nch; c0 += NB) {
+        u32x2v raw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (dump) {                                            // (KIVI_GQA_DUMP_SCORES: a run-time pointer, null in production)
+                const int j0 = (c0 + k) * 256 + lane * 4;
+                if (j0 < n) *(u32x2v*)(dump + j0) = raw[k];
+            }
+            const uint32_t w0 = raw[k][0], w1 = raw[k][1];
+            mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_max(__builtin_bit_cast(h2v, w0), __builtin_bit_cast(h2v, w1)));
+        }
+    }
+    const uint32_t mb = __builtin_bit_cast(uint32_t, mx2);
+    const float mx = wave_max(__builtin_fmaxf(h2f_bits((uint16_t)(mb & 0xFFFFu)), h2f_bits((uint16_t)(mb >> 16))));
+    const float nmx = -mx;
+    const f2v l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+    auto exps = [&](const u32x2v& raw, f2v& e01, f2v& e23) {       // kivi_exp(x - M) of the four scores of a chunk
+        const f2v d01 = (f2v){mf_sub_lo(raw[0], nmx), mf_sub_hi(raw[0], nmx)} * l2e;
+        const f2v d23 = (f2v){mf_sub_lo(raw[1], nmx), mf_sub_hi(raw[1], nmx)} * l2e;
+        e01 = (f2v){__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
+        e23 = (f2v){__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+    };
+    // ---- pass B: sum of exp
+    f2v acc = {0.f, 0.f};
+    for (int c0 = 0; c0 < nch; c0 += NB) {
+        u32x2v raw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            f2v e01, e23;
+            exps(raw[k], e01, e23);
+            acc += e01;
+            acc += e23;
+        }
+    }
+    const float sum = wave_sum(acc[0] + acc[1]);
+    const float inv = 1.0f / sum;
+    const int sp = mf_sp(sum, rsh);
+    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);
+    const _Float16 m_a4 = mf_p_mul_a(BITS == 4, rsh), m_a6 = mf_p_mul_a(true, rsh);
+    const f2v inv2 = {inv, inv};
+    // ---- pass C: p = fp16(e / sum) (:375), p'' back into the row (zeros from Tv on), the window's probabilities into pw_row
+    const int nchp = (n_pad + 255) >> 8;
+    for (int c0 = 0; c0 < nchp; c0 += NB) {
+        u32x2v raw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) raw[k] = load(c0 + k);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int j0 = (c0 + k) * 256 + lane * 4;
+            if (j0 >= n_pad) continue;
+            u32x2v o = {0u, 0u};
+            if (j0 < n) {
+                f2v e01, e23;
+                exps(raw[k], e01, e23);
+                const h2v p01 = __builtin_convertvector(e01 * inv2, h2v);
+                const h2v p23 = __builtin_convertvector(e23 * inv2, h2v);
+                if (j0 + 4 <= Tv) {
+                    const _Float16 m_a = (j0 & 4) ? m_a6 : m_a4;
+                    o[0] = __builtin_bit_cast(uint32_t, (p01 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
+                    o[1] = __builtin_bit_cast(uint32_t, (p23 * (h2v){m_a, m_a}) * (h2v){m_sp, m_sp});
+                } else {                                           // the chunk that holds the end of the packed prefix / the window
+                    const uint32_t w01 = __builtin_bit_cast(uint32_t, p01), w23 = __builtin_bit_cast(uint32_t, p23);
+                    const uint16_t pp[4] = {(uint16_t)(w01 & 0xFFFFu), (uint16_t)(w01 >> 16), (uint16_t)(w23 & 0xFFFFu), (uint16_t)(w23 >> 16)};
+                    uint16_t q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int j = j0 + e;
+                        if (j >= Tv && j < n) pw_row[j - Tv] = pp[e];
+                        q[e] = (j < Tv) ? mf_scale_p<BITS>(pp[e], sp, j) : (uint16_t)0;
+                    }
+                    o[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+                    o[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);
+                }
+            }
+            *(u32x2v*)(row + j0) = o;
+        }
+    }
+    return sp;
+}
+
 }  // namespace

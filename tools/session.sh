@@ -223,6 +223,27 @@ while [ $# -gt 0 ]; do
         timeout 300 $BN --batch 4 --steps 10 --warmup 3 > $O/r5c_b4.json 2>> $O/r5c.err; line $O/r5c_b4.json
         timeout 300 $BN --batch 4 --steps 10 --warmup 3 --form slices2 > $O/r5c_b4_slices2.json 2>> $O/r5c.err; line $O/r5c_b4_slices2.json
         tail -5 $O/r5c.err ;;
+    r5d)
+        # round 5, fourth look: the two flows of mf_row4_kernel for unsliced rows (phase softmax = default, in-stream = KIVI_MF_ROW4_FLOW=stream in
+        # the tuning build) against the round-4 tree, one box, alternating; parity of the row forms first
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=5 \
+            -k "sliced or two_launch_form or (decode_steps_match and row) or (fixtures and row) or (dynamic_range and row and (1e-4 or 30000))" > $O/r5d_tests.log 2>&1
+        echo "r5d tests rc=$?" | tee -a $O/status.log; tail -10 $O/r5d_tests.log | cut -c1-200
+        for i in 1 2 3; do
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5d_c4_r4tree_$i.json 2>> $O/r5d.err ); line $O/r5d_c4_r4tree_$i.json
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5d_c4_psm_$i.json 2>> $O/r5d.err; line $O/r5d_c4_psm_$i.json
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5d_c4_stream_$i.json 2>> $O/r5d.err; line $O/r5d_c4_stream_$i.json
+        done
+        ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --bits 4 --steps 10 --warmup 3 > $O/r5d_c4b4_r4tree.json 2>> $O/r5d.err ); line $O/r5d_c4b4_r4tree.json
+        timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/r5d_c4b4_psm.json 2>> $O/r5d.err; line $O/r5d_c4b4_psm.json
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/r5d_c4b4_stream.json 2>> $O/r5d.err; line $O/r5d_c4b4_stream.json
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5d_row4_phases_psm.log 2>&1; sed -n 2,14p $O/r5d_row4_phases_psm.log
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5d_row4_phases_stream.log 2>&1; sed -n 2,14p $O/r5d_row4_phases_stream.log
+        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5d_c5.json 2>> $O/r5d.err; line $O/r5d_c5.json
+        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5d_c70.json 2>> $O/r5d.err; line $O/r5d_c70.json
+        timeout 300 $BN $C70 --steps 10 --warmup 3 --form split > $O/r5d_c70_split.json 2>> $O/r5d.err; line $O/r5d_c70_split.json
+        tail -5 $O/r5d.err ;;
     forms)
         # round 5: the launch plan (auto) against the forced forms, same box, alternating: BASELINE config 4, the config-5 per-GPU slice,
         # the 70B-like slice, R = 8 at B = 64, and small grouped-query batches
