@@ -239,9 +239,10 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 // t in [w0, w1) (llama_kivi.py:384; the last token is the new value, appended here, :377), and -- `flusher` -- the
 // quantisation of the token leaving the window into its VT slot (:386-399).  NTH threads; `pw`: R x PW halves of LDS
 // that hold the fp16 probabilities of tokens [w0, w1) at index t - w0 and ZEROS from w1 - w0 up to NW * TW.  A lane owns two
-// channels; wave w takes the TW (a multiple of 8) consecutive tokens w0 + w TW ..., so the probabilities of eight tokens of a head
-// are ONE 16-byte LDS read and the whole walk is branch-free (round 4 walked tokens w, w + NW, ... with two branches and R
-// two-byte LDS reads per token, each behind its own wait: 6.7 us per block at residual_length 128, profiles/r05_row4_phases.log).
+// channels; wave w takes tw consecutive tokens w0 + w tw ... (tw = the window's tokens per wave, rounded up to 8; <= TW), so the
+// probabilities of eight tokens of a head are ONE 16-byte LDS read and a group of eight is walked branch-free (round 4 walked
+// tokens w, w + NW, ... with two branches and R two-byte LDS reads per token, each behind its own wait: 6.7 us per block at
+// residual_length 128, profiles/r05_row4_phases.log).
 // Two halves, so that the loads fly while the caller does something else (the row kernels request before their softmax):
 // request() issues the loads of the first WPRE tokens of every wave (and of the token that leaves the window, and of the code
 // word it will be merged into), finish() loads what is left in one batch and consumes everything once pw holds the probabilities.
@@ -255,6 +256,7 @@ struct GqaWindow {
     uint32_t vv[NPRE];
     uint32_t wold;
     uint16_t xflush;
+    int tw;                    // tokens per wave of this window (a multiple of 8)
 
     __device__ __forceinline__ static uint16_t* wrow(const GqaVArgs& a, uint16_t* vbuf, int t) {
         // row of window token t: a ring of win_rows rows (no compaction, residual_length + 1 rows suffice) or the linear buffer
@@ -269,15 +271,19 @@ struct GqaWindow {
         if constexpr (BITS == 4) return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + vt4_word(tt, d);
         return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
     }
-    // the two channels (2 lane, 2 lane + 1) of window token t, zeros past w1
-    __device__ __forceinline__ static uint32_t vload(const GqaVArgs& a, uint16_t* vbuf, const uint16_t* vnew, int t, int w1) {
+    // the two channels (2 lane, 2 lane + 1) of window token t (past w1: of a row that exists -- the walk masks those).  t is WAVE-UNIFORM (callers pass the wave index through
+    // readfirstlane): the row address is scalar arithmetic and the load is unconditional (a row that exists is read for t >= w1) --
+    // as a conditional load of a per-lane pointer every token cost two branches and ~30 vector instructions (40 tokens per wave:
+    // ~4 us in front of the barrier, profiles/r05_row4_flows.log)
+    __device__ __forceinline__ static uint32_t vload(const GqaVArgs& a, uint16_t* vbuf, const uint16_t* vnew, int t, int w0, int w1) {
         const int lane = threadIdx.x & 63;
-        const uint16_t* vrow = (t < a.res_len) ? wrow(a, vbuf, t) : vnew;
-        return (t < w1) ? *(const uint32_t*)(vrow + 2 * lane) : 0u;
+        const int tc = t < w1 ? t : w0;
+        const uint16_t* vrow = (tc < a.res_len) ? wrow(a, vbuf, tc) : vnew;
+        return *(const uint32_t*)(vrow + 2 * lane);                 // (no select here: it would wait for the load at once)
     }
 
     __device__ __forceinline__ void request(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher) {
-        const int wave = threadIdx.x >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
         const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
         xflush = 0; wold = 0;
@@ -285,13 +291,15 @@ struct GqaWindow {
             xflush = wrow(a, vbuf, 0)[threadIdx.x];
             if (BITS == 4 || ((threadIdx.x >> 4) & 1) == 0) wold = *flush_word(a, b, hk, threadIdx.x);
         }
+        const int nwt = w1 > w0 ? w1 - w0 : 0;
+        tw = (((nwt + NW - 1) / NW) + 7) & ~7;                     // (<= TW: nwt <= 129)
 #pragma unroll
-        for (int u = 0; u < NPRE; u++) vv[u] = vload(a, vbuf, vnew, w0 + wave * TW + u, w1);
+        for (int u = 0; u < NPRE; u++) vv[u] = vload(a, vbuf, vnew, w0 + wave * tw + u, w0, w1);
     }
 
     __device__ __forceinline__ void finish(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
                                            const uint16_t (*pw)[PW], float (*ow)[2]) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
         const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
 #pragma unroll
@@ -299,25 +307,26 @@ struct GqaWindow {
         // the tokens request() did not prefetch are loaded a group of eight ahead of their use
         uint32_t nx[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) nx[e] = (e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * TW + e, w1) : 0u;
+        for (int e = 0; e < 8; e++) nx[e] = (e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * tw + e, w0, w1) : 0u;
 #pragma unroll
         for (int g = 0; g < TW / 8; g++) {
+            if (8 * g >= tw) break;                                // (wave-uniform: a short window ends early)
             uint32_t cur[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) cur[e] = (8 * g + e < NPRE) ? vv[8 * g + e < NPRE ? 8 * g + e : 0] : nx[e];
             if (g + 1 < TW / 8) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) nx[e] = (8 * (g + 1) + e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * TW + 8 * (g + 1) + e, w1) : 0u;
+                for (int e = 0; e < 8; e++) nx[e] = (8 * (g + 1) + e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * tw + 8 * (g + 1) + e, w0, w1) : 0u;
             }
             constexpr int RH = R > 4 ? 4 : R;                      // heads per pass (R = 8: two passes: 16 instead of 32 registers of probabilities)
 #pragma unroll
             for (int r0 = 0; r0 < R; r0 += RH) {
                 u32x4 pv[RH];                                      // the probabilities of 8 tokens of these heads (zeros past the window)
 #pragma unroll
-                for (int rr = 0; rr < RH; rr++) pv[rr] = *(const u32x4*)(&pw[r0 + rr][wave * TW + 8 * g]);
+                for (int rr = 0; rr < RH; rr++) pv[rr] = *(const u32x4*)(&pw[r0 + rr][wave * tw + 8 * g]);
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const uint32_t v = cur[e];
+                    const uint32_t v = (w0 + wave * tw + 8 * g + e < w1) ? cur[e] : 0u;     // (tokens past the window: zeros, whatever was read)
                     const float v0 = h2f_bits((uint16_t)(v & 0xFFFFu)), v1 = h2f_bits((uint16_t)(v >> 16));
 #pragma unroll
                     for (int rr = 0; rr < RH; rr++) {
@@ -333,7 +342,7 @@ struct GqaWindow {
             if constexpr (NPRE < TW) __builtin_amdgcn_sched_barrier(0);
         }
         // V append (:377): the new value becomes window row res_len -- by the wave that owns that token
-        if (a.res_len >= w0 && a.res_len < w1 && (a.res_len - w0) / TW == wave)
+        if (a.res_len >= w0 && a.res_len < w1 && (a.res_len - w0) / tw == wave)
             *(uint32_t*)(wrow(a, vbuf, a.res_len) + 2 * lane) = *(const uint32_t*)(vnew + 2 * lane);
         if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
             const int d = threadIdx.x;

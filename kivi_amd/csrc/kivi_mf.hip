@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     stamp(5);
 
     // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
-    GqaWindow<1, NTH, MF_PW, (NW == 8 ? 5 : 9)> win;
+    GqaWindow<1, NTH, MF_PW, (NW == 8 ? 8 : 16)> win;              // (prefetched tokens per wave: the whole share of a 33- / 65-token window)
     win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
     for (int j = threadIdx.x; j < MF_PW; j += NTH) pw[0][j] = 0;    // (the window walk reads whole 8-token groups: zeros past the window;
                                                                    //  the softmax writes the probabilities behind its two barriers)

@@ -244,6 +244,30 @@ while [ $# -gt 0 ]; do
         timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5d_c70.json 2>> $O/r5d.err; line $O/r5d_c70.json
         timeout 300 $BN $C70 --steps 10 --warmup 3 --form split > $O/r5d_c70_split.json 2>> $O/r5d.err; line $O/r5d_c70_split.json
         tail -5 $O/r5d.err ;;
+    r5e)
+        # round 5, fifth look: the window's scalar row loads / tokens-per-wave: headline and config 4 against the round-4 tree, slices against
+        # two launches at the R = 8 and long-row shapes, small grouped-query batches
+        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=5 \
+            -k "sliced or two_launch_form or (fixtures and row) or (mf4_decode_steps_match and row)" > $O/r5e_tests.log 2>&1
+        echo "r5e tests rc=$?" | tee -a $O/status.log; tail -10 $O/r5e_tests.log | cut -c1-200
+        for i in 1 2; do
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/r5e_hl_r4tree_$i.json 2>> $O/r5e.err ); line $O/r5e_hl_r4tree_$i.json
+            timeout 300 $BN > $O/r5e_hl_new_$i.json 2>> $O/r5e.err; line $O/r5e_hl_new_$i.json
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5e_c4_r4tree_$i.json 2>> $O/r5e.err ); line $O/r5e_c4_r4tree_$i.json
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5e_c4_new_$i.json 2>> $O/r5e.err; line $O/r5e_c4_new_$i.json
+            for f in auto split; do
+                timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/r5e_c70_${f}_$i.json 2>> $O/r5e.err; line $O/r5e_c70_${f}_$i.json
+                timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/r5e_c5_${f}_$i.json 2>> $O/r5e.err; line $O/r5e_c5_${f}_$i.json
+            done
+        done
+        for f in auto split row; do
+            timeout 300 $BN --batch 4 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/r5e_b4_8k_$f.json 2>> $O/r5e.err; line $O/r5e_b4_8k_$f.json
+            timeout 300 $BN --batch 32 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/r5e_b32_8k_$f.json 2>> $O/r5e.err; line $O/r5e_b32_8k_$f.json
+        done
+        for f in auto split; do
+            timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 --form $f > $O/r5e_r8b64_$f.json 2>> $O/r5e.err; line $O/r5e_r8b64_$f.json
+        done
+        tail -5 $O/r5e.err ;;
     forms)
         # round 5: the launch plan (auto) against the forced forms, same box, alternating: BASELINE config 4, the config-5 per-GPU slice,
         # the 70B-like slice, R = 8 at B = 64, and small grouped-query batches
