@@ -695,9 +695,14 @@ static int mf_plan(int R, int units, int64_t n_rows, int nsbk, int res_cap, int 
     int S = 1;
     while (S <= nsbk && S <= 64 && blk_rows(S) > cap) S++;
     if (S > nsbk || S > 64) return 0;
-    // few units: more, shorter slices while a slice keeps >= 4 super-blocks (one per wave of its block in the K walk) and the grid
-    // stays within the 2 blocks per CU that are resident at once
-    while ((int64_t)units * S * 2 <= 512 && (nsbk + 2 * S - 1) / (2 * S) >= 4 && 2 * S <= 64 && blk_rows(2 * S) <= cap) S *= 2;
+    // more, shorter slices while a slice keeps >= 4 super-blocks (one per wave of its block in the K walk): rows that must be cut
+    // anyway until the grid fills the 2 blocks per CU that are resident at once; rows that fit only while there are fewer blocks than
+    // CUs -- a block that holds a whole row runs the faster phase-softmax flow and pays no exchange (32 / 8 heads, 8k keys, ms per
+    // 32-layer step: 32 units 1.84 unsliced, 1.01 in 4 slices, 1.08 in two launches; 256 units 1.97 unsliced, 2.04 in 2 slices, 2.05
+    // in two launches -- profiles/r05_forms.log)
+    auto can_double = [&](int S_) { return (nsbk + 2 * S_ - 1) / (2 * S_) >= 4 && 2 * S_ <= 64 && blk_rows(2 * S_) <= cap; };
+    if (S == 1) { while ((int64_t)units * S < 256 && can_double(S)) S *= 2; }
+    else { while ((int64_t)units * S * 2 <= 512 && can_double(S)) S *= 2; }
     if (S > 1 && units > KIVI_GQA_WS_COUNTERS / 2 - 1) S = blk_rows(1) <= cap ? 1 : 0;
     if (S == 1) {
         // (R = 8, 4000 keys: 128 units 1.65 ms per 32-layer step in one launch against 1.39 in two, 512 units 2.42 against 3.65;

@@ -238,11 +238,10 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
 // Window role of the sV launch: out_w[r][2 lane, 2 lane + 1] += probs[r, Tv + t] * V_window[t] for the window tokens
 // t in [w0, w1) (llama_kivi.py:384; the last token is the new value, appended here, :377), and -- `flusher` -- the
 // quantisation of the token leaving the window into its VT slot (:386-399).  NTH threads; `pw`: R x PW halves of LDS
-// that hold the fp16 probabilities of tokens [w0, w1) at index t - w0 and ZEROS from w1 - w0 up to NW * TW.  A lane owns two
-// channels; wave w takes tw consecutive tokens w0 + w tw ... (tw = the window's tokens per wave, rounded up to 8; <= TW), so the
-// probabilities of eight tokens of a head are ONE 16-byte LDS read and a group of eight is walked branch-free (round 4 walked
-// tokens w, w + NW, ... with two branches and R two-byte LDS reads per token, each behind its own wait: 6.7 us per block at
-// residual_length 128, profiles/r05_row4_phases.log).
+// that hold the fp16 probabilities of tokens [w0, w1) at index t - w0 and ZEROS from w1 - w0 up to the next multiple of 8.  A lane
+// owns two channels; wave w takes the GROUPS of eight consecutive tokens w, w + NW, ..., so the probabilities of eight tokens of a
+// head are ONE 16-byte LDS read and a group is walked branch-free (round 4 walked tokens w, w + NW, ... with two branches and R
+// two-byte LDS reads per token, each behind its own wait: 6.7 us per block at residual_length 128, profiles/r05_row4_flows.log).
 // Two halves, so that the loads fly while the caller does something else (the row kernels request before their softmax):
 // request() issues the loads of the first WPRE tokens of every wave (and of the token that leaves the window, and of the code
 // word it will be merged into), finish() loads what is left in one batch and consumes everything once pw holds the probabilities.
@@ -256,7 +255,7 @@ struct GqaWindow {
     uint32_t vv[NPRE];
     uint32_t wold;
     uint16_t xflush;
-    int tw;                    // tokens per wave of this window (a multiple of 8)
+    int ngr;                   // groups of eight tokens in this window
 
     __device__ __forceinline__ static uint16_t* wrow(const GqaVArgs& a, uint16_t* vbuf, int t) {
         // row of window token t: a ring of win_rows rows (no compaction, residual_length + 1 rows suffice) or the linear buffer
@@ -271,17 +270,30 @@ struct GqaWindow {
         if constexpr (BITS == 4) return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + vt4_word(tt, d);
         return mf_sb(a.vt, b, hk, a.Tv >> 9) + blk * LY::BLOCK_WORDS + (nn + 16 * kbq) * 4 + c;
     }
-    // the two channels (2 lane, 2 lane + 1) of window token t (past w1: of a row that exists -- the walk masks those).  t is WAVE-UNIFORM (callers pass the wave index through
-    // readfirstlane): the row address is scalar arithmetic and the load is unconditional (a row that exists is read for t >= w1) --
-    // as a conditional load of a per-lane pointer every token cost two branches and ~30 vector instructions (40 tokens per wave:
-    // ~4 us in front of the barrier, profiles/r05_row4_flows.log)
-    __device__ __forceinline__ static uint32_t vload(const GqaVArgs& a, uint16_t* vbuf, const uint16_t* vnew, int t, int w0, int w1) {
+    // The two channels (2 lane, 2 lane + 1) of the eight window tokens of group gidx (tokens w0 + 8 gidx + e; past the window: of the
+    // new value's row, the walk masks those).  gidx is WAVE-UNIFORM (the callers pass the wave index through readfirstlane): the row
+    // addresses are scalar arithmetic -- one multiply per group, then a stride and the ring's wrap per token -- and the loads are
+    // unconditional; as conditional loads of per-lane pointers every token cost two branches and ~30 vector instructions (40 tokens
+    // per wave: ~4 us in front of the barrier, profiles/r05_row4_flows.log).  E0 .. E1: the elements of the group to load.
+    template <int E0, int E1>
+    __device__ __forceinline__ static void gload(const GqaVArgs& a, uint16_t* vbuf, const uint16_t* vnew, int gidx, int w0, uint32_t* dst) {
         const int lane = threadIdx.x & 63;
-        const int tc = t < w1 ? t : w0;
-        const uint16_t* vrow = (tc < a.res_len) ? wrow(a, vbuf, tc) : vnew;
-        return *(const uint32_t*)(vrow + 2 * lane);                 // (no select here: it would wait for the load at once)
+        int r = a.win_start + w0 + 8 * gidx + E0;
+        if (a.win_rows && r >= a.win_rows) r -= a.win_rows;        // (t <= residual_length < win_rows: one wrap at most)
+        const uint16_t* p = vbuf + (int64_t)r * a.vres_st;
+#pragma unroll
+        for (int e = E0; e < E1; e++) {
+            const int t = w0 + 8 * gidx + e;
+            const uint16_t* vrow = (t < a.res_len) ? p : vnew;     // (t >= res_len: the new value, or past the window)
+            dst[e - E0] = *(const uint32_t*)(vrow + 2 * lane);    // (no select on the value here: it would wait for the load at once)
+            p += a.vres_st;
+            r++;
+            if (a.win_rows && r == a.win_rows) { r = 0; p = vbuf; }
+        }
     }
 
+    // w0, w1: the window's tokens [w0, w1), w1 = res_len + 1 (the new value is its last token).  Wave w takes the groups of eight
+    // tokens w, w + NW, ...
     __device__ __forceinline__ void request(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         uint16_t* vbuf = a.vres + b * a.vres_sb + hk * a.vres_sh;
@@ -291,10 +303,12 @@ struct GqaWindow {
             xflush = wrow(a, vbuf, 0)[threadIdx.x];
             if (BITS == 4 || ((threadIdx.x >> 4) & 1) == 0) wold = *flush_word(a, b, hk, threadIdx.x);
         }
-        const int nwt = w1 > w0 ? w1 - w0 : 0;
-        tw = (((nwt + NW - 1) / NW) + 7) & ~7;                     // (<= TW: nwt <= 129)
+        ngr = (w1 - w0 + 7) >> 3;                                  // groups of the window (<= 17)
 #pragma unroll
-        for (int u = 0; u < NPRE; u++) vv[u] = vload(a, vbuf, vnew, w0 + wave * tw + u, w0, w1);
+        for (int k = 0; k < (NPRE + 7) / 8; k++) {                 // the first NPRE token slots of the wave (whole and one partial group)
+            if (8 * k + 8 <= NPRE) gload<0, 8>(a, vbuf, vnew, wave + k * NW, w0, vv + 8 * k);
+            else gload<0, NPRE % 8 ? NPRE % 8 : 8>(a, vbuf, vnew, wave + k * NW, w0, vv + 8 * k);
+        }
     }
 
     __device__ __forceinline__ void finish(const GqaVArgs& a, int b, int hk, int w0, int w1, bool flusher,
@@ -304,29 +318,39 @@ struct GqaWindow {
         const uint16_t* vnew = a.vnew + b * a.vnew_sb + hk * a.vnew_sh;
 #pragma unroll
         for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
-        // the tokens request() did not prefetch are loaded a group of eight ahead of their use
+        // the token slots request() did not prefetch are loaded a group ahead of their use
+        constexpr int NG = TW / 8;                                 // groups per wave at most
         uint32_t nx[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) nx[e] = (e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * tw + e, w0, w1) : 0u;
+        for (int e = 0; e < 8; e++) nx[e] = 0u;
+        if constexpr (NPRE < 8) gload<NPRE, 8>(a, vbuf, vnew, wave, w0, nx + NPRE);
 #pragma unroll
-        for (int g = 0; g < TW / 8; g++) {
-            if (8 * g >= tw) break;                                // (wave-uniform: a short window ends early)
+        for (int k = 0; k < NG; k++) {
+            const int gidx = wave + k * NW;
+            if (gidx >= ngr) break;                                // (wave-uniform: a short window ends early)
             uint32_t cur[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) cur[e] = (8 * g + e < NPRE) ? vv[8 * g + e < NPRE ? 8 * g + e : 0] : nx[e];
-            if (g + 1 < TW / 8) {
+            for (int e = 0; e < 8; e++) cur[e] = (8 * k + e < NPRE) ? vv[8 * k + e < NPRE ? 8 * k + e : 0] : nx[e];
+            if (k + 1 < NG) {                                      // what the next group still needs from memory
+                constexpr int dummy = 0; (void)dummy;
+                const int e0 = (NPRE > 8 * (k + 1)) ? ((NPRE - 8 * (k + 1)) < 8 ? (NPRE - 8 * (k + 1)) : 8) : 0;   // (a constant after unrolling)
+                if (e0 == 0) gload<0, 8>(a, vbuf, vnew, gidx + NW, w0, nx);
+                else if (e0 < 8) {                                 // a group the prefetch covers partly (NPRE % 8 != 0)
+                    uint32_t tmp[8];
+                    gload<0, 8>(a, vbuf, vnew, gidx + NW, w0, tmp);
 #pragma unroll
-                for (int e = 0; e < 8; e++) nx[e] = (8 * (g + 1) + e >= NPRE) ? vload(a, vbuf, vnew, w0 + wave * tw + 8 * (g + 1) + e, w0, w1) : 0u;
+                    for (int e = 0; e < 8; e++) nx[e] = tmp[e];
+                }
             }
             constexpr int RH = R > 4 ? 4 : R;                      // heads per pass (R = 8: two passes: 16 instead of 32 registers of probabilities)
 #pragma unroll
             for (int r0 = 0; r0 < R; r0 += RH) {
                 u32x4 pv[RH];                                      // the probabilities of 8 tokens of these heads (zeros past the window)
 #pragma unroll
-                for (int rr = 0; rr < RH; rr++) pv[rr] = *(const u32x4*)(&pw[r0 + rr][wave * tw + 8 * g]);
+                for (int rr = 0; rr < RH; rr++) pv[rr] = *(const u32x4*)(&pw[r0 + rr][8 * gidx]);
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const uint32_t v = (w0 + wave * tw + 8 * g + e < w1) ? cur[e] : 0u;     // (tokens past the window: zeros, whatever was read)
+                    const uint32_t v = (w0 + 8 * gidx + e < w1) ? cur[e] : 0u;     // (token slots past the window: zeros, whatever was read)
                     const float v0 = h2f_bits((uint16_t)(v & 0xFFFFu)), v1 = h2f_bits((uint16_t)(v >> 16));
 #pragma unroll
                     for (int rr = 0; rr < RH; rr++) {
@@ -342,7 +366,7 @@ struct GqaWindow {
             if constexpr (NPRE < TW) __builtin_amdgcn_sched_barrier(0);
         }
         // V append (:377): the new value becomes window row res_len -- by the wave that owns that token
-        if (a.res_len >= w0 && a.res_len < w1 && (a.res_len - w0) / tw == wave)
+        if (a.res_len >= w0 && a.res_len < w1 && (((a.res_len - w0) >> 3) % NW) == wave)
             *(uint32_t*)(wrow(a, vbuf, a.res_len) + 2 * lane) = *(const uint32_t*)(vnew + 2 * lane);
         if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
             const int d = threadIdx.x;

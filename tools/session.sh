@@ -268,6 +268,24 @@ while [ $# -gt 0 ]; do
             timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 --form $f > $O/r5e_r8b64_$f.json 2>> $O/r5e.err; line $O/r5e_r8b64_$f.json
         done
         tail -5 $O/r5e.err ;;
+    r5f)
+        # round 5, sixth look: the group-strided window walk: headline against the round-4 tree, config 4, 128-unit rows
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=5 \
+            -k "sliced or two_launch_form or (fixtures and row) or (match_reference_logic and row and (2-2 or 4-4 or 3-3 or 32-8))" > $O/r5f_tests.log 2>&1
+        echo "r5f tests rc=$?" | tee -a $O/status.log; tail -10 $O/r5f_tests.log | cut -c1-200
+        for i in 1 2 3; do
+            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/r5f_hl_r4tree_$i.json 2>> $O/r5f.err ); line $O/r5f_hl_r4tree_$i.json
+            timeout 300 $BN > $O/r5f_hl_new_$i.json 2>> $O/r5f.err; line $O/r5f_hl_new_$i.json
+        done
+        ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5f_c4_r4tree.json 2>> $O/r5f.err ); line $O/r5f_c4_r4tree.json
+        timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5f_c4_new.json 2>> $O/r5f.err; line $O/r5f_c4_new.json
+        for f in auto split row; do
+            timeout 300 $BN --batch 16 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/r5f_b16_8k_$f.json 2>> $O/r5f.err; line $O/r5f_b16_8k_$f.json
+        done
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5f_row4_phases_psm.log 2>&1; sed -n 2,14p $O/r5f_row4_phases_psm.log
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T timeout 300 python tools/mf_row_phases.py > $O/r5f_row_phases.log 2>&1; sed -n 2,14p $O/r5f_row_phases.log
+        tail -5 $O/r5f.err ;;
     forms)
         # round 5: the launch plan (auto) against the forced forms, same box, alternating: BASELINE config 4, the config-5 per-GPU slice,
         # the 70B-like slice, R = 8 at B = 64, and small grouped-query batches
