@@ -281,14 +281,24 @@ struct GqaWindow {
         int r = a.win_start + w0 + 8 * gidx + E0;
         if (a.win_rows && r >= a.win_rows) r -= a.win_rows;        // (t <= residual_length < win_rows: one wrap at most)
         const uint16_t* p = vbuf + (int64_t)r * a.vres_st;
+        if (!a.win_rows || r + (E1 - E0) <= a.win_rows) {          // the group's rows do not wrap (all but one group of a ring): a stride per token
 #pragma unroll
-        for (int e = E0; e < E1; e++) {
-            const int t = w0 + 8 * gidx + e;
-            const uint16_t* vrow = (t < a.res_len) ? p : vnew;     // (t >= res_len: the new value, or past the window)
-            dst[e - E0] = *(const uint32_t*)(vrow + 2 * lane);    // (no select on the value here: it would wait for the load at once)
-            p += a.vres_st;
-            r++;
-            if (a.win_rows && r == a.win_rows) { r = 0; p = vbuf; }
+            for (int e = E0; e < E1; e++) {
+                const int t = w0 + 8 * gidx + e;
+                const uint16_t* vrow = (t < a.res_len) ? p : vnew; // (t >= res_len: the new value, or past the window)
+                dst[e - E0] = *(const uint32_t*)(vrow + 2 * lane); // (no select on the value here: it would wait for the load at once)
+                p += a.vres_st;
+            }
+        } else {
+#pragma unroll
+            for (int e = E0; e < E1; e++) {
+                const int t = w0 + 8 * gidx + e;
+                const uint16_t* vrow = (t < a.res_len) ? p : vnew;
+                dst[e - E0] = *(const uint32_t*)(vrow + 2 * lane);
+                p += a.vres_st;
+                r++;
+                if (r == a.win_rows) { r = 0; p = vbuf; }
+            }
         }
     }
 
@@ -305,7 +315,10 @@ struct GqaWindow {
         }
         ngr = (w1 - w0 + 7) >> 3;                                  // groups of the window (<= 17)
 #pragma unroll
+        for (int u = 0; u < NPRE; u++) vv[u] = 0u;
+#pragma unroll
         for (int k = 0; k < (NPRE + 7) / 8; k++) {                 // the first NPRE token slots of the wave (whole and one partial group)
+            if (wave + k * NW >= ngr) break;                       // (wave-uniform: nothing of the window there)
             if (8 * k + 8 <= NPRE) gload<0, 8>(a, vbuf, vnew, wave + k * NW, w0, vv + 8 * k);
             else gload<0, NPRE % 8 ? NPRE % 8 : 8>(a, vbuf, vnew, wave + k * NW, w0, vv + 8 * k);
         }

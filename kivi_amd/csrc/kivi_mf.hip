@@ -605,7 +605,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
 // last slice holds the tokens from the super-block of token Tv on -- the fp16 residual, the window, the appends and the V flush.
 // Dynamic LDS: [R][n_pad] fp16 scores -> p''; reused for the per-wave partial sums at the end.
 // VHL: hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>: 8 instead of 16 matrix instructions per block)
-constexpr int MF_NSEG = 20;                                        // 512-token segments the rows of a block can hold (9216 / 512 = 18)
 
 __device__ __forceinline__ uint16_t mf_add_mask(uint16_t h, uint16_t m) {      // fp16(x + mask), clamped at the fp16 minimum (:366-372)
     float v = (float)(_Float16)(h2f_bits(h) + h2f_bits(m));
@@ -643,9 +642,9 @@ __device__ __forceinline__ void mf_probs_inplace_row(uint16_t* row, int t0, int 
     *(u32x4*)p = o;
 }
 
-// LSTAT: the statistics of a wave's segments are carried per LANE through the K walk (a running (max, sum exp) of the lane's eight
-// scores per segment and head, rescaled when the maximum moves) and reduced across the wave ONCE at the end of the walk, instead
-// of two wave reductions per segment and head (each a chain of ~10 dependent DPP / readlane operations)
+// In-stream statistics are carried per LANE through the K walk (a running (max, sum exp) of the lane's eight scores per segment and
+// head, rescaled when the maximum moves) and reduced across the wave ONCE at the end of the walk; two wave reductions per segment
+// and head (each a chain of ~10 dependent DPP / readlane operations) measured 1-2 % slower (profiles/r05_row4_flows.log, "2434").
 // R = 1 (nh == nh_kv; OCC = 4: four blocks per CU in <= 128 registers): the same block over mf_k_seq1 / MfVStream<1> -- the sliced form of
 // multi-head rows (mf_row_kernel keeps the unsliced one)
 // PSM ("phase softmax", unsliced rows only): the round-4 flow -- the K walk only writes the scores, every wave then takes whole rows
@@ -653,7 +652,7 @@ __device__ __forceinline__ void mf_probs_inplace_row(uint16_t* row, int t0, int 
 // measures FASTER than the in-stream form for a block that holds a whole row (BASELINE config 4, one box, alternating: 97.8 us
 // against 104.0-104.8: the exponentials cost the same wherever they run, and inside the streams they delay a wave's next request
 // -- profiles/r05_row4_flows.log); the in-stream form is what makes slices possible (their statistics must exist before the exchange).
-template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, bool LSTAT = true, int OCC = 2, bool PSM = false>
+template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, int OCC = 2, bool PSM = false>
 __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
     constexpr int NTH = NW * 64;
     static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
@@ -666,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     extern __shared__ __attribute__((aligned(16))) uint16_t rows[];   // [R][n_pad]
     __shared__ float zl[NW][128];
     __shared__ uint16_t pw[R][MF_PW];
-    __shared__ float st_lds[R][MF_NSEG][2];                        // (max, sum exp) of every 512-token segment of the R rows
+    __shared__ float st_lds[R][NW][2];                             // (max, sum exp) of every wave's segments of the R rows
     __shared__ int sp_lds[R];
     __shared__ int bid_lds;
     __shared__ uint32_t q_lds[R == 1 ? NW : 1][64];                // R = 1: the normalised q operand of mf_k_seq1
@@ -721,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     // ---- packed qK^T: wave w walks super-blocks sb_lo + w, sb_lo + w + NW, ...; the rows hold the SCALED scores
     // fp16(fp16(s) * inv_scale) (:339; = kivi_scaled_score): two at a time -- one packed conversion, two v_fma_mix
     const int hb = (4 * (lane >> 4)) % R;
-    float lm[R], ll[R];                                            // LSTAT: this lane's running (max, sum exp(x - max)) of every head
+    float lm[R], ll[R];                                            // this lane's running (max, sum exp(x - max)) of every head
 #pragma unroll
     for (int rr = 0; rr < R; rr++) { lm[rr] = -__builtin_inff(); ll[rr] = 0.f; }
     {
@@ -772,35 +771,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
                 }
                 if (dump0 && valid) *(u32x4*)(dump0 + (int64_t)rr * ak.out_sh + (int64_t)sb * KIVI_MF_SB_TOKENS + lane * 8) = v;
                 const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
-                if constexpr (LSTAT) {
-                    if (valid) {                                   // (no cross-lane step inside: lanes past the segment's end just skip it)
-                        const float mo = lm[rr];
-                        const float mn_ = __builtin_fmaxf(mo, m);
-                        const float ms = mn_ == -__builtin_inff() ? 0.f : mn_;             // (a lane whose scores are all -inf so far)
-                        fp2 acc = {ll[rr] * kivi_exp(mo - ms), 0.f};
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const uint32_t xw = v[i];
-                            const fp2 d = (fp2){mf_sub_lo(xw, -ms), mf_sub_hi(xw, -ms)} * l2e;   // kivi_exp(x - m)
-                            acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
-                        }
-                        lm[rr] = mn_;
-                        ll[rr] = acc[0] + acc[1];
-                    }
-                } else {
-                    m = wave_max(valid ? m : -__builtin_inff());
-                    fp2 acc = {0.f, 0.f};
+                if (valid) {                                       // (no cross-lane step inside: lanes past the segment's end just skip it)
+                    const float mo = lm[rr];
+                    const float mn_ = __builtin_fmaxf(mo, m);
+                    const float ms = mn_ == -__builtin_inff() ? 0.f : mn_;                 // (a lane whose scores are all -inf so far)
+                    fp2 acc = {ll[rr] * kivi_exp(mo - ms), 0.f};
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t xw = v[i];
-                        const fp2 d = (fp2){mf_sub_lo(xw, -m), mf_sub_hi(xw, -m)} * l2e;   // kivi_exp(x - m)
+                        const fp2 d = (fp2){mf_sub_lo(xw, -ms), mf_sub_hi(xw, -ms)} * l2e;       // kivi_exp(x - m)
                         acc += (fp2){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
                     }
-                    const float l = wave_sum(valid ? acc[0] + acc[1] : 0.f);
-                    if (lane == 0) {
-                        st_lds[rr][seg][0] = m;
-                        st_lds[rr][seg][1] = l;
-                    }
+                    lm[rr] = mn_;
+                    ll[rr] = acc[0] + acc[1];
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -818,7 +801,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
             }, seg_done);
         }
     }
-    if constexpr (LSTAT && !PSM) {                                 // the wave's (max, sum exp) of every head: one entry per wave
+    if constexpr (!PSM) {                                          // the wave's (max, sum exp) of every head: one entry per wave
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
             const float m = wave_max(lm[rr]);
@@ -929,7 +912,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
             if (lane == 0) sp_lds[r] = spr;
         }
     } else {
-        const int nseg_loc = LSTAT ? NW : sb_hi - sb_lo;          // entries of st_lds: one per wave, or one per segment
+        const int nseg_loc = NW;                                   // entries of st_lds: one per wave
         float Ls[R];
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
@@ -1247,18 +1230,17 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad, S);   \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
-        if (R == 1) KIVI_ROW4_LAUNCH(opt1, 2, 3, 4, false, false, 1, 2, true, 4);
-        if (R == 8 && psm) KIVI_ROW4_LAUNCH(opt8p, 4, 2, 4, false, false, 8, 2, true, 2, true);
+        if (R == 1) KIVI_ROW4_LAUNCH(opt1, 2, 3, 4, false, false, 1, 2, 4);
+        if (R == 8 && psm) KIVI_ROW4_LAUNCH(opt8p, 4, 2, 4, false, false, 8, 2, 2, true);
         if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
-        if (bits == 4 && psm) KIVI_ROW4_LAUNCH(opt44p, 4, 3, 4, false, true, 4, 4, true, 2, true);
+        if (bits == 4 && psm) KIVI_ROW4_LAUNCH(opt44p, 4, 3, 4, false, true, 4, 4, 2, true);
         if (bits == 4) KIVI_ROW4_LAUNCH(opt44, 4, 3, 4, false, true, 4, 4);
 #ifdef KIVI_TUNING
         static unsigned long long opt_t[16] = {0};
-        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<K ring><V ring><waves>"; + 1000: chained hi / lo in the sV phase; + 2000: statistics by wave reductions per segment
+        static const char* fr4 = KIVI_TUNE_ENV("KIVI_MF_ROW4");          // "<K ring><V ring><waves>"; + 1000: chained hi / lo in the sV phase
         const int cfg = fr4 ? atoi(fr4) : 434;
-        if (v.dbg && psm) KIVI_ROW4_LAUNCH(opt_t[11], 4, 3, 4, true, true, 4, 2, true, 2, true);
+        if (v.dbg && psm) KIVI_ROW4_LAUNCH(opt_t[11], 4, 3, 4, true, true, 4, 2, 2, true);
         if (v.dbg && cfg == 844) KIVI_ROW4_LAUNCH(opt_t[9], 8, 4, 4, true);
-        if (v.dbg && cfg == 2434) KIVI_ROW4_LAUNCH(opt_t[10], 4, 3, 4, true, true, 4, 2, false);
         if (v.dbg) KIVI_ROW4_LAUNCH(opt_t[0], 4, 3, 4, true);
         if (cfg == 234) KIVI_ROW4_LAUNCH(opt_t[1], 2, 3, 4);
         if (cfg == 834) KIVI_ROW4_LAUNCH(opt_t[2], 8, 3, 4);
@@ -1266,10 +1248,8 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (cfg == 844) KIVI_ROW4_LAUNCH(opt_t[4], 8, 4, 4);
         if (cfg == 424) KIVI_ROW4_LAUNCH(opt_t[5], 4, 2, 4);
         if (cfg == 1434) KIVI_ROW4_LAUNCH(opt_t[6], 4, 3, 4, false, false);
-        if (cfg == 2434) KIVI_ROW4_LAUNCH(opt_t[7], 4, 3, 4, false, true, 4, 2, false);
-        if (cfg == 2844) KIVI_ROW4_LAUNCH(opt_t[8], 8, 4, 4, false, true, 4, 2, false);
 #endif
-        if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, true, 2, true);
+        if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, 2, true);
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH
     }

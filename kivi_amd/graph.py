@@ -9,6 +9,13 @@ Tq / Tv / residual and window lengths from a 32-byte device struct.  All layers 
 serves the model: per step the host uploads six numbers (a one-thread kernel), replays the graph, advances its own copy of the
 lengths (`kivi_mf_step_advance`) and -- every residual_length steps -- launches the K flushes (`kivi_kt_pack`), outside the graph.
 The graph is re-captured when the geometry class changes (every ~512 steps per side) or a cache had to grow.
+
+Replayed and eager steps agree bit for bit whenever they follow the same launch plan (kivi_mf_launch_plan).  The plan of a captured
+step is the plan of its whole geometry class -- sized for the class's longest row, ceil(Tq / 512) * 512 + residual_length keys --
+while an eager step is planned for its own row: in the narrow bands where the class's longest row no longer fits a block but the
+step's own row still does (nh == nh_kv: Tq in (7680, 8192]; nh / nh_kv = 4: Tq in (8704, 9216]) the eager step runs a block per row
+and the replayed one slices the row (nh / nh_kv in {4, 8}) or takes two launches; the outputs then agree within the hook bar (3e-3),
+the cache tuples bit for bit.
 """
 from __future__ import annotations
 

@@ -504,6 +504,41 @@ def test_step_advance_follows_the_reference_cache_policy(lib, T0, R):
     assert lib.kivi_mf_step_key(None, 1, 1, 1, 32, 0) == -1
 
 
+def test_launch_plan_is_a_function_of_the_geometry_class(lib):
+    """kivi_mf_launch_plan (include/kivi_hip.h): 0 = two launches, S >= 1 = one launch with S slices per row.  The plan of a step's
+    whole geometry class (dyn = 1: what a captured graph replays) never changes inside the class, forced forms are honoured when they
+    are valid and refused (0 = two launches) when they are not, slices always fit the LDS, and the shapes the measurements name get
+    the forms DESIGN section 3.6 lists."""
+    from kivi_amd import _lib
+    P = lambda B, nh, nkv, Tq, kres, R, flags=0, bits=2, dyn=0: lib.kivi_mf_launch_plan(B, nh, nkv, Tq, kres, R, flags, bits, dyn)   # noqa: E731
+    assert P(32, 32, 32, 4064, 16, 32) == 1                      # headline: a block per row (mf_row_kernel)
+    assert P(64, 32, 8, 8064, 0, 128) == 1                       # BASELINE config 4: a block per unit
+    assert P(16, 32, 8, 32640, 0, 128) == 4                      # config-5 per-GPU slice: 32k rows do not fit the LDS -> 4 slices of 16 super-blocks
+    assert P(16, 64, 8, 8064, 0, 128) == 4                       # 70B-like slice (nh / nh_kv = 8: 4608 keys per block)
+    assert P(64, 64, 8, 8064, 0, 128) == 2                       # ... at B = 64: the fewest slices that fit (1024 blocks: ticket ids)
+    assert P(4, 32, 8, 8064, 0, 128) == 4 and P(32, 32, 8, 8064, 0, 128) == 1 and P(16, 32, 8, 8064, 0, 128) == 2
+    assert P(8, 32, 8, 2048, 0, 128) == 0                        # few short rows: two launches
+    assert P(1, 32, 32, 32736, 16, 32) == 0 and P(4, 32, 32, 4064, 16, 32) == 1
+    assert P(64, 32, 8, 8064, 0, 128, _lib.GQA_FORCE_SPLIT) == 0 and P(4, 32, 8, 8064, 0, 128, _lib.GQA_FORCE_ROW) == 1
+    assert P(2, 8, 2, 1024, 76, 128, _lib.gqa_slices(2)) == 2 and P(2, 8, 2, 1024, 76, 128, _lib.gqa_slices(3)) == 0   # 2 super-blocks: no 3 slices
+    assert P(2, 4, 4, 1088, 12, 32, _lib.gqa_slices(2)) == 2 and P(2, 4, 4, 1088, 12, 32, _lib.gqa_slices(1)) == 1     # nh == nh_kv through the slice kernel
+    assert P(0, 32, 8, 64, 0, 32) == -1 and P(2, 32, 5, 64, 0, 32) == -1
+    for nh, nkv, cap in ((32, 8, 9216), (64, 8, 4608)):
+        for B in (1, 4, 16, 64):
+            for Tq in range(0, 40000, 1664):
+                for R in (32, 128):
+                    Tq_ = Tq // R * R
+                    nsb = (Tq_ + 511) // 512
+                    cls = P(B, nh, nkv, Tq_, 0, R, 0, 2, 1)
+                    for kres in (0, R // 2, R - 1):              # one class, one plan (device-resident lengths)
+                        assert P(B, nh, nkv, Tq_, kres, R, 0, 2, 1) == cls
+                    S = P(B, nh, nkv, Tq_, R - 1, R)
+                    if S > 1:                                    # the longest row of a block: max(ceil(nsb / S), 2) super-blocks + the residual
+                        assert S <= nsb and max((nsb + S - 1) // S, 2) * 512 + R + 1 <= cap
+                    elif S == 1:
+                        assert Tq_ + R <= cap
+
+
 def test_decode_layer_dyn_refuses_before_launching(lib):
     """kivi_mf_decode_layer_dyn validates the step being captured and the room its geometry class needs (score pitch, capacity)
     without a device."""

@@ -1,8 +1,10 @@
 """GPU: decode steps with DEVICE-RESIDENT lengths (kivi_mf_decode_layer_dyn, include/kivi_hip.h: kivi_mf_step) and their replay
 from a hipGraph (kivi_amd/graph.py) against the eager layer step (kivi_mf_decode_layer): same kernels, same arithmetic -> outputs
 and cache tuples BIT-identical, step after step, through K flushes, V flushes, the window ring wrapping, changes of the geometry
-class (a 512-token boundary of either store) and cache growth.  The eager step itself is pinned against the reference logic in
-tests/test_mfma_gpu.py / tests/test_hook_gpu.py."""
+class (a 512-token boundary of either store) and cache growth -- in every form: two launches, a block per row, rows cut into slices
+(whose geometry the blocks derive from the device-resident lengths).  The eager step itself is pinned against the reference logic in
+tests/test_mfma_gpu.py / tests/test_hook_gpu.py.  (Eager and replayed steps follow the same launch plan in all these cases; the
+narrow bands where they do not are described in kivi_amd/graph.py.)"""
 import pytest
 import torch
 
@@ -22,7 +24,8 @@ def _tuples_equal(a, b):
                                                                 (2, 4, 4, 600, 64, "split", True, 2), (2, 8, 2, 500, 32, "split", False, 2),
                                                                 (1, 16, 2, 480, 32, "split", False, 2), (2, 16, 2, 300, 32, "row", False, 2),
                                                                 (8, 32, 32, 4080, 32, "auto", False, 2),
-                                                                (2, 8, 2, 460, 32, "row", True, 4), (2, 8, 2, 500, 32, "split", False, 4)])
+                                                                (2, 8, 2, 460, 32, "row", True, 4), (2, 8, 2, 500, 32, "split", False, 4),
+                                                                (2, 8, 2, 1100, 128, "slices2", True, 2), (2, 16, 2, 1500, 32, "slices3", False, 2)])
 def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked, bits):
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
@@ -31,7 +34,7 @@ def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked, bit
     cfg = KiviConfig(bits, bits, 32, R)
     k0, v0 = make_kv(1, B, nh_kv, T0, D, "outlier").cuda(), make_kv(2, B, nh_kv, T0, D).cuda()
     a = make_layer_cache(cfg, B, nh_kv, D, T0 + 8, "cuda", num_heads=nh)          # small capacity: both must grow on the way
-    a.flags = {"row": _lib.GQA_FORCE_ROW, "split": _lib.GQA_FORCE_SPLIT, "auto": 0}[form]
+    a.flags = _lib.gqa_slices(int(form[6:])) if form.startswith("slices") else {"row": _lib.GQA_FORCE_ROW, "split": _lib.GQA_FORCE_SPLIT, "auto": 0}[form]
     a.prefill(k0, v0)
     b = a.clone()
     drv = MfStepDriver([b])

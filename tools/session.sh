@@ -15,14 +15,16 @@
 #   ab <lib.so>...   same-box A/B of bench.py (headline + config 4) between the in-tree library and the given builds
 #                    (tools/build_variant.sh; KIVI_TUNING=1 KIVI_HIP_LIB=...)
 #   phases           per-wave phase timeline of mf_row_kernel / mf_row4_kernel (tuning build, tools/mf_row_phases.py)
-#   row4ab           mf_row4_kernel variants at BASELINE config 4 (tuning build: KIVI_MF_ROW4 = <K ring><V ring><waves>
-#                    + 1000 / 2000 for hi / lo rows in the qK^T / sV phase, KIVI_MF_STAG_US): parity of the variants through the
-#                    row-form tests, then same-box bench lines
+#   row4ab           mf_row4_kernel ring variants of the in-stream flow at BASELINE config 4 (tuning build: KIVI_MF_ROW4 = <K ring><V ring><waves>,
+#                    + 1000: chained hi / lo sV; KIVI_MF_ROW4_FLOW=stream): parity of the variants through the row-form tests, then same-box bench lines
 #   xcd              two-launch form with a unit's blocks on one XCD (tuning build, KIVI_MF_XCD) against the plain block order
 #   mf4              4-bit K / V on the matrix pipe: parity tests, then config 4 at --bits 4 against the VALU path
 #   mf4prof          config 4 at --bits 4: kernel trace medians + HBM traffic; the config-5 slice at --bits 4 against the VALU path
 #   forms            round 5: the library's launch plan against forced forms (two launches / a block per row / N slices per row) at BASELINE
 #                    config 4, the config-5 slice, the 70B-like slice, R = 8 at B = 64 and small grouped-query batches (bench.py --form)
+#   flows            round 5: phase-softmax vs in-stream flow of mf_row4_kernel (and the round-4 tree from a worktree _r4/, if present) at BASELINE
+#                    config 4 + headline, phase timelines
+#   packs            kt_pack / vt_pack at 2 and 4 bits on 1 GiB of fp16
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -50,7 +52,7 @@ trace_one() {  # <name> <skip> <bench args...>
     rm -rf $O/trace_$name
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -o b -- $BN "$@" > $O/trace_${name}_bench.json 2> $O/trace_$name.err
     cd $R
-    python tools/trace_median.py $(find $O/trace_$name -name "*kernel_trace.csv" | head -1) --skip $skip --match mf_ decode_row gemv_ kt_pack vt_pack quant_pack \
+    python tools/trace_median.py $(find $O/trace_$name -name "*kernel_trace.csv" | head -1) --skip $skip --skip-for gemv_k_kernel=12 quant_pack=0 --match mf_ decode_row gemv_ kt_pack vt_pack quant_pack \
         --json $O/trace_median_$name.json > $O/trace_median_$name.log 2>&1
     cp $(find $O/trace_$name -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$name.csv 2>/dev/null
     rm -rf $O/trace_$name
@@ -124,18 +126,13 @@ while [ $# -gt 0 ]; do
         KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/row4_phases.log 2>&1; tail -30 $O/row4_phases.log ;;
     row4ab)
         T=$R/kivi_amd/_variants/libkivi_tuning.so
-        for cfg in 1443 2443 3443; do
-            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg timeout 600 python -m pytest tests/test_mfma_gpu.py tests/test_hook_gpu.py -m gpu -x -q \
+        for cfg in 434 444 1434; do
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg KIVI_MF_ROW4_FLOW=stream timeout 600 python -m pytest tests/test_mfma_gpu.py tests/test_hook_gpu.py -m gpu -x -q \
                 -k "(row and fixtures) or matches_two_launch" > $O/row4_parity_$cfg.log 2>&1; echo "parity $cfg rc=$?" | tee -a $O/status.log; tail -3 $O/row4_parity_$cfg.log
         done
         for i in 1 2; do
-            for cfg in 443 1443 2443 3443 3843 3444 3844 3243; do
-                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/c4_${cfg}_$i.json 2>> $O/row4ab.err; line $O/c4_${cfg}_$i.json
-            done
-        done
-        for cfg in 443 3443 3843; do
-            for us in 8 14 20 28; do
-                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg KIVI_MF_STAG_US=$us timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/c4_${cfg}_stag$us.json 2>> $O/row4ab.err; line $O/c4_${cfg}_stag$us.json
+            for cfg in 434 234 834 444 844 424 1434; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg KIVI_MF_ROW4_FLOW=stream timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/c4_${cfg}_$i.json 2>> $O/row4ab.err; line $O/c4_${cfg}_$i.json
             done
         done ;;
     xcd)
@@ -167,141 +164,39 @@ while [ $# -gt 0 ]; do
         pmc_one config4_4bit '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 4, "group": 32, "residual": 128}' $C4 --bits 4
         timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5.json 2>> $O/mf4.err; line $O/mf4_c5.json
         KIVI_TUNING=1 KIVI_NO_MFMA_LAYOUT=1 timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5_valu.json 2>> $O/mf4.err; line $O/mf4_c5_valu.json ;;
-    r5a)
-        # round 5, first look: the restructured mf_row4_kernel (statistics in the K walk, probabilities in the V stream, slices) and the
-        # second range mark through their parity tests, then BASELINE config 4 / config-5 slice / 70B slice, plan vs two launches
-        timeout 1500 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_graph_gpu.py -m gpu -q --tb=short --maxfail=12 \
-            -k "sliced or match_reference_logic or two_launch_form or full_size or dynamic_range or graph or dyn" > $O/r5a_tests.log 2>&1
-        echo "r5a tests rc=$?" | tee -a $O/status.log; tail -40 $O/r5a_tests.log | cut -c1-300
-        for f in auto split; do
-            timeout 300 $BN $C4 --steps 10 --warmup 3 --form $f > $O/r5a_c4_$f.json 2>> $O/r5a.err; line $O/r5a_c4_$f.json
-            timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/r5a_c5_$f.json 2>> $O/r5a.err; line $O/r5a_c5_$f.json
-            timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/r5a_c70_$f.json 2>> $O/r5a.err; line $O/r5a_c70_$f.json
-        done
-        timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/r5a_c4_4bit.json 2>> $O/r5a.err; line $O/r5a_c4_4bit.json
-        tail -5 $O/r5a.err ;;
-    r5b)
-        # round 5, second look: parity of the rewritten residual phase / lane-local statistics / 4-bit packers, then one-box A/B at BASELINE
-        # config 4: the round-4 tree (_r4/, git worktree of 96aba04) against this tree's default and ring / statistics variants (tuning build)
-        T=$R/kivi_amd/_variants/libkivi_tuning.so
-        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=12 \
-            -k "sliced or two_launch_form or kt4_pack or vt4_pack or (mf4_decode_steps_match and row)" > $O/r5b_tests.log 2>&1
-        echo "r5b tests rc=$?" | tee -a $O/status.log; tail -25 $O/r5b_tests.log | cut -c1-200
-        BITS=4 timeout 200 python tools/mf_prefill_time.py > $O/r5b_pack4_time.log 2>&1; tail -6 $O/r5b_pack4_time.log
-        for i in 1 2; do
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5b_c4_r4tree_$i.json 2>> $O/r5b.err ); line $O/r5b_c4_r4tree_$i.json
-            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5b_c4_new_$i.json 2>> $O/r5b.err; line $O/r5b_c4_new_$i.json
-            for cfg in 2434 844 2844 444; do
-                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5b_c4_${cfg}_$i.json 2>> $O/r5b.err; line $O/r5b_c4_${cfg}_$i.json
-            done
-        done
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5b_row4_phases.log 2>&1; tail -24 $O/r5b_row4_phases.log
-        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5b_c5.json 2>> $O/r5b.err; line $O/r5b_c5.json
-        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5b_c70.json 2>> $O/r5b.err; line $O/r5b_c70.json
-        tail -5 $O/r5b.err ;;
-    r5c)
-        # round 5, third look: barriers that keep global loads in flight, the contiguous window walk, read-before-store range marks, the
-        # slice kernel for nh == nh_kv
-        T=$R/kivi_amd/_variants/libkivi_tuning.so
-        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=8 \
-            -k "sliced or two_launch_form or kt4_pack or vt4_pack or kt_pack_equals or vt_pack_equals or (mf4_decode_steps_match and row) or (fixtures and (row or default))" > $O/r5c_tests.log 2>&1
-        echo "r5c tests rc=$?" | tee -a $O/status.log; tail -14 $O/r5c_tests.log | cut -c1-200
-        BITS=4 timeout 200 python tools/mf_prefill_time.py > $O/r5c_pack4_time.log 2>&1; tail -4 $O/r5c_pack4_time.log
-        BITS=2 timeout 200 python tools/mf_prefill_time.py > $O/r5c_pack2_time.log 2>&1; tail -4 $O/r5c_pack2_time.log
-        for i in 1 2; do
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5c_c4_r4tree_$i.json 2>> $O/r5c.err ); line $O/r5c_c4_r4tree_$i.json
-            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5c_c4_new_$i.json 2>> $O/r5c.err; line $O/r5c_c4_new_$i.json
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/r5c_hl_r4tree_$i.json 2>> $O/r5c.err ); line $O/r5c_hl_r4tree_$i.json
-            timeout 300 $BN > $O/r5c_hl_new_$i.json 2>> $O/r5c.err; line $O/r5c_hl_new_$i.json
-            timeout 300 $BN --form slices1 > $O/r5c_hl_slices1_$i.json 2>> $O/r5c.err; line $O/r5c_hl_slices1_$i.json
-            timeout 300 $BN --form slices2 > $O/r5c_hl_slices2_$i.json 2>> $O/r5c.err; line $O/r5c_hl_slices2_$i.json
-        done
-        timeout 300 $BN $C4 --steps 10 --warmup 3 --form slices2 > $O/r5c_c4_slices2.json 2>> $O/r5c.err; line $O/r5c_c4_slices2.json
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5c_row4_phases.log 2>&1; sed -n 2,14p $O/r5c_row4_phases.log
-        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5c_c5.json 2>> $O/r5c.err; line $O/r5c_c5.json
-        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5c_c70.json 2>> $O/r5c.err; line $O/r5c_c70.json
-        timeout 300 $BN --batch 4 --steps 10 --warmup 3 > $O/r5c_b4.json 2>> $O/r5c.err; line $O/r5c_b4.json
-        timeout 300 $BN --batch 4 --steps 10 --warmup 3 --form slices2 > $O/r5c_b4_slices2.json 2>> $O/r5c.err; line $O/r5c_b4_slices2.json
-        tail -5 $O/r5c.err ;;
-    r5d)
-        # round 5, fourth look: the two flows of mf_row4_kernel for unsliced rows (phase softmax = default, in-stream = KIVI_MF_ROW4_FLOW=stream in
-        # the tuning build) against the round-4 tree, one box, alternating; parity of the row forms first
-        T=$R/kivi_amd/_variants/libkivi_tuning.so
-        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=5 \
-            -k "sliced or two_launch_form or (decode_steps_match and row) or (fixtures and row) or (dynamic_range and row and (1e-4 or 30000))" > $O/r5d_tests.log 2>&1
-        echo "r5d tests rc=$?" | tee -a $O/status.log; tail -10 $O/r5d_tests.log | cut -c1-200
-        for i in 1 2 3; do
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5d_c4_r4tree_$i.json 2>> $O/r5d.err ); line $O/r5d_c4_r4tree_$i.json
-            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5d_c4_psm_$i.json 2>> $O/r5d.err; line $O/r5d_c4_psm_$i.json
-            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5d_c4_stream_$i.json 2>> $O/r5d.err; line $O/r5d_c4_stream_$i.json
-        done
-        ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --bits 4 --steps 10 --warmup 3 > $O/r5d_c4b4_r4tree.json 2>> $O/r5d.err ); line $O/r5d_c4b4_r4tree.json
-        timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/r5d_c4b4_psm.json 2>> $O/r5d.err; line $O/r5d_c4b4_psm.json
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/r5d_c4b4_stream.json 2>> $O/r5d.err; line $O/r5d_c4b4_stream.json
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5d_row4_phases_psm.log 2>&1; sed -n 2,14p $O/r5d_row4_phases_psm.log
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5d_row4_phases_stream.log 2>&1; sed -n 2,14p $O/r5d_row4_phases_stream.log
-        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/r5d_c5.json 2>> $O/r5d.err; line $O/r5d_c5.json
-        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/r5d_c70.json 2>> $O/r5d.err; line $O/r5d_c70.json
-        timeout 300 $BN $C70 --steps 10 --warmup 3 --form split > $O/r5d_c70_split.json 2>> $O/r5d.err; line $O/r5d_c70_split.json
-        tail -5 $O/r5d.err ;;
-    r5e)
-        # round 5, fifth look: the window's scalar row loads / tokens-per-wave: headline and config 4 against the round-4 tree, slices against
-        # two launches at the R = 8 and long-row shapes, small grouped-query batches
-        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=5 \
-            -k "sliced or two_launch_form or (fixtures and row) or (mf4_decode_steps_match and row)" > $O/r5e_tests.log 2>&1
-        echo "r5e tests rc=$?" | tee -a $O/status.log; tail -10 $O/r5e_tests.log | cut -c1-200
-        for i in 1 2; do
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/r5e_hl_r4tree_$i.json 2>> $O/r5e.err ); line $O/r5e_hl_r4tree_$i.json
-            timeout 300 $BN > $O/r5e_hl_new_$i.json 2>> $O/r5e.err; line $O/r5e_hl_new_$i.json
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5e_c4_r4tree_$i.json 2>> $O/r5e.err ); line $O/r5e_c4_r4tree_$i.json
-            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5e_c4_new_$i.json 2>> $O/r5e.err; line $O/r5e_c4_new_$i.json
-            for f in auto split; do
-                timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/r5e_c70_${f}_$i.json 2>> $O/r5e.err; line $O/r5e_c70_${f}_$i.json
-                timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/r5e_c5_${f}_$i.json 2>> $O/r5e.err; line $O/r5e_c5_${f}_$i.json
-            done
-        done
-        for f in auto split row; do
-            timeout 300 $BN --batch 4 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/r5e_b4_8k_$f.json 2>> $O/r5e.err; line $O/r5e_b4_8k_$f.json
-            timeout 300 $BN --batch 32 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/r5e_b32_8k_$f.json 2>> $O/r5e.err; line $O/r5e_b32_8k_$f.json
-        done
-        for f in auto split; do
-            timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 --form $f > $O/r5e_r8b64_$f.json 2>> $O/r5e.err; line $O/r5e_r8b64_$f.json
-        done
-        tail -5 $O/r5e.err ;;
-    r5f)
-        # round 5, sixth look: the group-strided window walk: headline against the round-4 tree, config 4, 128-unit rows
-        T=$R/kivi_amd/_variants/libkivi_tuning.so
-        timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_mfma4_gpu.py tests/test_hook_gpu.py -m gpu -q --tb=short --maxfail=8 --durations=5 \
-            -k "sliced or two_launch_form or (fixtures and row) or (match_reference_logic and row and (2-2 or 4-4 or 3-3 or 32-8))" > $O/r5f_tests.log 2>&1
-        echo "r5f tests rc=$?" | tee -a $O/status.log; tail -10 $O/r5f_tests.log | cut -c1-200
-        for i in 1 2 3; do
-            ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/r5f_hl_r4tree_$i.json 2>> $O/r5f.err ); line $O/r5f_hl_r4tree_$i.json
-            timeout 300 $BN > $O/r5f_hl_new_$i.json 2>> $O/r5f.err; line $O/r5f_hl_new_$i.json
-        done
-        ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/r5f_c4_r4tree.json 2>> $O/r5f.err ); line $O/r5f_c4_r4tree.json
-        timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/r5f_c4_new.json 2>> $O/r5f.err; line $O/r5f_c4_new.json
-        for f in auto split row; do
-            timeout 300 $BN --batch 16 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/r5f_b16_8k_$f.json 2>> $O/r5f.err; line $O/r5f_b16_8k_$f.json
-        done
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/r5f_row4_phases_psm.log 2>&1; sed -n 2,14p $O/r5f_row4_phases_psm.log
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T timeout 300 python tools/mf_row_phases.py > $O/r5f_row_phases.log 2>&1; sed -n 2,14p $O/r5f_row_phases.log
-        tail -5 $O/r5f.err ;;
     forms)
-        # round 5: the launch plan (auto) against the forced forms, same box, alternating: BASELINE config 4, the config-5 per-GPU slice,
-        # the 70B-like slice, R = 8 at B = 64, and small grouped-query batches
-        for i in 1 2; do
-            for f in auto split; do
-                timeout 300 $BN $C4 --steps 10 --warmup 3 --form $f > $O/forms_c4_${f}_$i.json 2>> $O/forms.err; line $O/forms_c4_${f}_$i.json
-                timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/forms_c5_${f}_$i.json 2>> $O/forms.err; line $O/forms_c5_${f}_$i.json
-                timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/forms_c70_${f}_$i.json 2>> $O/forms.err; line $O/forms_c70_${f}_$i.json
-                timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 --form $f > $O/forms_r8b64_${f}_$i.json 2>> $O/forms.err; line $O/forms_r8b64_${f}_$i.json
-                timeout 300 $BN --batch 4 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/forms_b4_8k_${f}_$i.json 2>> $O/forms.err; line $O/forms_b4_8k_${f}_$i.json
-                timeout 300 $BN --batch 32 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/forms_b32_8k_${f}_$i.json 2>> $O/forms.err; line $O/forms_b32_8k_${f}_$i.json
-            done
+        # round 5: the library's launch plan (auto) against forced forms on ONE box: BASELINE config 4, the config-5 per-GPU slice, the 70B-like
+        # slice, R = 8 at B = 64 (1024 blocks: ticket ids), grouped-query rows of few units
+        for f in auto split; do
+            timeout 300 $BN $C5 --steps 6 --warmup 2 --form $f > $O/forms_c5_$f.json 2>> $O/forms.err; line $O/forms_c5_$f.json
+            timeout 300 $BN $C70 --steps 10 --warmup 3 --form $f > $O/forms_c70_$f.json 2>> $O/forms.err; line $O/forms_c70_$f.json
+            timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 --form $f > $O/forms_r8b64_$f.json 2>> $O/forms.err; line $O/forms_r8b64_$f.json
         done
-        timeout 300 $BN --batch 32 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form row > $O/forms_b32_8k_row.json 2>> $O/forms.err; line $O/forms_b32_8k_row.json
-        timeout 300 $BN $C4 --steps 10 --warmup 3 --form slices2 > $O/forms_c4_slices2.json 2>> $O/forms.err; line $O/forms_c4_slices2.json
-        timeout 300 $BN $C5 --steps 6 --warmup 2 --form slices8 > $O/forms_c5_slices8.json 2>> $O/forms.err; line $O/forms_c5_slices8.json ;;
+        for f in auto split row; do
+            timeout 300 $BN $C4 --steps 10 --warmup 3 --form $f > $O/forms_c4_$f.json 2>> $O/forms.err; line $O/forms_c4_$f.json
+            for b in 4 16 32; do
+                timeout 300 $BN --batch $b --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3 --form $f > $O/forms_b${b}_8k_$f.json 2>> $O/forms.err; line $O/forms_b${b}_8k_$f.json
+            done
+        done ;;
+    flows)
+        # round 5: the two flows of mf_row4_kernel for unsliced rows at BASELINE config 4 (phase softmax = product, in-stream = KIVI_MF_ROW4_FLOW=stream in
+        # the tuning build) and, when a worktree of the round-4 tree exists (git worktree add _r4 96aba04 && (cd _r4 && python -m kivi_amd.build)), that
+        # tree from its own directory; one box, alternating; then the phase timelines of both flows and of mf_row_kernel
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        for i in 1 2 3; do
+            [ -d $R/_r4 ] && { ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv $C4 --steps 10 --warmup 3 > $O/flows_c4_r4tree_$i.json 2>> $O/flows.err ); line $O/flows_c4_r4tree_$i.json; }
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/flows_c4_psm_$i.json 2>> $O/flows.err; line $O/flows_c4_psm_$i.json
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/flows_c4_stream_$i.json 2>> $O/flows.err; line $O/flows_c4_stream_$i.json
+            [ -d $R/_r4 ] && { ( cd $R/_r4 && timeout 300 python bench.py --no-cpu-baseline --no-hook-kgemv > $O/flows_hl_r4tree_$i.json 2>> $O/flows.err ); line $O/flows_hl_r4tree_$i.json; }
+            timeout 300 $BN > $O/flows_hl_new_$i.json 2>> $O/flows.err; line $O/flows_hl_new_$i.json
+        done
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/row4_phases_psm.log 2>&1; sed -n 2,14p $O/row4_phases_psm.log
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_FLOW=stream B=64 NHKV=8 T0=8064 R=128 LAYERS=6 timeout 300 python tools/mf_row_phases.py > $O/row4_phases_stream.log 2>&1; sed -n 2,14p $O/row4_phases_stream.log
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T timeout 300 python tools/mf_row_phases.py > $O/row_phases.log 2>&1; sed -n 2,14p $O/row_phases.log ;;
+    packs)
+        # prompt-pass packers of the matrix-pipe layout on 1 GiB of fp16 (2- and 4-bit), same box
+        BITS=2 timeout 200 python tools/mf_prefill_time.py > $O/pack2_time.log 2>&1; tail -4 $O/pack2_time.log
+        BITS=4 timeout 200 python tools/mf_prefill_time.py > $O/pack4_time.log 2>&1; tail -4 $O/pack4_time.log ;;
     sq)
         name=$1; shift
         extra=()

@@ -27,6 +27,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--skip", type=int, default=0, help="calls of every matched kernel to drop from the front (warm-up)")
+    ap.add_argument("--skip-for", nargs="*", default=[], metavar="SUBSTR=N",
+                    help="a different warm-up count for kernels whose name contains SUBSTR (e.g. gemv_k_kernel=12: the single-layer K-GEMV loop "
+                         "of bench.py makes one warm-up pass over its 12 caches)")
     ap.add_argument("--match", nargs="*", default=DEFAULT)
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
@@ -40,13 +43,15 @@ def main():
                                       "wg": r["Workgroup_Size_X"]})
         d["us"].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     out = {}
+    skip_for = [(x.split("=")[0], int(x.split("=")[1])) for x in args.skip_for]
     for k, d in per.items():
-        us = [u for _, u in sorted(d["us"])][args.skip:]
+        skip = next((n for sub, n in skip_for if sub in k), args.skip)
+        us = [u for _, u in sorted(d["us"])][skip:]
         if not us:
             continue
         s = sorted(us)
         q = lambda f: round(s[min(len(s) - 1, int(f * len(s)))], 2)   # noqa: E731
-        out[k] = {"calls": len(us), "skipped_warmup_calls": min(args.skip, len(d["us"])), "median_us": q(0.5),
+        out[k] = {"calls": len(us), "skipped_warmup_calls": min(skip, len(d["us"])), "median_us": q(0.5),
                   "mean_us": round(sum(us) / len(us), 2), "min_us": round(s[0], 2), "p10_us": q(0.1), "p90_us": q(0.9),
                   "vgpr": int(d["vgpr"]), "agpr": int(d["agpr"]), "sgpr": int(d["sgpr"]), "lds_bytes": int(d["lds"]),
                   "scratch_bytes": int(d["scratch"]), "grid_threads": int(d["grid"]), "workgroup": int(d["wg"])}
