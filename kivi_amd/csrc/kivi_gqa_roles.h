@@ -333,6 +333,7 @@ struct GqaWindow {
         for (int rr = 0; rr < R; rr++) ow[rr][0] = ow[rr][1] = 0.f;
         // the token slots request() did not prefetch are loaded a group ahead of their use
         constexpr int NG = TW / 8;                                 // groups per wave at most
+        const int gnew = (a.res_len >= w0 && a.res_len < w1) ? ((a.res_len - w0) >> 3) : -1, enew = (a.res_len - w0) & 7;   // group / slot of the new value
         uint32_t nx[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) nx[e] = 0u;
@@ -354,6 +355,12 @@ struct GqaWindow {
 #pragma unroll
                     for (int e = 0; e < 8; e++) nx[e] = tmp[e];
                 }
+            }
+            if (gidx == gnew) {                                    // V append (:377): the new value becomes window row res_len -- from the
+                uint32_t vn_ = cur[0];                             // registers it was loaded into (a fresh load would put a memory round
+#pragma unroll                                                     // trip into the latency-bound middle of the step)
+                for (int e = 1; e < 8; e++) vn_ = (enew == e) ? cur[e] : vn_;
+                *(uint32_t*)(wrow(a, vbuf, a.res_len) + 2 * lane) = vn_;
             }
             constexpr int RH = R > 4 ? 4 : R;                      // heads per pass (R = 8: two passes: 16 instead of 32 registers of probabilities)
 #pragma unroll
@@ -378,9 +385,6 @@ struct GqaWindow {
             // top and the kernel pays for TW more registers)
             if constexpr (NPRE < TW) __builtin_amdgcn_sched_barrier(0);
         }
-        // V append (:377): the new value becomes window row res_len -- by the wave that owns that token
-        if (a.res_len >= w0 && a.res_len < w1 && (((a.res_len - w0) >> 3) % NW) == wave)
-            *(uint32_t*)(wrow(a, vbuf, a.res_len) + 2 * lane) = *(const uint32_t*)(vnew + 2 * lane);
         if (flusher && threadIdx.x < 128) {   // waves 0 and 1 (wave-uniform)
             const int d = threadIdx.x;
             const uint32_t key = h_key(xflush);
