@@ -36,8 +36,11 @@ class LaunchProbe:
         return (self.lib.kivi_last_timed_kernel() or b"").decode()
 
 
+_SPLIT = 1      # _lib.GQA_FORCE_SPLIT
+
+
 def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False, expect_kernel=None, D=128, layout="hook",
-                stage_ab=False, outlier=False):
+                stage_ab=False, outlier=False, extra_flags=0):
     """Full-size decode steps on the GPU; hook_ref on the sampled (b, kv head) slices.  Returns the kernels seen.
     layout "hook": the hook-state layout (KiviLayerCache, VALU kernels); "auto": what make_layer_cache picks for the shape
     (the matrix-pipe layout for g=32 / D=128: 2-bit with nh / nh_kv in {1, 4, 8}, 4-bit with nh / nh_kv = 4).
@@ -68,6 +71,8 @@ def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False
     if stage_ab:
         assert layer.layout == "mfma"
         layer.flags |= _lib.GQA_DUMP_SCORES
+    if extra_flags:
+        layer.flags |= extra_flags
     layer.prefill(k0, v0)
     pasts = {}
     for (b, hk) in samples:
@@ -160,14 +165,18 @@ def test_config4_shape_mf_row4_kernel_stages_on_outlier_keys(oracle):
     print("worst ratio vs the 2e-3 attend bar:", worst)
 
 
-@pytest.mark.parametrize("B,T0,kernel", [(64, 8192 - 4, "mf_row4_kernel"), (2, 32768 + 125, "mf_k_kernel")])
-def test_4bit_gqa_shapes_on_the_matrix_pipe_stages(oracle, B, T0, kernel):
+@pytest.mark.parametrize("B,T0,kernel,split", [(64, 8192 - 4, "mf_row4_kernel", False), (2, 32768 + 125, "mf_row4_kernel", False),
+                                               (2, 32768 + 125, "mf_k_kernel", True)])
+def test_4bit_gqa_shapes_on_the_matrix_pipe_stages(oracle, B, T0, kernel, split):
     """4-bit K / V, 32 / 8 heads (the reference's Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53; round 4): BASELINE config 4's
-    geometry (B = 64, 8k keys, R = 128: one mf_row4_kernel launch per layer, across a K flush at step 4) and the config-5 slice's row
-    length (32k keys: mf_k_kernel + mf_v_kernel), keys with outlier channels, stage by stage (rows the softmax consumed within 1e-3,
-    attend half on those rows within 2e-3), 9-tuples of the sampled units bit-identical to the reference logic's."""
+    geometry (B = 64, 8k keys, R = 128: one mf_row4_kernel launch per layer, a block per unit, across a K flush at step 4) and the
+    config-5 slice's row length (32k keys: since round 5 ONE launch with every row cut into 16 slices -- 16 units x 16 blocks that
+    exchange their softmax statistics inside the launch; and, forced, the two-launch form mf_k_kernel + mf_v_kernel), keys with outlier
+    channels, masks, stage by stage (rows the softmax consumed within 1e-3, attend half on those rows within 2e-3), 9-tuples of the
+    sampled units bit-identical to the reference logic's."""
     seen, worst = run_sampled(B=B, nh=32, nh_kv=8, T0=T0, R=128, bits=4, g=32, steps=8, samples=[(0, 0), (B - 1, 7), (B // 2, 3)],
-                              seed=23, expect_kernel=kernel, layout="auto", stage_ab=True, outlier=True, masked=(B == 2))
+                              seed=23, expect_kernel=kernel, layout="auto", stage_ab=True, outlier=True, masked=(B == 2),
+                              extra_flags=_SPLIT if split else 0)
     print("worst ratio vs the 2e-3 attend bar:", worst)
 
 
