@@ -147,6 +147,14 @@ def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=25.0, threads=None):
     nthr = threads or max(1, min(32, ncpu))
     prev = torch.get_num_threads()
     torch.set_num_threads(nthr)
+    # ... and the process pinned to `nthr` neighbouring CPUs for the duration (one socket / NUMA node on the GPU boxes: unpinned, the
+    # repetitions of the round-5 first run spread from 4 to 100 ms)
+    prev_aff = None
+    try:
+        prev_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(prev_aff)[:nthr]))
+    except (AttributeError, OSError):
+        prev_aff = None
     torch.manual_seed(0)
     k = torch.randn((1, nh, T, D)).half()
     v = torch.randn((1, nh, T, D)).half()
@@ -162,11 +170,17 @@ def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=25.0, threads=None):
         if (len(dec) >= 30 and time.perf_counter() - t_start > budget_s) or len(dec) >= 200 or time.perf_counter() - t_start > 4 * budget_s:
             break
     torch.set_num_threads(prev)
+    if prev_aff is not None:
+        try:
+            os.sched_setaffinity(0, prev_aff)
+        except OSError:
+            pass
     reps = len(dec)
     ds = sorted(dec)
     per_layer_row = ds[reps // 2]                   # median
     return {
         "value": 1.0 / (per_layer_row * layers), "unit": "tokens/s", "cores": nthr, "host_cpus": ncpu, "kind": "port",
+        "pinned_to_cpus": sorted(prev_aff)[:nthr] if prev_aff is not None else None,
         "value_at_min": 1.0 / (ds[0] * layers), "value_at_max": 1.0 / (ds[-1] * layers),
         "ms_per_row_and_layer": {"median": round(per_layer_row * 1e3, 2), "min": round(ds[0] * 1e3, 2), "max": round(ds[-1] * 1e3, 2),
                                  "p10": round(ds[reps // 10] * 1e3, 2), "p90": round(ds[(9 * reps) // 10] * 1e3, 2)},
