@@ -20,6 +20,7 @@
 #   xcd              two-launch form with a unit's blocks on one XCD (tuning build, KIVI_MF_XCD) against the plain block order
 #   mf4              4-bit K / V on the matrix pipe: parity tests, then config 4 at --bits 4 against the VALU path
 #   mf4prof          config 4 at --bits 4: kernel trace medians + HBM traffic; the config-5 slice at --bits 4 against the VALU path
+#   mf4pmc           ... its first half only (trace medians + HBM traffic at config 4, --bits 4)
 #   forms            round 5: the library's launch plan against forced forms (two launches / a block per row / N slices per row) at BASELINE
 #                    config 4, the config-5 slice, the 70B-like slice, R = 8 at B = 64 and small grouped-query batches (bench.py --form)
 #   flows            round 5: phase-softmax vs in-stream flow of mf_row4_kernel (and the round-4 tree from a worktree _r4/, if present) at BASELINE
@@ -164,6 +165,10 @@ while [ $# -gt 0 ]; do
         pmc_one config4_4bit '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 4, "group": 32, "residual": 128}' $C4 --bits 4
         timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5.json 2>> $O/mf4.err; line $O/mf4_c5.json
         KIVI_TUNING=1 KIVI_NO_MFMA_LAYOUT=1 timeout 300 $BN $C5 --bits 4 --steps 6 --warmup 2 > $O/mf4_c5_valu.json 2>> $O/mf4.err; line $O/mf4_c5_valu.json ;;
+    mf4pmc)
+        # the first half of mf4prof only: BASELINE config 4 at --bits 4, kernel trace medians + HBM traffic
+        trace_one config4_4bit 96 $C4 --bits 4 --steps 10 --warmup 3
+        pmc_one config4_4bit '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 4, "group": 32, "residual": 128}' $C4 --bits 4 ;;
     forms)
         # round 5: the library's launch plan (auto) against forced forms on ONE box: BASELINE config 4, the config-5 per-GPU slice, the 70B-like
         # slice, R = 8 at B = 64 (1024 blocks: ticket ids), grouped-query rows of few units
