@@ -41,6 +41,15 @@ __device__ __forceinline__ float dpp_mov_f(float v) {
 // the two B operands (token tile 0 / 1 for K, channel tile 0 / 1 for V) of one code word: 3 views + 8 masks
 struct MfB { h8 b0, b1; };
 __device__ __forceinline__ MfB mf_views(uint32_t w) {
+#if defined(KIVI_TUNING) && defined(KIVI_PROBE_NO_UNPACK)
+    // bound probe (tools/build_variant.sh nounpack -DKIVI_TUNING -DKIVI_PROBE_NO_UNPACK; WRONG results): ONE instruction per code word
+    // instead of 11 -- what a launch would cost if the unpack were free (profiles/r05_unpack_bound.log)
+    const uint32_t y = w & 0x03FF03FFu;
+    MfB p;
+    p.b0 = as_h8(y, y, y, y);
+    p.b1 = as_h8(y, y, y, y);
+    return p;
+#endif
     const uint32_t x1 = w << 4, x2 = w >> 4, x3 = __builtin_amdgcn_perm(w, w, 0x02030001u);
     MfB r;
     r.b0 = as_h8(w & MF_M1, x1 & MF_M1, w & MF_M2, x1 & MF_M2);
