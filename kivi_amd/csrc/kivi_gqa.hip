@@ -280,6 +280,30 @@ __device__ __forceinline__ Mf4Word mf4_word_of(int wi) {
     return {wi >> 8, l & 15, l >> 4, wi & 3};
 }
 
+// OR across the four lanes of a quad as a reduce-scatter: v[j] (32 per lane, already shifted to the lane's bit positions) -> out[jj] =
+// OR over the quad of v[8 (lane & 3) + jj].  Two exchange steps (xor 1 on bit 3 of j, xor 2 on bit 4), each lane keeping the half it
+// will own and handing the other half to its partner: 72 instructions for the 32 words of a quad, every lane ending with the 8 words it
+// stores -- the all-lanes form (two full ORs per word + a store predicated on the owner) was 128 + 32 exec-mask regions.
+__device__ __forceinline__ void quad_or_scatter32(const uint32_t (&v)[32], uint32_t (&out)[8]) {
+    const bool b0 = threadIdx.x & 1, b1 = threadIdx.x & 2;
+    uint32_t a[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int jlo = (q & 7) | ((q >> 3) << 4), jhi = jlo | 8;
+        uint32_t lo = v[jlo], hi = v[jhi];
+        asm("" : "+v"(lo), "+v"(hi));                      // (values, not addresses: hipcc otherwise selects the INDEX and walks a 32-way chain)
+        const uint32_t keep = b0 ? hi : lo, send = b0 ? lo : hi;
+        a[q] = keep | dpp_or<0xB1>(send);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        uint32_t lo = a[jj], hi = a[jj + 8];
+        asm("" : "+v"(lo), "+v"(hi));
+        const uint32_t keep = b1 ? hi : lo, send = b1 ? lo : hi;
+        out[jj] = keep | dpp_or<0x4E>(send);
+    }
+}
+
 // Round 5: the structure of the 2-bit packers (four waves per workgroup, one 32-token block each; the 32 x 128 tile comes in through
 // LDS with 16-byte loads, packed 16-bit statistics and quantiser on the lane's two channels / tokens at once, the block's 512 code
 // words meet in LDS and leave as two 1 KiB stores) -- the round-4 kernels (one 128-thread block per 32 tokens, scalar keys, codes
@@ -316,11 +340,13 @@ __global__ __launch_bounds__(256) void kt_pack4_kernel(const uint16_t* k, int64_
     const int i = lane & 3;
     const int c = lane >> 4, kb = (lane >> 2) & 3;
 #pragma unroll
-    for (int t = 0; t < 32; t++) {
-        uint32_t w = cq[t] << (4 * i);
-        w |= dpp_or<0xB1>(w);
-        w |= dpp_or<0x4E>(w);
-        if ((t >> 3) == i) stw[(t >> 4) * 256 + ((t & 15) + 16 * kb) * 4 + c] = w;
+    for (int t = 0; t < 32; t++) cq[t] <<= 4 * i;
+    uint32_t own[8];                                       // the words of tokens t = 8 i + jj
+    quad_or_scatter32(cq, own);
+    {
+        uint32_t* dst = stw + (i >> 1) * 256 + (8 * (i & 1) + 16 * kb) * 4 + c;      // (t >> 4) * 256 + ((t & 15) + 16 kb) * 4 + c
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) dst[4 * jj] = own[jj];
     }
     __builtin_amdgcn_wave_barrier();
     if (!live_tile) return;
@@ -386,11 +412,13 @@ __global__ __launch_bounds__(256) void vt_pack4_kernel(const uint16_t* v, int64_
     // word (tile, n, kb, c) = the 8 tokens 8 kb + e of channel 32 c + 16 tile + n, element e at bits 4 (e >> 1) + 16 (e & 1): this lane
     // holds e = 2 ee, 2 ee + 1 in the halves of cq[j], j = 16 tile + n; the four lanes of a quad (ee) complete a word
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        uint32_t w = cq[j] << (4 * ee);
-        w |= dpp_or<0xB1>(w);
-        w |= dpp_or<0x4E>(w);
-        if ((j >> 3) == ee) stw[(j >> 4) * 256 + ((j & 15) + 16 * kb) * 4 + c] = w;
+    for (int j = 0; j < 32; j++) cq[j] <<= 4 * ee;
+    uint32_t own[8];                                       // the words j = 8 ee + jj
+    quad_or_scatter32(cq, own);
+    {
+        uint32_t* dst = stw + (ee >> 1) * 256 + (8 * (ee & 1) + 16 * kb) * 4 + c;    // (j >> 4) * 256 + ((j & 15) + 16 kb) * 4 + c
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) dst[4 * jj] = own[jj];
     }
     __builtin_amdgcn_wave_barrier();
     if (!live_tile) return;
