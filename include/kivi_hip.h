@@ -45,16 +45,28 @@
 extern "C" {
 #endif
 
-#define KIVI_ABI_VERSION 2
+#define KIVI_ABI_VERSION 3   /* 3: range words carry an explicit byte 2 (a zero word = default placement); sliced launches always take
+                                  ticket ids, the workspace's counter area holds a device error word; KIVI_ETIMEOUT, kivi_device_error */
 
 #define KIVI_EINVAL (-1)       /* unsupported bits / group size / shape */
 #define KIVI_EALIGN (-2)       /* pointer or stride alignment the kernels rely on is violated */
 #define KIVI_EUNSUPPORTED (-3) /* valid in the reference, not implemented here */
+#define KIVI_ETIMEOUT (-4)     /* a block of an EARLIER sliced launch gave up waiting for a partner block (see kivi_device_error) */
 
 typedef void* kivi_stream_t; /* hipStream_t */
 
 int kivi_abi_version(void);
 const char* kivi_last_error(void);
+/* Sticky, asynchronous device-side error of this process (like a stream error of the runtime): 0, or KIVI_ETIMEOUT when a block of
+ * a sliced one-launch decode step (kivi_gqa_decode / kivi_mf_decode_layer*, rows cut into S > 1 slices) gave up after ~1 s of
+ * waiting for a partner block of its unit -- that unit's output of that step is NaN.  The blocks report through one word of
+ * host-visible memory the library owns (the only allocation it ever makes: 64 bytes of pinned host memory, on first use), so the
+ * host can look without synchronising: the NEXT kivi_gqa_decode / kivi_mf_decode_layer* call returns KIVI_ETIMEOUT once (with a
+ * message naming the unit) and clears the error -- the arrival counters of the timed-out launch have been put back to zero by its
+ * last block, the call after that runs normally.  kivi_device_error() returns and clears the same state explicitly (after a
+ * stream synchronisation it is exact).  The same code is also left in the device error word of the launch's workspace (word
+ * 16382 of the counter area) for callers that keep everything on the device. */
+int kivi_device_error(void);
 
 /* ---------------------------------------------------------------- pack --- */
 
@@ -266,10 +278,13 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  *   placement of q and p a group scale >= 512 would overflow them where the reference's fp32 `scale * code + zero`
  *   (quant/csrc/gemv_cuda.cu:407-413) stays finite, and group scales in the fp16 subnormals would leave the hi part without its
  *   low bits.  So every entry point that WRITES scales (kivi_kt_pack, kivi_vt_pack, the relayouts towards the layout, the V flush
- *   inside kivi_gqa_decode) marks BYTE 0 of the unit's word when it writes a scale >= 256 (inf / NaN included) and BYTE 1 when it
- *   writes a scale >= 2^-8 (byte stores: concurrent writers never lose a mark), and the consumers place q / p 2^10 lower for a unit
- *   with byte 0 set (finite for every finite fp16 scale), 2^8 higher for a unit with neither byte set (all its scales < 2^-8),
- *   unchanged otherwise.  Sticky (never cleared by the library); a caller that copies a store copies its words.
+ *   inside kivi_gqa_decode) marks BYTE 0 of the unit's word when it writes a scale >= 256 (inf / NaN included), BYTE 1 when it
+ *   writes a scale >= 2^-8 and BYTE 2 with every scale it writes ("the writers of this unit keep byte 1"; byte stores of the value
+ *   1: concurrent writers never lose a mark), and the consumers place q / p 2^10 lower for a unit with byte 0 set (finite for
+ *   every finite fp16 scale), 2^8 higher for a unit with byte 2 set and bytes 0, 1 clear (all its scales are KNOWN to be < 2^-8),
+ *   unchanged otherwise -- in particular for a ZERO word: a store filled by a caller's own packer, or copied without its words, gets
+ *   the default placement (ABI version 2 placed it higher and overflowed on ordinary data).  Sticky (never cleared by the
+ *   library); a caller that copies a store copies its words; a caller that writes scales itself marks the bytes the same way.
  * The reference has no counterpart: it expands codes / scale / mn nh / nh_kv times (models/mistral_kivi.py:58-67,
  * :381-385, :441-445) or lets the CUDA kernel map heads (quant/csrc/gemv_cuda.cu:361-365).
  *
@@ -319,8 +334,12 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * For nh / nh_kv in {4, 8} LONGER rows (and rows of few units, to fill the chip) are cut into S slices of whole super-blocks, one
  * block per slice, still in ONE launch: the slices of a unit exchange their (max, sum exp) through `stats` (arrival counters in the
  * second half of the workspace's counter area), form the same probabilities a single block would, and their partial outputs meet
- * in `workspace` (S slots per unit).  Blocks of such a launch wait for each other: every block is resident at once (<= 512), or
- * block ids are handed out in start order by a ticket counter (the last word of the counter area).
+ * in `workspace` (S slots per unit).  Blocks of such a launch wait for each other, so their ids are ALWAYS handed out in start
+ * order by a ticket counter (the last word of the counter area; ABI version 2 skipped it when the grid fitted the chip, which an
+ * ordinary launch cannot guarantee: other streams, a CU mask): a waiting block's partners have started, or belong to the unit at
+ * the dispatch front and start as soon as any older block finishes.  The wait is bounded (~1 s); a block that gives up poisons its
+ * unit's output with NaN, records KIVI_ETIMEOUT (kivi_device_error; word 16382 of the counter area) and the launch's last blocks
+ * still put every counter back to zero.  At most 8190 units take a sliced form.
  * Otherwise two launches:
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies
  *      1/sqrt(D) and the mask (:339, :364-372), writes the scaled scores to `scores` and (max, sum exp) of every

@@ -123,6 +123,7 @@ class MfLayerDesc(ctypes.Structure):
 SIGNATURES = {
     "kivi_abi_version": (_i32, []),
     "kivi_last_error": (ctypes.c_char_p, []),
+    "kivi_device_error": (_i32, []),
     "kivi_quant_pack_lastdim": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "kivi_quant_pack_k_tmajor": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
                                         _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
@@ -188,6 +189,14 @@ class KiviHipError(RuntimeError):
     rc = None
 
 
+ABI_VERSION = 3      # include/kivi_hip.h: KIVI_ABI_VERSION (3: range words with an explicit byte 2, ticket ids always, device error word)
+
+
+class KiviTimeout(KiviHipError):
+    """KIVI_ETIMEOUT: a block of an EARLIER sliced launch gave up waiting for a partner (that step's output holds NaN for the unit);
+    the error is cleared by being reported, the next call runs normally."""
+
+
 class KiviUnsupported(KiviHipError):
     """KIVI_EUNSUPPORTED: valid request, no tuned kernel for this shape (callers may compose the unfused ops)."""
 
@@ -206,8 +215,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.kivi_abi_version() != 2:
-        raise KiviHipError(f"ABI version mismatch: library reports {lib.kivi_abi_version()}, binding expects 2")
+    if lib.kivi_abi_version() != ABI_VERSION:
+        raise KiviHipError(f"ABI version mismatch: library reports {lib.kivi_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 
@@ -215,7 +224,7 @@ def load() -> ctypes.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().kivi_last_error().decode(errors="replace")
-        err = (KiviUnsupported if rc == -3 else KiviHipError)(f"{what} failed (rc={rc}): {msg}")
+        err = {-3: KiviUnsupported, -4: KiviTimeout}.get(rc, KiviHipError)(f"{what} failed (rc={rc}): {msg}")
         err.rc = rc
         raise err
 

@@ -37,26 +37,37 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+TUNING_LIB = os.path.join(HERE, "_variants", "libkivi_tuning.so")
+
+
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
+def build_tuning(force: bool = False, verbose: bool = False) -> str:
+    """The -DKIVI_TUNING build (environment knobs, losing / diagnostic instantiations, fault injection): never loaded by the product
+    path -- tools/ and tests/test_timeout_gpu.py select it with KIVI_TUNING=1 KIVI_HIP_LIB=<this file>."""
+    return build(force, verbose, lib=TUNING_LIB, extra=["-DKIVI_TUNING", "-Wno-unused-value"], objname="_build_tuning")
+
+
+def build(force: bool = False, verbose: bool = False, lib: str = LIB, extra=(), objname: str = "_build") -> str:
+    if not force and not needs_build(lib):
+        return lib
+    LIB = lib                                          # noqa: N806 (the rest of the function writes `LIB`)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "_build")
+    objdir = os.path.join(HERE, objname)
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -79,3 +90,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose=True)
     print("built", path)
+    if "--tuning" in sys.argv:
+        print("built", build_tuning(force="--force" in sys.argv, verbose=True))

@@ -1,6 +1,7 @@
 // Error plumbing and version of the C ABI (include/kivi_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "kivi_common.h"
 
@@ -15,6 +16,41 @@ void kivi_set_error(const char* fmt, ...) {
 
 extern "C" int kivi_abi_version(void) { return KIVI_ABI_VERSION; }
 extern "C" const char* kivi_last_error(void) { return g_err; }
+
+// ---- sticky device-side error (include/kivi_hip.h, kivi_device_error): two ints of pinned, host-coherent memory -- [0] the error
+// code a kernel left (0 = none), [1] the unit it was for -- that the kernels of a sliced launch get a device pointer to.  The only
+// allocation the library makes; if it fails the pointer stays null and a timeout is visible as NaN (and in the workspace's error
+// word) only.
+#include <mutex>
+static int* g_dev_err_host = nullptr;
+static int* g_dev_err_dev = nullptr;
+int* kivi_device_error_word() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !h) { (void)hipGetLastError(); return; }
+        memset(h, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_dev_err_host = (int*)h;
+        g_dev_err_dev = (int*)d;
+    });
+    return g_dev_err_dev;
+}
+// returns and clears the error; `unit` (or null) receives the unit it was recorded for
+int kivi_take_device_error(int* unit) {
+    if (!g_dev_err_host) return 0;
+    const int e = __atomic_exchange_n(g_dev_err_host, 0, __ATOMIC_ACQ_REL);
+    if (e && unit) *unit = __atomic_load_n(g_dev_err_host + 1, __ATOMIC_ACQUIRE);
+    return e;
+}
+extern "C" int kivi_device_error(void) {
+    int unit = -1;
+    const int e = kivi_take_device_error(&unit);
+    if (e) kivi_set_error("a block of an earlier sliced decode launch gave up waiting for a partner block of (batch row, kv head) unit %d: "
+                          "that step's output holds NaN for the unit", unit);
+    return e ? KIVI_ETIMEOUT : 0;
+}
 
 // ---- per-dispatch timing events (instrumentation for bench.py / tools; not on the drop-in surface)
 static thread_local KiviLaunchEvents g_events = {nullptr, nullptr};

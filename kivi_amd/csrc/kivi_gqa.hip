@@ -694,35 +694,57 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
 //          when there are few units; the slices exchange their softmax statistics inside the launch)
 // A pure function of the step's geometry class (kivi_mf_step_key) and the call's constants, so eager and replayed steps agree.
 // KIVI_GQA_SLICES(n) in the flags forces n slices (tests, tuning).
+// Longest row a block can hold.  The plan is made for the longest row of a geometry class, nsbk * 512 packed keys + residual_length
+// (<= 128) fp16 ones, so the caps are "whole super-blocks + a full residual": 16 super-blocks for a multi-head row (one fp16 row of
+// 8320 scores: 16.3 KiB, four blocks per CU), 18 for nh / nh_kv = 4 (four rows: 73 KiB, two blocks per CU in 160 KiB with ~4 KiB of
+// static LDS each), 9 super-blocks less the residual for nh / nh_kv = 8 (eight rows + ~6 KiB static: 4608 keys is what two blocks fit).
+constexpr int64_t MF_ROW1_CAP = 8192 + 128, MF_ROW4_CAP = 9216 + 128, MF_ROW8_CAP = 4608;
 static int mf_plan(int R, int units, int64_t n_rows, int nsbk, int res_cap, int flags, int bits = 2) {
     static const char* norow = KIVI_TUNE_ENV("KIVI_MF_NO_ROW");     // tuning aid: keep the two-launch form
     if ((flags & KIVI_GQA_FORCE_SPLIT) || (norow && atoi(norow))) return 0;
     if (R == 1) {
         const int f1 = (flags >> 8) & 0xFF;                         // KIVI_GQA_SLICES(n): the sliced form of multi-head rows (tests, tuning)
-        if (f1 == 1 && !(flags & KIVI_GQA_FORCE_ROW)) return n_rows <= 8192 ? 1 : 0;
+        if (f1 == 1 && !(flags & KIVI_GQA_FORCE_ROW)) return n_rows <= MF_ROW1_CAP ? 1 : 0;
         if (f1 > 1 && !(flags & KIVI_GQA_FORCE_ROW)) {
             const int spb = (nsbk + f1 - 1) / f1;
-            const bool ok = f1 <= nsbk && f1 <= 64 && (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1 <= 8192 && units <= KIVI_GQA_WS_COUNTERS / 2 - 1;
+            const bool ok = f1 <= nsbk && f1 <= 64 && (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1 <= 8192 && units <= KIVI_GQA_MAX_SLICED_UNITS;
             return ok ? f1 : 0;
         }
-        if (n_rows > 8192) return 0;
+        if (n_rows > MF_ROW1_CAP) {
+            // multi-head rows beyond 16 super-blocks (round 6; the reference's LongChat-7B-32K runs, docs/long_bench.md:5-26): ONE launch,
+            // every row cut into S slices of whole super-blocks, a block of mf_row4_kernel<R = 1> each (four blocks per CU) -- the
+            // fewest slices whose score row fits the block's 8192-key row, then doubled while the grid stays within the 4 blocks per
+            // CU that are resident at once and a slice keeps >= 4 super-blocks (one per wave of its block in the K walk).  Rounds 3-5
+            // ran these rows in two launches (scores + statistics through memory).
+            if (flags & KIVI_GQA_FORCE_ROW) return 0;
+            auto blk1 = [&](int S_) -> int64_t {
+                const int spb = (nsbk + S_ - 1) / S_;
+                return (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1;
+            };
+            int S = 2;
+            while (S <= nsbk && S <= 64 && blk1(S) > 8192) S++;
+            if (S > nsbk || S > 64 || units > KIVI_GQA_MAX_SLICED_UNITS) return 0;
+            while ((int64_t)units * S * 2 <= 1024 && 2 * S <= 64 && (nsbk + 2 * S - 1) / (2 * S) >= 4) S *= 2;
+            return S;
+        }
         // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
         // of a row block to take one super-block each (<= 4096 packed keys): then one launch beats two whatever the batch
         // (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79, profiles/r03_other_shapes.log)
         return (units >= 192 || nsbk <= 8 || (flags & KIVI_GQA_FORCE_ROW)) ? 1 : 0;
     }
     if (R != 4 && R != 8) return 0;
-    const int64_t cap = R == 4 ? 9216 : 4608;                       // keys whose R score rows fit the LDS of a block (mf_row4_kernel)
+    const int64_t cap = R == 4 ? MF_ROW4_CAP : MF_ROW8_CAP;         // keys whose R score rows fit the LDS of a block (mf_row4_kernel)
     auto blk_rows = [&](int S) -> int64_t {                         // the longest row of a block when a row is cut into S slices
         if (S <= 1) return n_rows;
         const int spb = (nsbk + S - 1) / S;
         return (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1;
     };
     const int forced = (flags & KIVI_GQA_FORCE_ROW) ? 1 : ((flags >> 8) & 0xFF);          // FORCE_ROW: a block per row
-    if (forced) return (forced <= (nsbk > 1 ? nsbk : 1) && forced <= 64 && blk_rows(forced) <= cap && (forced == 1 || units <= KIVI_GQA_WS_COUNTERS / 2 - 1)) ? forced : 0;
+    if (forced) return (forced <= (nsbk > 1 ? nsbk : 1) && forced <= 64 && blk_rows(forced) <= cap && (forced == 1 || units <= KIVI_GQA_MAX_SLICED_UNITS)) ? forced : 0;
+    const int nsb1 = nsbk > 1 ? nsbk : 1;                          // (Tq = 0 before the first K flush: one, empty, slice)
     int S = 1;
-    while (S <= nsbk && S <= 64 && blk_rows(S) > cap) S++;
-    if (S > nsbk || S > 64) return 0;
+    while (S <= nsb1 && S <= 64 && blk_rows(S) > cap) S++;
+    if (S > nsb1 || S > 64) return 0;
     // more, shorter slices while a slice keeps >= 4 super-blocks (one per wave of its block in the K walk): rows that must be cut
     // anyway until the grid fills the 2 blocks per CU that are resident at once; rows that fit only while there are fewer blocks than
     // CUs -- a block that holds a whole row runs the faster phase-softmax flow and pays no exchange (32 / 8 heads, 8k keys, ms per
@@ -731,7 +753,7 @@ static int mf_plan(int R, int units, int64_t n_rows, int nsbk, int res_cap, int 
     auto can_double = [&](int S_) { return (nsbk + 2 * S_ - 1) / (2 * S_) >= 4 && 2 * S_ <= 64 && blk_rows(2 * S_) <= cap; };
     if (S == 1) { while ((int64_t)units * S < 256 && can_double(S)) S *= 2; }
     else { while ((int64_t)units * S * 2 <= 512 && can_double(S)) S *= 2; }
-    if (S > 1 && units > KIVI_GQA_WS_COUNTERS / 2 - 1) S = blk_rows(1) <= cap ? 1 : 0;
+    if (S > 1 && units > KIVI_GQA_MAX_SLICED_UNITS) S = blk_rows(1) <= cap ? 1 : 0;
     if (S == 1) {
         // (R = 8, 4000 keys: 128 units 1.65 ms per 32-layer step in one launch against 1.39 in two, 512 units 2.42 against 3.65;
         // R = 4 at 4 bits, one launch vs two: 128 units x 8k keys 1.97 vs 1.73, 256 units x 2k 1.02 vs 1.17, 512 units x 2k 1.51 vs 2.05;
@@ -757,11 +779,13 @@ extern "C" int64_t kivi_mf_step_key(const kivi_mf_step* st, int B, int nh, int n
 }
 
 // The plan kivi_gqa_decode follows for a step (include/kivi_hip.h): 0 = two launches, S >= 1 = one launch with S slices per row
+// (ABI version 3: eager steps are planned for the longest row of their geometry class too -- `dyn` and `k_res_len` no longer enter --, so
+// an eager and a replayed step of the same position always take the same form and agree bit for bit)
 extern "C" int kivi_mf_launch_plan(int B, int nh, int nh_kv, int64_t Tq, int k_res_len, int residual_length, int flags, int bits, int dyn) {
     if (B <= 0 || nh_kv <= 0 || nh <= 0 || nh % nh_kv || Tq < 0 || k_res_len < 0 || residual_length <= 0) return -1;
+    (void)dyn;
     const int nsbk = (int)((Tq + KIVI_MF_SB_TOKENS - 1) / KIVI_MF_SB_TOKENS);
-    const int64_t n_rows = dyn ? (int64_t)nsbk * KIVI_MF_SB_TOKENS + residual_length : Tq + k_res_len + 1;
-    return mf_plan(nh / nh_kv, B * nh_kv, n_rows, nsbk, residual_length, flags, bits);
+    return mf_plan(nh / nh_kv, B * nh_kv, (int64_t)nsbk * KIVI_MF_SB_TOKENS + residual_length, nsbk, residual_length, flags, bits);
 }
 
 extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const void* kt, int64_t kt_sb, int64_t kt_sh,
@@ -792,7 +816,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     a.kres_sb = a.kres_sh = a.kres_st = a.knew_sb = a.knew_sh = 0;
     a.range = (const int*)kt_range;
     a.dyn = nullptr;
-    a.dump = 0; a.xcount = nullptr; a.ticket = nullptr;
+    a.dump = 0; a.xcount = nullptr; a.ticket = nullptr; a.err_ws = nullptr; a.err_host = nullptr;
     return kivi_mf_run_k(&a, B * nh_kv, bits, (hipStream_t)stream);
 }
 
@@ -856,6 +880,15 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
 
 extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stream) {
     KIVI_REQUIRE(p != nullptr, KIVI_EINVAL, "kivi_gqa_decode: null arguments");
+    {   // the sticky device-side error of an EARLIER sliced launch (include/kivi_hip.h, kivi_device_error): reported once, here, before
+        // anything of this step is enqueued; the counters of that launch are back at zero, so the caller may simply call again
+        int eu = -1;
+        if (kivi_take_device_error(&eu)) {
+            kivi_set_error("kivi_gqa_decode: a block of an earlier sliced decode launch gave up waiting for a partner block of (batch row, kv head) "
+                           "unit %d: that step's output holds NaN for the unit; nothing was enqueued for this call", eu);
+            return KIVI_ETIMEOUT;
+        }
+    }
     const int B = p->B, nh = p->nh, nh_kv = p->nh_kv, D = p->D, group_size = p->group_size, bits = p->bits;
     const int64_t T = p->Tq > p->Tv ? p->Tq : p->Tv;
     KIVI_MF_SHAPE_CHECK("kivi_gqa_decode");
@@ -919,8 +952,13 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_REQUIRE(units <= KIVI_GQA_WS_COUNTERS, KIVI_EUNSUPPORTED, "kivi_gqa_decode: more than %d (batch row, kv head) units", KIVI_GQA_WS_COUNTERS);
     static const char* wt = KIVI_TUNE_ENV("KIVI_GQA_WIN_TAIL");         // tuning aid: 0 = window shares inside the stream blocks
     const int win_blocks = (nsbv > 0 && !(wt && atoi(wt) == 0)) ? units : 0;
-    // launch plan: one launch (rows, or slices of rows, in the LDS) or two
-    const int plan = mf_plan(R, units, n_rows, nsbk, p->residual_length, p->flags, bits);
+    // launch plan: one launch (rows, or slices of rows, in the LDS) or two -- decided for the longest row of the step's geometry class
+    // (ceil(Tq / 512) * 512 + residual_length keys) whether or not the lengths are device-resident, so that an eager step and a
+    // replayed one of the same position take the same form (round 5 planned eager steps for their own row: in the bands where only
+    // the class bound exceeds a block -- nh == nh_kv: Tq in (7680, 8192], nh / nh_kv = 4: (8704, 9216] -- the two then differed in
+    // rounding).  The LDS of an eager launch is still sized for the step's own row (n_rows).
+    const int64_t n_class = (int64_t)nsbk * KIVI_MF_SB_TOKENS + p->residual_length;
+    const int plan = mf_plan(R, units, n_class, nsbk, p->residual_length, p->flags, bits);
     const int nslot = plan > 1 ? plan : (S + (win_blocks ? 1 : 0));
     const int64_t need = (int64_t)KIVI_GQA_WS_COUNTERS * 4 + (plan == 1 ? 0 : (int64_t)units * nslot * 2 * R * 128 * 4);
     KIVI_REQUIRE(p->workspace && (uintptr_t)p->workspace % 16 == 0 && p->workspace_bytes >= need, KIVI_EINVAL,
@@ -943,6 +981,8 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.dump = (p->flags & KIVI_GQA_DUMP_SCORES) != 0;
     k.xcount = (int*)p->workspace + KIVI_GQA_WS_COUNTERS / 2;
     k.ticket = (int*)p->workspace + KIVI_GQA_WS_COUNTERS - 1;
+    k.err_ws = (int*)p->workspace + KIVI_GQA_WS_COUNTERS - 2;
+    k.err_host = plan > 1 ? kivi_device_error_word() : nullptr;
     static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
     static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead
     KiviLaunchEvents held = {nullptr, nullptr};

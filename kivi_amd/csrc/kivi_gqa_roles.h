@@ -7,7 +7,9 @@
 
 namespace {
 
-constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace (one per unit)
+constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace: [0, 8192) one per unit (partial sums),
+                                              // [8192, 16382) one per unit (statistics exchange of sliced launches), 16382 the device error word, 16383 the ticket
+constexpr int KIVI_GQA_MAX_SLICED_UNITS = KIVI_GQA_WS_COUNTERS / 2 - 2;
 
 // The six lengths of a decode step in DEVICE memory (= kivi_mf_step of include/kivi_hip.h): when an argument block carries a
 // pointer to one, the kernels take the lengths from it instead of from their by-value arguments, so that a captured launch
@@ -44,11 +46,16 @@ struct GqaKArgs {
     const MfStep* dyn;          // device-resident lengths (or null): Tq, res_len are read from it
     // one-launch form (mf_row4_kernel): dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the fp16 rows the softmax statistics are taken
     // from (scaled, mask added) also go to `out`; rows cut into S > 1 slices: `stats` is the exchange buffer [unit][slice][R][2]
-    // of the slices' (max, sum exp), `xcount` [units] their arrival counters (zero between launches), `ticket` (or null: every
-    // block of the grid is resident at once) one counter that hands out the block ids in the order the blocks START
-    int dump;
+    // of the slices' (max, sum exp), `xcount` [units] their arrival counters (zero between launches), `ticket` (null for S = 1) one
+    // counter that hands out the block ids in the order the blocks START (always, for S > 1: blocks that wait for each other must
+    // not depend on the whole grid being resident at once -- other streams, a CU mask, a second sliced launch), `err_ws` the device
+    // error word of the workspace and `err_host` (or null) the process's host-visible one: a block that gives up waiting records
+    // KIVI_ETIMEOUT in both (kivi_device_error)
+    int dump;                   // bit 0: dump; bit 1 (-DKIVI_TUNING builds only): fault injection, slice 0 of unit 0 never arrives
     int* xcount;
     int* ticket;
+    int* err_ws;
+    int* err_host;
     __device__ __forceinline__ void take_dyn() {
         if (dyn) { Tq = dyn->Tq; res_len = dyn->k_res_len; }
     }

@@ -541,8 +541,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int sp = mf_row_softmax<NTH, 8192 / (NTH * 4)>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
-                                                        ak.dump ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
+    const int sp = mf_row_softmax<NTH, (8192 + 128 + NTH * 4 - 1) / (NTH * 4)>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
+                                                        (ak.dump & 1) ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
     __syncthreads();
     stamp(7);
 
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     uint16_t* kres = ak.kres + b * ak.kres_sb + hk * ak.kres_sh;
     const uint16_t* knew = ak.knew + b * ak.knew_sb + hk * ak.knew_sh;
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    uint16_t* dump0 = ak.dump ? ak.out + b * ak.out_sb + (int64_t)h0 * ak.out_sh : nullptr;
+    uint16_t* dump0 = (ak.dump & 1) ? ak.out + b * ak.out_sb + (int64_t)h0 * ak.out_sh : nullptr;
 
     // ---- the slice: super-blocks [sb_lo, sb_hi) of the unit's packed keys, the packed values of the same tokens; `last`: the slice
     // that also owns the fp16 residual, the window, the appends and the V flush -- it starts no later than the super-block of token
@@ -943,15 +943,29 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (payload written through before the arrival: cdna_hip_programming.md G16)
                 if (lane == 0) {
-                    __hip_atomic_fetch_add(ak.xcount + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // bounded: a partner that never arrives (a launch the library's residency rule does not cover) poisons the
-                    // unit's output with NaN after ~1 s instead of hanging the device
+                    bool arrive = true;
+#ifdef KIVI_TUNING
+                    if ((ak.dump & 2) && unit == 0 && slice == 0) arrive = false;     // fault injection (tests/test_mfma_gpu.py): a partner that never arrives
+#endif
+                    if (arrive) __hip_atomic_fetch_add(ak.xcount + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // bounded: the ticket order makes a missing partner impossible for an ordinary launch (see above); if one never
+                    // arrives all the same (~1 s of polls), the unit's output is poisoned with NaN instead of hanging the device AND
+                    // the step is reported: KIVI_ETIMEOUT in the workspace's error word and in the process's host-visible one, which
+                    // the next decode call returns (kivi_device_error).  The launch's last blocks still reset every counter.
                     int it = 0;
                     while (__hip_atomic_load(ak.xcount + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S && it < (1 << 21)) {
                         __builtin_amdgcn_s_sleep(16);
                         it++;
                     }
-                    xok_lds = it < (1 << 21);
+                    const bool ok_ = it < (1 << 21);
+                    xok_lds = ok_;
+                    if (!ok_) {
+                        if (ak.err_ws) __hip_atomic_store(ak.err_ws, -KIVI_ETIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ak.err_host) {
+                            __hip_atomic_store(ak.err_host + 1, unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(ak.err_host, -KIVI_ETIMEOUT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -1196,7 +1210,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
     KIVI_REQUIRE(S == 1 || k.ratio == 1 || k.ratio == 4 || k.ratio == 8, KIVI_EUNSUPPORTED, "mf_row: no sliced form for nh / nh_kv = %d", k.ratio);
     if (k.ratio == 4 || k.ratio == 8 || (k.ratio == 1 && (S > 1 || slice_kernel))) {
         const int R = k.ratio;
-        const int64_t cap = R == 4 ? 9216 : (R == 8 ? 4608 : 8192);    // keys whose R score rows fit the LDS of a block (R = 4 / 8: 72 KiB, two blocks per CU)
+        const int64_t cap = R == 4 ? 9216 + 128 : (R == 8 ? 4608 : 8192);    // keys whose R score rows fit the LDS of a block (mf_plan, kivi_gqa.hip: R = 4: 73 KiB, two blocks per CU)
         KIVI_REQUIRE(S >= 1 && S <= 64 && (S == 1 || S <= k.nsb), KIVI_EINVAL, "mf_row%d: %d slices for %d super-blocks", R, S, k.nsb);
         // the longest row of a block: the whole row, or (S > 1) max(ceil(nsb / S), 2) super-blocks + the residual (mf_row4_kernel)
         int64_t n_blk = n;
@@ -1211,11 +1225,16 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         const int occ = R == 1 ? 4 : 2;                             // blocks per CU
         if (lds < fin) lds = fin;
         const dim3 grid((unsigned)((int64_t)units * S));
-        // blocks that wait for each other (S > 1) must not wait for blocks that cannot start: with more blocks than the chip holds at
-        // once (2 per CU) the block ids come from the ticket counter (start order)
-        k.dump = dump;
-        if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; }
-        else if ((int64_t)units * S <= occ * (int64_t)mf_cu_count()) k.ticket = nullptr;
+        // blocks that wait for each other (S > 1) must not wait for blocks that cannot start: their ids ALWAYS come from the ticket
+        // counter (start order).  (Round 5 skipped it when the grid fitted 2 blocks per CU -- but an ordinary launch does not own the
+        // chip: other streams or processes, a CU mask, a second sliced launch can keep a waiting block's partners from starting.)
+        k.dump = dump ? 1 : 0;
+        (void)occ;
+#ifdef KIVI_TUNING
+        static const char* ft = KIVI_TUNE_ENV("KIVI_MF_FAULT_DROP_ARRIVAL");       // fault injection: see mf_row4_kernel
+        if (ft && atoi(ft) && S > 1) k.dump |= 2;
+#endif
+        if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; k.err_ws = nullptr; k.err_host = nullptr; }
         static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0, opt8p = 0, opt4p = 0, opt44p = 0;
         // a block per row (S = 1): the phase-softmax flow (PSM, see mf_row4_kernel); slices: the in-stream flow
         bool psm = S == 1 && R != 1;
@@ -1255,7 +1274,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
     }
     const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
     const dim3 grid((unsigned)units);
-    KIVI_REQUIRE(k.ratio == 1 && n <= 8192, KIVI_EUNSUPPORTED, "mf_row: nh / nh_kv = %d with rows of %lld keys has no one-launch kernel",
+    KIVI_REQUIRE(k.ratio == 1 && n <= 8192 + 128, KIVI_EUNSUPPORTED, "mf_row: nh / nh_kv = %d with rows of %lld keys has no one-launch kernel",
                  k.ratio, (long long)n);
     const size_t lds = (size_t)n_pad * 2;
     // (K ring, V ring) = (2, 3) code blocks in flight: 76.2 us per launch at the bench shape against 77.2 (2, 2), 76.7 (2, 4),
@@ -1275,7 +1294,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
     // few rows (under ~2 four-wave blocks per CU): eight waves per row, the row's own waves hide the latency
     static const char* f8 = KIVI_TUNE_ENV("KIVI_MF_ROW_NW8");            // tuning builds: 0 / 1 forces either
     const bool nw8 = f8 ? atoi(f8) != 0 : units <= 512;         // 256 rows: 30.3 -> 26.8 us, 384: 39.7 -> 37.0, 512: 45.8 -> 44.0, 768: 61.1 vs 65.4 (profiles/r03_other_shapes.log)
-    k.dump = dump;
+    k.dump = dump ? 1 : 0;
     // at most one block per CU (<= 256 rows): a row's waves are alone on their SIMDs and each is bound by the round trips of its own
     // ring (2 KiB of K / 3 KiB of V in flight stream ~3 GB/s per wave): rings of 8 blocks, 256 registers per wave
     static const char* fdp = KIVI_TUNE_ENV("KIVI_MF_ROW_DEEP");          // tuning builds: 0 / 1 forces either

@@ -58,15 +58,19 @@
 // of a row to <= 2^6, a group scale >= 512 would overflow the fp16 hi part where the reference's fp32 scale * code + zero
 // (quant/csrc/gemv_cuda.cu:407-413) stays finite -- and group scales in the fp16 subnormals (values ~1e-7) would push the hi part
 // into the subnormals and the lo part (the exact remainder) below the grid, where the reference still carries 24 bits.  Every
-// kernel that WRITES scales into a store (kivi_kt_pack, kivi_vt_pack, the relayouts, the V flush of the decode step) records two
+// kernel that WRITES scales into a store (kivi_kt_pack, kivi_vt_pack, the relayouts, the V flush of the decode step) records three
 // sticky per-(batch row, kv head) marks in the unit's range word (one BYTE each, written with byte stores: concurrent writers
 // never lose each other's mark):
 //   byte 0  a scale whose fp16 bits are >= KIVI_MF_BIG_SCALE_BITS (256.0; NaN / inf included) was written
 //   byte 1  a scale >= KIVI_MF_SMALL_SCALE_BITS (2^-8) was written
+//   byte 2  (ABI version 3) "the writers of this unit keep byte 1": set by every library writer with every scale it writes
 // The consumers place q (or the probabilities) by mf_range_shift(word): 2^KIVI_MF_BIG_SHIFT LOWER for a unit with byte 0 set
-// (128 * 65504 * 2^-10 < 2^13: every finite fp16 scale is safe), 2^KIVI_MF_SMALL_SHIFT HIGHER for a unit whose scales are ALL
-// below 2^-8 (round 5; q'' / p'' <= 2^15, the A operand < 2^7: a scale of 2^-24 still gives a hi part with all its bits), and
-// as before otherwise: units whose scales straddle neither bound compute bit for bit what they did before the marks existed.
+// (128 * 65504 * 2^-10 < 2^13: every finite fp16 scale is safe), 2^KIVI_MF_SMALL_SHIFT HIGHER for a unit that is KNOWN to hold only
+// scales below 2^-8 -- byte 2 set AND byte 1 clear (round 5; q'' / p'' <= 2^15, the A operand < 2^7: a scale of 2^-24 still gives a
+// hi part with all its bits) --, and as before otherwise: units whose scales straddle neither bound compute bit for bit what they
+// did before the marks existed.  A ZERO word means the default placement (ABI version 2 read it as "all scales < 2^-8" and placed
+// 2^8 higher: a store whose words were not written by the library's own writers -- a caller-side packer, a store copied without
+// its words -- then overflowed fp16 on ordinary data; version 3 needs the explicit byte 2 for the higher placement).
 #define KIVI_MF_BIG_SCALE_BITS 0x5C00u
 #define KIVI_MF_BIG_SHIFT 10
 #define KIVI_MF_SMALL_SCALE_BITS 0x1C00u
@@ -90,16 +94,17 @@
 #ifdef __HIPCC__
 // placement of q'' / p'' for a unit from its range word: -KIVI_MF_BIG_SHIFT, 0 or +KIVI_MF_SMALL_SHIFT (see above)
 __device__ __forceinline__ int mf_range_shift(int word) {
-    return (word & 0xFF) ? -KIVI_MF_BIG_SHIFT : ((word & 0xFF00) ? 0 : KIVI_MF_SMALL_SHIFT);
+    return (word & 0xFF) ? -KIVI_MF_BIG_SHIFT : (((word & 0xFFFF00) == 0x010000) ? KIVI_MF_SMALL_SHIFT : 0);
 }
-// The marks a writer leaves for (up to two) scales with these fp16 bits: sticky, byte stores.  The word is READ first and a byte is
-// stored only when its mark is missing: nearly every scale of ordinary data is >= 2^-8, and an unconditional store of byte 1 by
-// every lane of every packing wave serialised on the unit's one address (measured: kivi_kt_pack 10x slower).  A stale read costs a
-// redundant store, never a lost mark.
+// The marks a writer leaves for (up to two) scales with these fp16 bits: sticky, byte stores of the value 1.  The word is READ first
+// and a byte is stored only when its mark is missing: nearly every scale of ordinary data is >= 2^-8, and an unconditional store of
+// byte 1 by every lane of every packing wave serialised on the unit's one address (measured: kivi_kt_pack 10x slower).  A stale
+// read costs a redundant store, never a lost mark.
 __device__ __forceinline__ void mf_range_mark(int* word, uint32_t scale_bits, uint32_t scale_bits2 = 0u) {
     const uint32_t top = scale_bits > scale_bits2 ? scale_bits : scale_bits2;
-    if (top < KIVI_MF_SMALL_SCALE_BITS) return;
     const int cur = *reinterpret_cast<const volatile int*>(word);
+    if ((cur & 0xFF0000) == 0) reinterpret_cast<volatile unsigned char*>(word)[2] = 1;
+    if (top < KIVI_MF_SMALL_SCALE_BITS) return;
     if ((cur & 0xFF00) == 0) reinterpret_cast<volatile unsigned char*>(word)[1] = 1;
     if (top >= KIVI_MF_BIG_SCALE_BITS && (cur & 0xFF) == 0) reinterpret_cast<volatile unsigned char*>(word)[0] = 1;
 }

@@ -10,16 +10,15 @@ serves the model: per step the host uploads six numbers (a one-thread kernel), r
 lengths (`kivi_mf_step_advance`) and -- every residual_length steps -- launches the K flushes (`kivi_kt_pack`), outside the graph.
 The graph is re-captured when the geometry class changes (every ~512 steps per side) or a cache had to grow.
 
-Replayed and eager steps agree bit for bit whenever they follow the same launch plan (kivi_mf_launch_plan).  The plan of a captured
-step is the plan of its whole geometry class -- sized for the class's longest row, ceil(Tq / 512) * 512 + residual_length keys --
-while an eager step is planned for its own row: in the narrow bands where the class's longest row no longer fits a block but the
-step's own row still does (nh == nh_kv: Tq in (7680, 8192]; nh / nh_kv = 4: Tq in (8704, 9216]) the eager step runs a block per row
-and the replayed one slices the row (nh / nh_kv in {4, 8}) or takes two launches; the outputs then agree within the hook bar (3e-3),
-the cache tuples bit for bit.
+Replayed and eager steps agree bit for bit: both follow the launch plan of the step's whole geometry class (kivi_mf_launch_plan --
+sized for the class's longest row, ceil(Tq / 512) * 512 + residual_length keys; since round 6 an eager step is planned for that
+bound too, and the one-launch caps are whole super-blocks + a full residual, so the bands of round 5 where an eager step ran a block
+per row and the replayed one sliced the row are gone: tests/test_graph_gpu.py covers Tq just under 8192 / 9216).
 """
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Callable, List, Optional
 
 import torch
@@ -34,11 +33,23 @@ class MfStepDriver:
     def __init__(self, caches: List[KiviLayerCacheMF]):
         assert caches and all(isinstance(c, KiviLayerCacheMF) and c.ring for c in caches), "matrix-pipe caches only"
         c0 = caches[0]
-        self.caches = caches
+        # the caches are held WEAKLY: a driver (and the graph captured over it) kept on a model must not keep a finished request's KV
+        # cache alive (advisor r5); whoever steps the driver owns the caches
+        self._refs = [weakref.ref(c) for c in caches]
         self.lib = _lib.load()
         self.resync()
         self.dev = torch.zeros(4, dtype=torch.int64, device=c0.kt.device)       # kivi_mf_step in device memory (32 bytes)
         self._ptrs = None
+
+    @property
+    def caches(self) -> List[KiviLayerCacheMF]:
+        cs = [r() for r in self._refs]
+        assert all(c is not None for c in cs), "the caches this driver was built for are gone"
+        return cs
+
+    def serves(self, caches) -> bool:
+        """True when this driver was built for exactly these (still living) cache objects."""
+        return len(caches) == len(self._refs) and all(r() is c for r, c in zip(self._refs, caches))
 
     def resync(self) -> None:
         """Take the lengths from the caches again (they may have been advanced by eager steps or a new prompt since the last call)."""
@@ -59,7 +70,9 @@ class MfStepDriver:
         stale = False
         for c in self.caches:
             c.ensure_room(1)
-        ptrs = tuple((c.kt.data_ptr(), c.vt.data_ptr()) for c in self.caches) + (self.key(),)
+        # everything a captured launch holds a raw pointer to: the stores, the fp16 residual / window, the per-stream scratch
+        ptrs = tuple((c.kt.data_ptr(), c.vt.data_ptr(), c.k_res.data_ptr(), c.v_res.data_ptr()) +
+                     tuple(t.data_ptr() for t in c._desc(c.nh, c.kt.device)[4]) for c in self.caches) + (self.key(),)
         if ptrs != self._ptrs:
             stale, self._ptrs = True, ptrs
         _lib.check(self.lib.kivi_mf_step_upload(ctypes.byref(self.host), self.dev.data_ptr(), _lib.stream_ptr(self.dev)), "kivi_mf_step_upload")

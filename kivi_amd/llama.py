@@ -211,12 +211,12 @@ class LlamaForCausalLM_KIVI(nn.Module):
         out = []
         if whole:
             from .graph import GraphedDecode, MfStepDriver
-            # the driver and its captured graph live on the model, keyed by the caches and the static buffers they were built for: a
-            # second decode_graphed call over the same caches replays the graph it already has instead of paying an eager step and
-            # a 32-layer capture again (only a new geometry class or a reallocated cache re-captures: MfStepDriver.prepare)
-            key = (id(g),) + tuple(id(c) for c in caches)
+            # the driver and its captured graph live on the model, for the caches (held weakly: MfStepDriver.serves) and the static
+            # buffers they were built for: a second decode_graphed call over the same caches replays the graph it already has instead
+            # of paying an eager step and a 32-layer capture again (only a new geometry class or a reallocated buffer re-captures:
+            # MfStepDriver.prepare).  Nothing here keeps a finished request's KV cache alive.
             st = getattr(self, "_graphed", None)
-            if st is not None and st[0] == key:
+            if st is not None and st[0] is g and st[1].serves(caches):
                 drv, gd = st[1], st[2]
                 drv.resync()
             else:
@@ -229,7 +229,7 @@ class LlamaForCausalLM_KIVI(nn.Module):
                         g.post_fn(i)
 
                 gd = GraphedDecode(drv, body)
-                self._graphed = (key, drv, gd)
+                self._graphed = (g, drv, gd)
             for _ in range(steps):
                 out.append(g.tok.clone())
                 freqs = position * attn0.inv_freq.float()
@@ -259,6 +259,7 @@ class LlamaForCausalLM_KIVI(nn.Module):
         """generate() with the dense part of every decode step replayed from hipGraphs (see _build_graphs)."""
         logits, pasts = self.forward(input_ids)
         new = self.decode_graphed(logits.argmax(-1), pasts, input_ids.shape[1], max_new_tokens)
+        self._graphed = None        # the caches of this request die with it: so does the graph captured over them
         return torch.cat([input_ids, new], dim=1)
 
     @classmethod

@@ -36,7 +36,7 @@ def alloc_store(B: int, nh_kv: int, n_sb: int, device, bits: int = 2) -> torch.T
     """Zero-initialised storage of n_sb super-blocks per (batch row, kv head): logical shape (B, nh_kv, n_sb, sb_words(bits)) int32,
     in memory the super-block index sits outside the head index (the super-blocks in use form one dense region).
     The store's RANGE WORDS (include/kivi_hip.h: B * nh_kv int32; byte 0 marked by whatever writes a scale >= 256 into the unit,
-    byte 1 by whatever writes a scale >= 2^-8: `range_big` / `range_small`) live in the same allocation, right behind the
+    byte 1 by whatever writes a scale >= 2^-8, byte 2 by every library writer: `range_big` / `range_small`) live in the same allocation, right behind the
     super-blocks: `range_flags(store)` is the (B, nh_kv) view, and every wrapper below passes it along with the store."""
     W = sb_words(bits)
     main = B * n_sb * nh_kv * W
@@ -60,8 +60,9 @@ def range_big(store: torch.Tensor) -> torch.Tensor:
 
 
 def range_small(store: torch.Tensor) -> torch.Tensor:
-    """(B, nh_kv) bool: every scale written into the unit so far is < 2^-8 (q'' / p'' are placed 2^8 higher)."""
-    return (range_flags(store) & 0xFFFF) == 0
+    """(B, nh_kv) bool: the unit's writers keep the marks (byte 2) and every scale written into it so far is < 2^-8 (q'' / p'' are
+    placed 2^8 higher).  A zero word -- nothing written, or written by something that does not mark -- is NOT small."""
+    return (range_flags(store) & 0xFFFFFF) == 0x010000
 
 
 def copy_store(dst: torch.Tensor, src: torch.Tensor) -> None:

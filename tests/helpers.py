@@ -35,15 +35,33 @@ def load_golden(prefix: str):
     return out
 
 
-def gemv_close(got: torch.Tensor, ref: torch.Tensor, rtol: float = 1e-3):
-    """north_star bar for the fp16 GEMV: |a-b| <= rtol * max(|ref|, rms(ref_row)).
-    Returns (ok, worst ratio)."""
+# worst ratios seen by gemv_close since the last drain (tests/conftest.py writes them to the ratio log after every test)
+RATIOS = []
+
+
+def gemv_close(got: torch.Tensor, ref: torch.Tensor, rtol: float = 1e-3, ulps: float = 0.0):
+    """north_star bar for the fp16 GEMV, bare: |a-b| <= rtol * max(|ref|, rms(ref_row)) -- no ulp term.
+    A correctly rounded fp16 result 1 ulp from a NORMAL reference already fits under 1e-3 (ulp <= 9.77e-4 relative), so the only
+    slack kept is one subnormal ulp (2^-24 absolute) where |ref| is below the fp16 normal range, where a relative bar has no
+    meaning.  `ulps` (default 0; stage A of the decode-step checks passes 1): the compared tensor is NOT a GEMV output but the row the
+    softmax consumes, fp16(fp16(score) / sqrt(D)) (llama_kivi.py:339) -- a second fp16 rounding after the GEMV's, so two correct
+    GEMVs one ulp apart can land two ulps apart there; that many fp16 ulps of |ref| are added to the bound, and the bar is logged as
+    such.  Returns (ok, worst ratio against that bar); every call is recorded (RATIOS) and lands in the ratio log."""
     g, r = got.detach().cpu().float(), ref.detach().cpu().float()
+    if not r.numel():
+        return True, 0.0
     rms = r.pow(2).mean(dim=-1, keepdim=True).sqrt()
     bound = rtol * torch.maximum(r.abs(), rms)
-    # an fp16 result cannot be closer than half an ulp of the reference: allow 1 ulp of slack on top
-    ulp = torch.finfo(torch.float16).eps * r.abs().clamp_min(2.0 ** -14)
-    ratio = ((g - r).abs() / (bound + ulp)).max().item() if r.numel() else 0.0
+    bound = torch.where(r.abs() < 2.0 ** -14, bound + 2.0 ** -24, bound)
+    if ulps:
+        bound = bound + ulps * torch.finfo(torch.float16).eps * r.abs().clamp_min(2.0 ** -14)
+    err = (g - r).abs()
+    # inf / nan: equal non-finite values agree, anything else is a miss
+    same = (g == r) | (torch.isnan(g) & torch.isnan(r))
+    ratio_t = torch.where(same, torch.zeros_like(err), err / bound.clamp_min(2.0 ** -126))
+    ratio_t = torch.where(torch.isnan(ratio_t), torch.full_like(ratio_t, float("inf")), ratio_t)
+    ratio = ratio_t.max().item()
+    RATIOS.append((f"{rtol:g}" + (f"+{ulps:g}ulp" if ulps else ""), ratio, int(r.numel())))
     return ratio <= 1.0, ratio
 
 

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/kivi_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in kivi_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.kivi_abi_version() == 2
+    assert lib.kivi_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_variant_tables(lib):
@@ -518,25 +518,40 @@ def test_launch_plan_is_a_function_of_the_geometry_class(lib):
     assert P(64, 64, 8, 8064, 0, 128) == 2                       # ... at B = 64: the fewest slices that fit (1024 blocks: ticket ids)
     assert P(4, 32, 8, 8064, 0, 128) == 4 and P(32, 32, 8, 8064, 0, 128) == 1 and P(16, 32, 8, 8064, 0, 128) == 2
     assert P(8, 32, 8, 2048, 0, 128) == 0                        # few short rows: two launches
-    assert P(1, 32, 32, 32736, 16, 32) == 0 and P(4, 32, 32, 4064, 16, 32) == 1
+    assert P(4, 32, 32, 4064, 16, 32) == 1
+    # multi-head rows beyond 16 super-blocks (LongChat-7B-32K, docs/long_bench.md:5-26): one launch, sliced (round 6; two launches before)
+    assert P(1, 32, 32, 32736, 16, 32) == 20 and P(8, 32, 32, 32768, 0, 128) == 5 and P(16, 32, 32, 16384, 0, 128) == 3
+    assert P(8, 32, 32, 32768, 0, 128, _lib.GQA_FORCE_SPLIT) == 0 and P(8, 32, 32, 32768, 0, 128, _lib.GQA_FORCE_ROW) == 0
     assert P(64, 32, 8, 8064, 0, 128, _lib.GQA_FORCE_SPLIT) == 0 and P(4, 32, 8, 8064, 0, 128, _lib.GQA_FORCE_ROW) == 1
     assert P(2, 8, 2, 1024, 76, 128, _lib.gqa_slices(2)) == 2 and P(2, 8, 2, 1024, 76, 128, _lib.gqa_slices(3)) == 0   # 2 super-blocks: no 3 slices
     assert P(2, 4, 4, 1088, 12, 32, _lib.gqa_slices(2)) == 2 and P(2, 4, 4, 1088, 12, 32, _lib.gqa_slices(1)) == 1     # nh == nh_kv through the slice kernel
     assert P(0, 32, 8, 64, 0, 32) == -1 and P(2, 32, 5, 64, 0, 32) == -1
-    for nh, nkv, cap in ((32, 8, 9216), (64, 8, 4608)):
+    # Tq = 0 (before the first K flush): one, empty, slice -- the one-launch form when the units fill the chip (advisor r5)
+    assert P(64, 32, 8, 0, 5, 128) == 1 and P(32, 64, 8, 0, 5, 128) == 1 and P(2, 32, 8, 0, 5, 128) == 0 and P(32, 32, 32, 0, 5, 32) == 1
+    # the bands where only the class bound exceeded a block (advisor r4 / r5): the caps are whole super-blocks + a full residual now,
+    # and eager steps are planned for the class bound too
+    assert P(32, 32, 32, 8192, 31, 32) == 1 and P(32, 32, 32, 8160, 0, 32) == 1 and P(32, 32, 32, 8192 + 32, 0, 32) == 2
+    assert P(64, 32, 8, 9216, 127, 128) == 1 and P(64, 32, 8, 9088, 0, 128) == 1 and P(64, 32, 8, 9216 + 128, 0, 128) == 2
+    for nh, nkv, cap in ((32, 8, 9216 + 128), (64, 8, 4608), (32, 32, 8192 + 128)):
         for B in (1, 4, 16, 64):
             for Tq in range(0, 40000, 1664):
                 for R in (32, 128):
                     Tq_ = Tq // R * R
                     nsb = (Tq_ + 511) // 512
                     cls = P(B, nh, nkv, Tq_, 0, R, 0, 2, 1)
-                    for kres in (0, R // 2, R - 1):              # one class, one plan (device-resident lengths)
-                        assert P(B, nh, nkv, Tq_, kres, R, 0, 2, 1) == cls
-                    S = P(B, nh, nkv, Tq_, R - 1, R)
+                    for kres in (0, R // 2, R - 1):              # one class, one plan: eager (dyn = 0) and device-resident lengths alike
+                        assert P(B, nh, nkv, Tq_, kres, R, 0, 2, 1) == cls == P(B, nh, nkv, Tq_, kres, R, 0, 2, 0)
+                    S = cls
                     if S > 1:                                    # the longest row of a block: max(ceil(nsb / S), 2) super-blocks + the residual
-                        assert S <= nsb and max((nsb + S - 1) // S, 2) * 512 + R + 1 <= cap
+                        assert S <= nsb and max((nsb + S - 1) // S, 2) * 512 + R + 1 <= (8192 if nh == nkv else cap)
                     elif S == 1:
-                        assert Tq_ + R <= cap
+                        assert nsb * 512 + R <= cap
+
+
+def test_device_error_is_clear_without_a_device(lib):
+    """kivi_device_error (include/kivi_hip.h): the sticky error of sliced launches; nothing was launched -> 0, and asking does not
+    allocate or touch a device."""
+    assert lib.kivi_device_error() == 0 and lib.kivi_device_error() == 0
 
 
 def test_decode_layer_dyn_refuses_before_launching(lib):

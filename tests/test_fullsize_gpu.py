@@ -103,7 +103,7 @@ def run_sampled(B, nh, nh_kv, T0, R, bits, g, steps, samples, seed, masked=False
                 x_gpu = layer._native[4][0][b:b + 1, hs, :, :n].cpu()
                 ref, new_past, x_ref = H.decode_step(*args, attention_mask=m_cpu, return_scores=True)
                 live = x_ref.float() > -60000
-                ok, ra = gemv_close(torch.where(live, x_gpu.float(), 0.0), torch.where(live, x_ref.float(), 0.0), rtol=1e-3)
+                ok, ra = gemv_close(torch.where(live, x_gpu.float(), 0.0), torch.where(live, x_ref.float(), 0.0), rtol=1e-3, ulps=1)
                 assert ok, ("scores", s, b, hk, ra)
                 assert torch.equal(x_gpu[~live], x_ref[~live])
                 ref_b, _ = H.decode_step(*args, attention_mask=m_cpu, scores_override=x_gpu)
@@ -180,14 +180,26 @@ def test_4bit_gqa_shapes_on_the_matrix_pipe_stages(oracle, B, T0, kernel, split)
     print("worst ratio vs the 2e-3 attend bar:", worst)
 
 
-@pytest.mark.parametrize("B,T0,kernel", [(1, 32768 + 13, "mf_k_kernel"), (4, 4080, "mf_row_kernel"), (4, 6000, "mf_k_kernel"),
-                                         (16, 4080, "mf_row_kernel")])
-def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0, kernel):
-    """Few (batch row, head) rows: rows longer than the LDS row (B = 1 x 32k keys) and fewer than 192 rows of more than 8
-    super-blocks (B = 4 x 6000) run the two-launch form with the rows cut into slices; rows of at most 8 super-blocks take
-    the eight-wave row kernel whatever the batch (B = 4 / 16 x 4k)."""
+@pytest.mark.parametrize("B,T0,kernel,split", [(1, 32768 + 13, "mf_row4_kernel", False), (1, 32768 + 13, "mf_k_kernel", True),
+                                               (4, 4080, "mf_row_kernel", False), (4, 6000, "mf_k_kernel", False), (16, 4080, "mf_row_kernel", False)])
+def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0, kernel, split):
+    """Few (batch row, head) rows: rows longer than the LDS row (B = 1 x 32k keys) run ONE launch with every row cut into slices that
+    exchange their softmax statistics (round 6: mf_row4_kernel<R = 1>; the two-launch form, forced, stays covered), fewer than 192 rows
+    of more than 8 super-blocks (B = 4 x 6000) the two-launch form; rows of at most 8 super-blocks take the eight-wave row kernel
+    whatever the batch (B = 4 / 16 x 4k)."""
     run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=6, samples=[(0, 0), (B - 1, 31)], seed=15, layout="auto",
-                expect_kernel=kernel)
+                expect_kernel=kernel, extra_flags=_SPLIT if split else 0)
+
+
+@pytest.mark.parametrize("B,T0,R,bits", [(8, 32768 + 100, 128, 2), (16, 16384 + 100, 128, 2)])
+def test_longchat_shape_multi_head_long_rows_stages(oracle, B, T0, R, bits):
+    """The reference's LongChat-7B-32K configuration (docs/long_bench.md:5-26: 32 heads = 32 kv heads, KIVI-2, g = 32, R = 128) at
+    16k / 32k keys and B = 8 / 16: multi-head rows beyond 8192 keys in ONE launch (rows cut into 5 / 3 slices, mf_row4_kernel<R = 1>),
+    through a K flush (step 28), outlier key channels, masks, stage by stage against the oracle on sampled units, 9-tuples of the
+    sampled units bit-identical.  (Every unit of the same shape: tests/test_fullcover_gpu.py.)"""
+    seen, worst = run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=R, bits=bits, g=32, steps=30, samples=[(0, 0), (B - 1, 31), (B // 2, 13)],
+                              seed=24, expect_kernel="mf_row4_kernel", layout="auto", stage_ab=True, outlier=True, masked=True)
+    print("worst ratio vs the 2e-3 attend bar:", worst)
 
 
 def test_bench_shape_prompt_4080_k_flush_mid_page(oracle):

@@ -3,8 +3,8 @@ from a hipGraph (kivi_amd/graph.py) against the eager layer step (kivi_mf_decode
 and cache tuples BIT-identical, step after step, through K flushes, V flushes, the window ring wrapping, changes of the geometry
 class (a 512-token boundary of either store) and cache growth -- in every form: two launches, a block per row, rows cut into slices
 (whose geometry the blocks derive from the device-resident lengths).  The eager step itself is pinned against the reference logic in
-tests/test_mfma_gpu.py / tests/test_hook_gpu.py.  (Eager and replayed steps follow the same launch plan in all these cases; the
-narrow bands where they do not are described in kivi_amd/graph.py.)"""
+tests/test_mfma_gpu.py / tests/test_hook_gpu.py.  (Eager and replayed steps follow the same launch plan -- that of the step's geometry
+class -- everywhere, incl. Tq just under 8192 (nh == nh_kv) and 9216 (nh / nh_kv = 4): the last parameter sets.)"""
 import pytest
 import torch
 
@@ -25,7 +25,13 @@ def _tuples_equal(a, b):
                                                                 (1, 16, 2, 480, 32, "split", False, 2), (2, 16, 2, 300, 32, "row", False, 2),
                                                                 (8, 32, 32, 4080, 32, "auto", False, 2),
                                                                 (2, 8, 2, 460, 32, "row", True, 4), (2, 8, 2, 500, 32, "split", False, 4),
-                                                                (2, 8, 2, 1100, 128, "slices2", True, 2), (2, 16, 2, 1500, 32, "slices3", False, 2)])
+                                                                (2, 8, 2, 1100, 128, "slices2", True, 2), (2, 16, 2, 1500, 32, "slices3", False, 2),
+                                                                # the bands of advisor r4 / r5: the class bound (ceil(Tq / 512) * 512 + R) exceeds
+                                                                # 8192 / 9216 keys while the step's own row does not -- a block per row in both
+                                                                # (caps = whole super-blocks + a full residual), and the plan's own choice
+                                                                (2, 4, 4, 8000, 32, "row", False, 2), (2, 8, 2, 9000, 128, "row", True, 2),
+                                                                (2, 4, 4, 8100, 32, "auto", True, 2), (2, 8, 2, 9100, 128, "auto", False, 2),
+                                                                (2, 4, 4, 8130, 32, "auto", False, 2)])
 def test_dyn_steps_bit_identical_to_eager(B, nh, nh_kv, T0, R, form, masked, bits):
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
