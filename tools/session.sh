@@ -78,8 +78,27 @@ cd $R
 while [ $# -gt 0 ]; do
     stage=$1; shift
     case $stage in
+    r6new)
+        # round 6: the new parity evidence first -- every-unit fp64 reference, the timeout path, the graph-vs-eager bands, LongChat shapes
+        rm -f $R/gpurun_out/gemv_ratios.log
+        timeout 1500 python -m pytest tests/test_fullcover_gpu.py tests/test_timeout_gpu.py tests/test_graph_gpu.py tests/test_fullsize_gpu.py -m gpu -q -s --tb=short --maxfail=12 \
+            -k "fullcover or timeout or graph or longchat or small_batch" > $O/r6new.log 2>&1; echo "r6new rc=$?" | tee -a $O/status.log
+        grep -E "passed|failed|worst ratio|Error|error" $O/r6new.log | tail -40 | cut -c1-300
+        cp $R/gpurun_out/gemv_ratios.log $O/gemv_ratios_r6new.log 2>/dev/null ;;
+    long1)
+        # round 6: multi-head rows beyond 8192 keys (LongChat-7B-32K shape): the plan's one-launch sliced form against two launches, one box
+        for i in 1 2; do
+            for f in auto split; do
+                for sh in "8 32640" "16 32640" "8 16256" "16 16256" "1 32752"; do
+                    lb=${sh% *}; lt=${sh#* }
+                    timeout 300 $BN --batch $lb --heads 32 --kv-heads 32 --prompt $lt --residual 128 --steps 6 --warmup 2 --form $f > $O/long1_b${lb}_t${lt}_${f}_$i.json 2>> $O/long1.err; line $O/long1_b${lb}_t${lt}_${f}_$i.json
+                done
+            done
+        done ;;
     tests)
+        rm -f $R/gpurun_out/gemv_ratios.log
         timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/status.log
+        cp $R/gpurun_out/gemv_ratios.log $O/gemv_ratios.log 2>/dev/null
         tail -15 $O/pytest_gpu.log
         timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" >> $O/pytest_gpu.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.log ;;
     bench)
