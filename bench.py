@@ -53,6 +53,107 @@ def vgemv_bytes(B, nh, nh_kv, D, Tv, g, bits):
     return B * nh_kv * per_kv_head + B * nh * (Tv * 2 + D * 2)
 
 
+def row_bytes(info):
+    """ALGORITHMIC bytes of ONE fused decode-row launch from the launch hook's description of the step:
+    packed K + packed V (codes + scale + zero) + the fp16 residual / window + q + out; no score round trip."""
+    Bq, nhq, nkv, Dq = info["B"], info["nh"], info["nh_kv"], info["K"]
+    kb = kgemv_bytes(Bq, nhq, nkv, Dq, info["N"], info["group_size"], info["bits"])
+    return (kb - Bq * nhq * info["N"] * 2
+            + vgemv_bytes(Bq, nhq, nkv, Dq, info["Tv"], info["group_size"], info["v_bits"]) - Bq * nhq * info["Tv"] * 2
+            + Bq * nkv * (info["k_res"] + info["v_res"]) * Dq * 2)
+
+
+def pmc_traffic_entry(kname, want):
+    """HBM bytes per launch of `kname` at configuration `want` from the newest tracked rocprofv3 --pmc passes (profiles/)."""
+    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    for pf in reversed(profs):
+        try:
+            pj = json.load(open(pf))
+        except Exception:
+            continue
+        ent = next((e for key, e in pj.get("kernels", {}).items() if key.split("@")[0] == kname and e.get("config") == want), None)
+        if ent:
+            return ent["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pf)
+    return None, None
+
+
+# The other BASELINE.json configurations, measured by the default invocation so that the driver's own run carries them
+# (VERDICT r5 weak #9): a few layers of each shape, every launch of the fused kernel bracketed by HIP events.
+EXTRA_CONFIGS = [
+    ("roofline_config4", "BASELINE configs[3]: Llama-3-8B attention shape, B=64, 32 / 8 heads, 8k keys, 2b/2b g=32 R=128",
+     dict(B=64, nh=32, nh_kv=8, T0=8064, R=128, bits=2)),
+    ("roofline_config4_4bit", "the same geometry with 4-bit K / V (the reference's Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53)",
+     dict(B=64, nh=32, nh_kv=8, T0=8064, R=128, bits=4)),
+    ("roofline_config5_slice", "BASELINE configs[4], one GPU's share of the batch-sharded job: Mistral-7B attention shape, B=16, 32 / 8 heads, "
+     "32k keys, 2b/2b g=32 R=128", dict(B=16, nh=32, nh_kv=8, T0=32640, R=128, bits=2)),
+]
+
+
+def extra_config_roofline(label, c, dev, klib, D=128, g=32, n_layers=8, steps=14, warmup=2):
+    """`n_layers` layer caches of the shape (each ~0.4-1 GB: together far beyond the 256 MiB Infinity Cache), `warmup` + `steps`
+    decode steps over them, EVERY fused launch of the timed steps bracketed by a HIP event pair (>= 100 launches)."""
+    from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
+    from kivi_amd.quant import matmul
+    B, nh, nh_kv, T0, R, bits = c["B"], c["nh"], c["nh_kv"], c["T0"], c["R"], c["bits"]
+    cfg = KiviConfig(bits, bits, g, R)
+    layers = []
+    for _ in range(n_layers):
+        lc = make_layer_cache(cfg, B, nh_kv, D, T0 + warmup + steps + 1, dev, num_heads=nh)
+        k = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
+        v = torch.randn((B, nh_kv, T0, D), device=dev, dtype=torch.float16)
+        lc.prefill(k, v)
+        del k, v
+        layers.append(lc)
+    q = torch.randn((B, nh, 1, D), device=dev, dtype=torch.float16)
+    kn = torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16)
+    vn = torch.randn((B, nh_kv, 1, D), device=dev, dtype=torch.float16)
+    ev, timing = [], [False]
+
+    def hook(phase, kind, info):
+        if kind == "k" and phase == "pre" and timing[0]:
+            pair = (klib.kivi_event_create(), klib.kivi_event_create())
+            klib.kivi_set_launch_events(*pair)
+            ev.append((pair, row_bytes(info) if "Tv" in info else None))
+
+    matmul.launch_hook = hook
+    try:
+        torch.cuda.synchronize()
+        t0 = None
+        for s in range(warmup + steps):
+            if s == warmup:
+                torch.cuda.synchronize()
+                timing[0] = True
+                t0 = time.perf_counter()
+            for lc in layers:
+                kivi_attention_decode(q, kn, vn, lc)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    finally:
+        matmul.launch_hook = None
+    kname = (klib.kivi_last_timed_kernel() or b"").decode().split("<")[0].strip("( ")
+    us = sorted(klib.kivi_event_elapsed_us(a, b) for (a, b), _ in ev)
+    for (a, b), _ in ev:
+        klib.kivi_event_destroy(a)
+        klib.kivi_event_destroy(b)
+    nb = [r for _, r in ev if r is not None]
+    if not us or len(nb) != len(us):
+        return {"workload": label, "error": f"no fused launch was timed (kernel {kname!r})"}
+    n = len(us)
+    bytes_ = sum(nb) // n
+    med, avg = us[n // 2], sum(us) / n
+    fr = lambda t: round(bytes_ / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)       # noqa: E731
+    traffic, src = pmc_traffic_entry(kname, {"B": B, "nh": nh, "nh_kv": nh_kv, "prompt": T0, "bits": bits, "group": g, "residual": R})
+    return {"workload": label, "config": dict(c, head_dim=D, group_size=g, layers_timed=n_layers, steps=steps, warmup=warmup),
+            "kernel": kname, "launches": n, "sampled": "every fused launch of the timed steps (HIP events on the launch stream)",
+            "avg_launch_us": round(avg, 2), "median_launch_us": round(med, 2), "min_launch_us": round(us[0], 2),
+            "p10_launch_us": round(us[n // 10], 2), "p90_launch_us": round(us[(9 * n) // 10], 2),
+            "algorithmic_bytes_per_launch": bytes_, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": round(bytes_ / (med * 1e-6) / 1e9, 1), "frac": fr(med), "frac_at_avg": fr(avg), "frac_at_min": fr(us[0]),
+            "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / bytes_, 4), "traffic_source": src,
+            "ms_per_32_layer_step_incl_event_overhead": round(wall * 1e3 / steps * 32 / n_layers, 4),
+            "tokens_per_s_at_median_launch_32_layers": round(B / (med * 1e-6 * 32), 1)}
+
+
 def launch_ranks(n_gpus: int, argv, timeout_s: float = 3600.0) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, the same
     environment contract as torch.distributed.run) and wait for them.  Rank 0 inherits stdout (the JSON line)."""
@@ -135,24 +236,61 @@ def barrier(dist):
         dist.barrier()
 
 
+def _pick_cpus(n, allowed):
+    """n CPUs of ONE NUMA node, one per physical core (no SMT siblings), from the allowed set -- or the first n allowed ones when
+    the topology files are not readable.  Returns (cpus, note)."""
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            out.extend(range(int(a), int(b or a) + 1))
+        return out
+    try:
+        best = None
+        for node in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+            cpus = [c for c in parse(open(os.path.join(node, "cpulist")).read()) if c in allowed]
+            cores, seen = [], set()
+            for c in cpus:                                    # one hardware thread per core
+                try:
+                    sib = tuple(parse(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+                except OSError:
+                    sib = (c,)
+                if sib not in seen:
+                    seen.add(sib)
+                    cores.append(c)
+            if best is None or len(cores) > len(best[1]):
+                best = (os.path.basename(node), cores)
+        if best and len(best[1]) >= n:
+            return best[1][:n], f"{n} physical cores of NUMA {best[0]}"
+    except (OSError, ValueError):
+        pass
+    return sorted(allowed)[:n], "first allowed CPUs (no NUMA topology readable)"
+
+
 def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=25.0, threads=None):
     """The reference's pure-PyTorch fake-quant path (oracle/torch_fakequant.py port) on the host cores, on a bounded
     sample of the same workload: ONE batch row of ONE layer (nh heads x T tokens), decode-equivalent work =
-    unpack+dequantise K and V + the two GEMVs (the cache is already packed in a decode step; pack is timed and
-    reported separately).  Extrapolated to tokens/s for `layers` layers."""
+    unpack+dequantise K and V (unpack -> fp16 mul -> fp16 add, un-fused as in quant/new_pack.py:51-83) + the two matmuls (the cache
+    is already packed in a decode step; pack is timed and reported separately).  Extrapolated to tokens/s for `layers` layers.
+    Round 6 (the round-5 line swung 2.3x between two boxes, p10-p90 34-173 ms): a SMALL fixed thread count (8) pinned to physical
+    cores of one NUMA node -- 32 threads on a shared 256-CPU host mostly measured the neighbours --, >= 100 repetitions after 5
+    warm-up ones, median with p10 / p90 and their spread reported."""
     from oracle import torch_fakequant as TF
-    # a FIXED thread count (the box's cores, at most 32: the sample is one batch row x nh heads -- more threads than heads only add
-    # scheduling noise, which made the round-4 line swing 2x between boxes), >= 30 repetitions after 3 warm-up ones, median reported
     ncpu = os.cpu_count() or 1
-    nthr = threads or max(1, min(32, ncpu))
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = set(range(ncpu))
+    nthr = threads or max(1, min(8, len(allowed)))
+    cpus, pin_note = _pick_cpus(nthr, allowed)
     prev = torch.get_num_threads()
     torch.set_num_threads(nthr)
-    # ... and the process pinned to `nthr` neighbouring CPUs for the duration (one socket / NUMA node on the GPU boxes: unpinned, the
-    # repetitions of the round-5 first run spread from 4 to 100 ms)
     prev_aff = None
     try:
         prev_aff = os.sched_getaffinity(0)
-        os.sched_setaffinity(0, set(sorted(prev_aff)[:nthr]))
+        os.sched_setaffinity(0, set(cpus))
     except (AttributeError, OSError):
         prev_aff = None
     torch.manual_seed(0)
@@ -161,13 +299,19 @@ def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=25.0, threads=None):
     q = torch.randn((1, nh, 1, D)).half()
     a = torch.softmax(torch.randn((1, nh, 1, T)), -1).half()
     dec, pack, t_start = [], [], time.perf_counter()
-    for _ in range(3):                              # warm-up (first-touch of the fp32 intermediates, thread pool start)
-        TF.fakequant_decode_layer(q, a, k, v, g, bits)
+    for _ in range(5):                              # the prompt's pack (its own figure; also warms the thread pool)
+        t_p = time.perf_counter()
+        TF.quant_pack_lastdim(k.transpose(2, 3).contiguous(), g, bits)
+        TF.quant_pack_lastdim(v, g, bits)
+        pack.append(time.perf_counter() - t_p)
+    ws = {}                                         # the intermediates are written in place from the second call on: no fresh pages per repetition
+    for _ in range(5):                              # warm-up (first touch of the intermediates)
+        TF.fakequant_decode_layer(q, a, k, v, g, bits, ws)
     while True:
-        _, _, st = TF.fakequant_decode_layer(q, a, k, v, g, bits)
+        _, _, st = TF.fakequant_decode_layer(q, a, k, v, g, bits, ws)
         dec.append(st["dequant_s"] + st["gemv_s"])
-        pack.append(st["pack_s"])
-        if (len(dec) >= 30 and time.perf_counter() - t_start > budget_s) or len(dec) >= 200 or time.perf_counter() - t_start > 4 * budget_s:
+        el = time.perf_counter() - t_start
+        if (len(dec) >= 100 and el > budget_s) or len(dec) >= 400 or el > 3 * budget_s:
             break
     torch.set_num_threads(prev)
     if prev_aff is not None:
@@ -176,19 +320,25 @@ def cpu_baseline(B, nh, T, D, g, bits, layers, budget_s=25.0, threads=None):
         except OSError:
             pass
     reps = len(dec)
-    ds = sorted(dec)
+    ds, ps = sorted(dec), sorted(pack)
     per_layer_row = ds[reps // 2]                   # median
+
+    def pct(xs):
+        n_ = len(xs)
+        return {"median": round(xs[n_ // 2] * 1e3, 2), "min": round(xs[0] * 1e3, 2), "max": round(xs[-1] * 1e3, 2),
+                "p10": round(xs[n_ // 10] * 1e3, 2), "p90": round(xs[(9 * n_) // 10] * 1e3, 2), "reps": n_}
     return {
         "value": 1.0 / (per_layer_row * layers), "unit": "tokens/s", "cores": nthr, "host_cpus": ncpu, "kind": "port",
-        "pinned_to_cpus": sorted(prev_aff)[:nthr] if prev_aff is not None else None,
-        "value_at_min": 1.0 / (ds[0] * layers), "value_at_max": 1.0 / (ds[-1] * layers),
-        "ms_per_row_and_layer": {"median": round(per_layer_row * 1e3, 2), "min": round(ds[0] * 1e3, 2), "max": round(ds[-1] * 1e3, 2),
-                                 "p10": round(ds[reps // 10] * 1e3, 2), "p90": round(ds[(9 * reps) // 10] * 1e3, 2)},
-        "sample": f"ONE batch row (of the {B} the GPU step processes) x {nh} heads x T={T} x 1 layer, {reps} reps after 3 warm-up, "
-                  f"torch.set_num_threads({nthr}): unpack+dequant K,V + 2 matmuls, median {per_layer_row * 1e3:.0f} ms per row and layer "
-                  f"(pack of a full {T}-token prompt {sorted(pack)[reps // 2] * 1e3:.0f} ms, not in value); value = 1 / (median x {layers} "
-                  f"layers) = tokens/s of one sequence, extrapolated linearly over the batch (a batch of {B} takes {B}x as long per "
-                  f"step and yields {B} tokens: same tokens/s)",
+        "pinned_to_cpus": cpus if prev_aff is not None else None, "pinning": pin_note, "reps": reps,
+        "value_at_p10": 1.0 / (ds[reps // 10] * layers), "value_at_p90": 1.0 / (ds[(9 * reps) // 10] * layers),
+        "p10_p90_spread_vs_median": [round(ds[reps // 10] / per_layer_row - 1, 3), round(ds[(9 * reps) // 10] / per_layer_row - 1, 3)],
+        "ms_per_row_and_layer": pct(ds),
+        "pack_ms_per_row_and_layer": pct(ps),
+        "sample": f"ONE batch row (of the {B} the GPU step processes) x {nh} heads x T={T} x 1 layer, {reps} reps after 5 warm-up, "
+                  f"torch.set_num_threads({nthr}) on {pin_note}: unpack -> fp16 mul -> fp16 add (K and V) + 2 matmuls, median "
+                  f"{per_layer_row * 1e3:.0f} ms per row and layer (pack of a full {T}-token prompt {ps[len(ps) // 2] * 1e3:.0f} ms, reported "
+                  f"separately, not in value); value = 1 / (median x {layers} layers) = tokens/s of one sequence, extrapolated linearly "
+                  f"over the batch (a batch of {B} takes {B}x as long per step and yields {B} tokens: same tokens/s)",
         "port_of": "quant/new_pack.py:51-83 unpack_and_dequant_{k,v}cache + torch.matmul (procedure of quant/test.py:187-195), "
                    "vectorised (oracle/torch_fakequant.py, checked bit for bit against the C oracle)",
     }
@@ -242,6 +392,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: a sleep per step (launcher / reduction / JSON plumbing on CPU, gloo)")
     ap.add_argument("--form", default="auto", help="matrix-pipe layout, A/B: auto (the library's launch plan) | split (two launches) | "
                                                    "row (one launch, a block per row) | slicesN (one launch, N slices per row)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the roofline_config4 / _config4_4bit / _config5_slice objects")
     ap.add_argument("--kgemv-passes", type=int, default=10, help="timed passes over the rotating caches of the single-layer K-GEMV lines")
     args = ap.parse_args()
 
@@ -325,12 +476,7 @@ def main():
         e0, e1 = klib.kivi_event_create(), klib.kivi_event_create()
         klib.kivi_set_launch_events(e0, e1)
         kb = kgemv_bytes(info["B"], info["nh"], info["nh_kv"], info["K"], info["N"], info["group_size"], info["bits"])
-        rb = None
-        if "Tv" in info:   # what the fused decode-row launch moves: packed K + packed V + fp16 residual / window + q + out
-            Bq, nhq, nkv, Dq = info["B"], info["nh"], info["nh_kv"], info["K"]
-            rb = (kb - Bq * nhq * info["N"] * 2
-                  + vgemv_bytes(Bq, nhq, nkv, Dq, info["Tv"], info["group_size"], info["v_bits"]) - Bq * nhq * info["Tv"] * 2
-                  + Bq * nkv * (info["k_res"] + info["v_res"]) * Dq * 2)
+        rb = row_bytes(info) if "Tv" in info else None     # what the fused decode-row launch moves
         kev.append((e0, e1, kb, rb))
 
     if not args.no_kernel_events:
@@ -367,21 +513,11 @@ def main():
             tot_bytes = sum((r if row_fused else n) for _, _, n, r in kev)
             avg_us = sum(us) / len(us)
             achieved = tot_bytes / (sum(us) * 1e-6) / 1e9
-            traffic = None
-            traffic_src = None
-            profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
-            if profs:           # HBM bytes per launch from the newest rocprofv3 --pmc passes of the same command (profiles/)
-                try:
-                    pj = json.load(open(profs[-1]))
-                    want = {"B": B, "nh": nh, "nh_kv": nh_kv, "prompt": T0, "bits": bits, "group": g, "residual": R}
-                    # (one entry per kernel and configuration: "<kernel>" or "<kernel>@<label>")
-                    ent = next((e for key, e in pj.get("kernels", {}).items() if key.split("@")[0] == kname and e.get("config") == want), None)
-                    if ent:
-                        traffic = ent["hbm_bytes_per_launch"]
-                        traffic_src = ("profiles/" + os.path.basename(profs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                       "passes of this command, x2 gfx950 FETCH_SIZE correction; a tracked measurement, not collected in this run)")
-                except Exception:
-                    traffic = None
+            # HBM bytes per launch from the newest tracked rocprofv3 --pmc passes of the same command (profiles/)
+            traffic, traffic_src = pmc_traffic_entry(kname, {"B": B, "nh": nh, "nh_kv": nh_kv, "prompt": T0, "bits": bits, "group": g, "residual": R})
+            if traffic_src:
+                traffic_src += (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command, x2 gfx950 FETCH_SIZE correction; "
+                                "a tracked measurement, not collected in this run)")
             mf = getattr(layers[0], "layout", "hook") == "mfma"
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -511,6 +647,19 @@ def main():
             "roofline_single_layer_kgemv": single,
             "roofline_single_layer_kgemv_mf_layout": single_mf,
         }
+        default_workload = (B, nh, nh_kv, D, T0, bits, g, R, L) == (32, 32, 32, 128, 4080, 2, 32, 32, 32) and args.form == "auto"
+        if world == 1 and default_workload and not args.no_extra_configs and not args.unfused:
+            # the other BASELINE.json configurations (driver-visible: these keys ride on the one JSON line); the headline's caches are
+            # released first
+            del layers[:]
+            qs.clear(); ks.clear(); vs.clear()
+            torch.cuda.empty_cache()
+            for key, label, c in EXTRA_CONFIGS:
+                try:
+                    out[key] = extra_config_roofline(label, c, dev, klib)
+                except Exception as e:          # instrumentation must never cost the headline line
+                    out[key] = {"workload": label, "error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, nh, (T0 // R) * R, D, g, bits, L)   # the packed K prefix holds floor(T0 / R) * R tokens
         print(json.dumps(out))

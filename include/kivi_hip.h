@@ -25,7 +25,7 @@
  *                               reference extension's own argument layouts)
  *               a layer step:   kivi_decode_layer (hook-state cache: any 2- / 4-bit shape), kivi_mf_decode_layer and its
  *                               hipGraph form kivi_mf_decode_layer_dyn + kivi_mf_step_* (matrix-pipe cache: g = 32, D = 128,
- *                               2-bit with nh / nh_kv in {1, 4, 8} or 4-bit with nh / nh_kv = 4), with the packers of that
+ *                               2-bit with nh / nh_kv in {1, 4, 8} or 4-bit with nh / nh_kv in {1, 4}), with the packers of that
  *                               cache: kivi_kt_pack, kivi_vt_pack, kivi_kt_relayout, kivi_vt_relayout
  *   BUILDING BLOCKS (what the layer steps are composed of; exported for tests, tools and callers that keep their own cache
  *               bookkeeping -- same contracts, but no stability promise beyond the ABI version):  kivi_gemv_k_paged,
@@ -263,7 +263,7 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
 /* ------------------------------------ grouped queries on the matrix pipe --- */
 
 /*
- * MFMA-friendly cache layout (group_size 32, head_dim 128; bits = 2: nh / nh_kv in {1, 4, 8}; bits = 4 (round 4): nh / nh_kv = 4,
+ * MFMA-friendly cache layout (group_size 32, head_dim 128; bits = 2: nh / nh_kv in {1, 4, 8}; bits = 4: nh / nh_kv = 4 (round 4) or 1 (round 6: multi-head KIVI-4, e.g. LongChat-7B-32K),
  * the reference's published Mistral-7B + KIVI-4 shape): round 2 introduced it for grouped-query models, round 3 uses it for
  * multi-head models too (the matrix pipe takes the per-code multiply-adds off the vector ALU, which is what bounds the
  * hook-layout kernels).  Every entry point below takes `bits` and refuses (KIVI_EUNSUPPORTED) what is outside these sets.

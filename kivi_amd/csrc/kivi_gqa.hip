@@ -710,23 +710,14 @@ static int mf_plan(int R, int units, int64_t n_rows, int nsbk, int res_cap, int 
             const bool ok = f1 <= nsbk && f1 <= 64 && (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1 <= 8192 && units <= KIVI_GQA_MAX_SLICED_UNITS;
             return ok ? f1 : 0;
         }
-        if (n_rows > MF_ROW1_CAP) {
-            // multi-head rows beyond 16 super-blocks (round 6; the reference's LongChat-7B-32K runs, docs/long_bench.md:5-26): ONE launch,
-            // every row cut into S slices of whole super-blocks, a block of mf_row4_kernel<R = 1> each (four blocks per CU) -- the
-            // fewest slices whose score row fits the block's 8192-key row, then doubled while the grid stays within the 4 blocks per
-            // CU that are resident at once and a slice keeps >= 4 super-blocks (one per wave of its block in the K walk).  Rounds 3-5
-            // ran these rows in two launches (scores + statistics through memory).
-            if (flags & KIVI_GQA_FORCE_ROW) return 0;
-            auto blk1 = [&](int S_) -> int64_t {
-                const int spb = (nsbk + S_ - 1) / S_;
-                return (int64_t)(spb > 2 ? spb : 2) * KIVI_MF_SB_TOKENS + res_cap + 1;
-            };
-            int S = 2;
-            while (S <= nsbk && S <= 64 && blk1(S) > 8192) S++;
-            if (S > nsbk || S > 64 || units > KIVI_GQA_MAX_SLICED_UNITS) return 0;
-            while ((int64_t)units * S * 2 <= 1024 && 2 * S <= 64 && (nsbk + 2 * S - 1) / (2 * S) >= 4) S *= 2;
-            return S;
-        }
+        // Multi-head rows beyond 16 super-blocks (the reference's LongChat-7B-32K runs, docs/long_bench.md:5-26): TWO launches.  Round 6
+        // put the sliced one-launch form (mf_row4_kernel<R = 1>: the fewest slices whose score row fits a block, doubled while the grid
+        // stays within the 4 blocks per CU) into this plan and measured it against the two launches on one box (profiles/
+        // r06_long_rows.log, ms per 32-layer step, sliced / two launches): B = 8 x 32k 6.05 / 5.08, B = 16 x 32k 10.48 / 9.48, B = 8 x 16k
+        // 2.96 / 2.87, B = 16 x 16k 5.52 / 5.10, one 32k row 2.30 / 1.11 -- a multi-head row is ONE head, so the slices' statistics
+        // exchange and the in-stream softmax are pure overhead (as for the half-row slices of the headline shape, round 5), while the
+        // two launches already stream at 0.66-0.71 of the roofline each.  KIVI_GQA_SLICES(n) keeps the sliced form reachable (tests, A/B).
+        if (n_rows > MF_ROW1_CAP) return 0;
         // too few units: the split two-launch form fills the chip better -- unless the rows are short enough for the eight waves
         // of a row block to take one super-block each (<= 4096 packed keys): then one launch beats two whatever the batch
         // (32-160 rows: 0.64-0.68 ms per 32-layer step against 0.68-0.86; at 8000 keys 1.02 against 0.79, profiles/r03_other_shapes.log)
@@ -794,7 +785,7 @@ extern "C" int kivi_gqa_scores(const void* q, int64_t q_sb, int64_t q_sh, const 
     KIVI_MF_SHAPE_CHECK("kivi_gqa_scores");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_scores: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
-    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4, KIVI_EUNSUPPORTED, "kivi_gqa_scores: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4 || nh == nh_kv, KIVI_EUNSUPPORTED, "kivi_gqa_scores: 4-bit codes on the matrix pipe need nh / nh_kv in {1, 4} (got %d / %d)", nh, nh_kv);
     KIVI_REQUIRE(T >= 0 && T % 32 == 0, KIVI_EINVAL, "kivi_gqa_scores: T=%lld must be a multiple of 32", (long long)T);
     KIVI_REQUIRE(mf_store_ok(kt, kt_sb, kt_sh, kt_ss, bits), KIVI_EALIGN, "kivi_gqa_scores: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(kt_range && (uintptr_t)kt_range % 4 == 0, KIVI_EINVAL, "kivi_gqa_scores: null / misaligned range flags");
@@ -843,7 +834,7 @@ extern "C" int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, co
     KIVI_MF_SHAPE_CHECK("kivi_gqa_output");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_output: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
-    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4, KIVI_EUNSUPPORTED, "kivi_gqa_output: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4 || nh == nh_kv, KIVI_EUNSUPPORTED, "kivi_gqa_output: 4-bit codes on the matrix pipe need nh / nh_kv in {1, 4} (got %d / %d)", nh, nh_kv);
     KIVI_REQUIRE(T >= 0, KIVI_EINVAL, "kivi_gqa_output: negative length");
     KIVI_REQUIRE(mf_store_ok(vt, vt_sb, vt_sh, vt_ss, bits), KIVI_EALIGN, "kivi_gqa_output: cache storage must be 16-byte aligned super-blocks");
     KIVI_REQUIRE(probs && (uintptr_t)probs % 16 == 0 && p_sb % 8 == 0 && p_sh % 8 == 0 && p_sh >= ((T + 7) & ~(int64_t)7), KIVI_EALIGN,
@@ -894,7 +885,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     KIVI_MF_SHAPE_CHECK("kivi_gqa_decode");
     KIVI_REQUIRE(nh > 0 && nh % nh_kv == 0 && (nh / nh_kv == 1 || nh / nh_kv == 4 || nh / nh_kv == 8), KIVI_EUNSUPPORTED,
                  "kivi_gqa_decode: nh / nh_kv must be 1, 4 or 8 (got %d / %d)", nh, nh_kv);
-    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4, KIVI_EUNSUPPORTED, "kivi_gqa_decode: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, nh_kv);
+    KIVI_REQUIRE(bits == 2 || nh / nh_kv == 4 || nh == nh_kv, KIVI_EUNSUPPORTED, "kivi_gqa_decode: 4-bit codes on the matrix pipe need nh / nh_kv in {1, 4} (got %d / %d)", nh, nh_kv);
     const int R = nh / nh_kv;
     const int units = B * nh_kv;
     KIVI_REQUIRE(p->Tq >= 0 && p->Tq % 32 == 0 && p->Tv >= 0 && p->k_res_len >= 0 && p->k_res_len <= 128 && p->v_res_len >= 0 &&

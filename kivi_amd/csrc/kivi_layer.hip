@@ -129,8 +129,8 @@ extern "C" int kivi_mf_decode_layer(const kivi_mf_layer_desc* L, int64_t* st, co
     KIVI_REQUIRE((L->bits == 2 || L->bits == 4) && L->group_size == 32 && L->D == 128, KIVI_EUNSUPPORTED,
                  "kivi_mf_decode_layer: the MFMA cache layout covers 2- and 4-bit codes, group_size 32, head_dim 128 (got %d / %d / %d)",
                  L->bits, L->group_size, L->D);
-    KIVI_REQUIRE(L->bits == 2 || (L->nh_kv > 0 && nh == 4 * L->nh_kv), KIVI_EUNSUPPORTED,
-                 "kivi_mf_decode_layer: 4-bit codes on the matrix pipe need nh / nh_kv = 4 (got %d / %d)", nh, L->nh_kv);
+    KIVI_REQUIRE(L->bits == 2 || (L->nh_kv > 0 && (nh == 4 * L->nh_kv || nh == L->nh_kv)), KIVI_EUNSUPPORTED,
+                 "kivi_mf_decode_layer: 4-bit codes on the matrix pipe need nh / nh_kv in {1, 4} (got %d / %d)", nh, L->nh_kv);
     KIVI_REQUIRE(L->B > 0 && L->nh_kv > 0 && nh > 0 && nh % L->nh_kv == 0, KIVI_EINVAL, "kivi_mf_decode_layer: bad shape (B=%d nh=%d nh_kv=%d)",
                  L->B, nh, L->nh_kv);
     KIVI_REQUIRE(L->kt && L->vt && L->k_res && L->v_res && L->scores && L->stats && L->workspace && L->kt_range && L->vt_range, KIVI_EINVAL,

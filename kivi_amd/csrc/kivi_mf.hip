@@ -57,7 +57,7 @@ constexpr int mf_k_lds_words() { return (R == 1 ? 64 : 0) + R * 256; }   // R = 
 // DIAG (tuning builds, wrong results): 1 = nothing leaves the LDS (no flush), 2 = scores stored without the statistics
 template <int R, int W, int RING, int DIAG = 0, int BITS = 2>
 __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw) {
-    static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
+    static_assert(BITS == 2 || R == 4 || R == 1, "4-bit codes: nh / nh_kv in {1, 4}");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     // the step's lengths: by value, or device-resident (a.dyn).  (Only these two scalars: a mutable copy of the whole argument block
     // cost 3-8 % of the raw-score launch -- the flush lambda then reads its fields from a local object instead of the kernarg segment.)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * W) void mf_k_kernel(const GqaKArgs a, int spw)
     const int64_t tok_end = (int64_t)(sb0 + seq.n_sb) * KIVI_MF_SB_TOKENS;
     seq.ng_total = (int)(((Tq < tok_end ? Tq : tok_end) - (int64_t)sb0 * KIVI_MF_SB_TOKENS) / 32);
     if constexpr (R == 1) {
-        mf_k_seq1<RING>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, rsh,
+        mf_k_seq1<RING, BITS>(rk, seq, a.q + b * a.q_sb + (int64_t)h0 * a.q_sh, lds_w, rsh,
                         [&](int, int tt, float v) { lds_o[tt] = f2h_bits(v); }, flush_sb);
     } else {
         // R = 4 / 8: the same continuous walk (mf_k_seqR: scale requested a round ahead, the code ring runs across super-blocks)
@@ -183,9 +183,10 @@ int run_mf_k(GqaKArgs& a, int units, int bits, hipStream_t s) {
     const int W = ((int64_t)units * chunks >= 2048) ? 4 : 1;
     a.sb_blocks = (chunks + W - 1) / W;
     if ((int64_t)a.res_blocks + (int64_t)units * a.sb_blocks == 0) return 0;
-    KIVI_REQUIRE(bits == 2 || (bits == 4 && a.ratio == 4), KIVI_EUNSUPPORTED, "mf_k: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, a.ratio);
-    if (bits == 4) {                                                // 4-bit codes: nh / nh_kv = 4
-        if (W == 4) launch_mf_k<4, 4, 4, 0, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4, 0, 4>(a, units, spw, s);
+    KIVI_REQUIRE(bits == 2 || (bits == 4 && (a.ratio == 4 || a.ratio == 1)), KIVI_EUNSUPPORTED, "mf_k: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, a.ratio);
+    if (bits == 4) {                                                // 4-bit codes: nh / nh_kv in {1, 4}
+        if (a.ratio == 1) { if (W == 4) launch_mf_k<1, 4, 2, 0, 4>(a, units, spw, s); else launch_mf_k<1, 1, 2, 0, 4>(a, units, spw, s); }
+        else if (W == 4) launch_mf_k<4, 4, 4, 0, 4>(a, units, spw, s); else launch_mf_k<4, 1, 4, 0, 4>(a, units, spw, s);
         return kivi_launch_status("mf_k");
     }
     // two code blocks in flight per wave: 39.2 us per BASELINE configs[1] launch against 40.8 with four (fewer registers, the
@@ -269,7 +270,7 @@ constexpr int MF_PW = 200;                                       // >= NW * TW o
 // HL (R = 4): hi / lo of p'' * scale in MFMA rows (MfVStream<4, ., true>), as in mf_row4_kernel
 template <int R, int RING, bool PROB, bool HL = false, int BITS = 2>
 __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArgs a_in) {   // (R = 8: two blocks per CU, gqa_v_slices)
-    static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
+    static_assert(BITS == 2 || R == 4 || R == 1, "4-bit codes: nh / nh_kv in {1, 4}");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];                          // 4 waves x (R x 256 words of p'' | 128 words of dot sums)
     GqaVArgs a = a_in;
     a.take_dyn();
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
 // ak.dump (KIVI_GQA_DUMP_SCORES, tests): the fp16 row the softmax consumes (scaled, mask added) also goes to ak.out
 // OCC: waves per SIMD the register budget allows (4: 128 registers; 2: the few-rows instantiation with rings of 8 -- at most one
 // block per CU is resident anyway, so a wave may hold a half super-block of K and 8 blocks of V in flight)
-template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, int OCC = 4>
+// BITS = 4 (round 6): 4-bit K / V of a multi-head model (Llama-2-7B / LongChat-7B with KIVI-4) over the 4-bit super-blocks
+template <int KRING, int VRING, int NW, bool DBG = false, bool PRIO = true, int OCC = 4, int BITS = 2>
 __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad) {
     constexpr int NTH = NW * 64;
     GqaKArgs ak = ak_in;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
         const int last = wave + (seq.n_sb - 1) * NW;                // this wave's last super-block
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * last) < 16 ? (NG - 16 * last) : 16) : 0;
-        mf_k_seq1<KRING>(rk, seq, qrow, q_lds[wave], krsh,
+        mf_k_seq1<KRING, BITS>(rk, seq, qrow, q_lds[wave], krsh,
                          [&](int sb, int tt, float v) {
                              const uint16_t h = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
                              row[sb * KIVI_MF_SB_TOKENS + tt] = h;
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     const int nbw = (NB + NW - 1) / NW;
     const int b_lo = wave * nbw;
     const int b_hi = (b_lo + nbw < NB) ? b_lo + nbw : NB;
-    MfVStream<1, VRING> vs;
+    MfVStream<1, VRING, false, BITS> vs;
     vs.prime(rv, (uint32_t)(av.vt.sb_s * 4), b_lo, b_hi);
     // ---- residual scores q . [K_full | k_new] (fp32 accumulate, one rounding: the reference's fp16 matmul, :337) + K append
     for (int idx = threadIdx.x; idx < L * 8; idx += NTH) {
@@ -534,14 +536,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     stamp(5);
 
     // the fp16 window rows (and the token leaving it) are requested before the softmax and used after it
-    GqaWindow<1, NTH, MF_PW, (NW == 8 ? 8 : 16)> win;              // (prefetched tokens per wave: the whole share of a 33- / 65-token window)
+    GqaWindow<1, NTH, MF_PW, (NW == 8 ? 8 : 16), BITS> win;              // (prefetched tokens per wave: the whole share of a 33- / 65-token window)
     win.request(av, b, hk, 0, av.res_len + 1, av.flush != 0);
     for (int j = threadIdx.x; j < MF_PW; j += NTH) pw[0][j] = 0;    // (the window walk reads whole 8-token groups: zeros past the window;
                                                                    //  the softmax writes the probabilities behind its two barriers)
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int sp = mf_row_softmax<NTH, (8192 + 128 + NTH * 4 - 1) / (NTH * 4)>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
+    const int sp = mf_row_softmax<NTH, (8192 + 128 + NTH * 4 - 1) / (NTH * 4), BITS>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
                                                         (ak.dump & 1) ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
     __syncthreads();
     stamp(7);
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         vs.run(A, rv, b_lo, b_hi, row, 0, 0);
         stamp(9);
-        mf_v_finish<1, VRING, false>(A, zl[wave], red[wave]);
+        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave]);
     }
     __syncthreads();
     stamp(10);
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     constexpr int NTH = NW * 64;
     static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
     static_assert((R == 4) || ((R == 8 || R == 1) && !VHL), "R = 1 / 8: chained hi / lo sV");
-    static_assert(BITS == 2 || R == 4, "4-bit codes: nh / nh_kv = 4");
+    static_assert(BITS == 2 || R == 4 || R == 1, "4-bit codes: nh / nh_kv in {1, 4}");
     GqaKArgs ak = ak_in;
     GqaVArgs av = av_in;
     ak.take_dyn();
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
             __builtin_amdgcn_wave_barrier();
         };
         if constexpr (R == 1) {
-            mf_k_seq1<KRING>(rk, seq, q_h0, q_lds[wave], krsh, [&](int sb, int tt, float v) {
+            mf_k_seq1<KRING, BITS>(rk, seq, q_h0, q_lds[wave], krsh, [&](int sb, int tt, float v) {
                 rows[(sb - sb_lo) * KIVI_MF_SB_TOKENS + tt] = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
             }, seg_done);
         } else {
@@ -1115,9 +1117,12 @@ int kivi_mf_run_v(const void* v_args, int prob, int bits, hipStream_t s) {
 #endif
     const dim3 grid((unsigned)(a.units * a.S + a.win_blocks));
     const size_t lds = (size_t)4 * (R * 256 + 128) * 4;
-    KIVI_REQUIRE(bits == 2 || (bits == 4 && R == 4), KIVI_EUNSUPPORTED, "mf_v: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, R);
-    if (bits == 4) {                                                // 4-bit codes: nh / nh_kv = 4
-        if (prob) KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, true, false, 4>), grid, dim3(256), lds, s, a);
+    KIVI_REQUIRE(bits == 2 || (bits == 4 && (R == 4 || R == 1)), KIVI_EUNSUPPORTED, "mf_v: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, R);
+    if (bits == 4) {                                                // 4-bit codes: nh / nh_kv in {1, 4}
+        if (R == 1) {
+            if (prob) KIVI_LAUNCH_LDS((mf_v_kernel<1, 2, true, false, 4>), grid, dim3(256), lds, s, a);
+            else KIVI_LAUNCH_LDS((mf_v_kernel<1, 2, false, false, 4>), grid, dim3(256), lds, s, a);
+        } else if (prob) KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, true, false, 4>), grid, dim3(256), lds, s, a);
         else KIVI_LAUNCH_LDS((mf_v_kernel<4, 4, false, false, 4>), grid, dim3(256), lds, s, a);
         return kivi_launch_status("mf_v");
     }
@@ -1206,7 +1211,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
     GqaKArgs& k = *(GqaKArgs*)k_args;
     const GqaVArgs& v = *(const GqaVArgs*)v_args;
     const int64_t n = n_rows;
-    KIVI_REQUIRE(bits == 2 || (bits == 4 && k.ratio == 4), KIVI_EUNSUPPORTED, "mf_row: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, k.ratio);
+    KIVI_REQUIRE(bits == 2 || (bits == 4 && (k.ratio == 4 || k.ratio == 1)), KIVI_EUNSUPPORTED, "mf_row: %d-bit codes with nh / nh_kv = %d have no matrix-pipe kernel", bits, k.ratio);
     KIVI_REQUIRE(S == 1 || k.ratio == 1 || k.ratio == 4 || k.ratio == 8, KIVI_EUNSUPPORTED, "mf_row: no sliced form for nh / nh_kv = %d", k.ratio);
     if (k.ratio == 4 || k.ratio == 8 || (k.ratio == 1 && (S > 1 || slice_kernel))) {
         const int R = k.ratio;
@@ -1235,7 +1240,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (ft && atoi(ft) && S > 1) k.dump |= 2;
 #endif
         if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; k.err_ws = nullptr; k.err_host = nullptr; }
-        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0, opt8p = 0, opt4p = 0, opt44p = 0;
+        static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0, opt14 = 0, opt8p = 0, opt4p = 0, opt44p = 0;
         // a block per row (S = 1): the phase-softmax flow (PSM, see mf_row4_kernel); slices: the in-stream flow
         bool psm = S == 1 && R != 1;
 #ifdef KIVI_TUNING
@@ -1249,6 +1254,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad, S);   \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
+        if (R == 1 && bits == 4) KIVI_ROW4_LAUNCH(opt14, 2, 3, 4, false, false, 1, 4, 4);
         if (R == 1) KIVI_ROW4_LAUNCH(opt1, 2, 3, 4, false, false, 1, 2, 4);
         if (R == 8 && psm) KIVI_ROW4_LAUNCH(opt8p, 4, 2, 4, false, false, 8, 2, 2, true);
         if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
@@ -1299,6 +1305,12 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
     // ring (2 KiB of K / 3 KiB of V in flight stream ~3 GB/s per wave): rings of 8 blocks, 256 registers per wave
     static const char* fdp = KIVI_TUNE_ENV("KIVI_MF_ROW_DEEP");          // tuning builds: 0 / 1 forces either
     const bool deep = fdp ? atoi(fdp) != 0 : units <= 256;
+    if (bits == 4) {                                               // 4-bit multi-head rows (round 6): a ring slot is 2 x 16 bytes -- rings of (2, 3) fit four waves per SIMD all the same
+        if (deep) KIVI_LAUNCH_LDS((mf_row_kernel<4, 4, 8, false, true, 2, 4>), grid, dim3(512), lds, s, k, v, n_pad);
+        else if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8, false, true, 4, 4>), grid, dim3(512), lds, s, k, v, n_pad);
+        else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4, false, true, 4, 4>), grid, dim3(256), lds, s, k, v, n_pad);
+        return kivi_launch_status("mf_row");
+    }
     if (deep) KIVI_LAUNCH_LDS((mf_row_kernel<8, 8, 8, false, true, 2>), grid, dim3(512), lds, s, k, v, n_pad);
     else if (nw8) KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 8>), grid, dim3(512), lds, s, k, v, n_pad);
     else KIVI_LAUNCH_LDS((mf_row_kernel<2, 3, 4>), grid, dim3(256), lds, s, k, v, n_pad);

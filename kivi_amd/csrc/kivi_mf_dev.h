@@ -159,9 +159,13 @@ struct MfKSeq {
 // q_lds: 64 words of this wave's LDS (the normalised q operand is parked there: kept in registers, it and the loop-invariant
 // B operand of the zero-point product hipcc derives from it hold 32 registers across the whole loop).
 // rsh: the unit's range shift (wave-uniform; mf_load_q).
-template <int RING, typename Sink, typename Done>
+// BITS = 4 (round 6: multi-head KIVI-4, e.g. LongChat-7B / Llama-2-7B with 4-bit K / V): the same walk over the 4-bit super-blocks
+// (kivi_mfma_layout.h, "KT4"): a ring slot is two 16-byte loads (token tile 0 / 1), the four registers of a B operand carry ONE
+// exponent (aexp_b<4> = 6), a view is 2 instructions per register instead of 11 per 8.
+template <int RING, int BITS = 2, typename Sink, typename Done>
 __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint16_t* q_row, uint32_t* q_lds, int rsh, Sink&& sink, Done&& done) {
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring of 2, 4 or 8 code blocks");
+    typedef MfL<BITS> LY;
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     const int gp = m & 7;
@@ -181,17 +185,17 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
         const uint32_t so = sb_off(hq >> 1) + (uint32_t)(hq & 1) * 2048u;      // half a super-block: 8 groups x 256 bytes
         const uint32_t ro = live ? row_off : MF_DEAD_OFF;
 #pragma unroll
-        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_SCALE_WORD0 * 4 + ro + c * 512, so);
+        for (int c = 0; c < 4; c++) sv[c] = buf_load<u32x4, true>(rk, LY::SCALE_WORD0 * 4 + ro + c * 512, so);
 #pragma unroll
-        for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, KIVI_MF_SB_MN_WORD0 * 4 + ro + c * 512, so);
+        for (int c = 0; c < 4; c++) mv[c] = buf_load<u32x4, true>(rk, LY::MN_WORD0 * 4 + ro + c * 512, so);
     };
     request_half(0, true);
     const int g_last = W.ng_total - 1;
-    u32x4 wr[RING];
+    MfW<BITS> wr[RING];
     auto request_group = [&](int slot, int gi) {
         const bool live = gi <= g_last;
         const int gc = live ? gi : g_last;                          // (a valid scalar offset either way)
-        wr[slot] = buf_load<u32x4, true>(rk, live ? (uint32_t)(lane * 16) : MF_DEAD_OFF, sb_off(gc >> 4) + (uint32_t)(gc & 15) * 1024u);
+        mf_load_block<BITS>(wr[slot], rk, live ? (uint32_t)(lane * 16) : MF_DEAD_OFF, sb_off(gc >> 4) + (uint32_t)(gc & 15) * (uint32_t)(LY::BLOCK_WORDS * 4));
     };
 #pragma unroll
     for (int i = 0; i < RING; i++) {
@@ -212,15 +216,15 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
     const int ex = (int)(amax >> 10);
     const int sq = amax >= 0x7C00u ? 0 : 15 - (ex ? ex : 1);
     const int sa = sq + rsh;                                        // placement of the A operand (mf_load_q)
-    const uint32_t zf01 = mf_zfac(0, rsh), zf23 = mf_zfac(2, rsh);
+    const uint32_t zf01 = mf_zfac<BITS>(0, rsh), zf23 = mf_zfac<BITS>(2, rsh);
     {
         uint32_t qq0[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sa + aexp(i));
-                const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sa + aexp(i));
+                const float f0 = __builtin_ldexpf(h2f_bits(qv[c][2 * i]), sa + aexp_b<BITS>(i));
+                const float f1 = __builtin_ldexpf(h2f_bits(qv[c][2 * i + 1]), sa + aexp_b<BITS>(i));
                 qq0[c][i] = (uint32_t)f2h_bits(f0) | ((uint32_t)f2h_bits(f1) << 16);
             }
         if (m == 0) {
@@ -266,11 +270,11 @@ __device__ __forceinline__ void mf_k_seq1(rsrc_t rk, const MfKSeq& W, const uint
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int gi = hq * 8 + u * 4 + j;
-                const u32x4& w = wr[(UB + j) % RING];
+                const MfW<BITS>& w = wr[(UB + j) % RING];
                 f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const MfB b = mf_views(w[c]);
+                    const MfB b = mf_views_c<BITS>(w, c);
                     const h8 av = as_h8(A[c][0], A[c][1], A[c][2], A[c][3]);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b0, a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b.b1, a1, 0, 0, 0);
@@ -883,7 +887,7 @@ __device__ __forceinline__ uint32_t mf_scale_pair(uint32_t hpair, float inv) {
 // rsh: the range shift of the unit's V store (mf_sp).  dump (KIVI_GQA_DUMP_SCORES, tests; a run-time pointer, null otherwise: the
 // PRODUCT instantiation is the one the stage-A checks run on): the fp16 row as the softmax consumes it (scaled, mask added) also
 // goes to this row of the caller's score buffer.
-template <int NTH, int SMC>
+template <int NTH, int SMC, int BITS = 2>
 __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
                                               uint16_t* pw_row, float* sm_lds, int rsh, uint16_t* dump = nullptr) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
@@ -947,7 +951,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
     const float inv = 1.0f / sum;
     const int sp = mf_sp(sum, rsh);
     const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                   // 2^-10 .. 2^14
-    const _Float16 m_a4 = mf_p_mul_a(false, rsh), m_a6 = mf_p_mul_a(true, rsh);
+    const _Float16 m_a4 = mf_p_mul_a(BITS == 4, rsh), m_a6 = mf_p_mul_a(true, rsh);
     const f2v inv2 = {inv, inv};
 #pragma unroll
     for (int c = 0; c < SMC; c++) {
@@ -971,7 +975,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
                     for (int e = 0; e < 4; e++) {
                         const int j = j0 + e;
                         if (j >= Tv && j < n) pw_row[j - Tv] = pp[e];
-                        q[e] = (j < Tv) ? mf_scale_p(pp[e], sp, j) : (uint16_t)0;
+                        q[e] = (j < Tv) ? mf_scale_p<BITS>(pp[e], sp, j) : (uint16_t)0;
                     }
                     o[0] = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
                     o[1] = (uint32_t)q[2] | ((uint32_t)q[3] << 16);

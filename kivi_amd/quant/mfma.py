@@ -22,10 +22,10 @@ def sb_words(bits: int) -> int:
 
 
 def supported(k_bits: int, v_bits: int, group_size: int, head_dim: int, residual_length: int, ratio: int) -> bool:
-    """2-bit K and V: nh / nh_kv in {1, 4, 8}; 4-bit K and V (round 4): nh / nh_kv = 4."""
+    """2-bit K and V: nh / nh_kv in {1, 4, 8}; 4-bit K and V: nh / nh_kv = 4 (round 4) or 1 (round 6)."""
     if not (group_size == 32 and head_dim == 128 and residual_length % 32 == 0 and k_bits == v_bits):
         return False
-    return (k_bits == 2 and ratio in (1, 4, 8)) or (k_bits == 4 and ratio == 4)
+    return (k_bits == 2 and ratio in (1, 4, 8)) or (k_bits == 4 and ratio in (1, 4))
 
 
 def _flag_words(B: int, nh_kv: int) -> int:

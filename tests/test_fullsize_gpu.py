@@ -180,25 +180,28 @@ def test_4bit_gqa_shapes_on_the_matrix_pipe_stages(oracle, B, T0, kernel, split)
     print("worst ratio vs the 2e-3 attend bar:", worst)
 
 
-@pytest.mark.parametrize("B,T0,kernel,split", [(1, 32768 + 13, "mf_row4_kernel", False), (1, 32768 + 13, "mf_k_kernel", True),
-                                               (4, 4080, "mf_row_kernel", False), (4, 6000, "mf_k_kernel", False), (16, 4080, "mf_row_kernel", False)])
-def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0, kernel, split):
-    """Few (batch row, head) rows: rows longer than the LDS row (B = 1 x 32k keys) run ONE launch with every row cut into slices that
-    exchange their softmax statistics (round 6: mf_row4_kernel<R = 1>; the two-launch form, forced, stays covered), fewer than 192 rows
-    of more than 8 super-blocks (B = 4 x 6000) the two-launch form; rows of at most 8 super-blocks take the eight-wave row kernel
-    whatever the batch (B = 4 / 16 x 4k)."""
+@pytest.mark.parametrize("B,T0,kernel,flags", [(1, 32768 + 13, "mf_k_kernel", 0), (1, 32768 + 13, "mf_row4_kernel", 20 << 8),
+                                               (4, 4080, "mf_row_kernel", 0), (4, 6000, "mf_k_kernel", 0), (16, 4080, "mf_row_kernel", 0)])
+def test_small_batch_mf_split_rows_vs_oracle(oracle, B, T0, kernel, flags):
+    """Few (batch row, head) rows: rows longer than the LDS row (B = 1 x 32k keys) and fewer than 192 rows of more than 8
+    super-blocks (B = 4 x 6000) run the two-launch form with the rows cut into slices (the ONE-launch sliced form of long multi-head
+    rows, KIVI_GQA_SLICES(20): measured slower in round 6, kept and covered); rows of at most 8 super-blocks take the eight-wave row
+    kernel whatever the batch (B = 4 / 16 x 4k)."""
     run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=32, bits=2, g=32, steps=6, samples=[(0, 0), (B - 1, 31)], seed=15, layout="auto",
-                expect_kernel=kernel, extra_flags=_SPLIT if split else 0)
+                expect_kernel=kernel, extra_flags=flags)
 
 
-@pytest.mark.parametrize("B,T0,R,bits", [(8, 32768 + 100, 128, 2), (16, 16384 + 100, 128, 2)])
-def test_longchat_shape_multi_head_long_rows_stages(oracle, B, T0, R, bits):
-    """The reference's LongChat-7B-32K configuration (docs/long_bench.md:5-26: 32 heads = 32 kv heads, KIVI-2, g = 32, R = 128) at
-    16k / 32k keys and B = 8 / 16: multi-head rows beyond 8192 keys in ONE launch (rows cut into 5 / 3 slices, mf_row4_kernel<R = 1>),
-    through a K flush (step 28), outlier key channels, masks, stage by stage against the oracle on sampled units, 9-tuples of the
-    sampled units bit-identical.  (Every unit of the same shape: tests/test_fullcover_gpu.py.)"""
+@pytest.mark.parametrize("B,T0,R,bits,flags,kernel", [(8, 32768 + 100, 128, 2, 0, "mf_k_kernel"), (16, 16384 + 100, 128, 2, 0, "mf_k_kernel"),
+                                                      (8, 32768 + 100, 128, 2, 5 << 8, "mf_row4_kernel"), (8, 32768 + 100, 128, 4, 0, "mf_k_kernel"),
+                                                      (16, 16384 + 100, 128, 4, 3 << 8, "mf_row4_kernel")])
+def test_longchat_shape_multi_head_long_rows_stages(oracle, B, T0, R, bits, flags, kernel):
+    """The reference's LongChat-7B-32K configuration (docs/long_bench.md:5-26: 32 heads = 32 kv heads, KIVI-2 and KIVI-4, g = 32,
+    R = 128) at 16k / 32k keys and B = 8 / 16: multi-head rows beyond 8192 keys on the matrix pipe -- the plan's two launches
+    (mf_k_kernel -> mf_v_kernel) and, forced, ONE launch with the rows cut into 5 / 3 slices (mf_row4_kernel<R = 1>; measured slower,
+    profiles/r06_long_rows.log) --, through a K flush (step 28), outlier key channels, masks, stage by stage against the oracle on
+    sampled units, 9-tuples of the sampled units bit-identical.  (Every unit of the same shapes: tests/test_fullcover_gpu.py.)"""
     seen, worst = run_sampled(B=B, nh=32, nh_kv=32, T0=T0, R=R, bits=bits, g=32, steps=30, samples=[(0, 0), (B - 1, 31), (B // 2, 13)],
-                              seed=24, expect_kernel="mf_row4_kernel", layout="auto", stage_ab=True, outlier=True, masked=True)
+                              seed=24, expect_kernel=kernel, layout="auto", stage_ab=True, outlier=True, masked=True, extra_flags=flags)
     print("worst ratio vs the 2e-3 attend bar:", worst)
 
 

@@ -1,5 +1,6 @@
-"""GPU: 4-bit K / V on the matrix pipe (round 4; kivi_mfma_layout.h "KT4 / VT4", nh / nh_kv = 4 -- the reference's published
-Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53): the packers and relayouts are bit-exact against the reference-layout
+"""GPU: 4-bit K / V on the matrix pipe (kivi_mfma_layout.h "KT4 / VT4": round 4, nh / nh_kv = 4 -- the reference's published
+Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53; round 6, nh == nh_kv -- its multi-head KIVI-4 models, LongChat-7B-32K /
+Llama-2-7B, docs/long_bench.md:5-26): the packers and relayouts are bit-exact against the reference-layout
 4-bit pack (itself bit-exact vs the reference through the golden fixtures), qK^T and sV agree with the oracle's restatement of
 gemv_cuda.cu:265-427 within the north_star GEMV bar, the decode step stage by stage in both forms.  The reference-class hook
 fixtures of this shape (tests/golden/hook_*_b4_*.npz) are replayed by tests/test_hook_gpu.py on every layout."""
@@ -73,7 +74,8 @@ def _blocks(store, nb):
     return torch.cat(out, dim=-1)
 
 
-@pytest.mark.parametrize("B,nh,nh_kv,T", [(1, 4, 1, 32), (2, 8, 2, 544), (1, 4, 1, 1024), (3, 8, 2, 96), (16, 32, 8, 8192), (1, 32, 8, 4096)])
+@pytest.mark.parametrize("B,nh,nh_kv,T", [(1, 4, 1, 32), (2, 8, 2, 544), (1, 4, 1, 1024), (3, 8, 2, 96), (16, 32, 8, 8192), (1, 32, 8, 4096),
+                                          (1, 1, 1, 32), (2, 2, 2, 544), (3, 3, 3, 96), (8, 32, 32, 4096), (1, 4, 4, 32768)])
 def test_gqa4_scores_vs_oracle(mods, oracle, B, nh, nh_kv, T):
     mfma, new_pack, matmul = mods
     k = make_kv(3, B, nh_kv, T, 128, "outlier").cuda()
@@ -88,19 +90,21 @@ def test_gqa4_scores_vs_oracle(mods, oracle, B, nh, nh_kv, T):
     ok, ratio = gemv_close(out[..., :T], ref_gpu.cpu(), rtol=1.5e-3)
     assert ok, ratio
     for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
-        hs = slice(hk * 4, (hk + 1) * 4)
+        hs = slice(hk * (nh // nh_kv), (hk + 1) * (nh // nh_kv))
         ref = oracle.bmm_fA_qB_outer(32, q[b:b + 1, hs].cpu(), code[b:b + 1, hk:hk + 1].cpu(), scale[b:b + 1, hk:hk + 1].cpu(),
                                      mn[b:b + 1, hk:hk + 1].cpu(), BITS)
         ok, ratio = gemv_close(out[b:b + 1, hs, :, :T], ref)
         assert ok, (b, hk, ratio)
 
 
-def test_gqa4_exact_arithmetic(mods):
+@pytest.mark.parametrize("ratio", [4, 1])
+def test_gqa4_exact_arithmetic(mods, ratio):
     """Integer-valued K / V (codes = values 0..15) and small-integer q / power-of-two probabilities: every product and sum is
     exact, so the field positions, the four views, the head mapping, the hi / lo split and the centring (-7.5) must reproduce
     the dequantised matmuls exactly."""
     mfma, _, _ = mods
-    B, nh, nh_kv, T = 2, 8, 2, 1056
+    B, nh_kv, T = 2, 2, 1056
+    nh = nh_kv * ratio
     g = torch.Generator().manual_seed(0)
     k = torch.randint(0, 16, (B, nh_kv, T, 128), generator=g).half().cuda()
     k[:, :, ::32] = 0
@@ -110,7 +114,7 @@ def test_gqa4_exact_arithmetic(mods):
     mfma.kt_pack(k, store, 0, 32, BITS)
     out = torch.empty((B, nh, 1, T), dtype=torch.float16, device="cuda")
     mfma.gqa_scores(q, store, T, out, 32, BITS)
-    ref = torch.matmul(q.float(), k.float().repeat_interleave(4, dim=1).transpose(2, 3))
+    ref = torch.matmul(q.float(), k.float().repeat_interleave(ratio, dim=1).transpose(2, 3))
     assert torch.equal(out.float(), ref.half().float())
     T = 700
     v = torch.randint(0, 16, (B, nh_kv, T, 128), generator=g).half()
@@ -121,12 +125,13 @@ def test_gqa4_exact_arithmetic(mods):
     vst = mfma.alloc_store(B, nh_kv, 2, "cuda", BITS)
     mfma.vt_pack(v, vst, 32, BITS)
     o = mfma.gqa_output(p, vst, T, None, 32, BITS)
-    ref = torch.matmul(p[..., :T].float(), v.float().repeat_interleave(4, dim=1))
+    ref = torch.matmul(p[..., :T].float(), v.float().repeat_interleave(ratio, dim=1))
     assert torch.equal(o.float(), ref.half().float())
 
 
 @pytest.mark.parametrize("kind", ["softmax", "uniform", "sparse"])
-@pytest.mark.parametrize("B,nh,nh_kv,T", [(2, 4, 1, 33), (1, 8, 2, 544), (2, 32, 8, 8192), (1, 32, 8, 32768)])
+@pytest.mark.parametrize("B,nh,nh_kv,T", [(2, 4, 1, 33), (1, 8, 2, 544), (2, 32, 8, 8192), (1, 32, 8, 32768),
+                                          (2, 1, 1, 33), (1, 2, 2, 544), (4, 32, 32, 4064), (1, 4, 4, 32768)])
 def test_gqa4_output_vs_oracle(mods, oracle, B, nh, nh_kv, T, kind):
     mfma, new_pack, matmul = mods
     v = make_kv(21, B, nh_kv, T, 128, "outlier" if kind == "softmax" else "randn").cuda()
@@ -143,15 +148,16 @@ def test_gqa4_output_vs_oracle(mods, oracle, B, nh, nh_kv, T, kind):
     ok, ratio = gemv_close(out, ref_gpu.cpu(), rtol=1.5e-3)
     assert ok, ratio
     for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
-        hs = slice(hk * 4, (hk + 1) * 4)
+        hs = slice(hk * (nh // nh_kv), (hk + 1) * (nh // nh_kv))
         ref = oracle.bmm_fA_qB_outer(32, probs[b:b + 1, hs, :, :T].cpu().contiguous(), code[b:b + 1, hk:hk + 1].cpu(),
                                      scale[b:b + 1, hk:hk + 1].cpu(), mn[b:b + 1, hk:hk + 1].cpu(), BITS)
         ok, ratio = gemv_close(out[b:b + 1, hs], ref, rtol=1e-3)
         assert ok, (b, hk, ratio)
 
 
+@pytest.mark.parametrize("ratio", [4, 1])
 @pytest.mark.parametrize("mag", MAGS)
-def test_gqa4_dynamic_range(mods, oracle, mag):
+def test_gqa4_dynamic_range(mods, oracle, mag, ratio):
     """As tests/test_mfma_gpu.py::test_gqa_scores_dynamic_range / _output_: scales from the fp16 subnormals to ~4e3 (a 4-bit scale is
     a fifteenth of the range); the range words carry the mark for a scale >= 256 exactly for the units that hold one, and the mark
     for a scale >= 2^-8 likewise.  Every case is held to the same bars as the 2-bit twins: the GEMV bar (1e-3) against the ORACLE
@@ -161,7 +167,8 @@ def test_gqa4_dynamic_range(mods, oracle, mag):
     widened to 3); since round 5 a unit whose scales are all < 2^-8 places p'' 2^8 higher (mf_range_shift) and the case meets the
     plain bar."""
     mfma, new_pack, matmul = mods
-    B, nh, nh_kv, T = 2, 8, 2, 1056
+    B, nh_kv, T = 2, 2, 1056
+    nh = nh_kv * ratio
     k = _ranged(3, B, nh_kv, T, mag, 3).cuda()
     q = (make_kv(4, B, nh, 1, 128) * min(1.0, 300.0 / mag)).half().cuda()
     kst = mfma.alloc_store(B, nh_kv, 3, "cuda", BITS)
@@ -176,7 +183,7 @@ def test_gqa4_dynamic_range(mods, oracle, mag):
     ok, ratio = gemv_close(out[..., :T], ref.cpu(), rtol=1.5e-3)
     assert ok, ("scores", ratio)
     for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
-        hs = slice(hk * 4, (hk + 1) * 4)
+        hs = slice(hk * (nh // nh_kv), (hk + 1) * (nh // nh_kv))
         oref = oracle.bmm_fA_qB_outer(32, q[b:b + 1, hs].cpu(), code[b:b + 1, hk:hk + 1].cpu(), scale[b:b + 1, hk:hk + 1].cpu(),
                                       mn[b:b + 1, hk:hk + 1].cpu(), BITS)
         ok, ratio = gemv_close(out[b:b + 1, hs, :, :T], oref)
@@ -196,7 +203,7 @@ def test_gqa4_dynamic_range(mods, oracle, mag):
     ok, ratio = gemv_close(o, ref.cpu(), rtol=1.5e-3)
     assert ok, ("output", ratio)
     for (b, hk) in {(0, 0), (B - 1, nh_kv - 1)}:
-        hs = slice(hk * 4, (hk + 1) * 4)
+        hs = slice(hk * (nh // nh_kv), (hk + 1) * (nh // nh_kv))
         oref = oracle.bmm_fA_qB_outer(32, probs[b:b + 1, hs, :, :T].cpu().contiguous(), code[b:b + 1, hk:hk + 1].cpu(),
                                       scale[b:b + 1, hk:hk + 1].cpu(), mn[b:b + 1, hk:hk + 1].cpu(), BITS)
         ok, ratio = gemv_close(o[b:b + 1, hs], oref, rtol=1e-3)
@@ -205,7 +212,9 @@ def test_gqa4_dynamic_range(mods, oracle, mag):
 
 @pytest.mark.parametrize("form", ["split", "row"])
 @pytest.mark.parametrize("nh,nh_kv,T0,R,masked,kind", [(4, 1, 5, 32, False, "randn"), (8, 2, 70, 32, True, "outlier"),
-                                                         (16, 4, 600, 64, False, "randn")])
+                                                         (16, 4, 600, 64, False, "randn"),
+                                                         (2, 2, 5, 32, False, "randn"), (3, 3, 70, 32, True, "outlier"), (4, 4, 600, 64, False, "outlier"),
+                                                         (2, 2, 1100, 128, True, "randn")])
 def test_mf4_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked, kind, form):
     """tests/test_mfma_gpu.py::test_mf_decode_steps_match_reference_logic at 4 bits: R + 9 steps (a K flush through kt_pack4,
     V flushes into the 4-bit words, the window ring wrapping, cache growth), stage A (the softmax's input row, 1e-3) and stage B
@@ -216,13 +225,24 @@ def test_mf4_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, masked
     _stage_ab_steps(nh, nh_kv, T0, R, masked, form, R + 9, k_prompt=mk, k_step=mk, v_prompt=mo, v_step=mo, q_step=mo, bits=BITS)
 
 
+@pytest.mark.parametrize("nh,nh_kv,T0,R,masked,kind,S", [(4, 4, 1100, 32, True, "outlier", 2), (2, 2, 1100, 128, False, "randn", 1),
+                                                           (2, 2, 2100, 32, True, "outlier", 4)])
+def test_mf4_sliced_multi_head_rows_match_reference_logic(oracle, nh, nh_kv, T0, R, masked, kind, S):
+    """4-bit multi-head rows through the slice kernel (mf_row4_kernel<R = 1, BITS = 4>: what serves KIVI-4 rows beyond 8192 keys in one
+    launch): stage A / B at every step, 9-tuples bit-identical (cf. tests/test_mfma_gpu.py::test_mf_sliced_rows_match_reference_logic)."""
+    mk = lambda seed, h, T: make_kv(seed, 2, h, T, 128, kind)        # noqa: E731
+    mo = lambda seed, h, T: make_kv(seed, 2, h, T, 128)              # noqa: E731
+    _stage_ab_steps(nh, nh_kv, T0, R, masked, f"slices{S}", min(R + 9, 72), k_prompt=mk, k_step=mk, v_prompt=mo, v_step=mo, q_step=mo, bits=BITS)
+
+
 @pytest.mark.parametrize("form", ["split", "row"])
+@pytest.mark.parametrize("nh,nh_kv", [(8, 2), (2, 2)])
 @pytest.mark.parametrize("m0,m1", [(1e-4, 1e-4), (1e-4, 1.0), (1.0, 3e3), (3e4, 3e4)])
-def test_mf4_decode_steps_dynamic_range(oracle, m0, m1, form):
+def test_mf4_decode_steps_dynamic_range(oracle, m0, m1, form, nh, nh_kv):
     R, T0 = 32, 600
     qmag = min(1.0, 300.0 / max(m0, m1))
     layer = _stage_ab_steps(
-        8, 2, T0, R, False, form, R + 3,
+        nh, nh_kv, T0, R, False, form, R + 3,
         k_prompt=lambda seed, h, T: _ranged(seed, 2, h, T, m0, 3), k_step=lambda seed, h, T: _ranged(seed, 2, h, T, m1, 3),
         v_prompt=lambda seed, h, T: _ranged(seed, 2, h, T, m0, 2), v_step=lambda seed, h, T: _ranged(seed, 2, h, T, m1, 3),
         q_step=lambda seed, h, T: (make_kv(seed, 2, h, T, 128) * qmag).half(), check_at=(0, 5, R - 1, R, R + 2), bits=BITS)

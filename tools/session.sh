@@ -81,10 +81,23 @@ while [ $# -gt 0 ]; do
     r6new)
         # round 6: the new parity evidence first -- every-unit fp64 reference, the timeout path, the graph-vs-eager bands, LongChat shapes
         rm -f $R/gpurun_out/gemv_ratios.log
-        timeout 1500 python -m pytest tests/test_fullcover_gpu.py tests/test_timeout_gpu.py tests/test_graph_gpu.py tests/test_fullsize_gpu.py -m gpu -q -s --tb=short --maxfail=12 \
-            -k "fullcover or timeout or graph or longchat or small_batch" > $O/r6new.log 2>&1; echo "r6new rc=$?" | tee -a $O/status.log
+        timeout 1500 python -m pytest tests/test_fullcover_gpu.py tests/test_timeout_gpu.py tests/test_graph_gpu.py tests/test_fullsize_gpu.py tests/test_mfma4_gpu.py -m gpu -q -s --tb=short --maxfail=12 \
+            -k "fullcover or timeout or graph or longchat or small_batch or mfma4" > $O/r6new.log 2>&1; echo "r6new rc=$?" | tee -a $O/status.log
         grep -E "passed|failed|worst ratio|Error|error" $O/r6new.log | tail -40 | cut -c1-300
         cp $R/gpurun_out/gemv_ratios.log $O/gemv_ratios_r6new.log 2>/dev/null ;;
+    mf41)
+        # round 6: 4-bit multi-head K / V on the matrix pipe (nh == nh_kv) against the VALU kernels of the hook-state layout, one box, alternating:
+        # C2 at 4 bits (B = 8 / 32 / 64), LongChat-7B-32K + KIVI-4 rows (B = 8 x 16k / 32k)
+        for i in 1 2; do
+            for b in 32 8 64; do
+                timeout 300 $BN --bits 4 --batch $b --steps 10 --warmup 3 > $O/mf41_c2_b${b}_mf_$i.json 2>> $O/mf41.err; line $O/mf41_c2_b${b}_mf_$i.json
+                KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN --bits 4 --batch $b --steps 10 --warmup 3 > $O/mf41_c2_b${b}_valu_$i.json 2>> $O/mf41.err; line $O/mf41_c2_b${b}_valu_$i.json
+            done
+            for t in 16256 32640; do
+                timeout 300 $BN --bits 4 --batch 8 --prompt $t --residual 128 --steps 6 --warmup 2 > $O/mf41_b8_t${t}_mf_$i.json 2>> $O/mf41.err; line $O/mf41_b8_t${t}_mf_$i.json
+                KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN --bits 4 --batch 8 --prompt $t --residual 128 --steps 6 --warmup 2 > $O/mf41_b8_t${t}_valu_$i.json 2>> $O/mf41.err; line $O/mf41_b8_t${t}_valu_$i.json
+            done
+        done ;;
     long1)
         # round 6: multi-head rows beyond 8192 keys (LongChat-7B-32K shape): the plan's one-launch sliced form against two launches, one box
         for i in 1 2; do
@@ -97,7 +110,7 @@ while [ $# -gt 0 ]; do
         done ;;
     tests)
         rm -f $R/gpurun_out/gemv_ratios.log
-        timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/status.log
+        timeout 2000 python -m pytest tests -m gpu -q --maxfail=${MAXFAIL:-1} --durations=15 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/status.log
         cp $R/gpurun_out/gemv_ratios.log $O/gemv_ratios.log 2>/dev/null
         tail -15 $O/pytest_gpu.log
         timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" >> $O/pytest_gpu.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.log ;;
