@@ -3,9 +3,15 @@
 //   in (BS, 1, IC) fp16, kernel (BS_kv, OC/fpi, IC) int32, scale/zeros (BS_kv, OC/g, IC) fp16,
 //   out (BS, 1, OC) fp16.
 // The fast paths (kivi_gemv_k / kivi_gemv_v) read the hook-state layout and never need
-// these transposed tensors; this kernel exists for callers that already hold them
-// (quant/gemv.py:117,154).  One wave per (batch row, packed output row): lanes stride over
-// IC with coalesced dword loads, fpi fp32 accumulators per lane, butterfly reduction.
+// these transposed tensors; these kernels exist for callers that already hold them -- an
+// UNMODIFIED quant/matmul.py:198-219 lands here (quant/gemv.py:117,154 too).
+//   gemv_outer_dim_wide_kernel (round 6; IC % 4 == 0, group_size 32 / 64): a wave per quantisation GROUP of output
+//       columns -- 16-byte loads along IC for the code rows, scale / zero point / input loaded ONCE per group (the
+//       reference re-reads them for every packed row, gemv_cuda.cu:370-387), several groups' loads in flight per
+//       wave, the fpi sums of a packed row reduced by a halving butterfly; long IC (the sV shape) is split over the
+//       four waves of a block.  The same fp32 arithmetic as gemv_cuda.cu:401-426 up to summation order.
+//   gemv_outer_dim_kernel: the general fallback (any IC / group size): one wave per (batch row, packed output row),
+//       dword loads, written for clarity.
 #include "kivi_common.h"
 
 namespace {
@@ -69,6 +75,176 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_kernel(const uint16_t* __r
     if (lane < FPI) {
         const int64_t oc = row * FPI + off;
         if (oc < OC) out[bidx * OC + oc] = f2h_bits(acc[0] + z);
+    }
+}
+
+// ---- the tuned form.  LPR lanes per packed row (each lane 4 consecutive ic = one 16-byte code load): 32 when IC <= 128 (two rows
+// side by side in a wave), else 64.  RPL packed rows per lane = (g / fpi) / (64 / LPR).
+// NG > 1 (rows of at most LPR * 4 ic: ONE pass): NG consecutive groups per wave, all their loads issued before the first is used (a
+// wave then has NG x 1.5 KiB in flight instead of one round trip per group), the groups finished one after the other.
+// SPLIT: the four waves of a block take a quarter of IC each and meet in LDS (long IC: few groups, long rows).
+
+// sums over the LPR lanes of a packed row: FPI values per lane -> lane sl holds column `off` (sl < FPI; returned through `off`)
+template <int BITS> struct OdRow { float a[32 / BITS]; };
+template <int BITS, int LPR>
+__device__ __forceinline__ float outer_dim_row_reduce(float (&a)[32 / BITS], int lane, int& off) {
+    constexpr int FPI = 32 / BITS;
+#pragma unroll
+    for (int p = 0; p < FPI; p++) a[p] *= post_scale<BITS, KIVI_UNPACK_MIX>(p);
+    int n = FPI;
+    off = 0;
+    // halve the set of values while more than one is left, then plain sums.  (Constant trip counts in both loops -- the inner one runs
+    // to FPI / 2 under `i < half` -- so that hipcc unrolls them and every index into a[] is a constant.)
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) {
+        if (n > 1) {
+            const int half = n / 2;
+            const bool upper = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < FPI / 2; i++) {
+                if (i < half) {
+                    // (the two values are pinned in registers first: hipcc otherwise folds the selects into ONE dynamically indexed
+                    // read of a[] -- and the whole accumulator array moves to scratch memory)
+                    float lo = a[i], hi = a[i + half];
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    const float send = upper ? lo : hi;
+                    const float keep = upper ? hi : lo;
+                    a[i] = keep + __shfl_xor(send, m);
+                }
+            }
+            off += upper ? half : 0;
+            n = half;
+        } else {
+            a[0] += __shfl_xor(a[0], m);
+        }
+    }
+    return a[0];
+}
+
+__device__ __forceinline__ uint16_t half_of(const u32x2& v, int j) {       // element j (0..3) of four packed halves
+    const uint32_t w = (j >> 1) ? v[1] : v[0];
+    return (uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFFu));
+}
+
+template <int BITS, int LPR, int RPL, int NG, bool SPLIT>
+__global__ __launch_bounds__(256) void gemv_outer_dim_wide_kernel(const uint16_t* __restrict__ in, const uint32_t* __restrict__ kernel,
+                                                                  const uint16_t* __restrict__ scale, const uint16_t* __restrict__ zeros,
+                                                                  uint16_t* __restrict__ out, int64_t IC, int64_t OC, int g, int ratio,
+                                                                  int64_t ntask) {
+    constexpr int FPI = 32 / BITS;
+    constexpr int RPP = 64 / LPR;                               // packed rows side by side in one wave
+    constexpr int RPG = RPL * RPP;                              // packed rows per group = g / FPI
+    static_assert(!(SPLIT && NG > 1), "split rows: one group per block");
+    __shared__ float part[SPLIT ? 4 : 1][RPG * FPI + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane / LPR, sl = lane % LPR;                // which of the RPP rows, position along IC
+    const int64_t ngrp = OC / g;
+    const int64_t nrow = OC / FPI;
+    // tasks = (batch row, group); SPLIT: one task per block, else NG consecutive tasks per wave
+    const int64_t task0 = SPLIT ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x * 4 + wave) * NG;
+    if (task0 >= ntask) return;
+    if constexpr (NG > 1) {
+        // ---- one pass (IC <= LPR * 4): requests of all NG groups, then group after group
+        const int64_t ic0 = sl * 4;
+        const bool live = ic0 < IC;
+        u32x4 wv[NG][RPL];
+        u32x2 sv[NG], zv[NG], xv[NG];
+#pragma unroll
+        for (int t = 0; t < NG; t++) {
+            const int64_t task = task0 + t < ntask ? task0 + t : ntask - 1;
+            const int64_t bidx = task / ngrp, grp = task - bidx * ngrp, bk = bidx / ratio;      // gemv_cuda.cu:361-365
+            const bool on = live && task0 + t < ntask;
+            sv[t] = on ? *(const u32x2*)(scale + (bk * ngrp + grp) * IC + ic0) : u32x2{0, 0};
+            zv[t] = on ? *(const u32x2*)(zeros + (bk * ngrp + grp) * IC + ic0) : u32x2{0, 0};
+            xv[t] = on ? *(const u32x2*)(in + bidx * IC + ic0) : u32x2{0, 0};
+#pragma unroll
+            for (int r = 0; r < RPL; r++)
+                wv[t][r] = on ? __builtin_nontemporal_load((const u32x4*)(kernel + (bk * nrow + grp * RPG + r * RPP + sub) * IC + ic0)) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int t = 0; t < NG; t++) {
+            float acc[RPL][FPI], z = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPL; r++)
+#pragma unroll
+                for (int p = 0; p < FPI; p++) acc[r][p] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float x = h2f_bits(half_of(xv[t], j));
+                const float xs = x * h2f_bits(half_of(sv[t], j)) * qs_factor<KIVI_UNPACK_MIX>();
+                z = __builtin_fmaf(x, h2f_bits(half_of(zv[t], j)), z);
+#pragma unroll
+                for (int r = 0; r < RPL; r++) accum_word<BITS, KIVI_UNPACK_MIX>(wv[t][r][j], xs, acc[r]);
+            }
+#pragma unroll
+            for (int m = 1; m < LPR; m <<= 1) z += __shfl_xor(z, m);
+            const int64_t task = task0 + t;
+            const int64_t bidx = task / ngrp, grp = task - bidx * ngrp;
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                int off;
+                const float v = outer_dim_row_reduce<BITS, LPR>(acc[r], lane, off);
+                if (task < ntask && sl < FPI) out[bidx * OC + grp * g + (r * RPP + sub) * FPI + off] = f2h_bits(v + z);
+            }
+        }
+    } else {
+        // ---- one group, any IC: passes of LPR * 4 ic (SPLIT: this wave's quarter of the row)
+        int64_t ic_lo = 0, ic_hi = IC;
+        if constexpr (SPLIT) {
+            const int64_t chunk = ((IC + 3) / 4 + 3) / 4 * 4;  // a multiple of 4 ic per wave
+            ic_lo = wave * chunk;
+            ic_hi = ic_lo + chunk < IC ? ic_lo + chunk : IC;
+        }
+        const int64_t bidx = task0 / ngrp, grp = task0 - bidx * ngrp, bk = bidx / ratio;          // gemv_cuda.cu:361-365
+        const uint32_t* wp = kernel + (bk * nrow + grp * RPG + sub) * IC;                       // the lane's first packed row (:357)
+        const uint16_t* sp = scale + (bk * ngrp + grp) * IC;
+        const uint16_t* zp = zeros + (bk * ngrp + grp) * IC;
+        const uint16_t* ip = in + bidx * IC;
+        OdRow<BITS> acc[RPL];
+        float z = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPL; r++)
+#pragma unroll
+            for (int p = 0; p < FPI; p++) acc[r].a[p] = 0.f;
+        for (int64_t icb = ic_lo; icb < ic_hi; icb += LPR * 4) {  // (uniform trip count; lanes past the end contribute zeros)
+            const int64_t ic0 = icb + sl * 4;
+            const bool on = ic0 < ic_hi;
+            const u32x2 sv = on ? *(const u32x2*)(sp + ic0) : u32x2{0, 0};
+            const u32x2 zv = on ? *(const u32x2*)(zp + ic0) : u32x2{0, 0};
+            const u32x2 xv = on ? *(const u32x2*)(ip + ic0) : u32x2{0, 0};
+            u32x4 wv[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; r++)
+                wv[r] = on ? __builtin_nontemporal_load((const u32x4*)(wp + (int64_t)(r * RPP) * IC + ic0)) : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float x = h2f_bits(half_of(xv, j));
+                const float xs = x * h2f_bits(half_of(sv, j)) * qs_factor<KIVI_UNPACK_MIX>();
+                z = __builtin_fmaf(x, h2f_bits(half_of(zv, j)), z);
+#pragma unroll
+                for (int r = 0; r < RPL; r++) accum_word<BITS, KIVI_UNPACK_MIX>(wv[r][j], xs, acc[r].a);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) z += __shfl_xor(z, m);
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            int off;
+            const float v = outer_dim_row_reduce<BITS, LPR>(acc[r].a, lane, off);
+            if constexpr (SPLIT) {
+                if (sl < FPI) part[wave][(r * RPP + sub) * FPI + off] = v;
+            } else if (sl < FPI) {
+                out[bidx * OC + grp * g + (r * RPP + sub) * FPI + off] = f2h_bits(v + z);
+            }
+        }
+        if constexpr (SPLIT) {
+            if (lane == 0) part[wave][RPG * FPI] = z;
+            __syncthreads();
+            const float zt = (part[0][RPG * FPI] + part[1][RPG * FPI]) + (part[2][RPG * FPI] + part[3][RPG * FPI]);
+            for (int i = threadIdx.x; i < RPG * FPI; i += 256)
+                out[bidx * OC + grp * g + i] = f2h_bits((part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) + zt);
+        }
     }
 }
 
@@ -146,6 +322,28 @@ extern "C" int kivi_gemv_outer_dim(const void* in, const void* kernel, const voi
     KIVI_REQUIRE(BS * nrb < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_gemv_outer_dim: grid too large");
     dim3 grid((unsigned)(BS * nrb));
     hipStream_t s = (hipStream_t)stream;
+    // the tuned form: rows of whole 16-byte chunks (IC % 4 == 0, 16-byte aligned bases), group_size 32 / 64
+    const bool wide_ok = IC > 0 && IC % 4 == 0 && (group_size == 32 || group_size == 64) && (uintptr_t)kernel % 16 == 0 &&
+                         (uintptr_t)scale % 8 == 0 && (uintptr_t)zeros % 8 == 0 && (uintptr_t)in % 8 == 0;
+    if (wide_ok) {
+        const int64_t ntask = BS * (OC / group_size);
+        const bool split = IC > 512;                              // long rows (the sV shape): a block per group, IC over its four waves
+#define KIVI_WIDE(B_, LPR_, RPL_, NG_, SP_)                                                                                         \
+    hipLaunchKernelGGL((gemv_outer_dim_wide_kernel<B_, LPR_, RPL_, NG_, SP_>), dim3((unsigned)((SP_) ? ntask : (ntask + 4 * (NG_) - 1) / (4 * (NG_)))), \
+                       dim3(256), 0, s, (const uint16_t*)in, (const uint32_t*)kernel, (const uint16_t*)scale, (const uint16_t*)zeros,       \
+                       (uint16_t*)out, IC, OC, group_size, nh / nh_kv, ntask)
+        const int rpg = group_size / fpi;                         // packed rows per group: 2 / 4 (2-bit g = 32 / 64), 4 / 8 (4-bit)
+        const bool narrow = IC <= 128;                            // two rows side by side in a wave
+        bool done = true;
+        const bool one = IC <= 256;                               // 64 lanes x 4 ic: one pass
+        if (bit == 2 && rpg == 2) { if (split) KIVI_WIDE(2, 64, 2, 1, true); else if (narrow) KIVI_WIDE(2, 32, 1, 4, false); else if (one) KIVI_WIDE(2, 64, 2, 2, false); else KIVI_WIDE(2, 64, 2, 1, false); }
+        else if (bit == 2 && rpg == 4) { if (split) KIVI_WIDE(2, 64, 4, 1, true); else if (narrow) KIVI_WIDE(2, 32, 2, 2, false); else KIVI_WIDE(2, 64, 4, 1, false); }
+        else if (bit == 4 && rpg == 4) { if (split) KIVI_WIDE(4, 64, 4, 1, true); else if (narrow) KIVI_WIDE(4, 32, 2, 4, false); else KIVI_WIDE(4, 64, 4, 1, false); }
+        else if (bit == 4 && rpg == 8) { if (split) KIVI_WIDE(4, 64, 8, 1, true); else if (narrow) KIVI_WIDE(4, 32, 4, 1, false); else KIVI_WIDE(4, 64, 8, 1, false); }
+        else done = false;
+#undef KIVI_WIDE
+        if (done) return kivi_launch_status("gemv_outer_dim_wide");
+    }
     if (bit == 2)
         hipLaunchKernelGGL(gemv_outer_dim_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)in, (const uint32_t*)kernel,
                            (const uint16_t*)scale, (const uint16_t*)zeros, (uint16_t*)out, IC, OC, group_size,

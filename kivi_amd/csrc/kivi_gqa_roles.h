@@ -196,14 +196,14 @@ __device__ __forceinline__ void gqa_row_consts(const GqaVArgs& a, int b, int h0,
 // payload, drained, one relaxed arrival counter; cdna_hip_programming.md G16).
 // also_reset: a second per-unit counter the last block puts back to zero (the statistics exchange of the sliced one-launch form:
 // a block arrives here only after it has left that exchange, so nobody still reads the counter).
-template <int R>
+template <int R, int NTH = 256>
 __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int unit, int slot, const float* part_lds, int b, int h0,
                                                        int* also_reset = nullptr) {
     __shared__ int last_flag;
     constexpr int RD = R * 128;
     // part_lds = [quantised part | window part] of this block; workspace [unit][slot][2][RD]
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.ws + ((size_t)unit * a.nslot + slot) * 2 * RD);
-    for (int i = threadIdx.x; i < 2 * RD; i += 256)
+    for (int i = threadIdx.x; i < 2 * RD; i += NTH)
         __hip_atomic_store(dst + i, __builtin_bit_cast(uint32_t, part_lds[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -219,7 +219,7 @@ __device__ __forceinline__ void gqa_arrive_and_combine(const GqaVArgs& a, int un
     __syncthreads();
     if (!last_flag) return;
     const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a.ws + (size_t)unit * a.nslot * 2 * RD);
-    for (int i = threadIdx.x; i < RD; i += 256) {
+    for (int i = threadIdx.x; i < RD; i += NTH) {
         const int r = i >> 7, d = i & 127;
         float q = 0.f, w = 0.f;
         for (int s0 = 0; s0 < a.nslot; s0 += 4) {   // 8 independent loads in flight, added in slot order

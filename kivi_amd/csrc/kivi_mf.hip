@@ -657,7 +657,10 @@ __device__ __forceinline__ void mf_probs_inplace_row(uint16_t* row, int t0, int 
 template <int KRING, int VRING, int NW, bool DBG = false, bool VHL = true, int R = 4, int BITS = 2, int OCC = 2, bool PSM = false>
 __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak_in, const GqaVArgs av_in, int n_pad, int S) {
     constexpr int NTH = NW * 64;
-    static_assert(NW == 4, "four waves: the hand-off between slices (gqa_arrive_and_combine) walks with 256 threads");
+    // NW = 6 (round 6, a block per row only): SIX waves per block, two blocks per CU = three waves per SIMD in <= 168 registers -- the
+    // LDS (four score rows of up to 9344 keys: 73 KiB) allows two blocks per CU whatever their size, so the third wave per SIMD the
+    // latency-bound streams of this kernel lacked comes from wider blocks, not from more of them.
+    static_assert(NW == 4 || NW == 6, "four or six waves");
     static_assert((R == 4) || ((R == 8 || R == 1) && !VHL), "R = 1 / 8: chained hi / lo sV");
     static_assert(BITS == 2 || R == 4 || R == 1, "4-bit codes: nh / nh_kv in {1, 4}");
     GqaKArgs ak = ak_in;
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     }
     if (S > 1) {
         __syncthreads();
-        gqa_arrive_and_combine<R>(av, unit, slice, lf, b, h0, ak.xcount + unit);
+        gqa_arrive_and_combine<R, NTH>(av, unit, slice, lf, b, h0, ak.xcount + unit);
     }
     stamp(11);
     if (DBG && lane == 0) {
@@ -1226,7 +1229,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         KIVI_REQUIRE(n_blk <= cap, KIVI_EUNSUPPORTED, "mf_row%d: rows of %lld keys do not fit the LDS (<= %lld)", R, (long long)n_blk, (long long)cap);
         const int n_pad = (int)((n_blk + 4 + 31) / 32 * 32);
         size_t lds = (size_t)R * n_pad * 2;
-        const size_t fin = (size_t)(2 * 4 + 4 + 2) * R * 128 * 4;  // the per-wave partial sums + the block's sums reuse the rows
+        const size_t fin = (size_t)(2 * 6 + 6 + 2) * R * 128 * 4;  // the per-wave partial sums (up to six waves, hi and lo) + the block's sums reuse the rows
         const int occ = R == 1 ? 4 : 2;                             // blocks per CU
         if (lds < fin) lds = fin;
         const dim3 grid((unsigned)((int64_t)units * S));
@@ -1247,17 +1250,25 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         static const char* fl = KIVI_TUNE_ENV("KIVI_MF_ROW4_FLOW");      // A/B: "stream" = the in-stream flow for unsliced rows too
         if (fl && !strcmp(fl, "stream")) psm = false;
 #endif
-#define KIVI_ROW4_LAUNCH(OPT, ...)                                                                 \
+#define KIVI_ROW4_LAUNCH_T(OPT, THREADS, ...)                                                      \
     do {                                                                                           \
         const int rc = mf_lds_opt_in(mf_row4_kernel<__VA_ARGS__>, &OPT, "mf_row4");                \
         if (rc) return rc;                                                                         \
-        KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(256), lds, s, k, v, n_pad, S);   \
+        KIVI_LAUNCH_LDS((mf_row4_kernel<__VA_ARGS__>), grid, dim3(THREADS), lds, s, k, v, n_pad, S); \
         return kivi_launch_status("mf_row4");                                                      \
     } while (0)
+#define KIVI_ROW4_LAUNCH(OPT, ...) KIVI_ROW4_LAUNCH_T(OPT, 256, __VA_ARGS__)
         if (R == 1 && bits == 4) KIVI_ROW4_LAUNCH(opt14, 2, 3, 4, false, false, 1, 4, 4);
         if (R == 1) KIVI_ROW4_LAUNCH(opt1, 2, 3, 4, false, false, 1, 2, 4);
         if (R == 8 && psm) KIVI_ROW4_LAUNCH(opt8p, 4, 2, 4, false, false, 8, 2, 2, true);
         if (R == 8) KIVI_ROW4_LAUNCH(opt8, 4, 2, 4, false, false, 8);
+#ifdef KIVI_TUNING
+        static unsigned long long opt446[3] = {0};
+        static const char* f46 = KIVI_TUNE_ENV("KIVI_MF_ROW4_46");       // 4-bit codes, six waves per block: "<K ring><V ring>" (A/B; not the product)
+        if (bits == 4 && psm && f46 && atoi(f46) == 22) KIVI_ROW4_LAUNCH_T(opt446[0], 384, 2, 2, 6, false, true, 4, 4, 3, true);
+        if (bits == 4 && psm && f46 && atoi(f46) == 23) KIVI_ROW4_LAUNCH_T(opt446[1], 384, 2, 3, 6, false, true, 4, 4, 3, true);
+        if (bits == 4 && psm && f46 && atoi(f46) == 43) KIVI_ROW4_LAUNCH_T(opt446[2], 384, 4, 3, 6, false, true, 4, 4, 3, true);
+#endif
         if (bits == 4 && psm) KIVI_ROW4_LAUNCH(opt44p, 4, 3, 4, false, true, 4, 4, 2, true);
         if (bits == 4) KIVI_ROW4_LAUNCH(opt44, 4, 3, 4, false, true, 4, 4);
 #ifdef KIVI_TUNING
@@ -1274,9 +1285,31 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (cfg == 424) KIVI_ROW4_LAUNCH(opt_t[5], 4, 2, 4);
         if (cfg == 1434) KIVI_ROW4_LAUNCH(opt_t[6], 4, 3, 4, false, false);
 #endif
+        // a block per row, 2 bits, nh / nh_kv = 4: six waves per block (three per SIMD; see mf_row4_kernel) -- KIVI_MF_ROW4_NW=4 in tuning
+        // builds keeps the four-wave block for A/B
+        static unsigned long long opt4p6 = 0;
+        bool six = true;
+#ifdef KIVI_TUNING
+        static const char* fnw = KIVI_TUNE_ENV("KIVI_MF_ROW4_NW");
+        if (fnw && atoi(fnw) == 4) six = false;
+#endif
+#ifdef KIVI_TUNING
+        static unsigned long long opt6s[2] = {0};
+        static const char* fs6 = KIVI_TUNE_ENV("KIVI_MF_ROW4_S6");       // sliced rows (in-stream flow) with six waves per block: "<K ring><V ring>" (A/B)
+        if (!psm && R == 4 && bits == 2 && fs6 && atoi(fs6) == 22) KIVI_ROW4_LAUNCH_T(opt6s[0], 384, 2, 2, 6, false, true, 4, 2, 3, false);
+        if (!psm && R == 4 && bits == 2 && fs6 && atoi(fs6) == 43) KIVI_ROW4_LAUNCH_T(opt6s[1], 384, 4, 3, 6, false, true, 4, 2, 3, false);
+        static unsigned long long opt6[4] = {0};
+        static const char* fr6 = KIVI_TUNE_ENV("KIVI_MF_ROW4_6");        // "<K ring><V ring>" of the six-wave block
+        const int c6 = fr6 ? atoi(fr6) : 43;
+        if (psm && six && c6 == 23) KIVI_ROW4_LAUNCH_T(opt6[0], 384, 2, 3, 6, false, true, 4, 2, 3, true);
+        if (psm && six && c6 == 42) KIVI_ROW4_LAUNCH_T(opt6[1], 384, 4, 2, 6, false, true, 4, 2, 3, true);
+        if (psm && six && c6 == 22) KIVI_ROW4_LAUNCH_T(opt6[2], 384, 2, 2, 6, false, true, 4, 2, 3, true);
+#endif
+        if (psm && six) KIVI_ROW4_LAUNCH_T(opt4p6, 384, 4, 3, 6, false, true, 4, 2, 3, true);
         if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, 2, true);
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH
+#undef KIVI_ROW4_LAUNCH_T
     }
     const int n_pad = (int)((n + 4 + 31) / 32 * 32);            // >= 4 halves of -inf behind every row (mf_row_softmax)
     const dim3 grid((unsigned)units);

@@ -96,7 +96,7 @@ def test_decode_steps_every_unit(name, B, nh, nh_kv, T0, R, bits, steps, flags, 
             assert ok, (name, "scores", s, ra)
             assert torch.equal(x_gpu[~live], pre[~live]), (name, "masked scores", s)
             ref_b, _, _ = T64.decode_step(q, kn, vn, past, bits, bits, g, R, attention_mask=mask, scores_override=x_gpu.contiguous())
-            ok, rb = gemv_close(out, ref_b, rtol=2e-3)
+            ok, rb = gemv_close(out, ref_b, rtol=2e-3, ulps=1)
             assert ok, (name, "attend half", s, rb)
             worst["A"], worst["B"] = max(worst["A"], ra), max(worst["B"], rb)
         # end to end: REPORTED against the hook bar (3e-3), asserted at twice that.  Stage A + B above are the rigorous bars; what they

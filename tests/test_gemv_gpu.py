@@ -220,6 +220,31 @@ def test_compat_layout_vs_oracle(mods, oracle):
             assert got.shape == (B * nh, 1, OC)
 
 
+@pytest.mark.parametrize("IC,OC,GS", [(128, 256, 32), (64, 96, 32), (256, 128, 32), (384, 64, 32), (1000, 128, 32), (4064, 128, 32),
+                                      (128, 256, 64), (520, 128, 64), (132, 64, 32)])
+def test_compat_layout_tuned_kernel_vs_oracle(mods, oracle, IC, OC, GS):
+    """The tuned form of the literal pybind twin (gemv_outer_dim_wide_kernel, round 6: 16-byte loads along IC, scale / zero point once
+    per group) on every path of its dispatch: rows of <= 128 ic (two packed rows per wave, four groups' loads in flight: the qK^T
+    shape of an unmodified quant/matmul.py:198-219), one-pass rows of 256, looped rows, rows split over the four waves of a block
+    (the sV shape), group size 64, grouped queries -- against the oracle's restatement of gemv_cuda.cu:348-427, the bare 1e-3 bar."""
+    new_pack, _, kivi_gemv = mods
+    B, nh = 3, 4
+    g = torch.Generator().manual_seed(IC + OC)
+    inp = torch.randn((B * nh, 1, IC), generator=g).half()
+    for nh_kv in (nh, 2):
+        w = torch.randn((B * nh_kv, IC, OC), generator=g).half()
+        for bits in (2, 4):
+            code, scale, mn = new_pack.triton_quantize_and_pack_along_last_dim(w.view(B, nh_kv, IC, OC).cuda(), GS, bits)
+            qw = code.view(B * nh_kv, IC, -1).transpose(1, 2).contiguous()
+            s_t = scale.view(B * nh_kv, IC, -1).transpose(1, 2).contiguous()
+            z_t = mn.view(B * nh_kv, IC, -1).transpose(1, 2).contiguous()
+            got = kivi_gemv.gemv_forward_cuda_outer_dim(inp.cuda(), qw, s_t, z_t, bits, GS, nh, nh_kv)
+            ref = oracle.gemv_forward_outer_dim(inp, qw.cpu(), s_t.cpu(), z_t.cpu(), bits, GS, nh, nh_kv)
+            ok, ratio = gemv_close(got, ref)
+            assert ok, (nh_kv, bits, ratio)
+            assert got.shape == (B * nh, 1, OC) and torch.isfinite(got).all()
+
+
 def test_errors_like_reference(mods):
     _, matmul, kivi_gemv = mods
     fA = torch.zeros(1, 3, 1, 64, device="cuda", dtype=torch.float16)

@@ -327,7 +327,7 @@ def _stage_ab_steps(nh, nh_kv, T0, R, masked, form, steps, k_prompt, k_step, v_p
         assert ok, ("scores", s, ra)
         assert torch.equal(x_gpu[~live], x_ref[~live])
         ref_b, past_b = H.decode_step(q, kn, vn, past, bits, bits, g, R, attention_mask=mask, scores_override=x_gpu)
-        ok, rb = gemv_close(out, ref_b, rtol=2e-3)
+        ok, rb = gemv_close(out, ref_b, rtol=2e-3, ulps=1)
         assert ok, ("attend", s, rb)
         worst_a, worst_b = max(worst_a, ra), max(worst_b, rb)
         past = past_ref
@@ -442,7 +442,7 @@ def test_mf_decode_steps_dynamic_range(oracle, nh, nh_kv, m0, m1, form):
 @pytest.mark.parametrize("B,nh,nh_kv,T0,R,masked", [(2, 4, 4, 5, 32, False), (8, 32, 32, 1500, 32, True), (2, 2, 2, 8100, 32, False),
                                                      (4, 8, 8, 4080, 128, False), (2, 8, 2, 5, 32, False), (3, 16, 4, 1500, 64, True),
                                                      (2, 8, 2, 9000, 128, False), (8, 32, 8, 8000, 128, False),
-                                                     (2, 16, 2, 1500, 64, True), (2, 64, 8, 4400, 32, False)])
+                                                     (2, 16, 2, 1500, 64, True), (2, 64, 8, 4000, 32, False)])
 def test_mf_row_kernel_matches_two_launch_form(oracle, B, nh, nh_kv, T0, R, masked):
     """The one-launch row kernels (mf_row_kernel for nh == nh_kv, mf_row4_kernel for nh / nh_kv == 4 and -- rows up to 4608 keys --
     8: scores never leave the LDS) against the two-launch form of the same step (stage-checked above) on cloned caches: same packed qK^T arithmetic
@@ -475,13 +475,13 @@ def test_mf_row_kernel_matches_two_launch_form(oracle, B, nh, nh_kv, T0, R, mask
         torch.cuda.synchronize()
         assert (b"mf_row_kernel" if ratio == 1 else b"mf_row4_kernel") in (probe_lib.kivi_last_timed_kernel() or b"")
         ob = kivi_attention_decode(q, kn, vn, b_, attention_mask=mask)
-        ok, r = gemv_close(oa, ob, rtol=1.5e-3)
+        ok, r = gemv_close(oa, ob, rtol=1.5e-3, ulps=1)
         assert ok, (s, r)
         for (bb, h) in samples:
             hs = slice(h * ratio, (h + 1) * ratio)
             ref, pasts[(bb, h)] = H.decode_step(q[bb:bb + 1, hs].cpu(), kn[bb:bb + 1, h:h + 1].cpu(), vn[bb:bb + 1, h:h + 1].cpu(),
                                                 pasts[(bb, h)], 2, 2, g, R, attention_mask=None if mask is None else mask[bb:bb + 1].cpu())
-            ok, r = gemv_close(oa[bb:bb + 1, hs], ref, rtol=3e-3)
+            ok, r = gemv_close(oa[bb:bb + 1, hs], ref, rtol=3e-3, ulps=1)
             assert ok, (s, bb, h, r)
     ta, tb = a.as_tuple(), b_.as_tuple()
     for x, y in zip(ta[:8], tb[:8]):
@@ -518,7 +518,7 @@ def test_mf_decode_full_size_rows_vs_oracle(oracle, B, nh, nh_kv, T0, R):
             hs = slice(hk * ratio, (hk + 1) * ratio)
             ref, pasts[(b, hk)] = H.decode_step(q[b:b + 1, hs].cpu(), kn[b:b + 1, hk:hk + 1].cpu(), vn[b:b + 1, hk:hk + 1].cpu(),
                                                 pasts[(b, hk)], 2, 2, g, R)
-            ok, r_ = gemv_close(out[b:b + 1, hs], ref, rtol=3e-3)
+            ok, r_ = gemv_close(out[b:b + 1, hs], ref, rtol=3e-3, ulps=1)
             assert ok, (s, b, hk, r_)
     t = layer.as_tuple()
     for (b, hk) in samples:

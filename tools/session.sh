@@ -31,7 +31,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export PYTHONUNBUFFERED=1
-BN="python $R/bench.py --no-cpu-baseline --no-hook-kgemv"
+BN="python $R/bench.py --no-cpu-baseline --no-hook-kgemv --no-extra-configs"
 C4="--batch 64 --heads 32 --kv-heads 8 --prompt 8064 --residual 128"
 C5="--batch 16 --heads 32 --kv-heads 8 --prompt 32640 --residual 128"
 C70="--batch 16 --heads 64 --kv-heads 8 --prompt 8064 --residual 128"
@@ -53,7 +53,7 @@ trace_one() {  # <name> <skip> <bench args...>
     rm -rf $O/trace_$name
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -o b -- $BN "$@" > $O/trace_${name}_bench.json 2> $O/trace_$name.err
     cd $R
-    python tools/trace_median.py $(find $O/trace_$name -name "*kernel_trace.csv" | head -1) --skip $skip --skip-for gemv_k_kernel=12 quant_pack=0 --match mf_ decode_row gemv_ kt_pack vt_pack quant_pack \
+    python tools/trace_median.py $(find $O/trace_$name -name "*kernel_trace.csv" | head -1) --skip $skip --skip-for gemv_k_kernel=12 quant_pack=0 mf_row4_kernel=${ROW4_SKIP:-$skip} --match mf_ decode_row gemv_ kt_pack vt_pack quant_pack \
         --json $O/trace_median_$name.json > $O/trace_median_$name.log 2>&1
     cp $(find $O/trace_$name -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$name.csv 2>/dev/null
     rm -rf $O/trace_$name
@@ -85,6 +85,44 @@ while [ $# -gt 0 ]; do
             -k "fullcover or timeout or graph or longchat or small_batch or mfma4" > $O/r6new.log 2>&1; echo "r6new rc=$?" | tee -a $O/status.log
         grep -E "passed|failed|worst ratio|Error|error" $O/r6new.log | tail -40 | cut -c1-300
         cp $R/gpurun_out/gemv_ratios.log $O/gemv_ratios_r6new.log 2>/dev/null ;;
+    row6)
+        # round 6: mf_row4_kernel with SIX waves per block (three per SIMD; product) against the four-wave block (tuning build, KIVI_MF_ROW4_NW=4)
+        # and the ring variants of the six-wave block (KIVI_MF_ROW4_6=<K ring><V ring>), BASELINE config 4 + two other block-per-row shapes; one box
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        for cfg in 43 23 22; do
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_6=$cfg timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_hook_gpu.py -m gpu -x -q \
+                -k "(row and fixtures) or matches_two_launch or (decode_steps_match and row)" > $O/row6_parity_$cfg.log 2>&1; echo "row6 parity $cfg rc=$?" | tee -a $O/status.log; tail -2 $O/row6_parity_$cfg.log
+        done
+        for i in 1 2 3; do
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_product_$i.json 2>> $O/row6.err; line $O/row6_c4_product_$i.json
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=4 timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_nw4_$i.json 2>> $O/row6.err; line $O/row6_c4_nw4_$i.json
+            for cfg in 23 42 22; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_6=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c4_r${cfg}_$i.json
+            done
+        done
+        for i in 1 2; do      # 4-bit codes: the four-wave product block against six-wave variants (tuning build; these spill 36-52 bytes)
+            timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/row6_c4b4_product_$i.json 2>> $O/row6.err; line $O/row6_c4b4_product_$i.json
+            for cfg in 22 23; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_46=$cfg timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/row6_c4b4_r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c4b4_r${cfg}_$i.json
+            done
+        done
+        # sliced rows (in-stream flow): six waves per block (tuning build; these spill) against the product's four, config-5 slice + 70B-like slice
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_S6=22 timeout 900 python -m pytest tests/test_mfma_gpu.py -m gpu -x -q -k "sliced_rows" > $O/row6_parity_s6.log 2>&1; echo "row6 parity s6 rc=$?" | tee -a $O/status.log; tail -2 $O/row6_parity_s6.log
+        for i in 1 2; do
+            timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/row6_c5_product_$i.json 2>> $O/row6.err; line $O/row6_c5_product_$i.json
+            for cfg in 22 43; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_S6=$cfg timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/row6_c5_s6r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c5_s6r${cfg}_$i.json
+            done
+        done
+        for sh in "32 8064" "64 4032" "128 2048"; do
+            lb=${sh% *}; lt=${sh#* }
+            timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/row6_b${lb}_t${lt}_product.json 2>> $O/row6.err; line $O/row6_b${lb}_t${lt}_product.json
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=4 timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/row6_b${lb}_t${lt}_nw4.json 2>> $O/row6.err; line $O/row6_b${lb}_t${lt}_nw4.json
+        done ;;
+    compat)
+        # round 6: the literal pybind twin (kivi_gemv.gemv_forward_cuda_outer_dim on the reference's kernel-input layout) at C2, both widths
+        timeout 600 python -m pytest tests/test_gemv_gpu.py -m gpu -q -k "compat" > $O/compat_tests.log 2>&1; echo "compat tests rc=$?" | tee -a $O/status.log; tail -3 $O/compat_tests.log
+        timeout 600 python tools/compat_time.py > $O/compat_time.log 2>&1; BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time.log 2>&1; cat $O/compat_time.log ;;
     mf41)
         # round 6: 4-bit multi-head K / V on the matrix pipe (nh == nh_kv) against the VALU kernels of the hook-state layout, one box, alternating:
         # C2 at 4 bits (B = 8 / 32 / 64), LongChat-7B-32K + KIVI-4 rows (B = 8 x 16k / 32k)
@@ -130,8 +168,10 @@ while [ $# -gt 0 ]; do
     trace)
         # the driver's command incl. the BASELINE configs[1] loop through the reference's operator (cuda_bmm_fA_qB_outer -> gemv_k_kernel),
         # so that the kernel stats / trace medians carry a gemv_k_kernel row (the kernel the north-star target is written about)
+        # round 6: ... and the three extra BASELINE configurations of the default invocation (roofline_config4 / _config4_4bit / _config5_slice:
+        # 8 layers x (2 warm-up + 14 timed) steps each -> their mf_row4_kernel instantiations skip 16 warm-up launches)
         BN_SAVE=$BN; BN="python $R/bench.py --no-cpu-baseline"
-        trace_one bench 160
+        ROW4_SKIP=16 trace_one bench 160
         BN=$BN_SAVE ;;
     trace_c4) trace_one config4 96 $C4 --steps 10 --warmup 3 ;;
     trace_gqa)
