@@ -325,7 +325,8 @@ extern "C" int kivi_gemv_outer_dim(const void* in, const void* kernel, const voi
     // the tuned form: rows of whole 16-byte chunks (IC % 4 == 0, 16-byte aligned bases), group_size 32 / 64
     const bool wide_ok = IC > 0 && IC % 4 == 0 && (group_size == 32 || group_size == 64) && (uintptr_t)kernel % 16 == 0 &&
                          (uintptr_t)scale % 8 == 0 && (uintptr_t)zeros % 8 == 0 && (uintptr_t)in % 8 == 0;
-    if (wide_ok) {
+    static const char* old_only = KIVI_TUNE_ENV("KIVI_COMPAT_OLD");      // tuning builds, A/B: the general one-wave-per-packed-row kernel
+    if (wide_ok && !(old_only && atoi(old_only))) {
         const int64_t ntask = BS * (OC / group_size);
         const bool split = IC > 512;                              // long rows (the sV shape): a block per group, IC over its four waves
 #define KIVI_WIDE(B_, LPR_, RPL_, NG_, SP_)                                                                                         \

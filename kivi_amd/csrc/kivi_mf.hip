@@ -738,6 +738,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
         const int lastsb = sb_lo + wave + (seq.n_sb - 1) * NW;
         const int NG = Tq >> 5;
         seq.ng_total = seq.n_sb > 0 ? 16 * (seq.n_sb - 1) + ((NG - 16 * lastsb) < 16 ? (NG - 16 * lastsb) : 16) : 0;
+        if constexpr (PSM && NW == 6 && R == 4) {
+            // six waves, a block per row (the K walk only writes scores): the row's groups are dealt in CONTIGUOUS runs of whole ring
+            // rounds (4 groups) -- 16 super-blocks over six waves would be 3, 3, 3, 3, 2, 2 (the block waits for 48 groups), the runs
+            // are 44, 44, 44, 40, 40, 40
+            const int nu = (NG + 3) >> 2;
+            const int base = nu / NW, rem = nu - base * NW;
+            const int u0 = wave * base + (wave < rem ? wave : rem), un = base + (wave < rem ? 1 : 0);
+            const int g0 = 4 * u0;
+            int g1 = 4 * (u0 + un);
+            g1 = g1 < NG ? g1 : NG;
+            seq.sb_first = g0 >> 4;
+            seq.sb_stride = 1;
+            seq.g_first = g0 & 15;
+            seq.n_sb = g1 > g0 ? ((g1 + 15) >> 4) - seq.sb_first : 0;
+            seq.ng_total = g1 > g0 ? g1 - 16 * seq.sb_first : 0;
+        }
         // a finished super-block: [mask in place (:366-372),] (max, sum exp(x - max)) of the segment of every row
         auto seg_done = [&](int sb, int ng) {
             typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
@@ -798,7 +814,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
                 rows[(sb - sb_lo) * KIVI_MF_SB_TOKENS + tt] = kivi_scaled_score(f2h_bits(v), ak.inv_scale, false, 0);
             }, seg_done);
         } else {
-            mf_k_seqR<R, KRING, BITS>(rk, seq, q_h0, ak.q_sh, krsh, [&](int sb, int tt, int r, float v0, float v1) {
+            mf_k_seqR<R, KRING, BITS, (PSM && NW == 6 && R == 4)>(rk, seq, q_h0, ak.q_sh, krsh, [&](int sb, int tt, int r, float v0, float v1) {
                 const uint32_t hs = mf_scale_pair(mf_cvt_pair(v0, v1), ak.inv_scale);
                 uint16_t* dst = rows + (hb + r) * n_pad + (sb - sb_lo) * KIVI_MF_SB_TOKENS + tt;
                 dst[0] = (uint16_t)(hs & 0xFFFFu);                 // head hb + r at tokens tt, tt + 16
@@ -1285,27 +1301,27 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (cfg == 424) KIVI_ROW4_LAUNCH(opt_t[5], 4, 2, 4);
         if (cfg == 1434) KIVI_ROW4_LAUNCH(opt_t[6], 4, 3, 4, false, false);
 #endif
-        // a block per row, 2 bits, nh / nh_kv = 4: six waves per block (three per SIMD; see mf_row4_kernel) -- KIVI_MF_ROW4_NW=4 in tuning
-        // builds keeps the four-wave block for A/B
-        static unsigned long long opt4p6 = 0;
-        bool six = true;
+        // a block per row, 2 bits, nh / nh_kv = 4.  Round 6 built the "third wave per SIMD" the last review asked for and measured it (profiles/
+        // r06_six_wave.log): SIX waves per block (two blocks per CU by LDS -> three waves per SIMD in 168 registers, 36-56 bytes spilled) are
+        // 24 % SLOWER at BASELINE config 4 (122.3 against 98.6 us on one box, every ring combination 119.7-127.7), 39-43 % slower on 4k / 2k
+        // rows, equal with one block per CU (66.3 / 64.8) -- six waves on four SIMDs sit 2, 2, 1, 1: a SIMD carries a THIRD of the block's
+        // work instead of a quarter, which eats what the extra wave hides; and THREE four-wave blocks per CU where the LDS allows it
+        // (4k rows, launch bounds of 3 waves per SIMD) -- see KIVI_MF_ROW4_OCC3 below.  The product keeps four waves; the variants live in
+        // the tuning build: KIVI_MF_ROW4_NW=6 [KIVI_MF_ROW4_6=<K ring><V ring>], KIVI_MF_ROW4_OCC3=1.
 #ifdef KIVI_TUNING
+        static unsigned long long opt4p6 = 0, opt4o3 = 0;
         static const char* fnw = KIVI_TUNE_ENV("KIVI_MF_ROW4_NW");
-        if (fnw && atoi(fnw) == 4) six = false;
-#endif
-#ifdef KIVI_TUNING
-        static unsigned long long opt6s[2] = {0};
-        static const char* fs6 = KIVI_TUNE_ENV("KIVI_MF_ROW4_S6");       // sliced rows (in-stream flow) with six waves per block: "<K ring><V ring>" (A/B)
-        if (!psm && R == 4 && bits == 2 && fs6 && atoi(fs6) == 22) KIVI_ROW4_LAUNCH_T(opt6s[0], 384, 2, 2, 6, false, true, 4, 2, 3, false);
-        if (!psm && R == 4 && bits == 2 && fs6 && atoi(fs6) == 43) KIVI_ROW4_LAUNCH_T(opt6s[1], 384, 4, 3, 6, false, true, 4, 2, 3, false);
+        const bool six = fnw && atoi(fnw) == 6;
         static unsigned long long opt6[4] = {0};
         static const char* fr6 = KIVI_TUNE_ENV("KIVI_MF_ROW4_6");        // "<K ring><V ring>" of the six-wave block
         const int c6 = fr6 ? atoi(fr6) : 43;
         if (psm && six && c6 == 23) KIVI_ROW4_LAUNCH_T(opt6[0], 384, 2, 3, 6, false, true, 4, 2, 3, true);
         if (psm && six && c6 == 42) KIVI_ROW4_LAUNCH_T(opt6[1], 384, 4, 2, 6, false, true, 4, 2, 3, true);
         if (psm && six && c6 == 22) KIVI_ROW4_LAUNCH_T(opt6[2], 384, 2, 2, 6, false, true, 4, 2, 3, true);
-#endif
         if (psm && six) KIVI_ROW4_LAUNCH_T(opt4p6, 384, 4, 3, 6, false, true, 4, 2, 3, true);
+        static const char* fo3 = KIVI_TUNE_ENV("KIVI_MF_ROW4_OCC3");     // four-wave blocks compiled for three waves per SIMD (three blocks per CU where the LDS allows)
+        if (psm && fo3 && atoi(fo3)) KIVI_ROW4_LAUNCH(opt4o3, 2, 2, 4, false, true, 4, 2, 3, true);
+#endif
         if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, 2, true);
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH

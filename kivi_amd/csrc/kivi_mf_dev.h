@@ -151,7 +151,9 @@ template <int V> struct mf_ic { static constexpr int value = V; };
 struct MfKSeq {
     uint32_t sb_bytes;              // byte stride between consecutive super-blocks of the unit
     int sb_first, sb_stride, n_sb;  // this wave's super-blocks
-    int ng_total;                   // 32-token groups in the whole sequence
+    int ng_total;                   // 32-token groups in the whole sequence (counted from the first group of sb_first)
+    int g_first = 0;                // mf_k_seqR only (round 6): the sequence STARTS at this group of sb_first -- a multiple of the ring --, so
+                                    // that a row can be dealt to the waves of a block in contiguous runs of groups instead of whole super-blocks
 };
 
 // Scores go to sink(super-block index, token inside it, fp32 score).  RING = code blocks in flight (2 or 4).
@@ -348,7 +350,8 @@ __device__ __forceinline__ void mf_k_zero(QSrc&& qsrc, const u32x4* mv, const fl
 // instructions per group, the sums meeting through v_permlane16_swap -- : SQ_VALU_MFMA_BUSY_CYCLES fell from 0.74 to 0.40 of the
 // wave cycles and the launch did not get faster (BASELINE config 4: 108.0 us against 107.2 on the same box); not kept,
 // profiles/r04_row4_levers.log.)
-template <int R, int RING, int BITS = 2, typename Sink, typename Done>
+// OFF: the sequence starts at W.g_first (otherwise that field is ignored and the walk starts at group 0 of sb_first)
+template <int R, int RING, int BITS = 2, bool OFF = false, typename Sink, typename Done>
 __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint16_t* q_h0, int64_t q_sh, int rsh, Sink&& sink, Done&& done) {
     static_assert(R == 4 || R == 8, "4 or 8 query heads per kv head");
     typedef MfL<BITS> LY;
@@ -360,7 +363,9 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
     const int m = lane & 15, kb = lane >> 4;
     const int gl = (4 * kb) / RR;                                   // the group of the round whose scores this lane's registers hold
     const int hb = (4 * kb) % R;                                    // ... for the heads hb .. hb + 3
-    if (W.ng_total <= 0) return;
+    const int g_first = OFF ? W.g_first : 0;
+    if (W.ng_total <= g_first) return;
+    const int rq0 = g_first / GPR;                                // first round of the sequence (0 unless it starts inside sb_first)
     auto sb_off = [&](int sbi) { return (uint32_t)(W.sb_first + sbi * W.sb_stride) * W.sb_bytes; };
     const int g_last = W.ng_total - 1;
     const int n_round = (W.ng_total + GPR - 1) / GPR;
@@ -380,8 +385,8 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
 #pragma unroll
         for (int c = 0; c < 4; c++) zv[c] = buf_load<u32x4, true>(rk, (uint32_t)(LY::MN_WORD0 * 4 + kt_sm_word4(m, kb, c) * 4) + dead, sb_off(sbi));
     };
-    request_round(0, true);
-    request_z(0, true);
+    request_round(rq0, true);
+    request_z(rq0 / RR, true);
     MfW<BITS> wr[RING];
     auto request_group = [&](int slot, int gi) {
         const bool live = gi <= g_last;
@@ -390,7 +395,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
     };
 #pragma unroll
     for (int i = 0; i < RING; i++) {
-        request_group(i, i);
+        request_group(i, g_first + i);
         __builtin_amdgcn_sched_barrier(0);
     }
     MfQ<R> Q;
@@ -410,7 +415,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         constexpr int S0 = decltype(slot0)::value;
         const int sbi = rq / RR;                                    // 16 / GPR = RR rounds per super-block
         const int rs = rq - sbi * RR;
-        if (rs == 0) {                                              // a new super-block: its zero-point sums, then the next one's zero points
+        if (rs == 0 || rq == rq0) {                                 // a new super-block (or the sequence's first round): its zero-point sums, then the next one's zero points
             mf_k_zero<R, BITS>(qsrc, zv, zmul, zz, rsh);
             request_z(sbi + 1 < W.n_sb ? sbi + 1 : sbi, sbi + 1 < W.n_sb);
         }
@@ -466,7 +471,7 @@ __device__ __forceinline__ void mf_k_seqR(rsrc_t rk, const MfKSeq& W, const uint
         }
     };
     static_assert(RPT == 1 || RPT == 2 || RPT == 4, "1, 2 or 4 rounds per trip");
-    for (int rq = 0; rq < n_round; rq += RPT) {
+    for (int rq = rq0; rq < n_round; rq += RPT) {
         do_round(rq, mf_ic<0>{});
         if constexpr (RPT >= 2) {
             if (rq + 1 < n_round) do_round(rq + 1, mf_ic<GPR>{});

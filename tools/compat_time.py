@@ -25,7 +25,7 @@ def report(name, nbytes, fn):
     for i in range(NC):
         fn(i)
     med, mn, avg = timed(lambda i: fn(i % NC), 10 * NC)
-    print(f"{name}: median {med:.1f} us  min {mn:.1f}  avg {avg:.1f}  algorithmic {nbytes / 1e6:.1f} MB  ->  {nbytes / med / 1e6 / 8000:.3f} of 8 TB/s (median), {nbytes / mn / 1e6 / 8000:.3f} (min)")
+    print(f"{name}: median {med:.1f} us  min {mn:.1f}  avg {avg:.1f}  algorithmic {nbytes / 1e6:.1f} MB  ->  {nbytes / (med * 1e-6) / 8e12:.3f} of 8 TB/s (median), {nbytes / (mn * 1e-6) / 8e12:.3f} (min)")
 
 
 # ---- qK^T: in (B*nh, 1, D); kernel (B*nh, T/fpi, D); scale / zeros (B*nh, T/g, D)

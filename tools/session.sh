@@ -86,43 +86,49 @@ while [ $# -gt 0 ]; do
         grep -E "passed|failed|worst ratio|Error|error" $O/r6new.log | tail -40 | cut -c1-300
         cp $R/gpurun_out/gemv_ratios.log $O/gemv_ratios_r6new.log 2>/dev/null ;;
     row6)
-        # round 6: mf_row4_kernel with SIX waves per block (three per SIMD; product) against the four-wave block (tuning build, KIVI_MF_ROW4_NW=4)
-        # and the ring variants of the six-wave block (KIVI_MF_ROW4_6=<K ring><V ring>), BASELINE config 4 + two other block-per-row shapes; one box
+        # round 6: mf_row4_kernel with SIX waves per block (three per SIMD; tuning build: KIVI_MF_ROW4_NW=6, rings KIVI_MF_ROW4_6=<K ring><V ring>) against
+        # the product's four-wave block, BASELINE config 4 + shorter rows; 4-bit codes likewise (KIVI_MF_ROW4_46); one box.  (Session r6c ran this stage
+        # with the six-wave block as the product default and KIVI_MF_ROW4_NW=4 as the A/B side: profiles/r06_six_wave.log.)
         T=$R/kivi_amd/_variants/libkivi_tuning.so
         for cfg in 43 23 22; do
-            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_6=$cfg timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_hook_gpu.py -m gpu -x -q \
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=6 KIVI_MF_ROW4_6=$cfg timeout 900 python -m pytest tests/test_mfma_gpu.py tests/test_hook_gpu.py -m gpu -x -q \
                 -k "(row and fixtures) or matches_two_launch or (decode_steps_match and row)" > $O/row6_parity_$cfg.log 2>&1; echo "row6 parity $cfg rc=$?" | tee -a $O/status.log; tail -2 $O/row6_parity_$cfg.log
         done
         for i in 1 2 3; do
             timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_product_$i.json 2>> $O/row6.err; line $O/row6_c4_product_$i.json
-            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=4 timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_nw4_$i.json 2>> $O/row6.err; line $O/row6_c4_nw4_$i.json
-            for cfg in 23 42 22; do
-                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_6=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c4_r${cfg}_$i.json
+            for cfg in 43 23 42 22; do
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=6 KIVI_MF_ROW4_6=$cfg timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/row6_c4_nw6_r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c4_nw6_r${cfg}_$i.json
             done
         done
-        for i in 1 2; do      # 4-bit codes: the four-wave product block against six-wave variants (tuning build; these spill 36-52 bytes)
+        for i in 1 2; do      # 4-bit codes: the four-wave product block against six-wave variants (these spill 36-52 bytes)
             timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/row6_c4b4_product_$i.json 2>> $O/row6.err; line $O/row6_c4b4_product_$i.json
             for cfg in 22 23; do
                 KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_46=$cfg timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/row6_c4b4_r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c4b4_r${cfg}_$i.json
             done
         done
-        # sliced rows (in-stream flow): six waves per block (tuning build; these spill) against the product's four, config-5 slice + 70B-like slice
-        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_S6=22 timeout 900 python -m pytest tests/test_mfma_gpu.py -m gpu -x -q -k "sliced_rows" > $O/row6_parity_s6.log 2>&1; echo "row6 parity s6 rc=$?" | tee -a $O/status.log; tail -2 $O/row6_parity_s6.log
-        for i in 1 2; do
-            timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/row6_c5_product_$i.json 2>> $O/row6.err; line $O/row6_c5_product_$i.json
-            for cfg in 22 43; do
-                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_S6=$cfg timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/row6_c5_s6r${cfg}_$i.json 2>> $O/row6.err; line $O/row6_c5_s6r${cfg}_$i.json
-            done
-        done
         for sh in "32 8064" "64 4032" "128 2048"; do
             lb=${sh% *}; lt=${sh#* }
             timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/row6_b${lb}_t${lt}_product.json 2>> $O/row6.err; line $O/row6_b${lb}_t${lt}_product.json
-            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=4 timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/row6_b${lb}_t${lt}_nw4.json 2>> $O/row6.err; line $O/row6_b${lb}_t${lt}_nw4.json
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=6 timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/row6_b${lb}_t${lt}_nw6.json 2>> $O/row6.err; line $O/row6_b${lb}_t${lt}_nw6.json
         done ;;
     compat)
         # round 6: the literal pybind twin (kivi_gemv.gemv_forward_cuda_outer_dim on the reference's kernel-input layout) at C2, both widths
         timeout 600 python -m pytest tests/test_gemv_gpu.py -m gpu -q -k "compat" > $O/compat_tests.log 2>&1; echo "compat tests rc=$?" | tee -a $O/status.log; tail -3 $O/compat_tests.log
-        timeout 600 python tools/compat_time.py > $O/compat_time.log 2>&1; BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time.log 2>&1; cat $O/compat_time.log ;;
+        timeout 600 python tools/compat_time.py > $O/compat_time.log 2>&1; BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time.log 2>&1; cat $O/compat_time.log
+        # the general kernel (one wave per packed row: what rounds 1-5 shipped) on the same box: tuning build, KIVI_COMPAT_OLD=1
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_OLD=1 timeout 600 python tools/compat_time.py > $O/compat_time_old.log 2>&1; KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_OLD=1 BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time_old.log 2>&1; grep "gemv_outer_dim" $O/compat_time_old.log ;;
+    occ3)
+        # round 6: four-wave blocks of mf_row4_kernel compiled for THREE waves per SIMD (167 registers, rings 2 / 2; tuning build, KIVI_MF_ROW4_OCC3=1) where the
+        # LDS allows three blocks per CU (rows of <= 6.5k keys) against the product, one box
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        for i in 1 2; do
+            for sh in "64 4032" "128 2048" "96 6016" "64 8064"; do
+                lb=${sh% *}; lt=${sh#* }
+                timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/occ3_b${lb}_t${lt}_product_$i.json 2>> $O/occ3.err; line $O/occ3_b${lb}_t${lt}_product_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_OCC3=1 timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/occ3_b${lb}_t${lt}_occ3_$i.json 2>> $O/occ3.err; line $O/occ3_b${lb}_t${lt}_occ3_$i.json
+            done
+        done ;;
     mf41)
         # round 6: 4-bit multi-head K / V on the matrix pipe (nh == nh_kv) against the VALU kernels of the hook-state layout, one box, alternating:
         # C2 at 4 bits (B = 8 / 32 / 64), LongChat-7B-32K + KIVI-4 rows (B = 8 x 16k / 32k)
@@ -179,6 +185,8 @@ while [ $# -gt 0 ]; do
         trace_one config5slice 64 $C5 --steps 6 --warmup 2
         trace_one slice70b 96 $C70 --steps 10 --warmup 3 ;;
     pmc) pmc_one bench '{"B": 32, "nh": 32, "nh_kv": 32, "prompt": 4080, "bits": 2, "group": 32, "residual": 32}' ;;
+    pmc_c4b4) pmc_one config4_4bit '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 4, "group": 32, "residual": 128}' $C4 --bits 4 ;;
+    pmc_c5) pmc_one config5slice '{"B": 16, "nh": 32, "nh_kv": 8, "prompt": 32640, "bits": 2, "group": 32, "residual": 128}' $C5 ;;
     pmc_c4) pmc_one config4 '{"B": 64, "nh": 32, "nh_kv": 8, "prompt": 8064, "bits": 2, "group": 32, "residual": 128}' $C4 ;;
     e2e)
         timeout 900 python examples/mem_spd_test.py --recipe > $O/e2e_mem_spd_recipe.log 2>&1; echo "recipe rc=$?" | tee -a $O/status.log; tail -12 $O/e2e_mem_spd_recipe.log
