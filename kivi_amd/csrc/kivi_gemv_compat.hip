@@ -85,39 +85,59 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_kernel(const uint16_t* __r
 // SPLIT: the four waves of a block take a quarter of IC each and meet in LDS (long IC: few groups, long rows).
 
 // sums over the LPR lanes of a packed row: FPI values per lane -> lane sl holds column `off` (sl < FPI; returned through `off`)
+template <int V> struct od_ic { static constexpr int value = V; };
 template <int BITS> struct OdRow { float a[32 / BITS]; };
+
+// value of lane (l ^ M): a DPP operand modifier where the pattern exists on gfx950 (lanes 1, 2: quad permutations; 8: a rotation by half a
+// 16-lane row), the LDS crossbar (ds_bpermute) otherwise -- 15 of the 20 exchanges of a 2-bit group's reduction are DPP
+template <int M>
+__device__ __forceinline__ float od_xor(float v) {
+    if constexpr (M == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    else if constexpr (M == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    else if constexpr (M == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    else return __shfl_xor(v, M);
+}
+template <int LPR>
+__device__ __forceinline__ float od_row_sum(float z) {          // sum over the LPR lanes of a packed row (every lane gets it)
+    z += od_xor<1>(z);
+    z += od_xor<2>(z);
+    z += od_xor<4>(z);
+    z += od_xor<8>(z);
+    z += od_xor<16>(z);
+    if constexpr (LPR == 64) z += od_xor<32>(z);
+    return z;
+}
 template <int BITS, int LPR>
 __device__ __forceinline__ float outer_dim_row_reduce(float (&a)[32 / BITS], int lane, int& off) {
     constexpr int FPI = 32 / BITS;
 #pragma unroll
     for (int p = 0; p < FPI; p++) a[p] *= post_scale<BITS, KIVI_UNPACK_MIX>(p);
-    int n = FPI;
     off = 0;
-    // halve the set of values while more than one is left, then plain sums.  (Constant trip counts in both loops -- the inner one runs
-    // to FPI / 2 under `i < half` -- so that hipcc unrolls them and every index into a[] is a constant.)
+    // step K exchanges across lane bit K: while more than one value is left (FPI >> K > 1) the set is halved -- the lane with the bit set
+    // keeps the upper half --, then plain sums.  Every index into a[] is a compile-time constant (mf_ic steps, `if constexpr`).
+    auto step = [&](auto kc) {
+        constexpr int K = decltype(kc)::value, M = 1 << K;
+        if constexpr (M < LPR) {
+            if constexpr ((FPI >> K) > 1) {
+                constexpr int half = FPI >> (K + 1);
+                const bool upper = (lane & M) != 0;
 #pragma unroll
-    for (int m = 1; m < LPR; m <<= 1) {
-        if (n > 1) {
-            const int half = n / 2;
-            const bool upper = (lane & m) != 0;
-#pragma unroll
-            for (int i = 0; i < FPI / 2; i++) {
-                if (i < half) {
+                for (int i = 0; i < half; i++) {
                     // (the two values are pinned in registers first: hipcc otherwise folds the selects into ONE dynamically indexed
                     // read of a[] -- and the whole accumulator array moves to scratch memory)
                     float lo = a[i], hi = a[i + half];
                     asm volatile("" : "+v"(lo), "+v"(hi));
                     const float send = upper ? lo : hi;
                     const float keep = upper ? hi : lo;
-                    a[i] = keep + __shfl_xor(send, m);
+                    a[i] = keep + od_xor<M>(send);
                 }
+                off += upper ? half : 0;
+            } else {
+                a[0] += od_xor<M>(a[0]);
             }
-            off += upper ? half : 0;
-            n = half;
-        } else {
-            a[0] += __shfl_xor(a[0], m);
         }
-    }
+    };
+    step(od_ic<0>{}); step(od_ic<1>{}); step(od_ic<2>{}); step(od_ic<3>{}); step(od_ic<4>{}); step(od_ic<5>{});
     return a[0];
 }
 
@@ -177,8 +197,7 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_wide_kernel(const uint16_t
 #pragma unroll
                 for (int r = 0; r < RPL; r++) accum_word<BITS, KIVI_UNPACK_MIX>(wv[t][r][j], xs, acc[r]);
             }
-#pragma unroll
-            for (int m = 1; m < LPR; m <<= 1) z += __shfl_xor(z, m);
+            z = od_row_sum<LPR>(z);
             const int64_t task = task0 + t;
             const int64_t bidx = task / ngrp, grp = task - bidx * ngrp;
 #pragma unroll
@@ -226,8 +245,7 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_wide_kernel(const uint16_t
                 for (int r = 0; r < RPL; r++) accum_word<BITS, KIVI_UNPACK_MIX>(wv[r][j], xs, acc[r].a);
             }
         }
-#pragma unroll
-        for (int m = 1; m < LPR; m <<= 1) z += __shfl_xor(z, m);
+        z = od_row_sum<LPR>(z);
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
             int off;

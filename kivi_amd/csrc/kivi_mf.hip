@@ -1305,11 +1305,11 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         // r06_six_wave.log): SIX waves per block (two blocks per CU by LDS -> three waves per SIMD in 168 registers, 36-56 bytes spilled) are
         // 24 % SLOWER at BASELINE config 4 (122.3 against 98.6 us on one box, every ring combination 119.7-127.7), 39-43 % slower on 4k / 2k
         // rows, equal with one block per CU (66.3 / 64.8) -- six waves on four SIMDs sit 2, 2, 1, 1: a SIMD carries a THIRD of the block's
-        // work instead of a quarter, which eats what the extra wave hides; and THREE four-wave blocks per CU where the LDS allows it
-        // (4k rows, launch bounds of 3 waves per SIMD) -- see KIVI_MF_ROW4_OCC3 below.  The product keeps four waves; the variants live in
-        // the tuning build: KIVI_MF_ROW4_NW=6 [KIVI_MF_ROW4_6=<K ring><V ring>], KIVI_MF_ROW4_OCC3=1.
+        // work instead of a quarter, which eats what the extra wave hides.  (A BALANCED third wave -- three four-wave blocks per CU, below --
+        // is worth 4-9 % where the LDS allows it: config 4's 8k rows do not.)  The product keeps four waves per block; the six-wave
+        // instantiations live in the tuning build: KIVI_MF_ROW4_NW=6 [KIVI_MF_ROW4_6=<K ring><V ring>].
 #ifdef KIVI_TUNING
-        static unsigned long long opt4p6 = 0, opt4o3 = 0;
+        static unsigned long long opt4p6 = 0;
         static const char* fnw = KIVI_TUNE_ENV("KIVI_MF_ROW4_NW");
         const bool six = fnw && atoi(fnw) == 6;
         static unsigned long long opt6[4] = {0};
@@ -1319,9 +1319,25 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (psm && six && c6 == 42) KIVI_ROW4_LAUNCH_T(opt6[1], 384, 4, 2, 6, false, true, 4, 2, 3, true);
         if (psm && six && c6 == 22) KIVI_ROW4_LAUNCH_T(opt6[2], 384, 2, 2, 6, false, true, 4, 2, 3, true);
         if (psm && six) KIVI_ROW4_LAUNCH_T(opt4p6, 384, 4, 3, 6, false, true, 4, 2, 3, true);
-        static const char* fo3 = KIVI_TUNE_ENV("KIVI_MF_ROW4_OCC3");     // four-wave blocks compiled for three waves per SIMD (three blocks per CU where the LDS allows)
-        if (psm && fo3 && atoi(fo3)) KIVI_ROW4_LAUNCH(opt4o3, 2, 2, 4, false, true, 4, 2, 3, true);
 #endif
+        // THREE blocks per CU (round 6): where the four score rows of the geometry class's longest row leave room for a third block in
+        // the LDS (<= ~6.3k keys) AND the launch has at least three blocks per CU to place, the instantiation compiled for three waves
+        // per SIMD (167 registers, rings 2 / 2, no spill) runs 4-9 % faster (B=96 x 6k keys: 109.8 against 119.9 us; B=128 x 2k: 68.2
+        // against 71.1; with only two blocks per CU it is 1-2 % slower: profiles/r06_three_blocks.log).  The criterion uses the CLASS
+        // bound (nsb * 512 + residual_length keys), not the step's own row, so that eager and replayed steps pick the same instantiation
+        // (their V rings centre differently: not bit-identical to each other).
+        static unsigned long long opt4o3 = 0;
+        {
+            const int64_t n_class = (int64_t)k.nsb * KIVI_MF_SB_TOKENS + res_cap;
+            const size_t lds_class = (size_t)R * (size_t)((n_class + 4 + 31) / 32 * 32) * 2;
+            const int cus = mf_cu_count();
+            bool three = R == 4 && bits == 2 && psm && cus > 0 && lds_class + 3680 + 256 <= (160 * 1024) / 3 && units >= 3 * cus;
+#ifdef KIVI_TUNING
+            static const char* fo3 = KIVI_TUNE_ENV("KIVI_MF_ROW4_OCC3");     // 0 / 1: never / whenever the rows fit (A/B)
+            if (fo3) three = R == 4 && bits == 2 && psm && atoi(fo3) != 0;
+#endif
+            if (three) KIVI_ROW4_LAUNCH(opt4o3, 2, 2, 4, false, true, 4, 2, 3, true);
+        }
         if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, 2, true);
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH

@@ -51,6 +51,7 @@ SHAPES = [
     ("longchat_32k_sliced", 8, 32, 32, 32768 + 100, 128, 2, 3, 5 << 8, "mf_row4_kernel"),     # ... forced into ONE launch, 5 slices per row
     ("longchat_16k_4bit", 8, 32, 32, 16384 + 100, 128, 4, 4, 0, "mf_k_kernel"),               # KIVI-4, multi-head (round 6: 4 bits on the matrix pipe for nh == nh_kv)
     ("C2_4bit", 32, 32, 32, 4080, 32, 4, 20, 0, "mf_row_kernel"),
+    ("gqa_6k_three_blocks", 96, 32, 8, 6016 - 4, 128, 2, 6, 0, "mf_row4_kernel"),             # 768 units of <= 6.3k keys: the three-blocks-per-CU instantiation (round 6), K flush at step 4
 ]
 
 
