@@ -24,7 +24,15 @@ extern "C" const char* kivi_last_error(void) { return g_err; }
 #include <mutex>
 static int* g_dev_err_host = nullptr;
 static int* g_dev_err_dev = nullptr;
-int* kivi_device_error_word() {
+int* kivi_device_error_word(hipStream_t stream) {
+    // (never allocate while `stream` is being captured into a graph: an allocation call is not a capturable operation and would
+    // invalidate the capture.  A launch captured before the word exists simply carries a null pointer: its timeout would show as NaN
+    // and in the workspace's error word only.  GraphedDecode runs the first step of a geometry class eagerly, which allocates it.)
+    if (!g_dev_err_dev) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (st != hipStreamCaptureStatusNone) return nullptr;
+    }
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;

@@ -25,7 +25,7 @@ typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
 // ---- argument / launch error plumbing (host side) -------------------------
 void kivi_set_error(const char* fmt, ...);
-int* kivi_device_error_word();             // device pointer to the process's host-visible error word (or null): kivi_abi.hip
+int* kivi_device_error_word(hipStream_t stream);   // device pointer to the process's host-visible error word (or null): kivi_abi.hip
 int kivi_take_device_error(int* unit);     // returns and clears it
 
 #define KIVI_REQUIRE(cond, code, ...)      \

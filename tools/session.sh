@@ -170,7 +170,14 @@ while [ $# -gt 0 ]; do
         timeout 300 $BN $C4 --bits 4 --steps 10 --warmup 3 > $O/shape_config4_4bit.json 2>> $O/shapes.err; line $O/shape_config4_4bit.json
         timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/shape_config5_slice.json 2>> $O/shapes.err; line $O/shape_config5_slice.json
         timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/shape_70b_slice.json 2>> $O/shapes.err; line $O/shape_70b_slice.json
-        KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN > $O/shape_headline_hook_layout.json 2>> $O/shapes.err; line $O/shape_headline_hook_layout.json ;;
+        KIVI_TUNING=1 KIVI_NO_MFMA_MHA=1 timeout 300 $BN > $O/shape_headline_hook_layout.json 2>> $O/shapes.err; line $O/shape_headline_hook_layout.json
+        # round 6: LongChat-7B-32K shapes (multi-head rows beyond 8192 keys, KIVI-2 and KIVI-4), three blocks per CU on short grouped-query rows
+        for bt in "8 32640" "16 16256"; do
+            lb=${bt% *}; lt=${bt#* }
+            timeout 300 $BN --batch $lb --prompt $lt --residual 128 --steps 6 --warmup 2 > $O/shape_longchat_b${lb}_t${lt}.json 2>> $O/shapes.err; line $O/shape_longchat_b${lb}_t${lt}.json
+            timeout 300 $BN --bits 4 --batch $lb --prompt $lt --residual 128 --steps 6 --warmup 2 > $O/shape_longchat_b${lb}_t${lt}_4bit.json 2>> $O/shapes.err; line $O/shape_longchat_b${lb}_t${lt}_4bit.json
+        done
+        timeout 300 $BN --batch 96 --heads 32 --kv-heads 8 --prompt 6016 --residual 128 --steps 10 --warmup 3 > $O/shape_gqa_b96_6k.json 2>> $O/shapes.err; line $O/shape_gqa_b96_6k.json ;;
     trace)
         # the driver's command incl. the BASELINE configs[1] loop through the reference's operator (cuda_bmm_fA_qB_outer -> gemv_k_kernel),
         # so that the kernel stats / trace medians carry a gemv_k_kernel row (the kernel the north-star target is written about)
