@@ -328,9 +328,13 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * kivi_gqa_decode: the whole decode step of one layer over the KT / VT layouts.  ONE launch (packed qK^T -> LDS scores [softmax
  * statistics per 512-token segment inside the K walk] -> residual scores -> window -> packed sV with the probabilities made on the
  * fly) when the score rows of a (batch row, kv head) unit fit the LDS and the units fill the chip:
- *   nh == nh_kv      rows of <= 8192 keys and (>= 192 units, or <= 4096 packed keys at any batch)      -> mf_row_kernel
- *   nh / nh_kv == 4  rows of <= 9216 keys and >= 128 units (4-bit codes: >= 192)                       -> mf_row4_kernel
+ *   nh == nh_kv      rows of <= 16 super-blocks + a full residual (8320 keys) and (>= 192 units, or <= 4096 packed keys at any batch)
+ *                                                                                                      -> mf_row_kernel (2- and 4-bit codes)
+ *   nh / nh_kv == 4  rows of <= 18 super-blocks + a full residual (9344 keys) and >= 128 units (4-bit codes: >= 192) -> mf_row4_kernel
+ *                    (2-bit rows of <= ~6.3k keys with >= 3 blocks per CU: the instantiation that fits three blocks per CU)
  *   nh / nh_kv == 8  rows of <= 4608 keys and >= 192 units                                            -> mf_row4_kernel<R = 8>
+ * The plan is made for the LONGEST row of the step's geometry class (ceil(Tq / 512) * 512 + residual_length keys: kivi_mf_step_key),
+ * whether the lengths are passed by value or device-resident, so an eager step and a replayed one of the same position take the same form.
  * For nh / nh_kv in {4, 8} LONGER rows (and rows of few units, to fill the chip) are cut into S slices of whole super-blocks, one
  * block per slice, still in ONE launch: the slices of a unit exchange their (max, sum exp) through `stats` (arrival counters in the
  * second half of the workspace's counter area), form the same probabilities a single block would, and their partial outputs meet
@@ -340,7 +344,8 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * the dispatch front and start as soon as any older block finishes.  The wait is bounded (~1 s); a block that gives up poisons its
  * unit's output with NaN, records KIVI_ETIMEOUT (kivi_device_error; word 16382 of the counter area) and the launch's last blocks
  * still put every counter back to zero.  At most 8190 units take a sliced form.
- * Otherwise two launches:
+ * Otherwise two launches (incl. multi-head rows beyond 16 super-blocks: the sliced one-launch form of such rows is reachable through
+ * KIVI_GQA_SLICES(n) only -- measured slower than the two launches):
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies
  *      1/sqrt(D) and the mask (:339, :364-372), writes the scaled scores to `scores` and (max, sum exp) of every
  *      512-token segment to `stats`;

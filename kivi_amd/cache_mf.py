@@ -8,13 +8,14 @@ of v_mfma_f32_16x16x32_f16, so that the nh / nh_kv query heads of a kv head shar
 costing one FMA each (the shared-unpack VALU kernels run at ~0.35 of the HBM roofline for nh / nh_kv = 4).
 
 A decode step is ONE library call (kivi_mf_decode_layer: lengths, the launches, the K flush through kivi_kt_pack every R
-steps).  Launches: rows whose scores fit the LDS (nh = nh_kv: <= 8192 keys, nh / nh_kv = 4: <= 9216) and enough of them ->
-one (mf_row_kernel / mf_row4_kernel); otherwise two (packed qK^T + residual scores + K append + softmax statistics, then
+steps).  Launches: rows whose scores fit the LDS (nh = nh_kv: 16 super-blocks + the residual, nh / nh_kv = 4: 18) and enough of them
+-> one (mf_row_kernel / mf_row4_kernel; longer grouped-query rows: one launch of slices); otherwise two (packed qK^T + residual scores + K append + softmax statistics, then
 softmax-on-the-fly + packed sV + fp16 window + V append / quantise).  Every store carries range flags (quant/mfma.py) that
 keep the fp16 operands of the matrix pipe finite for any finite scale.
 
 Round 4: also 4-bit K / V for nh / nh_kv = 4 (the reference's published Mistral-7B + KIVI-4 shape, docs/long_bench.md:35-53): the same
-state machine and calls over 10240-word super-blocks (kivi_mfma_layout.h, "KT4 / VT4").
+state machine and calls over 10240-word super-blocks (kivi_mfma_layout.h, "KT4 / VT4").  Round 6: 4-bit K / V of multi-head models
+(Llama-2-7B / LongChat-7B-32K + KIVI-4, docs/long_bench.md:5-26) too.
 """
 from __future__ import annotations
 
@@ -66,7 +67,7 @@ def _scratch(device, B: int, nh: int, nh_kv: int, pitch: int, nseg: int, slices:
 
 class KiviLayerCacheMF:
     """One layer's quantised KV cache (capacity `max_len` tokens, appended in place): 2-bit with nh / nh_kv in {1, 4, 8}, 4-bit with
-    nh / nh_kv = 4."""
+    nh / nh_kv in {1, 4} (multi-head 4-bit: round 6)."""
 
     layout = "mfma"
 
@@ -74,7 +75,7 @@ class KiviLayerCacheMF:
                  dtype=torch.float16, num_heads: int = None):
         assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
         assert num_heads is not None and supported(cfg, head_dim, num_heads, num_kv_heads), \
-            "matrix-pipe layout: group 32, head_dim 128, residual_length <= 128; 2-bit with nh / nh_kv in {1, 4, 8} or 4-bit with nh / nh_kv = 4"
+            "matrix-pipe layout: group 32, head_dim 128, residual_length <= 128; 2-bit with nh / nh_kv in {1, 4, 8} or 4-bit with nh / nh_kv in {1, 4}"
         self.cfg = cfg
         R = cfg.residual_length
         self.B, self.nh_kv, self.D, self.nh = batch, num_kv_heads, head_dim, num_heads

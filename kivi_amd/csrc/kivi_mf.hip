@@ -1245,7 +1245,11 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         KIVI_REQUIRE(n_blk <= cap, KIVI_EUNSUPPORTED, "mf_row%d: rows of %lld keys do not fit the LDS (<= %lld)", R, (long long)n_blk, (long long)cap);
         const int n_pad = (int)((n_blk + 4 + 31) / 32 * 32);
         size_t lds = (size_t)R * n_pad * 2;
-        const size_t fin = (size_t)(2 * 6 + 6 + 2) * R * 128 * 4;  // the per-wave partial sums (up to six waves, hi and lo) + the block's sums reuse the rows
+        // the per-wave partial sums + the block's sums reuse the rows: [NP][R * 128] quantised part (hi and lo of every wave for R = 4) |
+        // [NW][R * 128] window part | [2][R * 128] hand-off.  (Sized for the FOUR waves of the product blocks: a blanket six-wave size cost
+        // nh / nh_kv = 8 its second block per CU -- 80 KB instead of 56 -- and 50 % of its speed for a session.)
+        auto fin_bytes = [&](int nw) { return (size_t)((R == 4 ? 2 * nw : nw) + nw + 2) * R * 128 * 4; };
+        const size_t fin = fin_bytes(4);
         const int occ = R == 1 ? 4 : 2;                             // blocks per CU
         if (lds < fin) lds = fin;
         const dim3 grid((unsigned)((int64_t)units * S));
@@ -1281,6 +1285,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
 #ifdef KIVI_TUNING
         static unsigned long long opt446[3] = {0};
         static const char* f46 = KIVI_TUNE_ENV("KIVI_MF_ROW4_46");       // 4-bit codes, six waves per block: "<K ring><V ring>" (A/B; not the product)
+        if (bits == 4 && psm && f46 && lds < fin_bytes(6)) lds = fin_bytes(6);
         if (bits == 4 && psm && f46 && atoi(f46) == 22) KIVI_ROW4_LAUNCH_T(opt446[0], 384, 2, 2, 6, false, true, 4, 4, 3, true);
         if (bits == 4 && psm && f46 && atoi(f46) == 23) KIVI_ROW4_LAUNCH_T(opt446[1], 384, 2, 3, 6, false, true, 4, 4, 3, true);
         if (bits == 4 && psm && f46 && atoi(f46) == 43) KIVI_ROW4_LAUNCH_T(opt446[2], 384, 4, 3, 6, false, true, 4, 4, 3, true);
@@ -1315,6 +1320,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         static unsigned long long opt6[4] = {0};
         static const char* fr6 = KIVI_TUNE_ENV("KIVI_MF_ROW4_6");        // "<K ring><V ring>" of the six-wave block
         const int c6 = fr6 ? atoi(fr6) : 43;
+        if (psm && six && lds < fin_bytes(6)) lds = fin_bytes(6);
         if (psm && six && c6 == 23) KIVI_ROW4_LAUNCH_T(opt6[0], 384, 2, 3, 6, false, true, 4, 2, 3, true);
         if (psm && six && c6 == 42) KIVI_ROW4_LAUNCH_T(opt6[1], 384, 4, 2, 6, false, true, 4, 2, 3, true);
         if (psm && six && c6 == 22) KIVI_ROW4_LAUNCH_T(opt6[2], 384, 2, 2, 6, false, true, 4, 2, 3, true);

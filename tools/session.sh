@@ -129,6 +129,23 @@ while [ $# -gt 0 ]; do
                 KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_OCC3=1 timeout 300 $BN --batch $lb --heads 32 --kv-heads 8 --prompt $lt --residual 128 --steps 10 --warmup 3 > $O/occ3_b${lb}_t${lt}_occ3_$i.json 2>> $O/occ3.err; line $O/occ3_b${lb}_t${lt}_occ3_$i.json
             done
         done ;;
+    confirm)
+        # round 6, last session: the library after the hand-off sizing fix (nh / nh_kv = 8 back at two blocks per CU): the ratio-8 shapes, one launch vs two
+        timeout 300 $BN $C70 --steps 10 --warmup 3 > $O/confirm_70b_slice.json 2>> $O/confirm.err; line $O/confirm_70b_slice.json
+        timeout 300 $BN $C70 --steps 10 --warmup 3 --form split > $O/confirm_70b_slice_split.json 2>> $O/confirm.err; line $O/confirm_70b_slice_split.json
+        timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 8064 --residual 128 --steps 6 --warmup 2 > $O/confirm_r8_b64_8k.json 2>> $O/confirm.err; line $O/confirm_r8_b64_8k.json
+        timeout 300 $BN --batch 64 --heads 64 --kv-heads 8 --prompt 4000 --residual 32 --steps 10 --warmup 3 > $O/confirm_r8_b64_4k.json 2>> $O/confirm.err; line $O/confirm_r8_b64_4k.json
+        timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/confirm_config4.json 2>> $O/confirm.err; line $O/confirm_config4.json
+        timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/confirm_config5_slice.json 2>> $O/confirm.err; line $O/confirm_config5_slice.json
+        cd /tmp && export TMPDIR=/tmp
+        timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -o c -- $R/tools/hbm_read_bw.bin 2 > $O/hbm_bw.log 2>&1; tail -4 $O/hbm_bw.log
+        python - $O <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/pmc_calib/**/*counter_collection.csv", recursive=True)
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == "FETCH_SIZE"] if f else []
+print("calibration: FETCH_SIZE units per launch", v[:4], "-> bytes per unit for 2 GiB of reads:", [round(2 * 2**30 / x, 2) for x in v[:4] if x])
+PY
+        cd $R ;;
     mf41)
         # round 6: 4-bit multi-head K / V on the matrix pipe (nh == nh_kv) against the VALU kernels of the hook-state layout, one box, alternating:
         # C2 at 4 bits (B = 8 / 32 / 64), LongChat-7B-32K + KIVI-4 rows (B = 8 x 16k / 32k)
