@@ -65,7 +65,7 @@ const char* kivi_last_error(void);
  * message naming the unit) and clears the error -- the arrival counters of the timed-out launch have been put back to zero by its
  * last block, the call after that runs normally.  kivi_device_error() returns and clears the same state explicitly (after a
  * stream synchronisation it is exact).  The same code is also left in the device error word of the launch's workspace (word
- * 16382 of the counter area) for callers that keep everything on the device. */
+ * 16375 of the counter area) for callers that keep everything on the device. */
 int kivi_device_error(void);
 
 /* ---------------------------------------------------------------- pack --- */
@@ -339,11 +339,12 @@ int kivi_gqa_output(const void* probs, int64_t p_sb, int64_t p_sh, const void* v
  * block per slice, still in ONE launch: the slices of a unit exchange their (max, sum exp) through `stats` (arrival counters in the
  * second half of the workspace's counter area), form the same probabilities a single block would, and their partial outputs meet
  * in `workspace` (S slots per unit).  Blocks of such a launch wait for each other, so their ids are ALWAYS handed out in start
- * order by a ticket counter (the last word of the counter area; ABI version 2 skipped it when the grid fitted the chip, which an
- * ordinary launch cannot guarantee: other streams, a CU mask): a waiting block's partners have started, or belong to the unit at
- * the dispatch front and start as soon as any older block finishes.  The wait is bounded (~1 s); a block that gives up poisons its
- * unit's output with NaN, records KIVI_ETIMEOUT (kivi_device_error; word 16382 of the counter area) and the launch's last blocks
- * still put every counter back to zero.  At most 8190 units take a sliced form.
+ * order by ticket counters (the last eight words of the counter area, one per blockIdx % 8: a single counter serialises a launch's
+ * atomics on one address; ABI version 2 skipped the ticket when the grid fitted the chip, which an ordinary launch cannot
+ * guarantee: other streams, a CU mask): a waiting block's partners have started, or belong to the units at the dispatch front
+ * and start as soon as any older block finishes.  The wait is bounded (~1 s); a block that gives up poisons its
+ * unit's output with NaN, records KIVI_ETIMEOUT (kivi_device_error; word 16375 of the counter area) and the launch's last blocks
+ * still put every counter back to zero.  At most 8183 units take a sliced form.
  * Otherwise two launches (incl. multi-head rows beyond 16 super-blocks: the sliced one-launch form of such rows is reachable through
  * KIVI_GQA_SLICES(n) only -- measured slower than the two launches):
  *   1. packed qK^T on the matrix pipe + fp16 residual scores + K append (llama_kivi.py:323-337); the epilogue applies

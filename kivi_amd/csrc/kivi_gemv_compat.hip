@@ -16,6 +16,8 @@
 
 namespace {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 template <int BITS>
 __global__ __launch_bounds__(256) void gemv_outer_dim_kernel(const uint16_t* __restrict__ in,
                                                              const uint32_t* __restrict__ kernel,
@@ -266,6 +268,122 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_wide_kernel(const uint16_t
     }
 }
 
+// ---- short rows (IC <= 256: the qK^T shape), round 6: the dot axis back INSIDE the lane.  With IC contiguous a lane of the wide kernel
+// above holds 4 channels of one packed row, so every row needs a 16-value reduction across its 32 lanes (~60 of ~180 vector instructions
+// per group).  Here a wave takes 64 consecutive packed rows and TRANSPOSES them through the LDS, 32 ic at a time: coalesced 16-byte
+// global loads (8 lanes per row segment) -> LDS tile [row][36 words] -> lane l reads ITS row with 16-byte LDS reads (the pitch of 36
+// words keeps both directions conflict-free) and accumulates its fpi outputs over all of IC exactly as kivi_gemv_k does on the
+// hook-state layout (accum_word, 1.56 instructions per code; no cross-lane step at all).  The group's scale / zero point come from a
+// small second tile (one fp16 pair per two ic, lanes of a group read the same word), the input row from an fp32 copy in the LDS
+// (broadcast reads).  The next 32 ic are in flight in registers while the current ones are multiplied.  Outputs: fpi consecutive fp16
+// per lane, consecutive lanes -> consecutive addresses.
+template <int BITS>
+__global__ __launch_bounds__(128) void gemv_outer_dim_rows_kernel(const uint16_t* __restrict__ in, const uint32_t* __restrict__ kernel,
+                                                                  const uint16_t* __restrict__ scale, const uint16_t* __restrict__ zeros,
+                                                                  uint16_t* __restrict__ out, int IC, int64_t OC, int g, int ratio, int tiles_per_b, int64_t ntile) {
+    constexpr int FPI = 32 / BITS;
+    constexpr int CH = 32, P = 36, PS = 17;                    // ic per chunk; code-tile pitch (words); scale / zero tile pitch (words = 2 halves)
+    __shared__ __attribute__((aligned(16))) uint32_t codes_lds[2][64 * P];
+    __shared__ uint32_t sm_lds[2][2][32 * PS];                 // [wave][scale | zero][group][ic pair]
+    __shared__ __attribute__((aligned(16))) float x_lds[2][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 2 + wave;
+    if (tile >= ntile) return;                                  // (whole wave; the waves of a block share nothing but the LDS allocation)
+    const int64_t bidx = tile / tiles_per_b;
+    const int t_in_b = (int)(tile - bidx * tiles_per_b);
+    const int64_t nrow = OC / FPI, ngrp = OC / g;
+    const int rpg = g / FPI;                                    // packed rows per group: 2, 4, 8 (a power of two)
+    const int rsh = rpg == 2 ? 1 : (rpg == 4 ? 2 : (rpg == 8 ? 3 : 4));
+    const int64_t row0 = (int64_t)t_in_b * 64;                  // first packed row of the tile
+    if (row0 >= nrow) return;                                   // (whole wave)
+    const int64_t bk = bidx / ratio;                            // gemv_cuda.cu:361-365
+    const int nrows = nrow - row0 < 64 ? (int)(nrow - row0) : 64;
+    const int ngt = (nrows + rpg - 1) >> rsh;                   // groups of the tile
+    const uint32_t* wp = kernel + (bk * nrow + row0) * IC;
+    const uint16_t* sp = scale + (bk * ngrp + (row0 >> rsh)) * IC;
+    const uint16_t* zp = zeros + (bk * ngrp + (row0 >> rsh)) * IC;
+    uint32_t* ct = codes_lds[wave];
+    uint32_t* st = sm_lds[wave][0];
+    uint32_t* zt = sm_lds[wave][1];
+    float* xl = x_lds[wave];
+    // the input row as fp32 (zeros past IC: partial chunks then contribute nothing)
+    for (int i = lane; i < 256; i += 64) xl[i] = i < IC ? h2f_bits(in[bidx * IC + i]) : 0.f;
+    const int nch = (IC + CH - 1) / CH;
+    // what a lane fetches per chunk: 8 x 16 bytes of codes (rows i * 8 + lane / 8, words (lane % 8) * 4 ..), 16 bytes of scale and of
+    // zero points (group lane / 4 [+ 16], halves (lane % 4) * 8 ..)
+    u32x4 cw[8], sw[2], zw[2];
+    auto fetch = [&](int c) {
+        const int ic0 = c * CH;
+        const int w = ic0 + (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int r = i * 8 + (lane >> 3);
+            cw[i] = (r < nrows && w < IC) ? __builtin_nontemporal_load((const u32x4*)(wp + (int64_t)r * IC + w)) : u32x4{0, 0, 0, 0};
+        }
+        const int h = ic0 + (lane & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int gq = i * 16 + (lane >> 2);
+            const bool on = gq < ngt && h < IC;                 // (IC % 8 == 0 is required by the dispatch)
+            sw[i] = on ? *(const u32x4*)(sp + (int64_t)gq * IC + h) : u32x4{0, 0, 0, 0};
+            zw[i] = on ? *(const u32x4*)(zp + (int64_t)gq * IC + h) : u32x4{0, 0, 0, 0};
+        }
+    };
+    float acc[FPI], z = 0.f;
+#pragma unroll
+    for (int p = 0; p < FPI; p++) acc[p] = 0.f;
+    const int gl = lane >> rsh;                                 // this lane's group inside the tile
+    fetch(0);
+    for (int c = 0; c < nch; c++) {
+        __builtin_amdgcn_wave_barrier();                        // the previous chunk's LDS reads are over (LDS operations of a wave complete in order)
+#pragma unroll
+        for (int i = 0; i < 8; i++) *(u32x4*)(ct + (i * 8 + (lane >> 3)) * P + (lane & 7) * 4) = cw[i];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int gq = i * 16 + (lane >> 2);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                st[gq * PS + (lane & 3) * 4 + k] = sw[i][k];
+                zt[gq * PS + (lane & 3) * 4 + k] = zw[i][k];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < nch) fetch(c + 1);                          // in flight during this chunk's arithmetic
+        const float* xc = xl + c * CH;
+#pragma unroll
+        for (int j4 = 0; j4 < CH / 4; j4++) {
+            const u32x4 w4 = *(const u32x4*)(ct + lane * P + j4 * 4);
+            const f32x4_t x4 = *(const f32x4_t*)(xc + j4 * 4);
+            const uint32_t s01 = st[gl * PS + j4 * 2], s23 = st[gl * PS + j4 * 2 + 1];
+            const uint32_t z01 = zt[gl * PS + j4 * 2], z23 = zt[gl * PS + j4 * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t sp2 = j < 2 ? s01 : s23, zp2 = j < 2 ? z01 : z23;
+                const float sc = h2f_bits((uint16_t)((j & 1) ? sp2 >> 16 : sp2 & 0xFFFFu));
+                const float zc = h2f_bits((uint16_t)((j & 1) ? zp2 >> 16 : zp2 & 0xFFFFu));
+                const float x = x4[j];
+                z = __builtin_fmaf(x, zc, z);
+                accum_word<BITS, KIVI_UNPACK_MIX>(w4[j], x * sc * qs_factor<KIVI_UNPACK_MIX>(), acc);
+            }
+        }
+    }
+    if (lane < nrows) {
+        uint16_t o[FPI];
+#pragma unroll
+        for (int p = 0; p < FPI; p++) o[p] = f2h_bits(acc[p] * post_scale<BITS, KIVI_UNPACK_MIX>(p) + z);
+        uint16_t* dst = out + bidx * OC + (row0 + lane) * FPI;
+#pragma unroll
+        for (int p = 0; p < FPI; p += 8) {
+            u32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (uint32_t)o[p + 2 * k] | ((uint32_t)o[p + 2 * k + 1] << 16);
+            *(u32x4*)(dst + p) = v;
+        }
+    }
+}
+
 // Legacy AWQ-style INNER-dim grouped 4-bit GEMV (gemv_kernel_g64 / gemv_kernel_g128, gemv_cuda.cu:60-184):
 //   out[b, oc] = fp16( sum_ic (scale[oc, ic/g] * code[oc, ic] + zero[oc, ic/g]) * in[b, ic] )
 // weight (OC, IC/8) int32 packed along IC, scale / zeros (OC, >= IC/g) fp16 with row pitch `sz_pitch`.
@@ -344,6 +462,23 @@ extern "C" int kivi_gemv_outer_dim(const void* in, const void* kernel, const voi
     const bool wide_ok = IC > 0 && IC % 4 == 0 && (group_size == 32 || group_size == 64) && (uintptr_t)kernel % 16 == 0 &&
                          (uintptr_t)scale % 8 == 0 && (uintptr_t)zeros % 8 == 0 && (uintptr_t)in % 8 == 0;
     static const char* old_only = KIVI_TUNE_ENV("KIVI_COMPAT_OLD");      // tuning builds, A/B: the general one-wave-per-packed-row kernel
+    static const char* no_rows = KIVI_TUNE_ENV("KIVI_COMPAT_NO_ROWS");   // tuning builds, A/B: the wide kernel for short rows too
+    // short rows (the qK^T shape): the transposing kernel -- lane = packed row, no cross-lane sums
+    const bool rows_ok = wide_ok && IC <= 256 && IC % 8 == 0 && (uintptr_t)scale % 16 == 0 && (uintptr_t)zeros % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                         (group_size / fpi) <= 16;
+    if (rows_ok && !(old_only && atoi(old_only)) && !(no_rows && atoi(no_rows))) {
+        const int64_t tiles_per_b = (nrow + 63) / 64;
+        const int64_t ntile = BS * tiles_per_b;
+        KIVI_REQUIRE((ntile + 1) / 2 < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_gemv_outer_dim: grid too large");
+        const dim3 grid2((unsigned)((ntile + 1) / 2));
+        if (bit == 2)
+            hipLaunchKernelGGL(gemv_outer_dim_rows_kernel<2>, grid2, dim3(128), 0, s, (const uint16_t*)in, (const uint32_t*)kernel, (const uint16_t*)scale,
+                               (const uint16_t*)zeros, (uint16_t*)out, (int)IC, OC, group_size, nh / nh_kv, (int)tiles_per_b, ntile);
+        else
+            hipLaunchKernelGGL(gemv_outer_dim_rows_kernel<4>, grid2, dim3(128), 0, s, (const uint16_t*)in, (const uint32_t*)kernel, (const uint16_t*)scale,
+                               (const uint16_t*)zeros, (uint16_t*)out, (int)IC, OC, group_size, nh / nh_kv, (int)tiles_per_b, ntile);
+        return kivi_launch_status("gemv_outer_dim_rows");
+    }
     if (wide_ok && !(old_only && atoi(old_only))) {
         const int64_t ntask = BS * (OC / group_size);
         const bool split = IC > 512;                              // long rows (the sV shape): a block per group, IC over its four waves

@@ -972,7 +972,7 @@ extern "C" int kivi_gqa_decode(const kivi_gqa_decode_args* p, kivi_stream_t stre
     k.dump = (p->flags & KIVI_GQA_DUMP_SCORES) != 0;
     k.xcount = (int*)p->workspace + KIVI_GQA_WS_COUNTERS / 2;
     k.ticket = (int*)p->workspace + KIVI_GQA_WS_COUNTERS - 1;
-    k.err_ws = (int*)p->workspace + KIVI_GQA_WS_COUNTERS - 2;
+    k.err_ws = (int*)p->workspace + KIVI_GQA_WS_COUNTERS - KIVI_GQA_TICKETS - 1;
     k.err_host = plan > 1 ? kivi_device_error_word((hipStream_t)stream) : nullptr;
     static const char* skipk = KIVI_TUNE_ENV("KIVI_GQA_SKIP_K");       // diagnostic (tools/mf_stage_error.py): the caller filled scores / stats
     static const char* timev = KIVI_TUNE_ENV("KIVI_GQA_TIME_V");       // tuning aid: a pending event pair brackets the sV launch instead

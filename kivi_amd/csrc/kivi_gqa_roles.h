@@ -8,8 +8,10 @@
 namespace {
 
 constexpr int KIVI_GQA_WS_COUNTERS = 16384;   // arrival counters at the head of the caller's workspace: [0, 8192) one per unit (partial sums),
-                                              // [8192, 16382) one per unit (statistics exchange of sliced launches), 16382 the device error word, 16383 the ticket
-constexpr int KIVI_GQA_MAX_SLICED_UNITS = KIVI_GQA_WS_COUNTERS / 2 - 2;
+                                              // [8192, 16375) one per unit (statistics exchange of sliced launches), 16375 the device error word,
+                                              // [16376, 16384) the eight ticket counters of sliced launches
+constexpr int KIVI_GQA_TICKETS = 8;           // ticket counters: a block takes its id from counter blockIdx % 8 (see mf_row4_kernel)
+constexpr int KIVI_GQA_MAX_SLICED_UNITS = KIVI_GQA_WS_COUNTERS / 2 - KIVI_GQA_TICKETS - 1;
 
 // The six lengths of a decode step in DEVICE memory (= kivi_mf_step of include/kivi_hip.h): when an argument block carries a
 // pointer to one, the kernels take the lengths from it instead of from their by-value arguments, so that a captured launch
@@ -46,9 +48,10 @@ struct GqaKArgs {
     const MfStep* dyn;          // device-resident lengths (or null): Tq, res_len are read from it
     // one-launch form (mf_row4_kernel): dump != 0 (KIVI_GQA_DUMP_SCORES, tests): the fp16 rows the softmax statistics are taken
     // from (scaled, mask added) also go to `out`; rows cut into S > 1 slices: `stats` is the exchange buffer [unit][slice][R][2]
-    // of the slices' (max, sum exp), `xcount` [units] their arrival counters (zero between launches), `ticket` (null for S = 1) one
-    // counter that hands out the block ids in the order the blocks START (always, for S > 1: blocks that wait for each other must
-    // not depend on the whole grid being resident at once -- other streams, a CU mask, a second sliced launch), `err_ws` the device
+    // of the slices' (max, sum exp), `xcount` [units] their arrival counters (zero between launches), `ticket` (null for S = 1) the
+    // LAST of KIVI_GQA_TICKETS counters (ticket[-c], c = blockIdx % 8) that hand out the block ids in the order the blocks START
+    // (always, for S > 1: blocks that wait for each other must not depend on the whole grid being resident at once -- other streams,
+    // a CU mask), `err_ws` the device
     // error word of the workspace and `err_host` (or null) the process's host-visible one: a block that gives up waiting records
     // KIVI_ETIMEOUT in both (kivi_device_error)
     int dump;                   // bit 0: dump; bit 1 (-DKIVI_TUNING builds only): fault injection, slice 0 of unit 0 never arrives

@@ -679,9 +679,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     int bid = (int)blockIdx.x;
     if (ak.ticket) {                                               // block ids in the order the blocks start (see above)
         if (threadIdx.x == 0) {
-            const int t = __hip_atomic_fetch_add(ak.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == (int)gridDim.x - 1) __hip_atomic_store(ak.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-            bid_lds = t;
+            // EIGHT counters, chosen by blockIdx % 8: ids c, c + 8, c + 16, ... in the start order of the blocks of class c.  One counter
+            // for the whole grid serialises its atomics on one address -- 512 blocks starting together: the last ticket ~7 us after
+            // the first, +13 % on the 70B-like slice once round 6 made the ticket unconditional (profiles/r06_confirm.log) --; a class has
+            // an eighth of the blocks and its own address.  Consecutive ids (the slices of a unit) sit in different classes with the same
+            // or neighbouring ticket numbers; blocks are dispatched in blockIdx order, so the classes advance together (on a chip whose
+            // XCDs take blockIdx round-robin a class IS an XCD's share: the XCD furthest behind finds all its partners started).
+            int c = (int)blockIdx.x & (KIVI_GQA_TICKETS - 1);
+            int nc = ((int)gridDim.x - c + KIVI_GQA_TICKETS - 1) / KIVI_GQA_TICKETS;                // blocks of this class
+            int step = KIVI_GQA_TICKETS;
+#ifdef KIVI_TUNING
+            if (ak.dump & 4) { c = 0; nc = (int)gridDim.x; step = 1; }                               // A/B: ONE counter for the whole grid (KIVI_MF_ONE_TICKET=1)
+#endif
+            const int t = __hip_atomic_fetch_add(ak.ticket - c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == nc - 1) __hip_atomic_store(ak.ticket - c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+            bid_lds = c + step * t;
         }
         __syncthreads();
         bid = __builtin_amdgcn_readfirstlane(bid_lds);
@@ -1261,6 +1273,8 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
 #ifdef KIVI_TUNING
         static const char* ft = KIVI_TUNE_ENV("KIVI_MF_FAULT_DROP_ARRIVAL");       // fault injection: see mf_row4_kernel
         if (ft && atoi(ft) && S > 1) k.dump |= 2;
+        static const char* f1t = KIVI_TUNE_ENV("KIVI_MF_ONE_TICKET");              // A/B: one ticket counter instead of eight
+        if (f1t && atoi(f1t) && S > 1) k.dump |= 4;
 #endif
         if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; k.err_ws = nullptr; k.err_host = nullptr; }
         static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0, opt14 = 0, opt8p = 0, opt4p = 0, opt44p = 0;

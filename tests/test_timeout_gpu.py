@@ -42,8 +42,8 @@ assert torch.isnan(got[0, :r]).all(), "unit 0 must be poisoned"
 assert torch.equal(got[0, r:], want[0, r:]) or (got[0, r:].float() - want[0, r:].float()).abs().max() < 2e-2, "other units untouched"
 assert torch.isfinite(got[1]).all()
 ws = a._native[4][2].view(torch.int32)
-assert int(ws[16382]) == 4, "device error word of the workspace"
-assert int(ws[:16382].abs().sum()) == 0 and int(ws[16383]) == 0, "arrival counters / ticket back at zero"
+assert int(ws[16375]) == 4, "device error word of the workspace"
+assert int(ws[:16375].abs().sum()) == 0 and int(ws[16376:16384].abs().sum()) == 0, "arrival counters / the eight tickets back at zero"
 q2, kn2, vn2 = make_kv(6, B, nh, 1, D).cuda(), make_kv(7, B, nh_kv, 1, D).cuda(), make_kv(8, B, nh_kv, 1, D).cuda()
 try:
     kivi_attention_decode(q2, kn2, vn2, a)

@@ -117,6 +117,7 @@ while [ $# -gt 0 ]; do
         timeout 600 python tools/compat_time.py > $O/compat_time.log 2>&1; BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time.log 2>&1; cat $O/compat_time.log
         # the general kernel (one wave per packed row: what rounds 1-5 shipped) on the same box: tuning build, KIVI_COMPAT_OLD=1
         T=$R/kivi_amd/_variants/libkivi_tuning.so
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_NO_ROWS=1 timeout 600 python tools/compat_time.py > $O/compat_time_wide.log 2>&1; KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_NO_ROWS=1 BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time_wide.log 2>&1; grep "gemv_outer_dim" $O/compat_time_wide.log
         KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_OLD=1 timeout 600 python tools/compat_time.py > $O/compat_time_old.log 2>&1; KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_OLD=1 BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time_old.log 2>&1; grep "gemv_outer_dim" $O/compat_time_old.log ;;
     occ3)
         # round 6: four-wave blocks of mf_row4_kernel compiled for THREE waves per SIMD (167 registers, rings 2 / 2; tuning build, KIVI_MF_ROW4_OCC3=1) where the
@@ -146,6 +147,16 @@ v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if r["Counter
 print("calibration: FETCH_SIZE units per launch", v[:4], "-> bytes per unit for 2 GiB of reads:", [round(2 * 2**30 / x, 2) for x in v[:4] if x])
 PY
         cd $R ;;
+    tickets)
+        # round 6: eight ticket counters (blockIdx % 8; product) against ONE (tuning build, KIVI_MF_ONE_TICKET=1) for the sliced one-launch forms, one box
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        for i in 1 2 3; do
+            for sh in "70b $C70 --steps 10 --warmup 3" "c5 $C5 --steps 6 --warmup 2" "b4_8k --batch 4 --heads 32 --kv-heads 8 --prompt 8064 --residual 128 --steps 10 --warmup 3"; do
+                n=${sh%% *}; a=${sh#* }
+                timeout 300 $BN $a > $O/tickets_${n}_eight_$i.json 2>> $O/tickets.err; line $O/tickets_${n}_eight_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ONE_TICKET=1 timeout 300 $BN $a > $O/tickets_${n}_one_$i.json 2>> $O/tickets.err; line $O/tickets_${n}_one_$i.json
+            done
+        done ;;
     mf41)
         # round 6: 4-bit multi-head K / V on the matrix pipe (nh == nh_kv) against the VALU kernels of the hook-state layout, one box, alternating:
         # C2 at 4 bits (B = 8 / 32 / 64), LongChat-7B-32K + KIVI-4 rows (B = 8 x 16k / 32k)
