@@ -277,12 +277,15 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_wide_kernel(const uint16_t
 // small second tile (one fp16 pair per two ic, lanes of a group read the same word), the input row from an fp32 copy in the LDS
 // (broadcast reads).  The next 32 ic are in flight in registers while the current ones are multiplied.  Outputs: fpi consecutive fp16
 // per lane, consecutive lanes -> consecutive addresses.
-template <int BITS>
+// CH: ic per chunk (32: fewer, larger stages, 29 KB of LDS per two-wave block; 16: 17 KB, twice the resident waves)
+template <int BITS, int CH>
 __global__ __launch_bounds__(128) void gemv_outer_dim_rows_kernel(const uint16_t* __restrict__ in, const uint32_t* __restrict__ kernel,
                                                                   const uint16_t* __restrict__ scale, const uint16_t* __restrict__ zeros,
                                                                   uint16_t* __restrict__ out, int IC, int64_t OC, int g, int ratio, int tiles_per_b, int64_t ntile) {
     constexpr int FPI = 32 / BITS;
-    constexpr int CH = 32, P = 36, PS = 17;                    // ic per chunk; code-tile pitch (words); scale / zero tile pitch (words = 2 halves)
+    constexpr int P = CH + 4, PS = CH / 2 + 1;                 // code-tile pitch (words: = 4 mod 8, so that 16-byte accesses of 8 consecutive lanes never share a bank); scale / zero tile pitch (words = 2 halves)
+    constexpr int LPR = CH / 4;                                // lanes per row segment of a chunk (16 bytes each)
+    constexpr int NLD = 64 / (64 / LPR);                       // code loads per lane and chunk: 64 rows / (64 / LPR rows per instruction)
     __shared__ __attribute__((aligned(16))) uint32_t codes_lds[2][64 * P];
     __shared__ uint32_t sm_lds[2][2][32 * PS];                 // [wave][scale | zero][group][ic pair]
     __shared__ __attribute__((aligned(16))) float x_lds[2][256];
@@ -310,21 +313,23 @@ __global__ __launch_bounds__(128) void gemv_outer_dim_rows_kernel(const uint16_t
     // the input row as fp32 (zeros past IC: partial chunks then contribute nothing)
     for (int i = lane; i < 256; i += 64) xl[i] = i < IC ? h2f_bits(in[bidx * IC + i]) : 0.f;
     const int nch = (IC + CH - 1) / CH;
-    // what a lane fetches per chunk: 8 x 16 bytes of codes (rows i * 8 + lane / 8, words (lane % 8) * 4 ..), 16 bytes of scale and of
-    // zero points (group lane / 4 [+ 16], halves (lane % 4) * 8 ..)
-    u32x4 cw[8], sw[2], zw[2];
+    // what a lane fetches per chunk: NLD x 16 bytes of codes (rows i * (64 / LPR) + lane / LPR, words (lane % LPR) * 4 ..), 16 bytes of
+    // scale and of zero points per 64 / (CH / 8) groups (halves (lane % (CH / 8)) * 8 ..)
+    constexpr int LPG = CH / 8;                                // lanes per group segment of scale / zero (8 halves each)
+    constexpr int NSM = (32 * LPG + 63) / 64;                  // scale loads per lane and chunk (32 groups at most)
+    u32x4 cw[NLD], sw[NSM], zw[NSM];
     auto fetch = [&](int c) {
         const int ic0 = c * CH;
-        const int w = ic0 + (lane & 7) * 4;
+        const int w = ic0 + (lane % LPR) * 4;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int r = i * 8 + (lane >> 3);
+        for (int i = 0; i < NLD; i++) {
+            const int r = i * (64 / LPR) + lane / LPR;
             cw[i] = (r < nrows && w < IC) ? __builtin_nontemporal_load((const u32x4*)(wp + (int64_t)r * IC + w)) : u32x4{0, 0, 0, 0};
         }
-        const int h = ic0 + (lane & 3) * 8;
+        const int h = ic0 + (lane % LPG) * 8;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int gq = i * 16 + (lane >> 2);
+        for (int i = 0; i < NSM; i++) {
+            const int gq = i * (64 / LPG) + lane / LPG;
             const bool on = gq < ngt && h < IC;                 // (IC % 8 == 0 is required by the dispatch)
             sw[i] = on ? *(const u32x4*)(sp + (int64_t)gq * IC + h) : u32x4{0, 0, 0, 0};
             zw[i] = on ? *(const u32x4*)(zp + (int64_t)gq * IC + h) : u32x4{0, 0, 0, 0};
@@ -338,14 +343,16 @@ __global__ __launch_bounds__(128) void gemv_outer_dim_rows_kernel(const uint16_t
     for (int c = 0; c < nch; c++) {
         __builtin_amdgcn_wave_barrier();                        // the previous chunk's LDS reads are over (LDS operations of a wave complete in order)
 #pragma unroll
-        for (int i = 0; i < 8; i++) *(u32x4*)(ct + (i * 8 + (lane >> 3)) * P + (lane & 7) * 4) = cw[i];
+        for (int i = 0; i < NLD; i++) *(u32x4*)(ct + (i * (64 / LPR) + lane / LPR) * P + (lane % LPR) * 4) = cw[i];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int gq = i * 16 + (lane >> 2);
+        for (int i = 0; i < NSM; i++) {
+            const int gq = i * (64 / LPG) + lane / LPG;
+            if (gq < 32) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                st[gq * PS + (lane & 3) * 4 + k] = sw[i][k];
-                zt[gq * PS + (lane & 3) * 4 + k] = zw[i][k];
+                for (int k = 0; k < 4; k++) {
+                    st[gq * PS + (lane % LPG) * 4 + k] = sw[i][k];
+                    zt[gq * PS + (lane % LPG) * 4 + k] = zw[i][k];
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -471,12 +478,14 @@ extern "C" int kivi_gemv_outer_dim(const void* in, const void* kernel, const voi
         const int64_t ntile = BS * tiles_per_b;
         KIVI_REQUIRE((ntile + 1) / 2 < ((int64_t)1 << 31), KIVI_EINVAL, "kivi_gemv_outer_dim: grid too large");
         const dim3 grid2((unsigned)((ntile + 1) / 2));
-        if (bit == 2)
-            hipLaunchKernelGGL(gemv_outer_dim_rows_kernel<2>, grid2, dim3(128), 0, s, (const uint16_t*)in, (const uint32_t*)kernel, (const uint16_t*)scale,
-                               (const uint16_t*)zeros, (uint16_t*)out, (int)IC, OC, group_size, nh / nh_kv, (int)tiles_per_b, ntile);
-        else
-            hipLaunchKernelGGL(gemv_outer_dim_rows_kernel<4>, grid2, dim3(128), 0, s, (const uint16_t*)in, (const uint32_t*)kernel, (const uint16_t*)scale,
-                               (const uint16_t*)zeros, (uint16_t*)out, (int)IC, OC, group_size, nh / nh_kv, (int)tiles_per_b, ntile);
+        static const char* fch = KIVI_TUNE_ENV("KIVI_COMPAT_CH");       // tuning builds, A/B: ic per chunk (16 | 32)
+        const int ch = fch ? atoi(fch) : 32;
+#define KIVI_ROWS(B_, CH_)                                                                                                                       \
+    hipLaunchKernelGGL((gemv_outer_dim_rows_kernel<B_, CH_>), grid2, dim3(128), 0, s, (const uint16_t*)in, (const uint32_t*)kernel, (const uint16_t*)scale, \
+                       (const uint16_t*)zeros, (uint16_t*)out, (int)IC, OC, group_size, nh / nh_kv, (int)tiles_per_b, ntile)
+        if (bit == 2) { if (ch == 16) KIVI_ROWS(2, 16); else KIVI_ROWS(2, 32); }
+        else { if (ch == 16) KIVI_ROWS(4, 16); else KIVI_ROWS(4, 32); }
+#undef KIVI_ROWS
         return kivi_launch_status("gemv_outer_dim_rows");
     }
     if (wide_ok && !(old_only && atoi(old_only))) {

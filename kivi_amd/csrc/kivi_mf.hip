@@ -1275,6 +1275,8 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
         if (ft && atoi(ft) && S > 1) k.dump |= 2;
         static const char* f1t = KIVI_TUNE_ENV("KIVI_MF_ONE_TICKET");              // A/B: one ticket counter instead of eight
         if (f1t && atoi(f1t) && S > 1) k.dump |= 4;
+        static const char* fnt = KIVI_TUNE_ENV("KIVI_MF_NO_TICKET");               // A/B: round 5's rule -- static block ids when the grid fits 2 (4) blocks per CU
+        if (fnt && atoi(fnt) && S > 1 && (int64_t)units * S <= occ * (int64_t)mf_cu_count()) k.ticket = nullptr;
 #endif
         if (S == 1) { k.ticket = nullptr; k.xcount = nullptr; k.err_ws = nullptr; k.err_host = nullptr; }
         static unsigned long long opt8 = 0, opt4 = 0, opt44 = 0, opt1 = 0, opt14 = 0, opt8p = 0, opt4p = 0, opt44p = 0;

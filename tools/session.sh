@@ -117,6 +117,8 @@ while [ $# -gt 0 ]; do
         timeout 600 python tools/compat_time.py > $O/compat_time.log 2>&1; BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time.log 2>&1; cat $O/compat_time.log
         # the general kernel (one wave per packed row: what rounds 1-5 shipped) on the same box: tuning build, KIVI_COMPAT_OLD=1
         T=$R/kivi_amd/_variants/libkivi_tuning.so
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_CH=16 timeout 600 python tools/compat_time.py > $O/compat_time_ch16.log 2>&1; KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_CH=16 BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time_ch16.log 2>&1; grep "gemv_outer_dim" $O/compat_time_ch16.log
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_CH=16 timeout 300 python -m pytest tests/test_gemv_gpu.py -m gpu -q -k "compat" > $O/compat_tests_ch16.log 2>&1; echo "compat ch16 tests rc=$?" | tee -a $O/status.log
         KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_NO_ROWS=1 timeout 600 python tools/compat_time.py > $O/compat_time_wide.log 2>&1; KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_NO_ROWS=1 BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time_wide.log 2>&1; grep "gemv_outer_dim" $O/compat_time_wide.log
         KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_OLD=1 timeout 600 python tools/compat_time.py > $O/compat_time_old.log 2>&1; KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_COMPAT_OLD=1 BITS=4 timeout 600 python tools/compat_time.py >> $O/compat_time_old.log 2>&1; grep "gemv_outer_dim" $O/compat_time_old.log ;;
     occ3)
@@ -155,6 +157,7 @@ PY
                 n=${sh%% *}; a=${sh#* }
                 timeout 300 $BN $a > $O/tickets_${n}_eight_$i.json 2>> $O/tickets.err; line $O/tickets_${n}_eight_$i.json
                 KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ONE_TICKET=1 timeout 300 $BN $a > $O/tickets_${n}_one_$i.json 2>> $O/tickets.err; line $O/tickets_${n}_one_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_NO_TICKET=1 timeout 300 $BN $a > $O/tickets_${n}_none_$i.json 2>> $O/tickets.err; line $O/tickets_${n}_none_$i.json
             done
         done ;;
     mf41)
