@@ -278,6 +278,18 @@ __global__ __launch_bounds__(256) void gemv_outer_dim_wide_kernel(const uint16_t
 // (broadcast reads).  The next 32 ic are in flight in registers while the current ones are multiplied.  Outputs: fpi consecutive fp16
 // per lane, consecutive lanes -> consecutive addresses.
 // CH: ic per chunk (32: fewer, larger stages, 29 KB of LDS per two-wave block; 16: 17 KB, twice the resident waves)
+// float(low | high half of a packed fp16 pair) * x + c in ONE instruction (v_fma_mix_f32: the half is converted on the fly, one rounding)
+__device__ __forceinline__ float od_mix_lo(uint32_t hp, float x, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float od_mix_hi(uint32_t hp, float x, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x), "v"(c));
+    return d;
+}
+
 template <int BITS, int CH>
 __global__ __launch_bounds__(128) void gemv_outer_dim_rows_kernel(const uint16_t* __restrict__ in, const uint32_t* __restrict__ kernel,
                                                                   const uint16_t* __restrict__ scale, const uint16_t* __restrict__ zeros,
@@ -368,11 +380,11 @@ __global__ __launch_bounds__(128) void gemv_outer_dim_rows_kernel(const uint16_t
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t sp2 = j < 2 ? s01 : s23, zp2 = j < 2 ? z01 : z23;
-                const float sc = h2f_bits((uint16_t)((j & 1) ? sp2 >> 16 : sp2 & 0xFFFFu));
-                const float zc = h2f_bits((uint16_t)((j & 1) ? zp2 >> 16 : zp2 & 0xFFFFu));
                 const float x = x4[j];
-                z = __builtin_fmaf(x, zc, z);
-                accum_word<BITS, KIVI_UNPACK_MIX>(w4[j], x * sc * qs_factor<KIVI_UNPACK_MIX>(), acc);
+                // x * scale and z += x * zero straight from the packed halves (no shift / convert: 2 instead of 6 instructions per word)
+                const float xs = (j & 1) ? od_mix_hi(sp2, x, 0.f) : od_mix_lo(sp2, x, 0.f);
+                z = (j & 1) ? od_mix_hi(zp2, x, z) : od_mix_lo(zp2, x, z);
+                accum_word<BITS, KIVI_UNPACK_MIX>(w4[j], xs * qs_factor<KIVI_UNPACK_MIX>(), acc);
             }
         }
     }
