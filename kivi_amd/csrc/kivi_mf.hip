@@ -1361,6 +1361,11 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
             if (three) KIVI_ROW4_LAUNCH(opt4o3, 2, 2, 4, false, true, 4, 2, 3, true);
         }
         if (psm) KIVI_ROW4_LAUNCH(opt4p, 4, 3, 4, false, true, 4, 2, 2, true);
+#ifdef KIVI_TUNING
+        static unsigned long long opt4s3 = 0;
+        static const char* fs3 = KIVI_TUNE_ENV("KIVI_MF_ROW4_SOCC3");    // A/B: slices (in-stream flow) compiled for three waves per SIMD (use with more, shorter slices)
+        if (fs3 && atoi(fs3)) KIVI_ROW4_LAUNCH(opt4s3, 2, 2, 4, false, true, 4, 2, 3, false);
+#endif
         KIVI_ROW4_LAUNCH(opt4, 4, 3, 4);
 #undef KIVI_ROW4_LAUNCH
 #undef KIVI_ROW4_LAUNCH_T

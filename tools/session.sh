@@ -149,6 +149,17 @@ v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if r["Counter
 print("calibration: FETCH_SIZE units per launch", v[:4], "-> bytes per unit for 2 GiB of reads:", [round(2 * 2**30 / x, 2) for x in v[:4] if x])
 PY
         cd $R ;;
+    socc3)
+        # round 6: the config-5 slice with MORE, shorter slices whose blocks fit three per CU, compiled for three waves per SIMD (in-stream flow: 168 registers,
+        # 68 bytes spilled; tuning build, KIVI_MF_ROW4_SOCC3=1) against the plan (4 slices, two blocks per CU), one box
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        for i in 1 2; do
+            timeout 300 $BN $C5 --steps 6 --warmup 2 > $O/socc3_c5_plan_$i.json 2>> $O/socc3.err; line $O/socc3_c5_plan_$i.json
+            for sl in 6 8; do
+                timeout 300 $BN $C5 --steps 6 --warmup 2 --form slices$sl > $O/socc3_c5_s${sl}_$i.json 2>> $O/socc3.err; line $O/socc3_c5_s${sl}_$i.json
+                KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_SOCC3=1 timeout 300 $BN $C5 --steps 6 --warmup 2 --form slices$sl > $O/socc3_c5_s${sl}_occ3_$i.json 2>> $O/socc3.err; line $O/socc3_c5_s${sl}_occ3_$i.json
+            done
+        done ;;
     tickets)
         # round 6: eight ticket counters (blockIdx % 8; product) against ONE (tuning build, KIVI_MF_ONE_TICKET=1) for the sliced one-launch forms, one box
         T=$R/kivi_amd/_variants/libkivi_tuning.so
