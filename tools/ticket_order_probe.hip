@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
     for (int lb : lds_bytes)
         for (int g : grids) {
             long mism = 0, total = 0, maxdist = 0;
-            double tsum = 0;
+            double tsum = 0, tmax_sum = 0, t99_sum = 0;
             int launches_with_any = 0;
             for (int r = 0; r < reps; r++) {
                 ticket_kernel<<<g, 256, lb>>>(counters, ids, ta, 5000);   // 100 MHz clock: 5000 ticks = 50 us
@@ -60,12 +61,16 @@ int main(int argc, char** argv) {
                     if (h[i] != i) { m++; long d = labs((long)h[i] - i) / 8; if (d > maxdist) maxdist = d; }
                     tsum += (double)ht[i];
                 }
+                std::vector<unsigned long long> srt(ht.begin(), ht.begin() + g);
+                std::sort(srt.begin(), srt.end());
+                tmax_sum += (double)srt[g - 1];
+                t99_sum += (double)srt[(size_t)(0.99 * (g - 1))];
                 mism += m;
                 total += g;
                 launches_with_any += m > 0;
             }
-            printf("lds %2d KiB grid %5d: %6ld of %7ld blocks got another id (%.2f %%), launches with any %d / %d, furthest %ld tickets, atomic round trip %.2f us avg\n",
-                   lb / 1024, g, mism, total, 100.0 * mism / total, launches_with_any, reps, maxdist, tsum / total / 100.0);
+            printf("lds %2d KiB grid %5d: %6ld of %7ld blocks got another id (%.2f %%), launches with any %d / %d, furthest %ld tickets, atomic round trip %.2f us avg, p99 %.2f, slowest of a launch %.2f\n",
+                   lb / 1024, g, mism, total, 100.0 * mism / total, launches_with_any, reps, maxdist, tsum / total / 100.0, t99_sum / reps / 100.0, tmax_sum / reps / 100.0);
         }
     return 0;
 }
