@@ -26,6 +26,8 @@
 #   flows            round 5: phase-softmax vs in-stream flow of mf_row4_kernel (and the round-4 tree from a worktree _r4/, if present) at BASELINE
 #                    config 4 + headline, phase timelines
 #   packs            kt_pack / vt_pack at 2 and 4 bits on 1 GiB of fp16
+#   shapes_g         round 6: g = 64 / 128, D = 64, nh / nh_kv = 2 (hook-state layout, VALU kernels) through bench.py
+#   fuzz             round 6: tools/fuzz_decode.py for FUZZ_SECONDS (600) with FUZZ_SEED (1)
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -220,6 +222,19 @@ PY
             timeout 300 $BN --bits 4 --batch $lb --prompt $lt --residual 128 --steps 6 --warmup 2 > $O/shape_longchat_b${lb}_t${lt}_4bit.json 2>> $O/shapes.err; line $O/shape_longchat_b${lb}_t${lt}_4bit.json
         done
         timeout 300 $BN --batch 96 --heads 32 --kv-heads 8 --prompt 6016 --residual 128 --steps 10 --warmup 3 > $O/shape_gqa_b96_6k.json 2>> $O/shapes.err; line $O/shape_gqa_b96_6k.json ;;
+    shapes_g)
+        # group sizes / head dims off the matrix-pipe layout (g = 64 is what the reference's own test procedures use, quant/test.py:21-54): the VALU
+        # kernels on the hook-state layout (decode_row_kernel)
+        timeout 300 $BN --group 64 --residual 64 --steps 10 --warmup 3 > $O/shape_g64_r64.json 2>> $O/shapes.err; line $O/shape_g64_r64.json
+        timeout 300 $BN --group 64 --residual 128 --steps 10 --warmup 3 > $O/shape_g64_r128.json 2>> $O/shapes.err; line $O/shape_g64_r128.json
+        timeout 300 $BN --group 64 --residual 128 --bits 4 --steps 10 --warmup 3 > $O/shape_g64_r128_4bit.json 2>> $O/shapes.err; line $O/shape_g64_r128_4bit.json
+        timeout 300 $BN --group 128 --residual 128 --steps 10 --warmup 3 > $O/shape_g128_r128.json 2>> $O/shapes.err; line $O/shape_g128_r128.json
+        timeout 300 $BN --head-dim 64 --heads 64 --kv-heads 64 --steps 10 --warmup 3 > $O/shape_d64.json 2>> $O/shapes.err; line $O/shape_d64.json
+        timeout 300 $BN --heads 32 --kv-heads 16 --steps 10 --warmup 3 > $O/shape_ratio2.json 2>> $O/shapes.err; line $O/shape_ratio2.json ;;
+    fuzz)
+        # randomised parity sweep against the fp64 torch reference (tools/fuzz_decode.py); FUZZ_SECONDS / FUZZ_SEED
+        timeout $(( ${FUZZ_SECONDS:-600} + 240 )) python tools/fuzz_decode.py --seconds ${FUZZ_SECONDS:-600} --seed ${FUZZ_SEED:-1} > $O/fuzz_seed${FUZZ_SEED:-1}.log 2> $O/fuzz_seed${FUZZ_SEED:-1}.err
+        echo "fuzz rc=$?" | tee -a $O/status.log; grep -c " ok " $O/fuzz_seed${FUZZ_SEED:-1}.log; grep "FAIL\|ERROR\|^#" $O/fuzz_seed${FUZZ_SEED:-1}.log | cut -c1-400 | tail -30 ;;
     trace)
         # the driver's command incl. the BASELINE configs[1] loop through the reference's operator (cuda_bmm_fA_qB_outer -> gemv_k_kernel),
         # so that the kernel stats / trace medians carry a gemv_k_kernel row (the kernel the north-star target is written about)
