@@ -23,7 +23,7 @@ Cache policy (llama_kivi.py:343-356, 386-399, 425-452):
 """
 from __future__ import annotations
 
-
+import math
 from dataclasses import dataclass
 from typing import Optional
 
@@ -79,12 +79,16 @@ class KiviLayerCache:
     """One layer's quantised KV cache with capacity `max_len` tokens, appended in place."""
 
     def __init__(self, cfg: KiviConfig, batch: int, num_kv_heads: int, head_dim: int, max_len: int,
-                 device, dtype=torch.float16, page_tokens: int = PAGE_TOKENS):
+                 device, dtype=torch.float16, page_tokens: int = None):
         assert dtype == torch.float16, "the reference extension is fp16 only (gemv_cuda.cu:526-529)"
         self.cfg = cfg
         R, g = cfg.residual_length, cfg.group_size
         self.B, self.nh_kv, self.D = batch, num_kv_heads, head_dim
         assert head_dim % g == 0 and head_dim % (32 // cfg.v_bits) == 0
+        if page_tokens is None:
+            # a K flush of R tokens must not straddle pages AND a page is whole tiles of the default qK^T kernels: the smallest common
+            # multiple (R = 32 / 64 / 128: 2048; R = 96 or 192: 6144 -- the reference accepts any multiple of the group size, llama_kivi.py:344)
+            page_tokens = PAGE_TOKENS * R // math.gcd(PAGE_TOKENS, R)
         assert page_tokens % R == 0 and page_tokens % g == 0, "a K flush of R tokens must not straddle pages"
         self.page_tokens = page_tokens
         self.cap = ((max_len + R - 1) // R) * R

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
             // the next super-block's scores fly during this one's stream
             if (i + 1 < n_my) mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), tok0 + 4 * KIVI_MF_SB_TOKENS, xv);
             __builtin_amdgcn_wave_barrier();
-            vs.run(A, rv, 16 * i, 16 * i + nb, lds_p, 512, 16 * i * 32);
+            vs.run(A, rv, 16 * i, 16 * i + nb, lds_p, 512, 16 * i * 32, rsh < 0);
         }
     }
 
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf);                     // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
+    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf, rsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT) : 1.0f);   // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
     if constexpr (HL) {
         for (int i = lane; i < R * 128; i += 64) Lf[i] += Lf[R * 128 + i];
         __builtin_amdgcn_wave_barrier();
@@ -424,8 +424,9 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
     if (threadIdx.x == 0) {
         int e = 0;
         if (m > 0.f && m < __builtin_inff()) e = -((int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u) - 127);
-        // + the range shift of the (batch row, kv head) the row reads (mf_sp)
-        sp[row] = (e < 0 ? 0 : (e > 14 ? 14 : e)) + mf_range_shift(range[b * nh_kv + h / (nh / nh_kv)]);
+        // + the positive range shift of the (batch row, kv head) the row reads (mf_sp)
+        const int rsh = mf_range_shift(range[b * nh_kv + h / (nh / nh_kv)]);
+        sp[row] = (e < 0 ? 0 : (e > 14 ? 14 : e)) + (rsh > 0 ? rsh : 0);
     }
 }
 
@@ -560,9 +561,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
         MfVAcc<1> A;
         mf_v_init(A);
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        vs.run(A, rv, b_lo, b_hi, row, 0, 0);
+        vs.run(A, rv, b_lo, b_hi, row, 0, 0, vrsh < 0);
         stamp(9);
-        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave]);
+        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave], vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT) : 1.0f);
     }
     __syncthreads();
     stamp(10);
@@ -1064,7 +1065,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     constexpr int PB = (16 / VRING) * VRING, NR = PB / VRING;
     static_assert(R <= NR, "a row of the next piece per ring round");
     if constexpr (PSM) {
-        vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0);                 // (the rows hold finished p'')
+        vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0, vrsh < 0);       // (the rows hold finished p'')
     } else {
         const int nb0 = (b_hi - b_lo) < PB ? (b_hi - b_lo) : PB;
         if (nb0 > 0) {
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 const int b0 = bp + r * VRING;
-                if (b0 < pe) vs.run(A, rv, b0, (b0 + VRING < pe) ? b0 + VRING : pe, rows, n_pad, tok0);
+                if (b0 < pe) vs.run(A, rv, b0, (b0 + VRING < pe) ? b0 + VRING : pe, rows, n_pad, tok0, vrsh < 0);
                 if (r < R && nbn > 0)
                     mf_probs_inplace_row<BITS>(rows + r * n_pad, pe * 32 - tok0, nbn * 32, Tv - pe * 32, M[r], invS[r], sp[r], vrsh);
                 __builtin_amdgcn_wave_barrier();
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part | [2][R * 128]
     float* resl = red + NP * R * 128;
     float* lf = resl + NW * R * 128;                               // the block's sums (hand-off between slices)
-    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128);
+    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128, vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT) : 1.0f);
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
         resl[wave * R * 128 + rr * 128 + 2 * lane] = ow[rr][0];

@@ -693,14 +693,33 @@ struct MfVStream {
     // ring keeps requesting up to b_last, so a caller may run() the stream piece by piece -- one super-block at a time with
     // the probabilities of the next one made in between -- without ever draining it).  ps_lds: the R rows of scaled
     // probabilities, row pitch `pitch` halves, indexed by (stream block * 32 + token in block) - tok0.
-    __device__ __forceinline__ void run(MfVAcc<R, HL>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0) {
+    // big (wave-uniform: the unit's V store holds a scale >= 256, mf_range_shift < 0): the SCALES of a ring round are taken
+    // 2^KIVI_MF_BIG_SHIFT lower before its blocks are multiplied (in place; exact for every scale >= 2^-4; R = 1: not in the lanes whose
+    // registers hold zero points), the probabilities stay where every other unit has them, and mf_v_finish brings the products back
+    // (`up`).  One branch per ring round that ordinary data never takes.  (Through round 6's first sessions it was p'' that went 2^10 lower: a peaked
+    // row -- Sp < 10 -- then rounded its small probabilities, at worst 2^-19 of the row's largest, which is invisible while a unit's
+    // values are of one magnitude and was 0.1-0.9 of the output in tools/fuzz_decode.py's units whose packed values are 10^5 times the
+    // window's.)
+    __device__ __forceinline__ void run(MfVAcc<R, HL>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0, bool big = false) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
         const int j = m & 3;
         const uint32_t lomask = (HL ? (m & 4) != 0 : (R == 1 && (j & 1))) ? 0xFFFFFFFFu : 0u;
+        // 2^-KIVI_MF_BIG_SHIFT in both halves (fp16 exponent field 15 - shift); R = 1: the lanes of rows j >= 2 hold zero points
+        const uint32_t bigf = (R == 1 && j >= 2) ? 0x3C003C00u : (uint32_t)(((15 - KIVI_MF_BIG_SHIFT) << 10) * 0x00010001u);
         const uint16_t* prow = ps_lds + (R == 1 ? 0 : (m % R) * pitch) + 8 * kb - tok0;      // the head of the lane's row
         if (b_hi <= b_lo) return;
         for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
+            if (big) {                                             // (at the top of the round: the blocks below stay as they are for everyone else)
+#pragma unroll
+                for (int s = 0; s < RING; s++) {
+#pragma unroll
+                    for (int q = 0; q < NS; q++) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) sr[s][q][i] = pk_mul(sr[s][q][i], bigf);
+                    }
+                }
+            }
 #pragma unroll
             for (int s = 0; s < RING; s++) {
                 const int bl = b0 + s;
@@ -721,11 +740,14 @@ struct MfVStream {
 // Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]; HL: [2][R][128], the hi and the lo
 // part of every output, to be added by the caller) -- 2^12 * (hi + lo sums) + zero-point term + 1.5 * sum p'' s.
 // `zl`: 128 floats of scratch LDS of this wave.
+// `up`: 2^KIVI_MF_BIG_SHIFT for a unit streamed with BIG (its scales went in that much lower: the products and the centring sums come
+// back here, the zero-point term never left), 1 otherwise.
 template <int R, int RING, bool HL, int BITS = 2>
-__device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, float* dst) {
+__device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, float* dst, float up = 1.0f) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, kb = lane >> 4;
-    constexpr float CF = MfCentre<RING, BITS>::f;                 // what the centring blocks subtracted per unit of A
+    const float CF = MfCentre<RING, BITS>::f * up;                // what the centring blocks subtracted per unit of A
+    const float PS = (float)(1 << KIVI_MF_PROD_SHIFT) * up;
     constexpr float W4 = BITS == 2 ? 0.0625f : 0.015625f;         // 2^-aexp of the registers 0, 1 (4-bit codes: 2^-6 like 2, 3)
     // per-lane dot sums -> LDS -> every lane gathers the four kb partials of the rows it needs
     if constexpr (HL) {
@@ -751,7 +773,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float v = (kb >> 1) ? A.acc[2 * s + 1][tile][r] : A.acc[2 * s][tile][r];
-                    dhl[r * 128 + 32 * c + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+                    dhl[r * 128 + 32 * c + 16 * tile + n] = __builtin_fmaf(v, PS, br[r]);
                 }
             }
         }
@@ -776,7 +798,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
                 v0 = (kb == c) ? A.acc[c][tile][0] : v0;
                 v1 = (kb == c) ? A.acc[c][tile][1] : v1;
             }
-            dst[32 * kb + 16 * tile + n] = __builtin_fmaf(v0 + v1, (float)(1 << KIVI_MF_PROD_SHIFT), br);
+            dst[32 * kb + 16 * tile + n] = __builtin_fmaf(v0 + v1, PS, br);
         }
     } else if constexpr (R == 4) {
         zl[lane] = __builtin_fmaf(CF, A.c4[0] * W4 + A.c6[0] * 0.015625f, A.z4[0] * W4 + A.z6[0] * 0.015625f);
@@ -795,7 +817,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
                 float v = A.acc[0][tile][r];
 #pragma unroll
                 for (int c = 1; c < 4; c++) v = (kb == c) ? A.acc[c][tile][r] : v;
-                dst[r * 128 + 32 * kb + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+                dst[r * 128 + 32 * kb + 16 * tile + n] = __builtin_fmaf(v, PS, br[r]);
             }
         }
     } else {
@@ -821,7 +843,7 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float v = (kb >> 1) ? A.acc[2 * s + 1][tile][r] : A.acc[2 * s][tile][r];
-                    dst[(hb + r) * 128 + 32 * c + 16 * tile + n] = __builtin_fmaf(v, (float)(1 << KIVI_MF_PROD_SHIFT), br[r]);
+                    dst[(hb + r) * 128 + 32 * c + 16 * tile + n] = __builtin_fmaf(v, PS, br[r]);
                 }
             }
         }
@@ -830,16 +852,16 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
 }
 
 // Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = clamp(floor(log2 sum), 0, 14),
-// so that p'' * scale stays a normal fp16 whatever the row length; plus `rsh`, the range shift of the unit's V store
-// (mf_range_shift, kivi_mfma_layout.h): 2^10 lower when it holds a scale >= 256, so that p'' * scale <= 2^-4 * scale is finite for
-// every finite scale; 2^8 higher when all its scales are < 2^-8 (p'' <= 2^15), so that p'' * scale keeps a normal hi part.
+// so that p'' * scale stays a normal fp16 whatever the row length; plus the POSITIVE part of `rsh`, the range shift of the unit's V
+// store (mf_range_shift, kivi_mfma_layout.h): 2^8 higher when all its scales are < 2^-8 (p'' <= 2^15), so that p'' * scale keeps a
+// normal hi part.  A unit that holds a scale >= 256 (rsh < 0) keeps the default placement of p'' -- its SCALES go in 2^10 lower
+// (mf_v_block<BIG>), so that p'' * scale <= 2^-4 * scale is finite for every finite scale without rounding a single probability.
 __device__ __forceinline__ int mf_sp(float sum, int rsh) {
     const int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
-    return (e < 0 ? 0 : (e > 14 ? 14 : e)) + rsh;
+    return (e < 0 ? 0 : (e > 14 ? 14 : e)) + (rsh > 0 ? rsh : 0);
 }
 // The two exact power-of-two factors that take a fp16 probability p to p'' = p * 2^(Sp + 4 | 6): first 2^(4 | 6) (times 2^8 for
-// a unit placed higher: p <= 1, the product is exact and <= 2^14), then 2^(Sp - max(rsh, 0)) = 2^-10 .. 2^14 (exact for an exponent
-// >= 0; with a negative one the smallest probabilities of a row round once, 2^-19 of the row's largest p'' at worst).
+// a unit placed higher: p <= 1, the product is exact and <= 2^14), then 2^(Sp - max(rsh, 0)) = 2^0 .. 2^14: both exact.
 __device__ __forceinline__ _Float16 mf_p_mul_a(bool reg23, int rsh) {       // reg23: registers 2, 3 of the operand (2^6), else 2^4
     return (_Float16)__builtin_ldexpf(1.0f, (reg23 ? 6 : 4) + (rsh > 0 ? rsh : 0));
 }

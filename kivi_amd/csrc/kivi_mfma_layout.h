@@ -64,8 +64,11 @@
 //   byte 0  a scale whose fp16 bits are >= KIVI_MF_BIG_SCALE_BITS (256.0; NaN / inf included) was written
 //   byte 1  a scale >= KIVI_MF_SMALL_SCALE_BITS (2^-8) was written
 //   byte 2  (ABI version 3) "the writers of this unit keep byte 1": set by every library writer with every scale it writes
-// The consumers place q (or the probabilities) by mf_range_shift(word): 2^KIVI_MF_BIG_SHIFT LOWER for a unit with byte 0 set
-// (128 * 65504 * 2^-10 < 2^13: every finite fp16 scale is safe), 2^KIVI_MF_SMALL_SHIFT HIGHER for a unit that is KNOWN to hold only
+// The consumers place the A operand by mf_range_shift(word): 2^KIVI_MF_BIG_SHIFT LOWER for a unit with byte 0 set (128 * 65504 *
+// 2^-10 < 2^13: every finite fp16 scale is safe) -- qK^T through the placement of q'', sV through the SCALES, which enter the product
+// 2^-10 times their value (exact for every scale >= 2^-4; mf_v_finish brings the sums back) while the probabilities stay where every
+// other unit has them: a probability moved 2^10 lower loses its low bits whenever the row is peaked, which the first sessions of
+// round 6 did and tools/fuzz_decode.py caught --, 2^KIVI_MF_SMALL_SHIFT HIGHER (q'' and p'' alike) for a unit that is KNOWN to hold only
 // scales below 2^-8 -- byte 2 set AND byte 1 clear (round 5; q'' / p'' <= 2^15, the A operand < 2^7: a scale of 2^-24 still gives a
 // hi part with all its bits) --, and as before otherwise: units whose scales straddle neither bound compute bit for bit what they
 // did before the marks existed.  A ZERO word means the default placement (ABI version 2 read it as "all scales < 2^-8" and placed

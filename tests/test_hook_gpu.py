@@ -125,7 +125,8 @@ def _cmp_cache(t_gpu, t_ref):
 @pytest.mark.parametrize("fused_kernels", ["native", "python", False])
 @pytest.mark.parametrize("nh,nh_kv,T0,R,g,bits", [(4, 4, 70, 32, 32, 2), (8, 2, 33, 32, 32, 2), (4, 2, 5, 32, 32, 2),
                                                    (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2), (6, 2, 40, 32, 32, 2),
-                                                   (4, 4, 130, 64, 64, 2), (2, 2, 260, 128, 128, 2)])
+                                                   (4, 4, 130, 64, 64, 2), (2, 2, 260, 128, 128, 2),
+                                                   (4, 2, 200, 96, 32, 2), (2, 2, 150, 192, 64, 4)])   # R = 96 / 192: pages of lcm(2048, R) tokens
 def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits, fused_kernels, monkeypatch):
     """"native": the one-call layer step (kivi_decode_layer); "python": the same launches with the bookkeeping in
     kivi_amd.attention; False: one launch per reference op."""
@@ -387,3 +388,46 @@ def test_eager_prompt_pass_applies_the_mask(oracle, nh, nh_kv):
     with pytest.raises(ValueError):
         kivi_attention_prefill(q.cuda(), k.cuda(), v.cuda(), make_layer_cache(cfg, B, nh_kv, D, T + 64, "cuda", num_heads=nh),
                                mask[:, :, :1].cuda())
+
+
+@pytest.mark.parametrize("R,g,bits", [(96, 32, 2), (192, 64, 4)])
+def test_residual_lengths_that_do_not_divide_a_page(R, g, bits):
+    """llama_kivi.py:344 accepts any residual length that is a multiple of the group size.  The hook-state layout pages K in whole
+    tiles of the qK^T kernels (2048 tokens); a flush of R tokens must not straddle a page, so R = 96 / 192 get pages of 6144 tokens.
+    Steps through K flushes on both sides of the first page boundary, every unit against the fp64 torch reference."""
+    import torch_ref64 as T64
+    from kivi_amd.attention import KiviConfig, KiviLayerCache, kivi_attention_decode
+    B, nh, nh_kv, D = 3, 4, 2, 128
+    T0 = 6144 - R - 20
+    steps = R + 30
+    cfg = KiviConfig(bits, bits, g, R)
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    k0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+    v0 = torch.randn((B, nh_kv, T0, D), device="cuda", dtype=torch.float16, generator=gen)
+    layer = KiviLayerCache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda")
+    assert layer.page_tokens == 6144 and layer.n_pages == 2
+    layer.prefill(k0, v0)
+    past = T64.prefill_cache(k0, v0, bits, bits, g, R)
+    names = ["K_code_T", "K_full", "K_scale_T", "K_mn_T", "V_code", "V_full", "V_scale", "V_mn"]
+
+    def same(a, b):
+        if a is None or b is None:
+            return (a is None or a.numel() == 0) and (b is None or b.numel() == 0)
+        a, b = a.contiguous(), b.contiguous()
+        return a.shape == b.shape and bool(torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a,
+                                                       b.view(torch.int16) if b.dtype == torch.float16 else b))
+    worst = 0.0
+    for s in range(steps):
+        q = torch.randn((B, nh, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        kn = torch.randn((B, nh_kv, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        vn = torch.randn((B, nh_kv, 1, D), device="cuda", dtype=torch.float16, generator=gen)
+        out = kivi_attention_decode(q, kn, vn, layer)
+        ref, past, _ = T64.decode_step(q, kn, vn, past, bits, bits, g, R)
+        ok, ratio = gemv_close(out, ref, rtol=3e-3, ulps=1)
+        assert ok, (s, ratio)
+        worst = max(worst, ratio)
+        if s % 16 == 0 or s == steps - 1:
+            for n, a, r in zip(names, layer.as_tuple()[:8], past[:8]):
+                assert same(a, r), (s, n)
+    assert layer.as_tuple()[8] == past[8] == T0 + steps
+    print(f"R = {R}: worst output ratio {worst:.3f} of 3e-3 (+1 ulp)")

@@ -5,13 +5,17 @@ tests/torch_ref64.py (no oracle, no HIP code in the reference).  Bars as in test
   * the 9-tuple after the prompt pass and after the last step: bit-identical;
   * matrix-pipe layout: the rows the softmax consumes at 1e-3 (+1 ulp: two fp16 roundings), the attend half on those rows at 2e-3
     (+1 ulp), masked scores identical;
-  * end to end: reported against 3e-3, a case FAILS above 2x (the reference softmax's own sensitivity to an ulp of a score).
+  * the two GEMVs on the final cache (the reference's operator on the 9-tuple; kivi_gqa_scores / kivi_gqa_output on the matrix-pipe
+    stores; peaked probability rows): the bare north_star bar, 1e-3;
+  * end to end: reported against 3e-3, a case FAILS above 2x for scores below 4 (the reference softmax's own sensitivity to an ulp of a
+    score), the allowance doubling with every binade of the largest score above that.
 
     python tools/fuzz_decode.py --seconds 600 --seed 1 > gpurun_out/fuzz.log
 
 Every case is reproducible from its line (`--only SEED:INDEX`).  Exit code 1 if any case failed.
 """
 import argparse
+import math
 import os
 import random
 import sys
@@ -98,6 +102,53 @@ def make(shape, dist, gen):
     return x.half()
 
 
+VERBOSE = False
+
+
+def diagnose(layer, out, ref_b, x_gpu, past, c, s):
+    """Stage-B failure: which units, and what their stores / probabilities look like."""
+    from kivi_amd.quant import mfma
+    g_, r_ = out.float(), ref_b.float()
+    rms = r_.pow(2).mean(dim=-1, keepdim=True).sqrt()
+    ratio = ((g_ - r_).abs() / (2e-3 * torch.maximum(r_.abs(), rms)).clamp_min(2.0 ** -24)).amax(dim=(-1, -2))     # (B, nh)
+    B, nh = ratio.shape
+    rat = nh // c["nh_kv"]
+    kflag, vflag = mfma.range_flags(layer.kt), mfma.range_flags(layer.vt)
+    p = torch.softmax(x_gpu.float(), -1).half()
+    Lv = past[5].shape[2] + 1
+    vs = past[6]
+    order = ratio.flatten().argsort(descending=True)[:4]
+    print(f"  step {s}: units over the bar: {(ratio > 1).sum().item()} of {B * nh}", flush=True)
+    # (a) the packed sV product alone, on the REFERENCE's probabilities (no exponential of ours in it): kivi_gqa_output against fp64
+    # (b) how sharp the reference's own rounding of p is: fp16(fp32 softmax) against fp16(fp64 softmax) of the same rows
+    Tv = vs.shape[2] if vs is not None else 0
+    part = None
+    if Tv:
+        pitch = (Tv + 7) // 8 * 8
+        ap = torch.zeros((B, nh, 1, pitch), dtype=torch.float16, device="cuda")
+        ap[..., :Tv] = p[..., :Tv]
+        got = mfma.gqa_output(ap, layer.vt, Tv, None, c["g"], c["v_bits"]).float()
+        want = T64.output64(p[..., :Tv], past[4], past[6], past[7], c["g"], c["v_bits"]).float()
+        part = ((got - want).abs() / (1e-3 * torch.maximum(want.abs(), want.pow(2).mean(-1, keepdim=True).sqrt())).clamp_min(2.0 ** -24)).amax(dim=(-1, -2))
+    rat_ = nh // c["nh_kv"]
+    vwin = torch.cat([past[5], torch.zeros_like(past[5][:, :, :1])], 2)     # (the new token's values are not in `past`: magnitudes only)
+    win_rms = torch.matmul(p[..., -Lv:].double(), T64._expand_heads(vwin, rat_).double()).pow(2).mean(-1).sqrt()[..., 0]
+    pk_rms = want.double().pow(2).mean(-1).sqrt()[..., 0] if Tv else torch.zeros_like(win_rms)
+    p64 = torch.softmax(x_gpu.double(), -1).to(torch.float32).half()
+    flips = (p64 != p).sum(dim=(-1, -2))
+    for o in order.tolist():
+        b, h = o // nh, o % nh
+        hk = h // rat
+        pk = p[b, h, 0, :-Lv].float()
+        pwin = p[b, h, 0, -Lv:].float()
+        vsc = vs[b, hk].float() if vs is not None else torch.zeros(1)
+        e = (g_[b, h, 0] - r_[b, h, 0]).abs().argmax().item()
+        print(f"    (b {b}, h {h}) ratio {ratio[b, h].item():.2f}: vt word {vflag[b, hk].item():#x} kt word {kflag[b, hk].item():#x}; packed V scales "
+              f"{vsc.min().item():.3g} .. {vsc.max().item():.3g}; window |v| max {past[5][b, hk].abs().max().item():.3g}; p: packed mass {pk.sum().item():.3g} "
+              f"max {pk.max().item():.3g}, window mass {pwin.sum().item():.3g}; out[{e}] {g_[b, h, 0, e].item():.6g} ref {r_[b, h, 0, e].item():.6g} row rms {rms[b, h, 0, 0].item():.3g}; packed product on the reference's p: {(part[b, h].item() if part is not None else 0):.3f} of 1e-3; "
+              f"p values that differ between an fp32 and an fp64 softmax: {flips[b, h].item()}; rms of the packed part {pk_rms[b, h].item():.3g}, of the window part (without the new token) {win_rms[b, h].item():.3g}", flush=True)
+
+
 def run_case(c, seed):
     from kivi_amd import _lib
     from kivi_amd.attention import KiviConfig, kivi_attention_decode, make_layer_cache
@@ -110,7 +161,7 @@ def run_case(c, seed):
     try:
         layer = make_layer_cache(cfg, B, nh_kv, D, T0 + steps + 1, "cuda", num_heads=nh)
     except AssertionError as e:                                     # a combination the cache classes refuse by contract
-        return f"skipped (refused: {e})", {"A": 0.0, "B": 0.0, "E": 0.0}, None
+        return f"skipped (refused: {e})", {"A": 0.0, "B": 0.0, "E": 0.0, "G": 0.0}, None
     mf = getattr(layer, "layout", "") == "mfma"
     if mf:
         layer.flags |= _lib.GQA_DUMP_SCORES | c["flags"]
@@ -118,7 +169,7 @@ def run_case(c, seed):
     past = T64.prefill_cache(k0, v0, kb, vb, g, R)
     del k0, v0
     check_tuple(layer, past, "after the prompt pass")
-    worst = {"A": 0.0, "B": 0.0, "E": 0.0}
+    worst = {"A": 0.0, "B": 0.0, "E": 0.0, "G": 0.0}
     for s in range(steps):
         q = make((B, nh, 1, D), "randn" if c["dist"] in ("mixed", "outlier") else c["dist"], gen)
         kn = make((B, nh_kv, 1, D), c["dist"], gen)
@@ -140,20 +191,73 @@ def run_case(c, seed):
             worst["A"] = max(worst["A"], ra)
             if not ok:
                 raise AssertionError(f"step {s}: scores ratio {ra:.3f} of 1e-3 (+1 ulp)")
-            if not torch.equal(x_gpu[~live], pre[~live]):
+            # masked positions: fp16(x + finfo.min) keeps x at the spacing of that binade (32), so two scores one ulp apart may land
+            # one such step apart; identical whenever |x| < 16 (tests/test_fullcover_gpu.py asserts equality on randn inputs)
+            if not bool(((x_gpu[~live].float() - pre[~live].float()).abs() <= 32.0).all()):
                 raise AssertionError(f"step {s}: masked scores differ")
             ref_b, _, _ = T64.decode_step(q, kn, vn, past, kb, vb, g, R, attention_mask=mask, scores_override=x_gpu.contiguous())
             ok, rb = gemv_close(out, ref_b, rtol=2e-3, ulps=1)
             worst["B"] = max(worst["B"], rb)
             if not ok:
+                if VERBOSE:
+                    diagnose(layer, out, ref_b, x_gpu, past, c, s)
                 raise AssertionError(f"step {s}: attend half ratio {rb:.3f} of 2e-3 (+1 ulp)")
+        # end to end: the reference softmax turns one fp16 ulp u of a score into a relative change u of its probability (|x| in [2, 4):
+        # u = 2e-3, the case the 2 x 3e-3 allowance was measured on); larger scores carry larger ulps, and the allowance follows them
         _, re_ = gemv_close(out, ref, rtol=3e-3)
-        worst["E"] = max(worst["E"], re_)
-        if re_ > 2.0:
-            raise AssertionError(f"step {s}: output ratio {re_:.3f} of 3e-3")
+        smax = pre.float().abs().masked_fill(pre.float() <= -60000, 0).max().item()
+        allow = 2.0 * max(1.0, 2.0 ** (math.floor(math.log2(max(smax, 1e-9))) - 10) / 2.0 ** -9)
+        worst["E"] = max(worst["E"], re_ / (allow / 2.0))
+        if re_ > allow:
+            raise AssertionError(f"step {s}: output ratio {re_:.3f} of 3e-3 (allowed {allow:.1f}: largest |score| {smax:.3g})")
         past = new_past
     check_tuple(layer, past, "after the last step")
+    worst["G"] = check_ops(layer, past, c, gen, mf)
     return "ok", worst, mf
+
+
+def check_ops(layer, past, c, gen, mf):
+    """The two GEMVs on the final cache, bare north_star bar (1e-3): the reference's operator on the 9-tuple (hook-state kernels) and,
+    on the matrix-pipe layout, kivi_gqa_scores / kivi_gqa_output on the layer's own stores.  Probabilities: peaked rows."""
+    from kivi_amd.quant import matmul, mfma
+    B, nh, D, g = c["B"], c["nh"], c["D"], c["g"]
+    kc, _, ks, km, vc, _, vs, vm, _ = past
+    worst = 0.0
+    q = make((B, nh, 1, D), "randn", gen)
+    if kc is not None:
+        Tq = kc.shape[-1] * (32 // c["k_bits"])
+        ref = T64.scores64(q, kc, ks, km, g, c["k_bits"])
+        if torch.isfinite(ref.float()).all():
+            ok, r = gemv_close(matmul.cuda_bmm_fA_qB_outer(g, q, kc, ks, km, c["k_bits"]), ref)
+            worst = max(worst, r)
+            if not ok:
+                raise AssertionError(f"qK^T through the reference operator: ratio {r:.3f} of 1e-3")
+            if mf:
+                o2 = torch.empty((B, nh, 1, Tq), dtype=torch.float16, device="cuda")
+                mfma.gqa_scores(q, layer.kt, Tq, o2, g, c["k_bits"])
+                ok, r = gemv_close(o2, ref)
+                worst = max(worst, r)
+                if not ok:
+                    raise AssertionError(f"kivi_gqa_scores: ratio {r:.3f} of 1e-3")
+    if vc is not None:
+        Tv = vc.shape[2]
+        sharp = (0.5, 3.0, 12.0)[int(torch.randint(3, (1,), generator=torch.Generator().manual_seed(Tv + B)).item())]
+        a = torch.softmax(torch.randn((B, nh, 1, Tv), device="cuda", generator=gen) * sharp, -1).half()
+        ref = T64.output64(a, vc, vs, vm, g, c["v_bits"])
+        if torch.isfinite(ref.float()).all():
+            ok, r = gemv_close(matmul.cuda_bmm_fA_qB_outer(g, a, vc, vs, vm, c["v_bits"]), ref)
+            worst = max(worst, r)
+            if not ok:
+                raise AssertionError(f"sV through the reference operator: ratio {r:.3f} of 1e-3")
+            if mf:
+                pitch = (Tv + 7) // 8 * 8
+                ap = torch.zeros((B, nh, 1, pitch), dtype=torch.float16, device="cuda")
+                ap[..., :Tv] = a
+                ok, r = gemv_close(mfma.gqa_output(ap, layer.vt, Tv, None, g, c["v_bits"]), ref)
+                worst = max(worst, r)
+                if not ok:
+                    raise AssertionError(f"kivi_gqa_output: ratio {r:.3f} of 1e-3")
+    return worst
 
 
 def main():
@@ -162,25 +266,28 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--only", default=None, help="SEED:INDEX of one case to re-run")
+    ap.add_argument("--verbose", action="store_true", help="per-unit diagnostics of a failing attend half")
     a = ap.parse_args()
+    global VERBOSE
+    VERBOSE = a.verbose
     t0 = time.time()
     n_ok = n_fail = n_skip = n_mf = 0
-    worst_all = {"A": 0.0, "B": 0.0, "E": 0.0}
+    worst_all = {"A": 0.0, "B": 0.0, "E": 0.0, "G": 0.0}
     idx = 0
     if a.only:
         a.seed, idx = (int(x) for x in a.only.split(":"))
         a.max_cases = idx + 1
     print(f"# tools/fuzz_decode.py --seconds {a.seconds} --seed {a.seed}: case index, configuration, layout, status, worst ratios "
-          f"(scores of 1e-3 +1 ulp / attend of 2e-3 +1 ulp / output of 3e-3)", flush=True)
+          f"(scores of 1e-3 +1 ulp / attend of 2e-3 +1 ulp / output of its allowance / the two GEMVs on the final cache of the bare 1e-3)", flush=True)
     while idx < a.max_cases and (a.only or time.time() - t0 < a.seconds):
         rng = random.Random(a.seed * 1_000_003 + idx)
         c = draw(rng)
         try:
             status, worst, mf = run_case(c, a.seed * 7919 + idx)
         except AssertionError as e:
-            status, worst, mf = f"FAIL: {e}", {"A": -1, "B": -1, "E": -1}, None
+            status, worst, mf = f"FAIL: {e}", {"A": -1, "B": -1, "E": -1, "G": -1}, None
         except Exception as e:                                      # an error code of the library, an unsupported combination
-            status, worst, mf = f"ERROR: {type(e).__name__}: {e}", {"A": -1, "B": -1, "E": -1}, None
+            status, worst, mf = f"ERROR: {type(e).__name__}: {e}", {"A": -1, "B": -1, "E": -1, "G": -1}, None
             traceback.print_exc(file=sys.stderr)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
@@ -194,10 +301,10 @@ def main():
         else:
             n_fail += 1
         print(f"{a.seed}:{idx} {c} {'matrix-pipe' if mf else 'hook-state' if mf is not None else '?'} {status} "
-              f"{worst['A']:.3f} {worst['B']:.3f} {worst['E']:.3f}", flush=True)
+              f"{worst['A']:.3f} {worst['B']:.3f} {worst['E']:.3f} {worst.get('G', 0.0):.3f}", flush=True)
         idx += 1
     print(f"# {n_ok} ok ({n_mf} on the matrix-pipe layout), {n_skip} skipped, {n_fail} FAILED in {time.time() - t0:.0f} s; worst ratios over the ok cases: "
-          f"scores {worst_all['A']:.3f}, attend {worst_all['B']:.3f}, output {worst_all['E']:.3f}", flush=True)
+          f"scores {worst_all['A']:.3f}, attend {worst_all['B']:.3f}, output {worst_all['E']:.3f} (of its allowance), GEMVs {worst_all['G']:.3f} of the bare 1e-3", flush=True)
     sys.exit(1 if n_fail else 0)
 
 
