@@ -584,10 +584,14 @@ __device__ __forceinline__ void mf_v_block(MfVAcc<R, HL>& A, const MfW<BITS>& w,
         A.z6[0] = dot2_f16(ps[2], sm[0][2], A.z6[0]);
         A.z6[0] = dot2_f16(ps[3], sm[0][3], A.z6[0]);
         if constexpr (CENTRE) {
-            A.c4[0] = dot2_f16(ps[0], sm[0][0], A.c4[0]);
-            A.c4[0] = dot2_f16(ps[1], sm[0][1], A.c4[0]);
-            A.c6[0] = dot2_f16(ps[2], sm[0][2], A.c6[0]);
-            A.c6[0] = dot2_f16(ps[3], sm[0][3], A.c6[0]);
+            // what THIS row (hi or lo) is centred with: the operand as the matrix pipe gets it.  (Until round 6 every lane summed the
+            // exact product p'' s here and mf_v_finish took the hi rows' sum for hi + lo -- the same number while lo is the exact
+            // remainder, but an operand below 2^-14 has no representable remainder, and the difference came back times the
+            // ring's centring weight: 2.5 % of the packed part in tests/test_mfma_gpu.py::test_big_value_units_... with rings of 8.)
+            A.c4[0] = dot2_f16(a[0], MF_ONE2, A.c4[0]);
+            A.c4[0] = dot2_f16(a[1], MF_ONE2, A.c4[0]);
+            A.c6[0] = dot2_f16(a[2], MF_ONE2, A.c6[0]);
+            A.c6[0] = dot2_f16(a[3], MF_ONE2, A.c6[0]);
         }
         const h8 av = as_h8(a[0], a[1], a[2], a[3]);
 #pragma unroll
@@ -781,11 +785,11 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
         zl[lane] = A.z4[0] * W4 + A.z6[0] * 0.015625f;
         zl[64 + lane] = A.c4[0] * W4 + A.c6[0] * 0.015625f;
         __builtin_amdgcn_wave_barrier();
-        // output lane (n, kb' = cg): sum p'' mn (rows 4 cg + 2) + CF * sum over the centring blocks of p'' s (rows 4 cg)
+        // output lane (n, kb' = cg): sum p'' mn (rows 4 cg + 2) + CF * sum over the centring blocks of the operands hi + lo (rows 4 cg, 4 cg + 1)
         float zc = 0.f, zm = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            zc += zl[64 + 4 * kb + 16 * k];
+            zc += zl[64 + 4 * kb + 16 * k] + zl[64 + 4 * kb + 1 + 16 * k];
             zm += zl[4 * kb + 2 + 16 * k];
         }
         const float br = __builtin_fmaf(CF, zc, zm);

@@ -126,7 +126,8 @@ def _cmp_cache(t_gpu, t_ref):
 @pytest.mark.parametrize("nh,nh_kv,T0,R,g,bits", [(4, 4, 70, 32, 32, 2), (8, 2, 33, 32, 32, 2), (4, 2, 5, 32, 32, 2),
                                                    (4, 4, 130, 64, 32, 4), (4, 1, 128, 128, 64, 2), (6, 2, 40, 32, 32, 2),
                                                    (4, 4, 130, 64, 64, 2), (2, 2, 260, 128, 128, 2),
-                                                   (4, 2, 200, 96, 32, 2), (2, 2, 150, 192, 64, 4)])   # R = 96 / 192: pages of lcm(2048, R) tokens
+                                                   (2, 2, 150, 192, 64, 4)])   # R = 192: pages of lcm(2048, R) = 6144 tokens (R = 96, every step, every
+                                                                              # unit, against the fp64 reference: test_residual_lengths_that_do_not_divide_a_page)
 def test_decode_steps_match_reference_logic(oracle, nh, nh_kv, T0, R, g, bits, fused_kernels, monkeypatch):
     """"native": the one-call layer step (kivi_decode_layer); "python": the same launches with the bookkeeping in
     kivi_amd.attention; False: one launch per reference op."""
