@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf, rsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT) : 1.0f);   // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
+    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf, rsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT_V) : 1.0f);   // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
     if constexpr (HL) {
         for (int i = lane; i < R * 128; i += 64) Lf[i] += Lf[R * 128 + i];
         __builtin_amdgcn_wave_barrier();
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         vs.run(A, rv, b_lo, b_hi, row, 0, 0, vrsh < 0);
         stamp(9);
-        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave], vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT) : 1.0f);
+        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave], vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT_V) : 1.0f);
     }
     __syncthreads();
     stamp(10);
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part | [2][R * 128]
     float* resl = red + NP * R * 128;
     float* lf = resl + NW * R * 128;                               // the block's sums (hand-off between slices)
-    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128, vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT) : 1.0f);
+    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128, vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT_V) : 1.0f);
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
         resl[wave * R * 128 + rr * 128 + 2 * lane] = ow[rr][0];

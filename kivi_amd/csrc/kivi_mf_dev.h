@@ -698,7 +698,8 @@ struct MfVStream {
     // the probabilities of the next one made in between -- without ever draining it).  ps_lds: the R rows of scaled
     // probabilities, row pitch `pitch` halves, indexed by (stream block * 32 + token in block) - tok0.
     // big (wave-uniform: the unit's V store holds a scale >= 256, mf_range_shift < 0): the SCALES of a ring round are taken
-    // 2^KIVI_MF_BIG_SHIFT lower before its blocks are multiplied (in place; exact for every scale >= 2^-4; R = 1: not in the lanes whose
+    // 2^KIVI_MF_BIG_SHIFT_V = 2^7 lower before its blocks are multiplied (in place; exact for every scale >= 2^-7; p'' <= 2^6, so the
+    // operand stays below 2^15 for every finite scale; R = 1: not in the lanes whose
     // registers hold zero points), the probabilities stay where every other unit has them, and mf_v_finish brings the products back
     // (`up`).  One branch per ring round that ordinary data never takes.  (Through round 6's first sessions it was p'' that went 2^10 lower: a peaked
     // row -- Sp < 10 -- then rounded its small probabilities, at worst 2^-19 of the row's largest, which is invisible while a unit's
@@ -709,8 +710,8 @@ struct MfVStream {
         const int m = lane & 15, kb = lane >> 4;
         const int j = m & 3;
         const uint32_t lomask = (HL ? (m & 4) != 0 : (R == 1 && (j & 1))) ? 0xFFFFFFFFu : 0u;
-        // 2^-KIVI_MF_BIG_SHIFT in both halves (fp16 exponent field 15 - shift); R = 1: the lanes of rows j >= 2 hold zero points
-        const uint32_t bigf = (R == 1 && j >= 2) ? 0x3C003C00u : (uint32_t)(((15 - KIVI_MF_BIG_SHIFT) << 10) * 0x00010001u);
+        // 2^-KIVI_MF_BIG_SHIFT_V in both halves (fp16 exponent field 15 - shift); R = 1: the lanes of rows j >= 2 hold zero points
+        const uint32_t bigf = (R == 1 && j >= 2) ? 0x3C003C00u : (uint32_t)(((15 - KIVI_MF_BIG_SHIFT_V) << 10) * 0x00010001u);
         const uint16_t* prow = ps_lds + (R == 1 ? 0 : (m % R) * pitch) + 8 * kb - tok0;      // the head of the lane's row
         if (b_hi <= b_lo) return;
         for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
@@ -744,7 +745,7 @@ struct MfVStream {
 // Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]; HL: [2][R][128], the hi and the lo
 // part of every output, to be added by the caller) -- 2^12 * (hi + lo sums) + zero-point term + 1.5 * sum p'' s.
 // `zl`: 128 floats of scratch LDS of this wave.
-// `up`: 2^KIVI_MF_BIG_SHIFT for a unit streamed with BIG (its scales went in that much lower: the products and the centring sums come
+// `up`: 2^KIVI_MF_BIG_SHIFT_V for a unit streamed with `big` (its scales went in that much lower: the products and the centring sums come
 // back here, the zero-point term never left), 1 otherwise.
 template <int R, int RING, bool HL, int BITS = 2>
 __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, float* dst, float up = 1.0f) {
@@ -858,8 +859,8 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
 // Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = clamp(floor(log2 sum), 0, 14),
 // so that p'' * scale stays a normal fp16 whatever the row length; plus the POSITIVE part of `rsh`, the range shift of the unit's V
 // store (mf_range_shift, kivi_mfma_layout.h): 2^8 higher when all its scales are < 2^-8 (p'' <= 2^15), so that p'' * scale keeps a
-// normal hi part.  A unit that holds a scale >= 256 (rsh < 0) keeps the default placement of p'' -- its SCALES go in 2^10 lower
-// (mf_v_block<BIG>), so that p'' * scale <= 2^-4 * scale is finite for every finite scale without rounding a single probability.
+// normal hi part.  A unit that holds a scale >= 256 (rsh < 0) keeps the default placement of p'' -- its SCALES go in 2^7 lower
+// (MfVStream::run, big), so that p'' * scale <= 2^-1 * scale is finite for every finite scale without rounding a single probability.
 __device__ __forceinline__ int mf_sp(float sum, int rsh) {
     const int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
     return (e < 0 ? 0 : (e > 14 ? 14 : e)) + (rsh > 0 ? rsh : 0);

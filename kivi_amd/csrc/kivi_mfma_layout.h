@@ -66,7 +66,7 @@
 //   byte 2  (ABI version 3) "the writers of this unit keep byte 1": set by every library writer with every scale it writes
 // The consumers place the A operand by mf_range_shift(word): 2^KIVI_MF_BIG_SHIFT LOWER for a unit with byte 0 set (128 * 65504 *
 // 2^-10 < 2^13: every finite fp16 scale is safe) -- qK^T through the placement of q'', sV through the SCALES, which enter the product
-// 2^-10 times their value (exact for every scale >= 2^-4; mf_v_finish brings the sums back) while the probabilities stay where every
+// 2^-KIVI_MF_BIG_SHIFT_V = 2^-7 times their value (exact for every scale >= 2^-7; mf_v_finish brings the sums back) while the probabilities stay where every
 // other unit has them: a probability moved 2^10 lower loses its low bits whenever the row is peaked, which the first sessions of
 // round 6 did and tools/fuzz_decode.py caught --, 2^KIVI_MF_SMALL_SHIFT HIGHER (q'' and p'' alike) for a unit that is KNOWN to hold only
 // scales below 2^-8 -- byte 2 set AND byte 1 clear (round 5; q'' / p'' <= 2^15, the A operand < 2^7: a scale of 2^-24 still gives a
@@ -76,6 +76,7 @@
 // its words -- then overflowed fp16 on ordinary data; version 3 needs the explicit byte 2 for the higher placement).
 #define KIVI_MF_BIG_SCALE_BITS 0x5C00u
 #define KIVI_MF_BIG_SHIFT 10
+#define KIVI_MF_BIG_SHIFT_V 7           // sV of such a unit: its scales enter 2^-7 times their value (p'' <= 2^6: 2^6 * 65504 * 2^-7 < 2^15)
 #define KIVI_MF_SMALL_SCALE_BITS 0x1C00u
 #define KIVI_MF_SMALL_SHIFT 8
 
