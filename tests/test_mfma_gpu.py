@@ -586,10 +586,10 @@ def test_decode_flushes_of_subnormal_groups_are_bit_exact(oracle, nh, nh_kv):
 def test_big_value_units_keep_their_small_probabilities(nh, nh_kv, bits, form):
     """A unit whose V store holds scales >= 256 (range word byte 0) AND a row whose probability mass sits on the newest token: the packed
     tokens' probabilities are ~2e-6 (fp16 subnormals), their values 2e4 times the new token's, so they still make half of the output.
-    The sV product of such a unit takes its SCALES 2^10 lower (MfVStream::run, big); while it was p'' that went lower (through round
-    6's first sessions) those probabilities were rounded to 0-2 subnormal ulps and this test's outputs were 10-30 % off (found by
-    tools/fuzz_decode.py).  The attend half on the GPU's own rows against the fp64 reference; the allowance is 4 x the 2e-3 stage-B bar:
-    what remains at this placement is the matrix pipe's alignment loss on operands below 2^-14, ~0.3 % here."""
+    The sV product of such a unit takes its SCALES 2^7 lower (MfVStream::run, big); while it was p'' that went 2^10 lower (through
+    round 6's first sessions) those probabilities were rounded to 0-2 subnormal ulps and this test's outputs were up to 37 % off (ratio 184
+    of the bar on that library, profiles/r06_big_value_units.log; found by tools/fuzz_decode.py).  The attend half on the GPU's own rows
+    against the fp64 reference at the stage-B bar (2e-3 + 1 ulp): 0.47-0.67 of it in the row and the two-launch form, R = 1, 4, 8, 2 and 4 bits."""
     import math
 
     import torch_ref64 as T64
@@ -622,8 +622,8 @@ def test_big_value_units_keep_their_small_probabilities(nh, nh_kv, bits, form):
         assert ok, ("scores", s, ra)
         p = torch.softmax(x_gpu.float(), -1)
         assert 1e-7 < p[..., : n - R - 1].max().item() < 1e-5 and p[..., -1].min().item() > 0.99
-        _, rb = gemv_close(out, ref_b, rtol=2e-3, ulps=1)
+        ok, rb = gemv_close(out, ref_b, rtol=2e-3, ulps=1)
         worst = max(worst, rb)
-        assert rb <= 4.0, ("attend half", s, rb)
+        assert ok, ("attend half", s, rb)
         past = new_past
     print(f"worst attend-half ratio {worst:.3f} of 2e-3 (+1 ulp)")
