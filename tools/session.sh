@@ -28,6 +28,7 @@
 #   packs            kt_pack / vt_pack at 2 and 4 bits on 1 GiB of fp16
 #   shapes_g         round 6: g = 64 / 128, D = 64, nh / nh_kv = 2 (hook-state layout, VALU kernels) through bench.py
 #   fuzz             round 6: tools/fuzz_decode.py for FUZZ_SECONDS (600) with FUZZ_SEED (1)
+#   sq6              round 6: SQ counters of mf_row4_kernel at config 4: four-wave product, six-wave block, three blocks per CU (B=96 x 6k)
 #   sq <name> <args> SQ counters (wave cycles, VALU / MFMA instructions and busy cycles, waits) of one bench command
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 TAG=${SESSION_TAG:-s}
@@ -357,6 +358,30 @@ PY
         cd $R
         python tools/sq_counters.py $(find $O/sq_$name -name "*counter_collection.csv" | head -1) > $O/sq_$name.log 2>&1; cat $O/sq_$name.log
         rm -rf $O/sq_$name ;;
+    sq6)
+        # round 6: SQ counters of mf_row4_kernel at BASELINE config 4 -- the product's four-wave block (two blocks per CU), the six-wave block
+        # (tuning build, KIVI_MF_ROW4_NW=6, rings 4 / 3), and the three-blocks-per-CU instantiation at B=96 x 6k -- one box
+        T=$R/kivi_amd/_variants/libkivi_tuning.so
+        sq_pass() {  # <name> <bench args...>   (environment of the caller)
+            local name=$1; shift
+            cd /tmp && export TMPDIR=/tmp
+            rm -rf $O/sq_$name
+            timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv \
+                -d $O/sq_$name -o p -- $BN --steps 2 --warmup 1 --no-kernel-events "$@" > $O/sq_$name.run.log 2>&1
+            cd $R
+            echo "== $name" >> $O/sq6.log
+            python tools/sq_counters.py $(find $O/sq_$name -name "*counter_collection.csv" | head -1) >> $O/sq6.log 2>&1
+            rm -rf $O/sq_$name
+        }
+        rm -f $O/sq6.log
+        sq_pass config4_four_waves $C4
+        KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=6 KIVI_MF_ROW4_6=43 sq_pass config4_six_waves $C4
+        sq_pass b96_6k_three_blocks --batch 96 --heads 32 --kv-heads 8 --prompt 6016 --residual 128
+        for i in 1 2; do
+            timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/sq6_c4_four_$i.json 2>> $O/sq6.err; line $O/sq6_c4_four_$i.json
+            KIVI_TUNING=1 KIVI_HIP_LIB=$T KIVI_MF_ROW4_NW=6 KIVI_MF_ROW4_6=43 timeout 300 $BN $C4 --steps 10 --warmup 3 > $O/sq6_c4_six_$i.json 2>> $O/sq6.err; line $O/sq6_c4_six_$i.json
+        done
+        cat $O/sq6.log ;;
     *) echo "unknown stage $stage" ;;
     esac
 done
