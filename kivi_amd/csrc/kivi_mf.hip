@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
 
     float M[R], invS[R];
     int sp[R];
+    int ksh = 0;                                                   // what the unit's scales take of the big-scale shift (mf_ksh), the largest over the R rows
     // range shift of the unit's V store: the blocks of a unit may read different words in the step whose V flush marks it (the token
     // the mark is for is not part of this step's packed prefix); every block undoes its own 2^Sp before the hand-off
     const int rsh = mf_range_shift(__builtin_amdgcn_readfirstlane(a.range[unit]));
@@ -299,12 +300,18 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
             M[rr] = 0.f;
             invS[rr] = 1.f;
             // (mf_row_sp_kernel read the same word: nothing marks a store between the two launches of kivi_gqa_output)
-            sp[rr] = a.sp_rows[(int64_t)b * a.nh + h0 + rr];
+            const int v = __builtin_amdgcn_readfirstlane(a.sp_rows[(int64_t)b * a.nh + h0 + rr]);      // Sp * 8 + ksh
+            sp[rr] = v >> 3;
+            ksh = (v & 7) > ksh ? (v & 7) : ksh;
         }
     } else {
         gqa_row_consts<R>(a, b, h0, M, invS);
 #pragma unroll
-        for (int rr = 0; rr < R; rr++) sp[rr] = mf_sp(1.0f / invS[rr], rsh);
+        for (int rr = 0; rr < R; rr++) {
+            sp[rr] = mf_sp(1.0f / invS[rr], rsh);
+            const int k = mf_ksh(1.0f / invS[rr], rsh);
+            ksh = k > ksh ? k : ksh;
+        }
     }
 
     const rsrc_t rx = make_rsrc(a.x + b * a.x_sb + (int64_t)h0 * a.x_sh, (uint32_t)((R - 1) * a.x_sh * 2 + ((a.Tv + 7) & ~(int64_t)7) * 2));
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
             // the next super-block's scores fly during this one's stream
             if (i + 1 < n_my) mf_probs_request<R>(rx, (uint32_t)(a.x_sh * 2), tok0 + 4 * KIVI_MF_SB_TOKENS, xv);
             __builtin_amdgcn_wave_barrier();
-            vs.run(A, rv, 16 * i, 16 * i + nb, lds_p, 512, 16 * i * 32, rsh < 0);
+            vs.run(A, rv, 16 * i, 16 * i + nb, lds_p, 512, 16 * i * 32, ksh);
         }
     }
 
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256, R == 8 ? 2 : 1) void mf_v_kernel(const GqaVArg
     // per-wave [quantised part (R x 128) | window part (R x 128)] -> the block's sum -> workspace hand-off
     __syncthreads();                                               // every wave is done with its p'' rows
     float* Lf = (float*)(lds_all + wave * WW);
-    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf, rsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT_V) : 1.0f);   // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
+    mf_v_finish<R, RING, HL, BITS>(A, zl, Lf, (float)(1 << ksh));   // Lf[r * 128 + d], before 2^-Sp (HL: hi part, lo part behind it)
     if constexpr (HL) {
         for (int i = lane; i < R * 128; i += 64) Lf[i] += Lf[R * 128 + i];
         __builtin_amdgcn_wave_barrier();
@@ -424,9 +431,11 @@ __global__ __launch_bounds__(256) void mf_row_sp_kernel(const uint16_t* p, int64
     if (threadIdx.x == 0) {
         int e = 0;
         if (m > 0.f && m < __builtin_inff()) e = -((int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u) - 127);
-        // + the positive range shift of the (batch row, kv head) the row reads (mf_sp)
+        // + the range shift of the (batch row, kv head) the row reads, as mf_sp / mf_ksh split it; stored as Sp * 8 + ksh
         const int rsh = mf_range_shift(range[b * nh_kv + h / (nh / nh_kv)]);
-        sp[row] = (e < 0 ? 0 : (e > 14 ? 14 : e)) + (rsh > 0 ? rsh : 0);
+        e = e < 0 ? 0 : (e > 14 ? 14 : e);
+        const int d = rsh < 0 ? mf_big_d(e) : 0;
+        sp[row] = (rsh < 0 ? e - d : e + rsh) * 8 + (rsh < 0 ? KIVI_MF_BIG_SHIFT_V - d : 0);
     }
 }
 
@@ -544,7 +553,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
     // ---- [mask +] fp32 softmax of the row (llama_kivi.py:364-375): the probabilities of the packed prefix go back into the
     // row as p'', the window's into pw
     const uint16_t* mrow = ak.mask ? ak.mask + b * ak.mask_sb : nullptr;
-    const int sp = mf_row_softmax<NTH, (8192 + 128 + NTH * 4 - 1) / (NTH * 4), BITS>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh,
+    int ksh;                                                       // (mf_ksh of the row: the scales' share of a big-scale unit's shift)
+    const int sp = mf_row_softmax<NTH, (8192 + 128 + NTH * 4 - 1) / (NTH * 4), BITS>(row, n, n_pad, Tv, mxl, mrow, pw[0], sm_lds, vrsh, ksh,
                                                         (ak.dump & 1) ? ak.out + b * ak.out_sb + (int64_t)hk * ak.out_sh : nullptr);
     __syncthreads();
     stamp(7);
@@ -561,9 +571,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row_kernel(const GqaKArgs ak_
         MfVAcc<1> A;
         mf_v_init(A);
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        vs.run(A, rv, b_lo, b_hi, row, 0, 0, vrsh < 0);
+        vs.run(A, rv, b_lo, b_hi, row, 0, 0, ksh);
         stamp(9);
-        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave], vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT_V) : 1.0f);
+        mf_v_finish<1, VRING, false, BITS>(A, zl[wave], red[wave], (float)(1 << ksh));
     }
     __syncthreads();
     stamp(10);
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     __shared__ float zl[NW][128];
     __shared__ uint16_t pw[R][MF_PW];
     __shared__ float st_lds[R][NW][2];                             // (max, sum exp) of every wave's segments of the R rows
-    __shared__ int sp_lds[R];
+    __shared__ int sp_lds[2 * R];                                  // Sp of the R rows | their mf_ksh (PSM: wave r holds row r's)
     __shared__ int bid_lds;
     __shared__ uint32_t q_lds[R == 1 ? NW : 1][64];                // R = 1: the normalised q operand of mf_k_seq1
     const int lane = threadIdx.x & 63;
@@ -933,6 +943,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     // slices of the unit exchange theirs
     float M[R], invS[R];
     int sp[R];
+    int ksh = 0;                                                   // the scales' share of a big-scale unit's shift (mf_ksh), the largest over the R rows
     if constexpr (PSM) {
         // ---- [mask +] softmax of the rows wave, wave + NW, ... (fp32, cast to fp16: :364-375): p'' in place, the window's into pw
 #pragma unroll
@@ -941,9 +952,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
         for (int r = wave; r < R; r += NW) {
             for (int j = lane; j < NW * decltype(win)::TW; j += 64) pw[r][j] = 0;      // (zeros past the window: its walk reads whole 8-token groups)
             __builtin_amdgcn_wave_barrier();
-            const int spr = mf_row_softmax_wave<BITS>(rows + r * n_pad, Tq + L, n_pad, Tv, mrow, pw[r], vrsh,
+            int kr;
+            const int spr = mf_row_softmax_wave<BITS>(rows + r * n_pad, Tq + L, n_pad, Tv, mrow, pw[r], vrsh, kr,
                                                       dump0 ? dump0 + (int64_t)r * ak.out_sh : nullptr);
-            if (lane == 0) sp_lds[r] = spr;
+            if (lane == 0) {
+                sp_lds[r] = spr;
+                sp_lds[R + r] = kr;
+            }
         }
     } else {
         const int nseg_loc = NW;                                   // entries of st_lds: one per wave
@@ -1021,6 +1036,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
         for (int rr = 0; rr < R; rr++) {
             invS[rr] = 1.0f / Ls[rr];
             sp[rr] = mf_sp(Ls[rr], vrsh);
+            const int k = mf_ksh(Ls[rr], vrsh);
+            ksh = k > ksh ? k : ksh;
         }
     }
     stamp(6);
@@ -1043,6 +1060,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
         for (int rr = 0; rr < R; rr++) sp_lds[rr] = sp[rr];
     }
     kivi_lds_barrier();                                            // pw complete; nobody reads scores past Tv any more
+    if constexpr (PSM) {
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) ksh = sp_lds[R + rr] > ksh ? sp_lds[R + rr] : ksh;
+    }
+    ksh = __builtin_amdgcn_readfirstlane(ksh);
     stamp(7);
 
     // ---- fp16 window of the R heads, V append, quantisation of the token leaving the window (:377-399)
@@ -1065,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     constexpr int PB = (16 / VRING) * VRING, NR = PB / VRING;
     static_assert(R <= NR, "a row of the next piece per ring round");
     if constexpr (PSM) {
-        vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0, vrsh < 0);       // (the rows hold finished p'')
+        vs.run(A, rv, b_lo, b_hi, rows, n_pad, 0, ksh);            // (the rows hold finished p'')
     } else {
         const int nb0 = (b_hi - b_lo) < PB ? (b_hi - b_lo) : PB;
         if (nb0 > 0) {
@@ -1080,7 +1102,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 const int b0 = bp + r * VRING;
-                if (b0 < pe) vs.run(A, rv, b0, (b0 + VRING < pe) ? b0 + VRING : pe, rows, n_pad, tok0, vrsh < 0);
+                if (b0 < pe) vs.run(A, rv, b0, (b0 + VRING < pe) ? b0 + VRING : pe, rows, n_pad, tok0, ksh);
                 if (r < R && nbn > 0)
                     mf_probs_inplace_row<BITS>(rows + r * n_pad, pe * 32 - tok0, nbn * 32, Tv - pe * 32, M[r], invS[r], sp[r], vrsh);
                 __builtin_amdgcn_wave_barrier();
@@ -1093,7 +1115,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mf_row4_kernel(const GqaKArgs ak
     float* red = reinterpret_cast<float*>(rows);                   // [NP][R * 128] quantised part | [NW][R * 128] window part | [2][R * 128]
     float* resl = red + NP * R * 128;
     float* lf = resl + NW * R * 128;                               // the block's sums (hand-off between slices)
-    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128, vrsh < 0 ? (float)(1 << KIVI_MF_BIG_SHIFT_V) : 1.0f);
+    mf_v_finish<R, VRING, VHL, BITS>(A, zl[wave], red + wave * (NP / NW) * R * 128, (float)(1 << ksh));
 #pragma unroll
     for (int rr = 0; rr < R; rr++) {
         resl[wave * R * 128 + rr * 128 + 2 * lane] = ow[rr][0];
@@ -1354,7 +1376,7 @@ int kivi_mf_run_row(void* k_args, const void* v_args, int units, int64_t n_rows,
             const int64_t n_class = (int64_t)k.nsb * KIVI_MF_SB_TOKENS + res_cap;
             const size_t lds_class = (size_t)R * (size_t)((n_class + 4 + 31) / 32 * 32) * 2;
             const int cus = mf_cu_count();
-            bool three = R == 4 && bits == 2 && psm && cus > 0 && lds_class + 3680 + 256 <= (160 * 1024) / 3 && units >= 3 * cus;
+            bool three = R == 4 && bits == 2 && psm && cus > 0 && lds_class + 3696 + 240 <= (160 * 1024) / 3 && units >= 3 * cus;
 #ifdef KIVI_TUNING
             static const char* fo3 = KIVI_TUNE_ENV("KIVI_MF_ROW4_OCC3");     // 0 / 1: never / whenever the rows fit (A/B)
             if (fo3) three = R == 4 && bits == 2 && psm && atoi(fo3) != 0;

@@ -697,21 +697,19 @@ struct MfVStream {
     // ring keeps requesting up to b_last, so a caller may run() the stream piece by piece -- one super-block at a time with
     // the probabilities of the next one made in between -- without ever draining it).  ps_lds: the R rows of scaled
     // probabilities, row pitch `pitch` halves, indexed by (stream block * 32 + token in block) - tok0.
-    // big (wave-uniform: the unit's V store holds a scale >= 256, mf_range_shift < 0): the SCALES of a ring round are taken
-    // 2^KIVI_MF_BIG_SHIFT_V = 2^7 lower before its blocks are multiplied (in place; exact for every scale >= 2^-7; p'' <= 2^6, so the
-    // operand stays below 2^15 for every finite scale; R = 1: not in the lanes whose
-    // registers hold zero points), the probabilities stay where every other unit has them, and mf_v_finish brings the products back
-    // (`up`).  One branch per ring round that ordinary data never takes.  (Through round 6's first sessions it was p'' that went 2^10 lower: a peaked
-    // row -- Sp < 10 -- then rounded its small probabilities, at worst 2^-19 of the row's largest, which is invisible while a unit's
-    // values are of one magnitude and was 0.1-0.9 of the output in tools/fuzz_decode.py's units whose packed values are 10^5 times the
-    // window's.)
-    __device__ __forceinline__ void run(MfVAcc<R, HL>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0, bool big = false) {
+    // ksh (wave-uniform; mf_ksh: > 0 only for a peaked row of a unit whose V store holds a scale >= 256; the largest over the R rows
+    // of the block): the SCALES of a ring round are taken 2^ksh lower (<= 2^3) before its blocks are multiplied (in place; exact for
+    // every scale >= 2^-11; R = 1: not in the lanes whose registers hold zero points) and mf_v_finish brings the products back (`up`).
+    // One branch per ring round that ordinary data never takes.
+    __device__ __forceinline__ void run(MfVAcc<R, HL>& A, rsrc_t rv, int b_lo, int b_hi, const uint16_t* ps_lds, int pitch, int tok0, int ksh = 0) {
         const int lane = threadIdx.x & 63;
         const int m = lane & 15, kb = lane >> 4;
         const int j = m & 3;
         const uint32_t lomask = (HL ? (m & 4) != 0 : (R == 1 && (j & 1))) ? 0xFFFFFFFFu : 0u;
-        // 2^-KIVI_MF_BIG_SHIFT_V in both halves (fp16 exponent field 15 - shift); R = 1: the lanes of rows j >= 2 hold zero points
-        const uint32_t bigf = (R == 1 && j >= 2) ? 0x3C003C00u : (uint32_t)(((15 - KIVI_MF_BIG_SHIFT_V) << 10) * 0x00010001u);
+        // 2^-ksh in both halves (fp16 exponent field 15 - ksh); R = 1: the lanes of rows j >= 2 hold zero points
+        ksh = __builtin_amdgcn_readfirstlane(ksh);
+        const uint32_t bigf = (R == 1 && j >= 2) ? 0x3C003C00u : (uint32_t)(((15 - ksh) << 10) * 0x00010001u);
+        const bool big = ksh > 0;
         const uint16_t* prow = ps_lds + (R == 1 ? 0 : (m % R) * pitch) + 8 * kb - tok0;      // the head of the lane's row
         if (b_hi <= b_lo) return;
         for (int b0 = b_lo; b0 < b_hi; b0 += RING) {
@@ -745,7 +743,7 @@ struct MfVStream {
 // Per-wave result: O[r][d] (before the 2^-Sp of the head) into `dst` (fp32, [R][128]; HL: [2][R][128], the hi and the lo
 // part of every output, to be added by the caller) -- 2^12 * (hi + lo sums) + zero-point term + 1.5 * sum p'' s.
 // `zl`: 128 floats of scratch LDS of this wave.
-// `up`: 2^KIVI_MF_BIG_SHIFT_V for a unit streamed with `big` (its scales went in that much lower: the products and the centring sums come
+// `up`: 2^ksh of MfVStream::run (the scales went in that much lower: the products and the centring sums come
 // back here, the zero-point term never left), 1 otherwise.
 template <int R, int RING, bool HL, int BITS = 2>
 __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, float* dst, float up = 1.0f) {
@@ -856,17 +854,29 @@ __device__ __forceinline__ void mf_v_finish(const MfVAcc<R, HL>& A, float* zl, f
     __builtin_amdgcn_wave_barrier();
 }
 
-// Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = clamp(floor(log2 sum), 0, 14),
+// Sp of a softmax row from its sum: the fp16 probabilities (<= 1 / sum) are scaled by 2^Sp, Sp = e = clamp(floor(log2 sum), 0, 14),
 // so that p'' * scale stays a normal fp16 whatever the row length; plus the POSITIVE part of `rsh`, the range shift of the unit's V
 // store (mf_range_shift, kivi_mfma_layout.h): 2^8 higher when all its scales are < 2^-8 (p'' <= 2^15), so that p'' * scale keeps a
-// normal hi part.  A unit that holds a scale >= 256 (rsh < 0) keeps the default placement of p'' -- its SCALES go in 2^7 lower
-// (MfVStream::run, big), so that p'' * scale <= 2^-1 * scale is finite for every finite scale without rounding a single probability.
-__device__ __forceinline__ int mf_sp(float sum, int rsh) {
+// normal hi part.  A unit that holds a scale >= 256 (rsh < 0) needs the operand p'' * scale 2^KIVI_MF_BIG_SHIFT_V = 2^7 lower to stay
+// finite for every finite scale.  As much of that as is LOSSLESS goes into p'' -- d = min(7, e + 4): p * 2^(e + (4 | 6) - d) is still
+// p times a non-negative power of two, so not one probability is rounded; Sp = e - d, -4 .. 7 -- and only the rest, mf_ksh = 7 - d =
+// max(0, 3 - e) bits, into the scales (MfVStream::run, ksh): nothing for a row whose sum is >= 8, at most 2^-3 for a peaked one
+// (exact for every scale >= 2^-11).  (Round 6 before its last sessions: all 2^10 into p'', which rounded the small probabilities of
+// a peaked row; then all 2^7 into the scales, which rounded scales below 2^-7 -- both found by tools/fuzz_decode.py.)
+__device__ __forceinline__ int mf_sp_e(float sum) {
     const int e = (int)((__builtin_bit_cast(uint32_t, sum) >> 23) & 255u) - 127;
-    return (e < 0 ? 0 : (e > 14 ? 14 : e)) + (rsh > 0 ? rsh : 0);
+    return e < 0 ? 0 : (e > 14 ? 14 : e);
 }
+__device__ __forceinline__ int mf_big_d(int e) { return (e + 4 < KIVI_MF_BIG_SHIFT_V) ? e + 4 : KIVI_MF_BIG_SHIFT_V; }
+__device__ __forceinline__ int mf_sp(float sum, int rsh) {
+    const int e = mf_sp_e(sum);
+    return rsh < 0 ? e - mf_big_d(e) : e + rsh;
+}
+// what is left for the scales of a row of a big-scale unit (0 for every other unit)
+__device__ __forceinline__ int mf_ksh(float sum, int rsh) { return rsh < 0 ? KIVI_MF_BIG_SHIFT_V - mf_big_d(mf_sp_e(sum)) : 0; }
 // The two exact power-of-two factors that take a fp16 probability p to p'' = p * 2^(Sp + 4 | 6): first 2^(4 | 6) (times 2^8 for
-// a unit placed higher: p <= 1, the product is exact and <= 2^14), then 2^(Sp - max(rsh, 0)) = 2^0 .. 2^14: both exact.
+// a unit placed higher: p <= 1, the product is exact and <= 2^14), then 2^(Sp - max(rsh, 0)) = 2^-4 .. 2^14: both exact (a negative
+// exponent only ever takes back part of the 2^(4 | 6): mf_sp).
 __device__ __forceinline__ _Float16 mf_p_mul_a(bool reg23, int rsh) {       // reg23: registers 2, 3 of the operand (2^6), else 2^4
     return (_Float16)__builtin_ldexpf(1.0f, (reg23 ? 6 : 4) + (rsh > 0 ? rsh : 0));
 }
@@ -918,10 +928,10 @@ __device__ __forceinline__ uint32_t mf_scale_pair(uint32_t hpair, float inv) {
 
 // rsh: the range shift of the unit's V store (mf_sp).  dump (KIVI_GQA_DUMP_SCORES, tests; a run-time pointer, null otherwise: the
 // PRODUCT instantiation is the one the stage-A checks run on): the fp16 row as the softmax consumes it (scaled, mask added) also
-// goes to this row of the caller's score buffer.
+// goes to this row of the caller's score buffer.  ksh (out): mf_ksh of the row.
 template <int NTH, int SMC, int BITS = 2>
 __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, int Tv, float mx_lane, const uint16_t* mrow,
-                                              uint16_t* pw_row, float* sm_lds, int rsh, uint16_t* dump = nullptr) {
+                                              uint16_t* pw_row, float* sm_lds, int rsh, int& ksh, uint16_t* dump = nullptr) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -982,6 +992,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
     for (int w = 1; w < NW; w++) sum += sm_lds[NW + w];
     const float inv = 1.0f / sum;
     const int sp = mf_sp(sum, rsh);
+    ksh = mf_ksh(sum, rsh);                                      // (what the scales of a big-scale unit still have to take: MfVStream::run)
     const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                   // 2^-10 .. 2^14
     const _Float16 m_a4 = mf_p_mul_a(BITS == 4, rsh), m_a6 = mf_p_mul_a(true, rsh);
     const f2v inv2 = {inv, inv};
@@ -1026,7 +1037,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
 // trips, four rows in sequence; profiles/r04_row4_levers.log.  Returns Sp (wave-uniform).
 template <int BITS = 2>
 __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_pad, int Tv, const uint16_t* mrow, uint16_t* pw_row, int rsh,
-                                                   uint16_t* dump) {
+                                                   int& ksh, uint16_t* dump) {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -1098,6 +1109,7 @@ __device__ __forceinline__ int mf_row_softmax_wave(uint16_t* row, int n, int n_p
     const float sum = wave_sum(acc[0] + acc[1]);
     const float inv = 1.0f / sum;
     const int sp = mf_sp(sum, rsh);
+    ksh = mf_ksh(sum, rsh);                                      // (what the scales of a big-scale unit still have to take: MfVStream::run)
     const _Float16 m_sp = mf_p_mul_sp(sp, rsh);
     const _Float16 m_a4 = mf_p_mul_a(BITS == 4, rsh), m_a6 = mf_p_mul_a(true, rsh);
     const f2v inv2 = {inv, inv};
