@@ -281,8 +281,8 @@ int kivi_decode_attend(const kivi_decode_attend_args* args, kivi_stream_t stream
  *   inside kivi_gqa_decode) marks BYTE 0 of the unit's word when it writes a scale >= 256 (inf / NaN included), BYTE 1 when it
  *   writes a scale >= 2^-8 and BYTE 2 with every scale it writes ("the writers of this unit keep byte 1"; byte stores of the value
  *   1: concurrent writers never lose a mark), and the consumers take the operand lower for a unit with byte 0 set (finite for
- *   every finite fp16 scale: qK^T places q 2^10 lower; sV takes the unit's SCALES 2^7 lower and leaves the probabilities where
- *   they are, so that a peaked row keeps its small ones -- exact for scales >= 2^-7), q / p 2^8 higher for a unit with byte 2 set
+ *   every finite fp16 scale: qK^T places q 2^10 lower; sV needs 2^7 and splits it -- the part that rounds no probability goes
+ *   into their placement, at most 3 bits into the unit's scales, exact for scales >= 2^-11), q / p 2^8 higher for a unit with byte 2 set
  *   and bytes 0, 1 clear (all its scales are KNOWN to be < 2^-8),
  *   unchanged otherwise -- in particular for a ZERO word: a store filled by a caller's own packer, or copied without its words, gets
  *   the default placement (ABI version 2 placed it higher and overflowed on ordinary data).  Sticky (never cleared by the

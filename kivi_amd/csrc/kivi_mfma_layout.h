@@ -64,11 +64,11 @@
 //   byte 0  a scale whose fp16 bits are >= KIVI_MF_BIG_SCALE_BITS (256.0; NaN / inf included) was written
 //   byte 1  a scale >= KIVI_MF_SMALL_SCALE_BITS (2^-8) was written
 //   byte 2  (ABI version 3) "the writers of this unit keep byte 1": set by every library writer with every scale it writes
-// The consumers place the A operand by mf_range_shift(word): 2^KIVI_MF_BIG_SHIFT LOWER for a unit with byte 0 set (128 * 65504 *
-// 2^-10 < 2^13: every finite fp16 scale is safe) -- qK^T through the placement of q'', sV through the SCALES, which enter the product
-// 2^-KIVI_MF_BIG_SHIFT_V = 2^-7 times their value (exact for every scale >= 2^-7; mf_v_finish brings the sums back) while the probabilities stay where every
-// other unit has them: a probability moved 2^10 lower loses its low bits whenever the row is peaked, which the first sessions of
-// round 6 did and tools/fuzz_decode.py caught --, 2^KIVI_MF_SMALL_SHIFT HIGHER (q'' and p'' alike) for a unit that is KNOWN to hold only
+// The consumers place the A operand by mf_range_shift(word): LOWER for a unit with byte 0 set -- qK^T through the placement of q''
+// (2^KIVI_MF_BIG_SHIFT: 128 * 65504 * 2^-10 < 2^13, every finite fp16 scale is safe), sV by 2^KIVI_MF_BIG_SHIFT_V = 2^7 split between
+// the probabilities and the scales so that neither is rounded (mf_sp / mf_ksh, kivi_mf_dev.h: the lossless part into p'', at most 3 bits
+// into the scales of a peaked row; found and refined with tools/fuzz_decode.py in round 6's last sessions) --, 2^KIVI_MF_SMALL_SHIFT
+// HIGHER (q'' and p'' alike) for a unit that is KNOWN to hold only
 // scales below 2^-8 -- byte 2 set AND byte 1 clear (round 5; q'' / p'' <= 2^15, the A operand < 2^7: a scale of 2^-24 still gives a
 // hi part with all its bits) --, and as before otherwise: units whose scales straddle neither bound compute bit for bit what they
 // did before the marks existed.  A ZERO word means the default placement (ABI version 2 read it as "all scales < 2^-8" and placed
@@ -76,7 +76,7 @@
 // its words -- then overflowed fp16 on ordinary data; version 3 needs the explicit byte 2 for the higher placement).
 #define KIVI_MF_BIG_SCALE_BITS 0x5C00u
 #define KIVI_MF_BIG_SHIFT 10
-#define KIVI_MF_BIG_SHIFT_V 7           // sV of such a unit: its scales enter 2^-7 times their value (p'' <= 2^6: 2^6 * 65504 * 2^-7 < 2^15)
+#define KIVI_MF_BIG_SHIFT_V 7           // sV of such a unit: p'' * scale 2^7 lower in total (p'' <= 2^6: 2^6 * 65504 * 2^-7 < 2^15), split by mf_sp / mf_ksh
 #define KIVI_MF_SMALL_SCALE_BITS 0x1C00u
 #define KIVI_MF_SMALL_SHIFT 8
 

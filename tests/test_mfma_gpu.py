@@ -586,7 +586,8 @@ def test_decode_flushes_of_subnormal_groups_are_bit_exact(oracle, nh, nh_kv):
 def test_big_value_units_keep_their_small_probabilities(nh, nh_kv, bits, form):
     """A unit whose V store holds scales >= 256 (range word byte 0) AND a row whose probability mass sits on the newest token: the packed
     tokens' probabilities are ~2e-6 (fp16 subnormals), their values 2e4 times the new token's, so they still make half of the output.
-    The sV product of such a unit takes its SCALES 2^7 lower (MfVStream::run, big); while it was p'' that went 2^10 lower (through
+    The sV product of such a unit needs its operand 2^7 lower and takes that where nothing is rounded (mf_sp / mf_ksh: here, a row sum of ~1,
+    4 bits in the placement of p'' -- still p times a power of two -- and 3 in the scales); while it was p'' that went 2^10 lower (through
     round 6's first sessions) those probabilities were rounded to 0-2 subnormal ulps and this test's outputs were up to 37 % off (ratio 184
     of the bar on that library, profiles/r06_big_value_units.log; found by tools/fuzz_decode.py).  The attend half on the GPU's own rows
     against the fp64 reference at the stage-B bar (2e-3 + 1 ulp): 0.47-0.67 of it in the row and the two-launch form, R = 1, 4, 8, 2 and 4 bits."""
