@@ -241,7 +241,7 @@ __device__ __forceinline__ void mf_probs_store(const u32x4* xv, int64_t tok0, in
     const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const _Float16 m_sp = mf_p_mul_sp(sp[r], rsh);             // 2^-10 .. 2^14
+        const _Float16 m_sp = mf_p_mul_sp(sp[r], rsh);             // 2^-4 .. 2^14 
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -637,7 +637,7 @@ __device__ __forceinline__ void mf_probs_inplace_row(uint16_t* row, int t0, int 
     const fp2 l2e = {1.44269504088896340736f, 1.44269504088896340736f};
     uint16_t* p = row + t0 + lane * 8;
     const u32x4 xv = *(const u32x4*)p;
-    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                    // 2^-10 .. 2^14
+    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                    // 2^-4 .. 2^14 
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; i++) {

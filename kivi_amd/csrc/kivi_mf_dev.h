@@ -993,7 +993,7 @@ __device__ __forceinline__ int mf_row_softmax(uint16_t* row, int n, int n_pad, i
     const float inv = 1.0f / sum;
     const int sp = mf_sp(sum, rsh);
     ksh = mf_ksh(sum, rsh);                                      // (what the scales of a big-scale unit still have to take: MfVStream::run)
-    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                   // 2^-10 .. 2^14
+    const _Float16 m_sp = mf_p_mul_sp(sp, rsh);                   // 2^-4 .. 2^14 
     const _Float16 m_a4 = mf_p_mul_a(BITS == 4, rsh), m_a6 = mf_p_mul_a(true, rsh);
     const f2v inv2 = {inv, inv};
 #pragma unroll
